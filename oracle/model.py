@@ -1,0 +1,231 @@
+"""ORACLE (test infrastructure, never shipped as product): floating-point hot path of 3D-LOTUS.
+
+Functional CPU/PyTorch-fp32 restatement of `SimplePolicyPTV3CA.forward(batch, compute_loss=True,
+compute_final_action=False)` with *flash-path* patch semantics (SURVEY.md Trap 1), the stale
+decoder CPE input (Trap 3) and injected order permutations (Trap 4).  Parameters are read from a
+plain `state_dict` with the reference's key grammar; gradients come from
+torch autograd on the CPU.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this.
+Pinned against the imported reference (with stand-ins for spconv / flash_attn / torch_scatter,
+see tests/golden/ref_harness.py) by tests/test_oracle_vs_reference.py and tests/golden/*.npz.
+
+Citations are relative to /root/reference/genrobo3d/models.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import front_end as fe
+
+
+def _t(a, dtype=torch.long):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+
+
+def subm_conv(x, nbr, weight, bias):
+    """spconv.SubMConv3d (PointTransformerV3/model.py:616-622, :845-852); weight (Cout,k,k,k,Cin);
+    out[p] = sum_t W[:,t,:] x[nbr[p,t]]."""
+    cout, cin = weight.shape[0], weight.shape[-1]
+    w = weight.reshape(cout, -1, cin)
+    out = x.new_zeros(x.shape[0], cout)
+    for t in range(nbr.shape[1]):
+        col = nbr[:, t]
+        rows = torch.nonzero(col >= 0).squeeze(1)
+        if rows.numel():
+            out = out.index_add(0, rows, x[col[rows]] @ w[:, t, :].t())
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+def _round_fp16(x, on):
+    return x.half().float() if on else x
+
+
+def patch_attention(qkv, lvl, order_index, H, qn_w, qn_b, kn_w, kn_b, patch_size, fp16_attn=False):
+    """SerializedAttention.forward flash branch, PointTransformerV3/model.py:478-551."""
+    N, C3 = qkv.shape
+    C = C3 // 3
+    d = C // H
+    order = lvl["order_t"][order_index][lvl["pad_t"]]
+    inverse = lvl["unpad_t"][lvl["inverse_t"][order_index]]
+    x = qkv[order].reshape(-1, 3, H, d)
+    q, k, v = x.unbind(1)
+    q = F.layer_norm(q, (d,), qn_w, qn_b, 1e-6)
+    k = F.layer_norm(k, (d,), kn_w, kn_b, 1e-6)
+    q, k, v = (_round_fp16(t_, fp16_attn) for t_ in (q, k, v))
+    scale = d ** -0.5
+    cu = lvl["cu_seqlens"].tolist()
+    outs = []
+    i = 0
+    while i < len(cu) - 1:  # batch runs of full patches
+        L = cu[i + 1] - cu[i]
+        j = i
+        while j + 1 < len(cu) - 1 and cu[j + 2] - cu[j + 1] == L:
+            j += 1
+        a, b = cu[i], cu[j + 1]
+        P = (b - a) // L
+        qq = q[a:b].reshape(P, L, H, d).transpose(1, 2)
+        kk = k[a:b].reshape(P, L, H, d).transpose(1, 2)
+        vv = v[a:b].reshape(P, L, H, d).transpose(1, 2)
+        s = (qq @ kk.transpose(-1, -2)) * scale
+        o = torch.softmax(s, dim=-1) @ vv
+        outs.append(o.transpose(1, 2).reshape(P * L, C))
+        i = j + 1
+    feat = _round_fp16(torch.cat(outs, 0), fp16_attn)
+    return feat[inverse]
+
+
+def cross_attention(q, kv, counts, ctx_counts, H, qn_w, qn_b, kn_w, kn_b, fp16_attn=False):
+    """CrossAttention.forward flash branch, PointTransformerV3/model_ca.py:46-67."""
+    N, C = q.shape
+    d = C // H
+    q = F.layer_norm(q.view(-1, H, d), (d,), qn_w, qn_b, 1e-6)
+    kv = kv.view(-1, 2, H, d)
+    k = F.layer_norm(kv[:, 0], (d,), kn_w, kn_b, 1e-6)
+    v = kv[:, 1]
+    q, k, v = (_round_fp16(t_, fp16_attn) for t_ in (q, k, v))
+    scale = d ** -0.5
+    outs = []
+    a = c = 0
+    for n, l in zip(counts, ctx_counts):
+        s = torch.einsum("qhd,khd->hqk", q[a:a + n], k[c:c + l]) * scale
+        outs.append(torch.einsum("hqk,khd->qhd", torch.softmax(s, -1), v[c:c + l]).reshape(n, C))
+        a += n
+        c += l
+    return _round_fp16(torch.cat(outs, 0), fp16_attn)
+
+
+class Oracle:
+    """sd: dict name -> tensor (reference key grammar).  cfg: dict(ptv3=..., action=..., loss=...)."""
+
+    def __init__(self, sd, cfg, training=False, fp16_attn=False, bn_momentum=0.01):
+        self.sd, self.cfg = sd, cfg
+        self.training = training
+        self.fp16_attn = fp16_attn
+        self.bn_momentum = bn_momentum
+        self.new_running = {}
+
+    # -- small helpers ---------------------------------------------------------------------
+    def lin(self, x, name):
+        return F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
+
+    def ln(self, x, name, eps=1e-5):
+        return F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], eps)
+
+    def bn(self, x, name):
+        """nn.BatchNorm1d(eps=1e-3, momentum=0.01), PointTransformerV3/model_ca.py:226."""
+        sd = self.sd
+        if self.training:
+            rm, rv = sd[name + ".running_mean"].clone(), sd[name + ".running_var"].clone()
+            y = F.batch_norm(x, rm, rv, sd[name + ".weight"], sd[name + ".bias"], True, self.bn_momentum, 1e-3)
+            self.new_running[name + ".running_mean"], self.new_running[name + ".running_var"] = rm, rv
+            return y
+        return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"],
+                            sd[name + ".weight"], sd[name + ".bias"], False, 0.0, 1e-3)
+
+    def mlp(self, x, name):
+        """MLP, PointTransformerV3/model.py:577-583 (dropouts are identity in every fixture)."""
+        return self.lin(F.gelu(self.lin(x, name + ".fc1")), name + ".fc2")
+
+    # -- blocks ----------------------------------------------------------------------------
+    def block(self, x, xs, lvl, name, H, patch_size):
+        """Block.forward, PointTransformerV3/model.py:659-680.  xs = sparse_conv_feat.features
+        (== x in the encoder, == proj_skip branch only in the decoder: Trap 3)."""
+        sd = self.sd
+        c = subm_conv(xs, lvl["nbr27_t"], sd[name + ".cpe.0.weight"], sd[name + ".cpe.0.bias"])
+        x = x + self.ln(self.lin(c, name + ".cpe.1"), name + ".cpe.2")
+        qkv = self.lin(self.ln(x, name + ".norm1.0"), name + ".attn.qkv")
+        a = patch_attention(qkv, lvl, 0, H, sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
+                            sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], patch_size,
+                            self.fp16_attn)
+        x = x + self.lin(a, name + ".attn.proj")
+        x = x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0")
+        return x
+
+    def ca_block(self, x, lvl, ctx, ctx_counts, name, H):
+        """CABlock.forward, PointTransformerV3/model_ca.py:135-152."""
+        sd = self.sd
+        q = self.lin(self.ln(x, name + ".norm1.0"), name + ".attn.q")
+        kv = self.lin(ctx, name + ".attn.kv")
+        a = cross_attention(q, kv, lvl["counts"].tolist(), ctx_counts, H,
+                            sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
+                            sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], self.fp16_attn)
+        x = x + self.lin(a, name + ".attn.proj")
+        x = x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0")
+        return x
+
+    # -- whole model -----------------------------------------------------------------------
+    def forward(self, batch, perms, compute_loss=True):
+        """SimplePolicyPTV3AdaNorm.forward + SimplePolicyPTV3CA.prepare_ptv3_batch,
+        simple_policy_ptv3.py:225-306, :403-431.  batch uses the reference schema
+        (pc_fts, npoints_in_batch, txt_embeds, txt_lens, gt_actions, disc_pos_probs)."""
+        p3, act = self.cfg["ptv3"], self.cfg["action"]
+        sd = self.sd
+        pc = batch["pc_fts"].float()
+        counts = list(batch["npoints_in_batch"])
+        n_lv = len(p3["enc_channels"])
+        levels = fe.build_all_levels(pc[:, :3].detach().numpy(), counts, n_lv,
+                                     patch_size=p3["enc_patch_size"][0], perms=perms,
+                                     grid_size=np.float32(act["voxel_size"]))
+        for lv in levels:
+            for k in ("order", "inverse"):
+                lv[k + "_t"] = _t(lv[k])
+            lv["pad_t"], lv["unpad_t"] = _t(lv["pad"]), _t(lv["unpad"])
+            lv["nbr27_t"] = _t(lv["nbr27"])
+        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")  # simple_policy_ptv3.py:414
+        ctx_counts = list(batch["txt_lens"])
+        out = {"levels": levels}
+
+        # Embedding, PointTransformerV3/model.py:844-861
+        x = subm_conv(pc, _t(levels[0]["nbr125"]), sd["ptv3_model.embedding.stem.conv.weight"], None)
+        x = F.gelu(self.bn(x, "ptv3_model.embedding.stem.norm"))
+        feats, skips = [], []
+        for s in range(n_lv):
+            name = f"ptv3_model.enc.enc{s}"
+            lvl = levels[s]
+            if s > 0:  # SerializedPooling, PointTransformerV3/model.py:713-790
+                proj = self.lin(x, name + ".down.proj")
+                cl = _t(lvl["cluster"]).view(-1, 1).expand(-1, proj.shape[1])
+                x = proj.new_zeros(lvl["grid"].shape[0], proj.shape[1]).scatter_reduce(
+                    0, cl, proj, reduce="amax", include_self=False)
+                x = F.gelu(self.bn(x, name + ".down.norm.0"))
+            x = self.block(x, x, lvl, name + ".block0", p3["enc_num_head"][s], p3["enc_patch_size"][s])
+            x = self.ca_block(x, lvl, ctx, ctx_counts, name + ".ca_block0", p3["enc_num_head"][s])
+            skips.append(x)
+        feats.append(x)
+        for s in reversed(range(n_lv - 1)):  # SerializedUnpooling, model.py:817-828
+            name = f"ptv3_model.dec.dec{s}"
+            lvl = levels[s]
+            up = F.gelu(self.bn(self.lin(x, name + ".up.proj.0"), name + ".up.proj.1"))
+            skip = F.gelu(self.bn(self.lin(skips[s], name + ".up.proj_skip.0"), name + ".up.proj_skip.1"))
+            x = skip + up[_t(levels[s + 1]["cluster"])]
+            x = self.block(x, skip, lvl, name + ".block0", p3["dec_num_head"][s], p3["dec_patch_size"][s])
+            x = self.ca_block(x, lvl, ctx, ctx_counts, name + ".ca_block0", p3["dec_num_head"][s])
+            feats.append(x)
+        out["feats"] = feats
+
+        # ActionHead.forward (heatmap_disc / max / euler_disc), simple_policy_ptv3.py:113-157
+        h = F.leaky_relu(self.lin(x, "act_proj_head.heatmap_mlp.0"), 0.02)
+        xt = self.lin(h, "act_proj_head.heatmap_mlp.3")  # (N, 3*2*pos_bins)
+        nb = xt.shape[1] // 3
+        xt = xt.view(-1, 3, nb).permute(1, 0, 2)  # 'n (c b) -> c n b'
+        pcs = torch.stack([t_.max(0)[0] for t_ in torch.split(x, counts)], 0)
+        ae = self.lin(F.leaky_relu(self.lin(pcs, "act_proj_head.action_mlp.0"), 0.02), "act_proj_head.action_mlp.3")
+        ebins = 360 // 5
+        xr = ae[..., : ebins * 3].reshape(-1, ebins, 3)
+        xo = ae[..., -1]
+        out.update(xt=xt, xr=xr, xo=xo)
+        if compute_loss:  # compute_loss, simple_policy_ptv3.py:308-373
+            gt = batch["gt_actions"].float()
+            pos = 0
+            for i, (lg, tg) in enumerate(zip(torch.split(xt, counts, dim=1), batch["disc_pos_probs"])):
+                pos = pos + F.cross_entropy(lg.reshape(3, -1), tg.float(), reduction="mean")
+            pos = pos / len(counts)
+            rot = F.cross_entropy(xr, gt[..., 3:-1].long(), reduction="mean")
+            opn = F.binary_cross_entropy_with_logits(xo, gt[..., -1], reduction="mean")
+            lc = self.cfg["loss"]
+            out["losses"] = dict(pos=pos, rot=rot, open=opn,
+                                 total=lc["pos_weight"] * pos + lc["rot_weight"] * rot + opn)
+        return out

@@ -1,0 +1,82 @@
+"""Canonical synthetic "GemBench-shape" key-step batch.
+
+The real input contract is the output of the reference's `ptv3_collate_fn`
+(genrobo3d/train/datasets/simple_policy_dataset.py:391-415): a ragged concat of per-key-step
+point clouds that are already 1 cm voxel-unique (preprocess/gen_simple_policy_data.py:89).  No
+dataset is available offline, so the bench and the tests use table-top scenes made of
+axis-aligned boxes plus an arm-stub column, surface-sampled on unique 1 cm voxels.
+
+Voxel uniqueness survives `trunc((coord - batch_min) / 0.01)` by construction: every cloud is
+shifted by a whole number of cells (its centroid rounded to the grid), sub-cell jitter is in
+[3, 8] mm, and the points of each cloud's minimal cell per axis sit at exactly 2 mm, so the
+batch-global minimum has the smallest sub-cell phase (>= 1 mm margin to every cell face).
+"""
+import numpy as np
+import torch
+
+
+def _box_surface(lo, hi):
+    """All integer voxels on the surface of the box [lo, hi) (inclusive-exclusive)."""
+    xs, ys, zs = (np.arange(lo[i], hi[i]) for i in range(3))
+    g = np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), -1).reshape(-1, 3)
+    on = ((g == lo) | (g == hi - 1)).any(1)
+    return g[on]
+
+
+def synth_cloud(rng, n):
+    vox = [_box_surface(np.array([27, 27, 0]), np.array([33, 33, 50]))]  # 6x6x50 cm arm stub
+    nbox = int(rng.integers(3, 7))
+    total = len(vox[0])
+    k = 0
+    while k < nbox or total < n * 1.05:
+        edge = rng.integers(5, 26, size=3)
+        c = rng.integers(0, 60, size=2)
+        lo = np.array([c[0] - edge[0] // 2, c[1] - edge[1] // 2, 0])
+        v = _box_surface(lo, lo + edge)
+        vox.append(v)
+        total += len(v)
+        k += 1
+    vox = np.unique(np.concatenate(vox, 0), axis=0)
+    if len(vox) < n:  # overlaps removed too much: recurse with a fresh scene
+        return synth_cloud(rng, n)
+    vox = vox[rng.permutation(len(vox))[:n]]
+    jit = rng.uniform(0.003, 0.008, size=vox.shape)
+    for a in range(3):
+        jit[vox[:, a] == vox[:, a].min(), a] = 0.002
+    cen = np.round(vox.mean(0)).astype(np.int64)
+    xyz = ((vox - cen) * 0.01 + jit).astype(np.float32)
+    rgb = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+    height = (xyz[:, 2:3] - xyz[:, 2].min()).astype(np.float32)
+    return np.concatenate([xyz, rgb, height], 1)
+
+
+def synth_batch(batch_size=16, npoints=4096, ragged=False, seed=0, pos_bins=15, txt_dim=512,
+                real_soft_labels=False):
+    """Returns a dict with the reference batch schema: pc_fts f32[N,7],
+    npoints_in_batch list, offset i64[B], txt_embeds f32[sumL,512], txt_lens list, gt_actions
+    f32[B,7], disc_pos_probs list of f32[3, n*2*pos_bins], ee_poses, step_ids."""
+    rng = np.random.default_rng(seed)
+    pcs, txt, probs = [], [], []
+    for b in range(batch_size):
+        n = int(rng.integers(npoints // 2, npoints + 1)) if ragged else npoints
+        pcs.append(synth_cloud(rng, n))
+        L = int(rng.integers(6, 20))
+        txt.append(rng.standard_normal((L, txt_dim)).astype(np.float32))
+        z = rng.standard_normal((3, n * 2 * pos_bins)).astype(np.float32)
+        z = np.exp(z - z.max(1, keepdims=True))
+        probs.append((z / z.sum(1, keepdims=True)).astype(np.float32))
+    gt = np.concatenate([rng.normal(0, 0.1, size=(batch_size, 3)),
+                         rng.integers(0, 72, size=(batch_size, 3)).astype(np.float64),
+                         rng.integers(0, 2, size=(batch_size, 1)).astype(np.float64)], 1).astype(np.float32)
+    npts = [len(p) for p in pcs]
+    return {
+        "pc_fts": torch.from_numpy(np.concatenate(pcs, 0)),
+        "npoints_in_batch": npts,
+        "offset": torch.from_numpy(np.cumsum(npts)).long(),
+        "txt_embeds": torch.from_numpy(np.concatenate(txt, 0)),
+        "txt_lens": [len(t) for t in txt],
+        "gt_actions": torch.from_numpy(gt),
+        "disc_pos_probs": [torch.from_numpy(p) for p in probs],
+        "ee_poses": torch.zeros(batch_size, 8),
+        "step_ids": torch.zeros(batch_size, dtype=torch.long),
+    }

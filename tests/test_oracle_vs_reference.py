@@ -1,0 +1,94 @@
+"""Live check of the oracle against the imported reference (build container only; skipped on
+the GPU box where /root/reference does not exist)."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.reference
+
+
+def _harness():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import ref_harness as rh
+
+    rh.install_shims()
+    return rh
+
+
+@pytest.mark.parametrize("variant,wvar,B,n,train", [("tiny", "scaled", 3, 700, True), ("tiny", "init", 2, 300, False),
+                                                    ("v1", "scaled", 2, 640, True)])
+def test_losses_and_grads_match_reference(variant, wvar, B, n, train):
+    rh = _harness()
+    from weights_util import seeded_state_dict
+    from robot_3dlotus_amd import config as lcfg, synth
+    from oracle.model import Oracle
+    from make_golden import zero_dropouts
+
+    ref, _ = rh.build_reference_policy(variant)
+    sd = seeded_state_dict(ref.state_dict(), 7, wvar)
+    ref.load_state_dict(sd, strict=True)
+    zero_dropouts(ref)
+    ref.train(train)
+    batch = synth.synth_batch(B, n, ragged=True, seed=21)
+    perms = []
+    with rh.neutralise_half(), rh.record_randperm(perms):
+        torch.manual_seed(3)
+        losses = rh.reference_forward(ref, copy.deepcopy(batch), full=(variant == "v1"))
+    losses["total"].backward()
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(lcfg.preset(variant)), training=train).forward(batch, [p.numpy() for p in perms])
+    for k in losses:
+        assert abs(losses[k].item() - out["losses"][k].item()) < 1e-5 * max(1, abs(losses[k].item()))
+    out["losses"]["total"].backward()
+    gmax = max(p.grad.norm().item() for p in ref.parameters())
+    for name, p in ref.named_parameters():
+        assert (p.grad - sdg[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
+
+
+def test_encode_matches_reference_all_depths():
+    rh = _harness()
+    from genrobo3d.models.PointTransformerV3.serialization import encode as ref_encode
+    from oracle import front_end as fe
+
+    rng = np.random.default_rng(0)
+    for depth in (1, 3, 7, 8, 9, 12, 16):
+        g = rng.integers(0, 2 ** depth, size=(3000, 3)).astype(np.int32)
+        b = rng.integers(0, 17, size=3000).astype(np.int64)
+        for o in fe.ORDERS:
+            r = ref_encode(torch.from_numpy(g), torch.from_numpy(b), depth, o).numpy()
+            np.testing.assert_array_equal(fe.encode(g, b, depth, o), r)
+
+
+def test_hilbert_roundtrip_through_reference_decoder():
+    """Hilbert codes decode back to coordinates with the reference's own decoder."""
+    rh = _harness()
+    from genrobo3d.models.PointTransformerV3.serialization import decode as ref_decode
+    from oracle import front_end as fe
+
+    rng = np.random.default_rng(1)
+    g = rng.integers(0, 2 ** 9, size=(2000, 3)).astype(np.int32)
+    b = rng.integers(0, 4, size=2000).astype(np.int64)
+    gc, bb = ref_decode(torch.from_numpy(fe.encode(g, b, 9, "hilbert")), 9, "hilbert")
+    np.testing.assert_array_equal(gc.numpy(), g)
+    np.testing.assert_array_equal(bb.numpy(), b)
+
+
+def test_state_template_matches_reference_layout():
+    """Checkpoint-format contract: 460 entries, same names and shapes."""
+    rh = _harness()
+    import golden_util as gu
+    from robot_3dlotus_amd import config as lcfg
+
+    for variant in ("v1", "tiny"):
+        ref, _ = rh.build_reference_policy(variant)
+        rsd = ref.state_dict()
+        t = gu.state_template(lcfg.preset(variant))
+        assert set(t) == set(rsd)
+        for k in t:
+            assert tuple(t[k].shape) == tuple(rsd[k].shape), k
+        if variant == "v1":
+            assert len(t) == 460
