@@ -1,0 +1,174 @@
+/* lotus_hip.h — C-ABI of liblotus_hip.so: the MI355X-native (gfx950) 3D-LOTUS hot path.
+ *
+ * The reference (vlc-robot/robot-3dlotus) has no FFI layer: its hot path calls three un-vendored
+ * native packages (spconv, flash_attn, torch_scatter) and ATen/cuBLAS from Python.  Each entry
+ * point below replaces one of those call sites; the citation names the reference file:line
+ * (relative to genrobo3d/models/) whose arithmetic it implements.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative LOTUS_E_* code; lotus_last_error() returns a
+ *     thread-local message.  Nothing throws, allocates device memory or synchronises the stream.
+ *   - all pointers are DEVICE pointers borrowed for the duration of the enqueue, unless marked
+ *     "host".  Tensors are dense row-major fp32; indices are int32; curve codes are int64.
+ *   - `stream` is a hipStream_t (the caller's current stream; 0 = default stream).
+ *   - workspaces are caller-allocated; sizes come from the matching *_workspace() function.
+ */
+#ifndef LOTUS_HIP_H
+#define LOTUS_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOTUS_OK 0
+#define LOTUS_E_ARG (-1)
+#define LOTUS_E_LAUNCH (-2)
+#define LOTUS_E_UNSUPPORTED (-3)
+#define LOTUS_E_WORKSPACE (-4)
+#define LOTUS_ACT_NONE 0
+#define LOTUS_ACT_GELU 1  /* nn.GELU() exact erf form */
+#define LOTUS_ACT_LEAKY 2 /* nn.LeakyReLU(0.02), simple_policy_ptv3.py:42 */
+
+const char* lotus_last_error(void);
+int lotus_abi_version(void);
+
+/* ---- front end (integer, bit-exact) ------------------------------------------------------- */
+/* Point.serialization grid step, PointTransformerV3/model.py:96-98: grid = int32(trunc((coord -
+ * coord.min(0)) / grid_size)) with an IEEE fp32 divide; gmax = max grid coordinate.  coord rows have
+ * stride ld floats (xyz = first three columns of pc_fts).  scratch: 4 x uint32. */
+int lotus_fe_grid(const float* coord, long ld, int n, float grid_size, int* grid, int* gmax, unsigned* scratch,
+                  void* stream);
+/* serialization.encode for the 4 curves, serialization/default.py:9-24, z_order.py:40-101,
+ * hilbert.py:91-198; depth = bit_length(gmax) (model.py:102).  Slot j of code[4][slot_stride] holds
+ * curve perm4[j] (host int[4]; 0 z, 1 z-trans, 2 hilbert, 3 hilbert-trans) — the shuffle_orders
+ * permutation of model.py:130-134 applied at the source.  state int32[8]: [0] |= error bits,
+ * [1] = depth. */
+int lotus_fe_encode(const int* grid, const int* batch, int n, const int* gmax, const int* perm4, int depth_bound,
+                    int* state, long long* code, long slot_stride, void* stream);
+/* torch.argsort(code) + inverse scatter, model.py:121-128, as a stable LSD radix sort of the 4
+ * rows (ties by index).  n is read from n_ptr (device int); slot_stride of every buffer == n_max. */
+size_t lotus_fe_sort_workspace(int n_max);
+int lotus_fe_sort(const long long* code, long slot_stride, const int* n_ptr, int n_max, int key_bits,
+                  long long* skeys, int* order, int* inverse, void* workspace, size_t workspace_bytes, void* stream);
+/* Index part of SerializedPooling.forward, model.py:726-772 (torch.unique + sort + head gather):
+ * cluster[n], CSR seg_start[n_child+1] into order0, n_child (device int), child code (rows
+ * permuted by perm4, host int[4]), child grid/batch and per-cloud child counts. */
+int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* order0, const int* pgrid,
+                  const int* pbatch, const int* n_ptr, int n_max, const int* perm4, int nbatch, int* cluster,
+                  int* seg_start, int* n_child, long long* ccode, int* cgrid, int* cbatch, int* ccounts,
+                  void* stream);
+/* torch_scatter.segment_csr(coord, reduce="mean"), model.py:763-765 */
+int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_start, int n_child, float* ccoord,
+                        void* stream);
+/* SerializedAttention.get_padding_and_inverse, model.py:410-466, composed with order/inverse:
+ * gidx[i] = order[pad[i]], owner[i] = (unpad[inverse[gidx[i]]] == i).  off/offp: int32 [B+1]
+ * exclusive prefix sums of the per-cloud counts / padded counts. */
+int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int K, int npad, int* gidx, int* owner,
+                   void* stream);
+/* spconv submanifold neighbour lookup (SubMConv3d call sites model.py:615-622, :844-853): tap-major
+ * nbr int32 [ksize^3][n], -1 = absent, duplicates -> lowest index (SURVEY.md Trap 5). */
+size_t lotus_fe_neighbours_workspace(int n);
+int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int* nbr, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* ---- dense layers (fp32 MFMA) ------------------------------------------------------------- */
+/* nn.Linear (+GELU/LeakyReLU, +Dropout, +residual): y = dropout(act(x w^T + bias)) + residual;
+ * `pre` (optional) receives x w^T + bias.  Call sites: model.py:386-387,572-574,623,707,804-805;
+ * model_ca.py:27-31; simple_policy_ptv3.py:40-68,387. */
+int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                     float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
+                     void* stream);
+/* dx = (dy w) * act'(pre) * dropmask + add : chain rule through the producer of this layer's input */
+int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* stream);
+size_t lotus_linear_wgrad_workspace(int M, int N, int K);
+/* dw (+)= dy^T x, db (+)= colsum(dy); deterministic split-K */
+int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- submanifold sparse convolution (spconv.SubMConv3d, model.py:615-622, :844-853) -------- */
+/* mode 0 fwd: y[n][cout] = sum_t W[:,t,:] x[nbr[t][.]] + bias (+ add); mode 1 dgrad: x = dy, y = dx.
+ * w is (cout, k, k, k, cin) row-major; rowidx (optional) = processing order of the rows. */
+int lotus_subm_conv(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
+                    const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* stream);
+size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout);
+int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
+                          int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ---- normalisation ------------------------------------------------------------------------ */
+/* nn.LayerNorm (model.py:624,627,645; model_ca.py:114,124): y = LN(x) (+ res) */
+int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int M, int C, float eps, void* stream);
+size_t lotus_layernorm_bwd_workspace(int M, int C);
+int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* nn.BatchNorm1d(eps=1e-3, momentum=0.01) (+GELU), model_ca.py:226: statistics are exposed as
+ * double sums[2*C+1] = (sum, sumsq, row count) so that a caller can all-reduce them across ranks (SyncBatchNorm,
+ * train_simple_policy.py:116-117) between _stats and _finalize. */
+size_t lotus_batchnorm_workspace(int M, int C);
+int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
+                          void* stream);
+int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, float* running_mean,
+                             float* running_var, int C, float eps, float momentum, void* stream);
+int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
+                               float eps, void* stream);
+int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float* y, int M, int C, int act, void* stream);
+int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, double* sums, int M, int C, int act,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const double* sums, float* dx, float* dgamma,
+                              float* dbeta, int M, int C, int act, int train, int accumulate, void* stream);
+
+/* ---- attention ---------------------------------------------------------------------------- */
+/* flash_attn_varlen_qkvpacked_func (model.py:543-549) and flash_attn_varlen_kvpacked_func
+ * (model_ca.py:62-66) with the preceding q_norm/k_norm LayerNorm(d, eps) (model.py:532-533,
+ * model_ca.py:52-53), in fp32.  tiles: int32 [ntiles][4] = q_start, q_len, k_start, k_len (<= 128).
+ * Row r of q lives at q + r*q_ld + q_off + h*d; k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d. */
+int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+                        const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
+                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
+                        long out_ld, float* lse, int H, int d, float scale, float eps, void* stream);
+size_t lotus_attention_bwd_workspace(int nblocks, int H);
+/* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len */
+int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+                        const int* qidx, const int* kidx, const int* owner, const int* tiles, const int* blocks,
+                        int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
+                        const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
+                        int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
+                        int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        int H, int d, float scale, float eps, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- pooling, head, losses ---------------------------------------------------------------- */
+/* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */
+int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,
+                       void* stream);
+int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int n, int C, float* dx, void* stream);
+/* SerializedUnpooling: parent.feat + point.feat[inverse], model.py:824 */
+int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream);
+int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream);
+/* ActionHead reduce == 'max': per-cloud torch.max(x, 0), simple_policy_ptv3.py:117-119 */
+int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream);
+int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
+                        void* stream);
+/* compute_loss (heatmap_disc / euler_disc), simple_policy_ptv3.py:322-373: losses[4] = pos, rot,
+ * open, total.  xt [n][3*nb]; ae [B][nrot*3+1]; tgt = concatenated disc_pos_probs; gt [B][ga]. */
+int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
+                   int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
+                   void* stream);
+int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                   const float* dae_saved, const float* gl, float pos_w, float rot_w, int B, int n, int nb, int nrot,
+                   float* dxt, float* dae_out, void* stream);
+/* elementwise plumbing */
+int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
+/* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */
+int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOTUS_HIP_H */

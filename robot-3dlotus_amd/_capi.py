@@ -1,0 +1,124 @@
+"""ctypes binding of csrc/liblotus_hip.so.
+
+The prototypes are read from include/lotus_hip.h (single source of truth), so a signature change
+in the header is picked up here and checked by tests/test_capi.py.  There is no CPU fallback: if the
+library is missing, `lib()` raises with the build instruction.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblotus_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lotus_hip.h")
+
+_CTYPES = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t, "unsigned long long": ctypes.c_ulonglong, "unsigned": ctypes.c_uint,
+}
+
+
+def parse_header(path=HEADER_PATH):
+    """-> {name: (restype, [argtypes], [argnames])} for every `lotus_*` prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w \*]*?)\s*\b(lotus_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret == "const char*":
+            restype = ctypes.c_char_p
+        else:
+            restype = _CTYPES[ret]
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                    argnames.append(a.split("*")[-1].strip())
+                else:
+                    ty, nm = a.rsplit(" ", 1)
+                    ty = ty.replace("const ", "").strip()
+                    argtypes.append(_CTYPES[ty])
+                    argnames.append(nm)
+        protos[name] = (restype, argtypes, argnames)
+    return protos
+
+
+class LotusError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise LotusError(
+                f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+                "Build it with `python robot-3dlotus_amd/csrc/build.py` or `__graft_entry__.build()`.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, (restype, argtypes, _) in self.protos.items():
+            f = getattr(self.cdll, name)
+            f.restype = restype
+            f.argtypes = argtypes
+            self.fn[name] = f
+
+    def last_error(self):
+        return self.fn["lotus_last_error"]().decode()
+
+
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = _Lib()
+    return _LIB
+
+
+def _conv(a):
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return a.data_ptr()
+    return a
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Call an int-returning entry point; tensors -> device pointers; appends the current stream."""
+    L = lib()
+    rc = L.fn[name](*[_conv(a) for a in args], stream_ptr())
+    if rc != 0:
+        raise LotusError(f"{name} failed ({rc}): {L.last_error()}")
+
+
+def query(name, *args):
+    """Call a size_t-returning *_workspace() function."""
+    return lib().fn[name](*args)
+
+
+class Workspace:
+    """Grow-only per-device scratch buffer.  All ops run in stream order on the current stream, so
+    one buffer can be reused by consecutive calls."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device, slot=0):
+        key = (device, slot)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+WS = Workspace()

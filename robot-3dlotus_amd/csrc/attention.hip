@@ -1,0 +1,502 @@
+// lotus-hip: tile attention forward/backward in exact fp32 (MFMA 32x32x2) — one kernel pair
+// serves both attention sites of the reference:
+//   * SerializedAttention (PointTransformerV3/model.py:468-557, flash var-len path): patches of
+//     <= 128 serialised points; q/k/v rows are gathered from qkv[N][3C] through order[pad]; the
+//     result is scattered back through the owner positions (unpad[inverse]).
+//   * CrossAttention (PointTransformerV3/model_ca.py:46-101): a 128-row tile of one cloud's
+//     points attends to that cloud's <= 128 instruction tokens.
+// q and k get a per-head LayerNorm(d, eps=1e-6) (qk_norm) inside the kernel.  The reference runs
+// the softmax core in fp16 (model.py:544); here it is fp32 end-to-end, which is what the 1e-4
+// logit parity against the fp32-ideal oracle requires (SURVEY.md Trap 2).
+//
+// LDS plan (floats): Q[128][33] K[128][33] V[128][33] (dO[128][33]) S[128][129]; everything a
+// (tile, head) needs stays on chip between the QK^T, softmax and PV stages.
+#include "common.h"
+
+#define AT 128        // tile rows (queries) and max keys
+#define ALD 33        // row stride of the [128][d<=32] images
+#define SLD 129       // row stride of the score image
+
+struct AttnP {
+  const float* q; long q_ld; int q_off;
+  const float* kv; long kv_ld; int k_off, v_off;
+  const int* qidx;    // row gather for the q side (null = identity)
+  const int* kidx;    // row gather for the k/v side (null = identity)
+  const int* owner;   // per q position: write/use this row (null = all)
+  const int* tiles;   // [ntiles][4] = q_start, q_len, k_start, k_len
+  const int* blocks;  // bwd: [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len
+  const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;
+  float* out; long out_ld;   // fwd output rows (indexed like q rows)
+  float* lse;                // [npos][H]
+  // backward
+  const float* dout;         // gradient of out (same indexing as out)
+  float* dq; long dq_ld; int dq_off;
+  float* dkv; long dkv_ld; int dk_off, dv_off; long dkv_part_stride;
+  float* ln_part;            // [nblocks * H][4][32]  dgamma_q, dbeta_q, dgamma_k, dbeta_k
+  int atomic_out;            // 1: atomicAdd into dq/dkv (self-attention with borrowed rows)
+  int H, d;
+  float scale, eps;
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) z[r] = 0.f;
+  return z;
+}
+
+// Load `len` rows (gathered through idx) of d floats at column offset coff into img[128][ALD];
+// rows >= len and columns >= d are zero.  8 threads per row, float4 each.
+__device__ __forceinline__ void load_rows(float* img, const float* base, long ld, int coff, const int* rows_s,
+                                          int len, int d) {
+  const int sub = threadIdx.x & 7;
+  for (int r = threadIdx.x >> 3; r < AT; r += 32) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < len && sub * 4 < d) v = *reinterpret_cast<const float4*>(base + (long)rows_s[r] * ld + coff + sub * 4);
+    float* o = img + r * ALD + sub * 4;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+}
+
+// Per-row LayerNorm over d of img rows [0, len): img <- xhat (AFFINE=false) or xhat*g+b.
+template <bool AFFINE>
+__device__ __forceinline__ void ln_rows(float* img, float* rstd_s, int row, int len, int d, float eps,
+                                        const float* g_s, const float* b_s) {
+  if (row >= len) {
+    if (row < AT) rstd_s[row] = 0.f;
+    return;
+  }
+  float* x = img + row * ALD;
+  float m = 0.f;
+  for (int j = 0; j < d; ++j) m += x[j];
+  m /= d;
+  float v = 0.f;
+  for (int j = 0; j < d; ++j) {
+    const float c = x[j] - m;
+    v += c * c;
+  }
+  const float rs = rsqrtf(v / d + eps);
+  rstd_s[row] = rs;
+  for (int j = 0; j < d; ++j) {
+    const float xh = (x[j] - m) * rs;
+    x[j] = AFFINE ? xh * g_s[j] + b_s[j] : xh;
+  }
+}
+
+struct AttnSmem {
+  float* Q; float* K; float* V; float* dO; float* S;
+  float* qrstd; float* krstd; float* Dv; float* lse;
+  float* gq; float* bq; float* gk; float* bk;
+  int* qrow; int* krow; int* qown;
+};
+
+__device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
+  AttnSmem s;
+  float* p = base;
+  s.Q = p; p += AT * ALD;
+  s.K = p; p += AT * ALD;
+  s.V = p; p += AT * ALD;
+  s.dO = p; if (bwd) p += AT * ALD;
+  s.S = p; p += AT * SLD;
+  s.qrstd = p; p += AT;
+  s.krstd = p; p += AT;
+  s.Dv = p; p += AT;
+  s.lse = p; p += AT;
+  s.gq = p; p += 32; s.bq = p; p += 32; s.gk = p; p += 32; s.bk = p; p += 32;
+  s.qrow = (int*)p; p += AT;
+  s.krow = (int*)p; p += AT;
+  s.qown = (int*)p; p += AT;
+  return s;
+}
+static size_t attn_smem_bytes(bool bwd) {
+  return (size_t)((bwd ? 4 : 3) * AT * ALD + AT * SLD + 4 * AT + 4 * 32 + 3 * AT) * sizeof(float);
+}
+
+__device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
+  const int t = threadIdx.x;
+  if (t < 32) {
+    const bool in = t < p.d;
+    s.gq[t] = in ? p.qn_w[t] : 0.f;
+    s.bq[t] = in ? p.qn_b[t] : 0.f;
+    s.gk[t] = in ? p.kn_w[t] : 0.f;
+    s.bk[t] = in ? p.kn_b[t] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  AttnSmem s = carve(smem, false);
+  const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1;
+  const int h = blockIdx.y, d = p.d;
+  const int q_start = p.tiles[blockIdx.x * 4 + 0], q_len = p.tiles[blockIdx.x * 4 + 1];
+  const int k_start = p.tiles[blockIdx.x * 4 + 2], k_len = p.tiles[blockIdx.x * 4 + 3];
+
+  if (tid < AT) {
+    s.qrow[tid] = tid < q_len ? (p.qidx ? p.qidx[q_start + tid] : q_start + tid) : -1;
+    s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+    s.qown[tid] = tid < q_len ? (p.owner ? p.owner[q_start + tid] : 1) : 0;
+  }
+  load_affine(p, s);
+  __syncthreads();
+  load_rows(s.Q, p.q, p.q_ld, p.q_off + h * d, s.qrow, q_len, d);
+  load_rows(s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len, d);
+  load_rows(s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len, d);
+  __syncthreads();
+  if (tid < AT) ln_rows<true>(s.Q, s.qrstd, tid, q_len, d, p.eps, s.gq, s.bq);
+  else ln_rows<true>(s.K, s.krstd, tid - AT, k_len, d, p.eps, s.gk, s.bk);
+  __syncthreads();
+
+  const int r0 = wave * 32;
+  const int ktiles = (k_len + 31) / 32;
+  // S = scale * Q K^T
+  if (r0 < q_len) {
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    for (int kk = 0; kk < d; kk += 2) {
+      const float a = s.Q[(r0 + l31) * ALD + kk + hh];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + kk + hh], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < ktiles) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s.S[row * SLD + t * 32 + l31] = acc[t][r] * p.scale;
+        }
+      }
+  }
+  __syncthreads();
+  // row softmax (2 threads per row)
+  {
+    const int row = tid >> 1, half = tid & 1;
+    const int c0 = half * 64, c1 = min(k_len, c0 + 64);
+    float* srow = s.S + row * SLD;
+    float m = -INFINITY;
+    if (row < q_len)
+      for (int c = c0; c < c1; ++c) m = fmaxf(m, srow[c]);
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    float sum = 0.f;
+    if (row < q_len)
+      for (int c = c0; c < c1; ++c) {
+        const float e = expf(srow[c] - m);
+        srow[c] = e;
+        sum += e;
+      }
+    sum += __shfl_xor(sum, 1, 64);
+    const float inv = sum > 0.f ? 1.f / sum : 0.f;
+    if (row < q_len) {
+      for (int c = c0; c < c1; ++c) srow[c] *= inv;
+      for (int c = max(c1, c0); c < c0 + 64; ++c) srow[c] = 0.f;  // keys beyond k_len
+      if (half == 0 && p.lse) p.lse[(long)(q_start + row) * p.H + h] = m + logf(sum);
+    }
+  }
+  __syncthreads();
+  // O = P V
+  if (r0 < q_len) {
+    f32x16 acc = zero16();
+    const int kend = (k_len + 1) & ~1;
+    for (int kk = 0; kk < kend; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(r0 + l31) * SLD + kk + hh], s.V[(kk + hh) * ALD + l31], acc, 0, 0, 0);
+    if (l31 < d) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < q_len && s.qown[row]) p.out[(long)s.qrow[row] * p.out_ld + h * d + l31] = acc[r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ void store_rows(const float* img, float* base, long ld, int coff, const int* rows_s,
+                                           const int* own_s, int len, int d, int atomic) {
+  const int sub = threadIdx.x & 7;
+  for (int r = threadIdx.x >> 3; r < len; r += 32) {
+    if (own_s && !own_s[r]) continue;
+    if (sub * 4 >= d) continue;
+    const float* v = img + r * ALD + sub * 4;
+    float* o = base + (long)rows_s[r] * ld + coff + sub * 4;
+    if (atomic) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
+    } else {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+// LN backward of rows [0,len) in place: g (in: d wrt normalised+affine output) -> d wrt raw input.
+__device__ __forceinline__ void ln_rows_bwd(float* g, const float* xh, const float* rstd_s, int row, int len, int d,
+                                            const float* gam) {
+  if (row >= len) return;
+  float* gr = g + row * ALD;
+  const float* xr = xh + row * ALD;
+  float s1 = 0.f, s2 = 0.f;
+  for (int j = 0; j < d; ++j) {
+    const float t = gr[j] * gam[j];
+    s1 += t;
+    s2 += t * xr[j];
+  }
+  s1 /= d;
+  s2 /= d;
+  const float rs = rstd_s[row];
+  for (int j = 0; j < d; ++j) gr[j] = rs * (gr[j] * gam[j] - s1 - xr[j] * s2);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  AttnSmem s = carve(smem, true);
+  __shared__ float lnacc[4][32];
+  const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1;
+  const int h = blockIdx.y, d = p.d;
+  const int* bd = p.blocks + blockIdx.x * 6;
+  const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3];
+  const int k_start = bd[4], k_len = bd[5];
+  const int r0 = wave * 32;
+  const int ktiles = (k_len + 31) / 32;
+
+  if (tid < AT) s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+  if (tid < 4 * 32) lnacc[tid >> 5][tid & 31] = 0.f;
+  load_affine(p, s);
+  __syncthreads();
+  load_rows(s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len, d);
+  load_rows(s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len, d);
+  __syncthreads();
+  if (tid >= AT) ln_rows<false>(s.K, s.krstd, tid - AT, k_len, d, p.eps, nullptr, nullptr);
+  __syncthreads();
+
+  f32x16 acc_dv = zero16(), acc_dk = zero16();
+  const float gk_l = s.gk[l31], bk_l = s.bk[l31], gq_l = s.gq[l31], bq_l = s.bq[l31];
+
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int tile = first_tile + ti * tile_step;
+    const int q_start = p.tiles[tile * 4 + 0], q_len = p.tiles[tile * 4 + 1];
+    if (tid < AT) {
+      s.qrow[tid] = tid < q_len ? (p.qidx ? p.qidx[q_start + tid] : q_start + tid) : -1;
+      s.qown[tid] = tid < q_len ? (p.owner ? p.owner[q_start + tid] : 1) : 0;
+      s.lse[tid] = tid < q_len ? p.lse[(long)(q_start + tid) * p.H + h] : 0.f;
+    }
+    __syncthreads();
+    load_rows(s.Q, p.q, p.q_ld, p.q_off + h * d, s.qrow, q_len, d);
+    {  // dO rows (zero for non-owners) and D = rowsum(dO * O)
+      const int sub = tid & 7;
+      for (int r = tid >> 3; r < AT; r += 32) {
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dsum = 0.f;
+        if (r < q_len && s.qown[r] && sub * 4 < d) {
+          const long o = (long)s.qrow[r] * p.out_ld + h * d + sub * 4;
+          g = *reinterpret_cast<const float4*>(p.dout + o);
+          const float4 ov = *reinterpret_cast<const float4*>(p.out + o);
+          dsum = g.x * ov.x + g.y * ov.y + g.z * ov.z + g.w * ov.w;
+        }
+        float* o = s.dO + r * ALD + sub * 4;
+        o[0] = g.x; o[1] = g.y; o[2] = g.z; o[3] = g.w;
+        dsum += __shfl_xor(dsum, 1, 64);
+        dsum += __shfl_xor(dsum, 2, 64);
+        dsum += __shfl_xor(dsum, 4, 64);
+        if (sub == 0) s.Dv[r] = dsum;
+      }
+    }
+    __syncthreads();
+    if (tid < AT) ln_rows<false>(s.Q, s.qrstd, tid, q_len, d, p.eps, nullptr, nullptr);
+    __syncthreads();
+
+    // P = exp(scale * Qn Kn^T - lse), zero outside the valid (q_len, k_len) rectangle
+    if (r0 < q_len) {
+      f32x16 acc[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = zero16();
+      for (int kk = 0; kk < d; kk += 2) {
+        const int k = kk + hh;
+        const float a = s.Q[(r0 + l31) * ALD + k] * s.gq[k] + s.bq[k];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < ktiles)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + k] * s.gk[k] + s.bk[k], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int col = t * 32 + l31;
+          const bool ok = t < ktiles && row < q_len && col < k_len;
+          s.S[row * SLD + col] = ok ? expf(acc[t][r] * p.scale - s.lse[row]) : 0.f;
+        }
+      }
+    } else {
+      for (int i = l31 + 32 * hh; i < 32 * AT; i += 64) s.S[(r0 + i / AT) * SLD + (i % AT)] = 0.f;
+    }
+    __syncthreads();
+    // dV += P^T dO   (wave owns key rows r0..r0+31)
+    const int qend = (q_len + 1) & ~1;
+    if (r0 < k_len) {
+      for (int kk = 0; kk < qend; kk += 2)
+        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31], s.dO[(kk + hh) * ALD + l31], acc_dv, 0, 0, 0);
+    }
+    // dP = dO V^T  (wave owns query rows)
+    f32x16 dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dp[t] = zero16();
+    if (r0 < q_len) {
+      for (int kk = 0; kk < d; kk += 2) {
+        const float a = s.dO[(r0 + l31) * ALD + kk + hh];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (t < ktiles) dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.V[(t * 32 + l31) * ALD + kk + hh], dp[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    // dS = scale * P * (dP - D), in place over P
+    if (r0 < q_len) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ktiles) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float* sp = s.S + row * SLD + t * 32 + l31;
+            *sp = p.scale * (*sp) * (dp[t][r] - s.Dv[row]);
+          }
+        }
+    }
+    __syncthreads();
+    // dKn += dS^T Qn  (wave owns key rows) ; dQn = dS Kn (wave owns query rows)
+    if (r0 < k_len) {
+      for (int kk = 0; kk < qend; kk += 2)
+        acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31],
+                                                      s.Q[(kk + hh) * ALD + l31] * gq_l + bq_l, acc_dk, 0, 0, 0);
+    }
+    f32x16 acc_dq = zero16();
+    if (r0 < q_len) {
+      const int kend = (k_len + 1) & ~1;
+      for (int kk = 0; kk < kend; kk += 2)
+        acc_dq = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(r0 + l31) * SLD + kk + hh],
+                                                      s.K[(kk + hh) * ALD + l31] * gk_l + bk_l, acc_dq, 0, 0, 0);
+    }
+    __syncthreads();  // dO image is free now: reuse it for dQn
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      s.dO[row * ALD + l31] = (r0 < q_len && l31 < d) ? acc_dq[r] : 0.f;
+    }
+    __syncthreads();
+    // q_norm affine gradients (column pass), then LN backward (row pass), then store
+    if (tid < 64) {
+      const int which = tid >> 5, j = tid & 31;  // 0: dgamma_q, 1: dbeta_q
+      float a = 0.f;
+      if (j < d)
+        for (int r = 0; r < q_len; ++r) a += which == 0 ? s.dO[r * ALD + j] * s.Q[r * ALD + j] : s.dO[r * ALD + j];
+      lnacc[which][j] += a;
+    }
+    __syncthreads();
+    if (tid < AT) ln_rows_bwd(s.dO, s.Q, s.qrstd, tid, q_len, d, s.gq);
+    __syncthreads();
+    store_rows(s.dO, p.dq, p.dq_ld, p.dq_off + h * d, s.qrow, s.qown, q_len, d, 0);  // one owner per row
+    __syncthreads();
+  }
+
+  // ---- K / V gradients of this block
+  // dV straight from registers -> V image (V no longer needed), dKn -> dO image
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    s.V[row * ALD + l31] = (l31 < d) ? acc_dv[r] : 0.f;
+    s.dO[row * ALD + l31] = (l31 < d) ? acc_dk[r] : 0.f;
+  }
+  __syncthreads();
+  if (tid >= 64 && tid < 128) {
+    const int which = (tid - 64) >> 5, j = tid & 31;  // 2: dgamma_k, 3: dbeta_k
+    float a = 0.f;
+    if (j < d)
+      for (int r = 0; r < k_len; ++r) a += which == 0 ? s.dO[r * ALD + j] * s.K[r * ALD + j] : s.dO[r * ALD + j];
+    lnacc[2 + which][j] = a;
+  }
+  __syncthreads();
+  if (tid < AT) ln_rows_bwd(s.dO, s.K, s.krstd, tid, k_len, d, s.gk);
+  __syncthreads();
+  float* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+  store_rows(s.dO, dkv, p.dkv_ld, p.dk_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out);
+  store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out);
+  if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
+}
+
+// out4[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
+__global__ void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1, float* o2, float* o3,
+                                      int nb, int d, int accumulate) {
+  const int which = threadIdx.x >> 5, j = threadIdx.x & 31;
+  if (j >= d) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[((long)b * 4 + which) * 32 + j];
+  float* o = which == 0 ? o0 : which == 1 ? o1 : which == 2 ? o2 : o3;
+  o[j] = accumulate ? o[j] + s : s;
+}
+
+static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
+
+extern "C" {
+
+// Forward.  tiles: int32 [ntiles][4] (device).  Rows: q row r lives at q + r*q_ld + q_off + h*d;
+// k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d; out rows are indexed like q rows.
+int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+                        const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
+                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
+                        long out_ld, float* lse, int H, int d, float scale, float eps, void* stream) {
+  LOTUS_CHECK_ARG(q && kv && tiles && out && check_geom(H, d) == 0, "lotus_attention_fwd: bad arguments (H=%d d=%d)", H, d);
+  if (ntiles == 0) return LOTUS_OK;
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.q = q; p.q_ld = q_ld; p.q_off = q_off; p.kv = kv; p.kv_ld = kv_ld; p.k_off = k_off; p.v_off = v_off;
+  p.qidx = qidx; p.kidx = kidx; p.owner = owner; p.tiles = tiles;
+  p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
+  p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
+  const size_t sm = attn_smem_bytes(false);
+  (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_attention_fwd");
+  return LOTUS_OK;
+}
+
+size_t lotus_attention_bwd_workspace(int nblocks, int H) { return (size_t)nblocks * H * 4 * 32 * sizeof(float); }
+
+// Backward.  blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.
+// dq/dkv must be zero-initialised by the caller when atomic_out = 1.  With atomic_out = 0 every
+// (part_slot, key row, head) is written exactly once (plain stores, deterministic).
+int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+                        const int* qidx, const int* kidx, const int* owner, const int* tiles, const int* blocks,
+                        int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
+                        const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
+                        int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
+                        int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        int H, int d, float scale, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+  LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
+                  "lotus_attention_bwd: bad arguments");
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_attention_bwd_workspace(nblocks, H),
+                  "lotus_attention_bwd: workspace too small");
+  if (nblocks == 0) return LOTUS_OK;
+  AttnP p;
+  memset(&p, 0, sizeof(p));
+  p.q = q; p.q_ld = q_ld; p.q_off = q_off; p.kv = kv; p.kv_ld = kv_ld; p.k_off = k_off; p.v_off = v_off;
+  p.qidx = qidx; p.kidx = kidx; p.owner = owner; p.tiles = tiles; p.blocks = blocks;
+  p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
+  p.out = (float*)out; p.dout = dout; p.out_ld = out_ld; p.lse = (float*)lse;
+  p.dq = dq; p.dq_ld = dq_ld; p.dq_off = dq_off;
+  p.dkv = dkv; p.dkv_ld = dkv_ld; p.dk_off = dk_off; p.dv_off = dv_off; p.dkv_part_stride = dkv_part_stride;
+  p.atomic_out = atomic_out; p.ln_part = (float*)workspace;
+  p.H = H; p.d = d; p.scale = scale; p.eps = eps;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t sm = attn_smem_bytes(true);
+  (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblocks, H), dim3(256), sm, st, p);
+  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(1), dim3(128), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
+                     nblocks * H, d, accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_attention_bwd");
+  return LOTUS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// lotus-hip: shared device/host helpers (gfx950 / CDNA4 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define LOTUS_OK 0
+#define LOTUS_E_ARG (-1)
+#define LOTUS_E_LAUNCH (-2)
+#define LOTUS_E_UNSUPPORTED (-3)
+#define LOTUS_E_WORKSPACE (-4)
+
+void lotus_set_error(const char* fmt, ...);
+
+#define LOTUS_CHECK_ARG(cond, ...)          \
+  do {                                      \
+    if (!(cond)) {                          \
+      lotus_set_error(__VA_ARGS__);         \
+      return LOTUS_E_ARG;                   \
+    }                                       \
+  } while (0)
+
+#define LOTUS_LAUNCH_CHECK(name)                                                   \
+  do {                                                                             \
+    hipError_t e_ = hipGetLastError();                                             \
+    if (e_ != hipSuccess) {                                                        \
+      lotus_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return LOTUS_E_LAUNCH;                                                       \
+    }                                                                              \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// activation codes shared by the C-ABI
+#define LOTUS_ACT_NONE 0
+#define LOTUS_ACT_GELU 1
+#define LOTUS_ACT_LEAKY 2  // LeakyReLU(0.02), simple_policy_ptv3.py:42
+
+__device__ __forceinline__ float gelu_f(float x) {  // exact erf form (nn.GELU default)
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+  if (act == LOTUS_ACT_GELU) return gelu_f(x);
+  if (act == LOTUS_ACT_LEAKY) return x > 0.f ? x : 0.02f * x;
+  return x;
+}
+__device__ __forceinline__ float act_grad_f(float pre, int act) {
+  if (act == LOTUS_ACT_GELU) return gelu_grad_f(pre);
+  if (act == LOTUS_ACT_LEAKY) return pre > 0.f ? 1.f : 0.02f;
+  return 1.f;
+}
+
+// Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless so the backward
+// pass regenerates the identical mask from (seed, element index).
+__device__ __forceinline__ uint32_t lotus_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
+  return lotus_hash32(seed, idx) >= thresh ? inv_keep : 0.f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,352 @@
+// lotus-hip: submanifold sparse convolution (the spconv.SubMConv3d call sites of the reference:
+// PointTransformerV3/model.py:615-622 (3^3 CPE of every Block) and :844-853 (5^3 stem); 29 % of
+// all MACs) as gather-GEMMs on the fp32 MFMA path.
+//
+//   fwd   : y[p, :]  = sum_t W[:, t, :]   x[nbr[t][p], :] + b
+//   dgrad : dx[q, :] = sum_t W[:, T-1-t, :]^T dy[nbr[t][q], :]      (mirrored taps)
+//   wgrad : dW[:, t, :] = sum_p dy[p, :] (x) x[nbr[t][p], :]        (active pairs compacted per tap)
+//
+// The neighbour table is tap-major int32 nbr[T][N] (-1 = absent) built once per level by the
+// front-end (front_end.hip) and shared by the encoder and decoder Blocks of that level.
+// Output rows are processed in serialised (space-filling-curve) order so that a 128-row block is
+// spatially coherent: taps with no active neighbour in the block are skipped for the whole block,
+// and per-wave 32-row groups skip their MFMAs through a ballot mask.
+#include "mma.h"
+
+int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);
+
+struct ConvP {
+  const float* x;   // [n][KD] gathered operand (features, or dy for dgrad)
+  const float* w;   // [cout][T][cin]
+  float* y;         // [n][ND]
+  const float* bias;
+  const float* add;  // [n][ND] optional addend
+  const int* nbr;    // [T][n]
+  const int* rowidx; // [n] processing order or null
+  int n, T, cin, cout;
+  int KD, ND;        // reduction / output channels
+  int mirror;        // dgrad: use tap T-1-t of the weights
+};
+
+template <int BM, int BN, bool B_KC>
+__global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A4 = BM * LOTUS_BK / 4 / 256, B4 = BN * LOTUS_BK / 4 / 256;
+  __shared__ float As[LdsTile<BM, true>::kFloats];
+  __shared__ float Bs[LdsTile<BN, B_KC>::kFloats];
+  __shared__ int prow_s[BM];
+  __shared__ int n_active_s;
+  extern __shared__ int dyn_s[];  // nb_s[T][BM], tapmask[T], active[T]
+  int* nb_s = dyn_s;
+  int* tapmask_s = dyn_s + p.T * BM;
+  int* active_s = tapmask_s + p.T;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
+
+  for (int r = tid; r < BM; r += 256) {
+    const int m = m0 + r;
+    prow_s[r] = m < p.n ? (p.rowidx ? p.rowidx[m] : m) : -1;
+  }
+  __syncthreads();
+  // neighbour slab + per-tap activity of each 32-row group (wave ballot)
+  for (int t = wave; t < p.T; t += 4) {
+    int mask = 0;
+    for (int r0 = 0; r0 < BM; r0 += 64) {
+      const int pr = prow_s[r0 + lane];
+      const int nb = pr >= 0 ? p.nbr[(long)t * p.n + pr] : -1;
+      nb_s[t * BM + r0 + lane] = nb;
+      const unsigned long long b = __ballot(nb >= 0);
+      if (b & 0xffffffffull) mask |= 1 << (r0 / 32);
+      if (b >> 32) mask |= 1 << (r0 / 32 + 1);
+    }
+    if (lane == 0) tapmask_s[t] = mask;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0;
+    for (int t = 0; t < p.T; ++t)
+      if (tapmask_s[t]) active_s[c++] = t;
+    n_active_s = c;
+  }
+  __syncthreads();
+  const int n_active = n_active_s;
+  const int kchunks = (p.KD + LOTUS_BK - 1) / LOTUS_BK;
+  const int iters = n_active * kchunks;
+  const long wld = (long)p.T * p.cin;
+  const bool a_vec = (p.KD % 4 == 0) && (((uintptr_t)p.x) % 16 == 0);
+  const bool b_vec = B_KC ? ((p.cin % 4 == 0) && (((uintptr_t)p.w) % 16 == 0))
+                          : ((p.cin % 4 == 0) && (((uintptr_t)p.w) % 16 == 0));
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float asum_unused[TM];
+
+  float4 ra[A4], rb[B4];
+  auto gload = [&](int it) {
+    const int t = active_s[it / kchunks];
+    const int k0 = (it % kchunks) * LOTUS_BK;
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const int f = tid + q * 256;
+      const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+      const int src = nb_s[t * BM + row];
+      ra[q] = src >= 0 ? load4_guard(p.x, p.KD, src, k0 + kq * 4, p.n, p.KD, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int tw = p.mirror ? (p.T - 1 - t) : t;
+    const float* wb = p.w + (long)tw * p.cin;
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int f = tid + q * 256;
+      if (B_KC) {  // B(k, j) = w[j][tw][k]
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        rb[q] = load4_guard(wb, wld, n0 + row, k0 + kq * 4, p.ND, p.KD, b_vec);
+      } else {  // B(k, j) = w[k][tw][j]
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        rb[q] = load4_guard(wb, wld, k0 + kr, n0 + jq * 4, p.KD, p.ND, b_vec);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int q = 0; q < A4; ++q) {
+      const int f = tid + q * 256;
+      const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+      const float v[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) As[LdsTile<BM, true>::idx(row, kq * 4 + e)] = v[e];
+    }
+#pragma unroll
+    for (int q = 0; q < B4; ++q) {
+      const int f = tid + q * 256;
+      const float v[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+      if (B_KC) {
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
+      } else {
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[kr * BN + jq * 4]) = rb[q];
+      }
+    }
+  };
+
+  if (iters > 0) {
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+      const bool more = it + 1 < iters;
+      if (more) gload(it + 1);
+      const int t = active_s[it / kchunks];
+      const unsigned tm_mask = ((unsigned)tapmask_s[t] >> ((wave >> 1) * TM)) & ((1u << TM) - 1);
+      if (tm_mask) mma_slab<BM, BN, true, B_KC, false>(As, Bs, wr0, wc0, acc, asum_unused, tm_mask);
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + acc_col(wc0, tn);
+      if (col >= p.ND) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int pr = prow_s[acc_row(wr0, tm, r)];
+        if (pr < 0) continue;
+        const long o = (long)pr * p.ND + col;
+        float v = acc[tm][tn][r] + bv;
+        if (p.add) v += p.add[o];
+        p.y[o] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------ wgrad
+struct ConvWgP {
+  const float* dy;  // [n][cout]
+  const float* x;   // [n][cin]
+  const int* nbr;   // [T][n]
+  float* part;      // [nsplit][cout][T][cin]
+  float* bias_part; // [nsplit][cout] or null
+  int n, T, cin, cout, chunk;  // chunk = points per split (<= WG_MAX_PAIRS)
+};
+#define WG_MAX_PAIRS 2048
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
+  constexpr int BM = 64, BN = 64;
+  __shared__ float As[LOTUS_BK * BM];
+  __shared__ float Bs[LOTUS_BK * BN];
+  __shared__ int pair_p[WG_MAX_PAIRS + LOTUS_BK];
+  __shared__ int pair_q[WG_MAX_PAIRS + LOTUS_BK];
+  __shared__ int wave_cnt[4];
+  __shared__ int total_s;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_ci = (p.cin + BN - 1) / BN;
+  const int co0 = (blockIdx.x / tiles_ci) * BM, ci0 = (blockIdx.x % tiles_ci) * BN;
+  const int t = blockIdx.y;
+  const int p0 = blockIdx.z * p.chunk, p1 = min(p.n, p0 + p.chunk);
+  const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+
+  // ordered compaction of the active (p, q = nbr[t][p]) pairs of this split
+  if (tid == 0) total_s = 0;
+  __syncthreads();
+  for (int base = p0; base < p1; base += 256) {
+    const int pp = base + tid;
+    const int q = pp < p1 ? p.nbr[(long)t * p.n + pp] : -1;
+    const unsigned long long b = __ballot(q >= 0);
+    const int rank = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(b);
+    __syncthreads();
+    int off = total_s;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (q >= 0) {
+      pair_p[off + rank] = pp;
+      pair_q[off + rank] = q;
+    }
+    __syncthreads();
+    if (tid == 0) total_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+  }
+  const int total = total_s;
+  for (int i = total + tid; i < total + LOTUS_BK; i += 256) {
+    pair_p[i] = -1;
+    pair_q[i] = -1;
+  }
+  __syncthreads();
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  float asum[1] = {0.f};
+  const bool a_vec = (p.cout % 4 == 0) && (((uintptr_t)p.dy) % 16 == 0);
+  const bool b_vec = (p.cin % 4 == 0) && (((uintptr_t)p.x) % 16 == 0);
+  const int kr = tid / 16, cq = tid % 16;  // one float4 per thread per operand: row kr, cols cq*4..
+
+  float4 ra, rb;
+  auto gload = [&](int k0) {
+    const int pp = pair_p[k0 + kr], qq = pair_q[k0 + kr];
+    ra = pp >= 0 ? load4_guard(p.dy, p.cout, pp, co0 + cq * 4, p.n, p.cout, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rb = qq >= 0 ? load4_guard(p.x, p.cin, qq, ci0 + cq * 4, p.n, p.cin, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&]() {
+    *reinterpret_cast<float4*>(&As[kr * BM + cq * 4]) = ra;
+    *reinterpret_cast<float4*>(&Bs[kr * BN + cq * 4]) = rb;
+  };
+  if (total > 0) {
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int k0 = 0; k0 < total; k0 += LOTUS_BK) {
+      const bool more = k0 + LOTUS_BK < total;
+      if (more) gload(k0 + LOTUS_BK);
+      mma_slab<BM, BN, false, false, true>(As, Bs, wr0, wc0, acc, asum);
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+  float* part = p.part + (long)blockIdx.z * p.cout * p.T * p.cin;
+  const int col = ci0 + acc_col(wc0, 0);
+  if (col < p.cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = co0 + acc_row(wr0, 0, r);
+      if (row < p.cout) part[((long)row * p.T + t) * p.cin + col] = acc[0][0][r];
+    }
+  }
+  // bias gradient = column sums of dy over all points: the centre tap is active for every point
+  if (p.bias_part && t == p.T / 2 && ci0 == 0 && (wave & 1) == 0) {
+    const float s = asum[0] + __shfl_xor(asum[0], 32, 64);
+    const int i = co0 + wr0 + (tid & 31);
+    if ((tid & 32) == 0 && i < p.cout) p.bias_part[(long)blockIdx.z * p.cout + i] = s;
+  }
+}
+
+static size_t conv_dyn_lds(int T, int BM) { return (size_t)(T * BM + 2 * T) * sizeof(int); }
+
+extern "C" {
+
+// mode 0: fwd  (x [n][cin]  -> y [n][cout]);  mode 1: dgrad (x = dy [n][cout] -> y = dx [n][cin]).
+int lotus_subm_conv(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
+                    const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* stream) {
+  LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  ConvP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.w = w; p.y = y; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
+  p.n = n; p.T = T; p.cin = cin; p.cout = cout;
+  p.KD = mode == 0 ? cin : cout;
+  p.ND = mode == 0 ? cout : cin;
+  p.mirror = mode == 1;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 block(256);
+  const size_t dyn = conv_dyn_lds(T, 128);
+  LOTUS_CHECK_ARG(dyn + 20000 <= 160 * 1024, "lotus_subm_conv: %d taps do not fit LDS", T);
+  if (p.ND <= 64) {
+    dim3 grid(cdiv(p.ND, 64), cdiv(n, 128));
+    if (mode == 0) {
+      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      hipLaunchKernelGGL((conv_kernel<128, 64, true>), grid, block, dyn, st, p);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      hipLaunchKernelGGL((conv_kernel<128, 64, false>), grid, block, dyn, st, p);
+    }
+  } else {
+    dim3 grid(cdiv(p.ND, 128), cdiv(n, 128));
+    if (mode == 0) {
+      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      hipLaunchKernelGGL((conv_kernel<128, 128, true>), grid, block, dyn, st, p);
+    } else {
+      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      hipLaunchKernelGGL((conv_kernel<128, 128, false>), grid, block, dyn, st, p);
+    }
+  }
+  LOTUS_LAUNCH_CHECK("lotus_subm_conv");
+  return LOTUS_OK;
+}
+
+size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout) {
+  const int nsplit = cdiv(n > 0 ? n : 1, WG_MAX_PAIRS);
+  return (size_t)nsplit * ((size_t)cout * T * cin + cout) * sizeof(float);
+}
+
+// dw [cout][T][cin] (+)= sum_p dy[p] (x) x[nbr[t][p]] ;  db [cout] (+)= colsum(dy)
+int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
+                          int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  LOTUS_CHECK_ARG(dy && x && dw && nbr && n >= 0, "lotus_subm_conv_wgrad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int nsplit = cdiv(n > 0 ? n : 1, WG_MAX_PAIRS);
+  const size_t wsz = (size_t)cout * T * cin;
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)nsplit * (wsz + cout) * sizeof(float),
+                  "lotus_subm_conv_wgrad: workspace too small");
+  ConvWgP p;
+  p.dy = dy; p.x = x; p.nbr = nbr; p.part = (float*)workspace;
+  p.bias_part = db ? p.part + (size_t)nsplit * wsz : nullptr;
+  p.n = n; p.T = T; p.cin = cin; p.cout = cout; p.chunk = WG_MAX_PAIRS;
+  dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
+  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+  LOTUS_LAUNCH_CHECK("lotus_subm_conv_wgrad");
+  int rc = lotus_reduce_parts(p.part, dw, (long)wsz, (long)wsz, nsplit, accumulate, st);
+  if (rc) return rc;
+  if (db) rc = lotus_reduce_parts(p.bias_part, db, cout, cout, nsplit, accumulate, st);
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,295 @@
+// lotus-hip: dense fp32 MFMA GEMMs with fused epilogues — the nn.Linear call sites of the
+// 3D-LOTUS hot path (66 % of all MACs): qkv/proj/fc1/fc2/cpe.1/q/kv/down.proj/
+// up.proj/heads, forward, dgrad and wgrad.
+//
+//   fwd   : Y[M,N]  = act(X[M,K] W[N,K]^T + b) (+ residual)      A k-contig, B k-contig
+//   dgrad : dX[M,K] = (dY[M,N] W[N,K]) * act'(pre) (+ add)        A k-contig, B j-contig
+//   wgrad : dW[N,K] = dY[M,N]^T X[M,K], db = colsum(dY)           A i-contig, B j-contig, split-K
+//
+// wgrad is deterministic: split-K partials go to a caller-provided workspace and are summed in a
+// fixed order by a second kernel (no float atomics).
+#include "mma.h"
+
+struct GemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;
+  const float* bias;      // [N]
+  const float* residual;  // [M][ldc], added after the activation
+  float* pre;             // [M][ldc], pre-activation (after bias) saved for backward
+  const float* mulpre;    // [M][ldc], dgrad: multiply by act'(mulpre)
+  int act;   // activation applied to the value
+  int dact;  // derivative code used with mulpre
+  int klen;          // K range per blockIdx.z (multiple of BK)
+  long part_stride;  // C += z * part_stride when gridDim.z > 1
+  float* bias_part;  // wgrad: [gridDim.z][M] column sums of dY
+  int a_vec, b_vec;  // 16-byte vector loads allowed
+  // output dropout (applied after act, before residual): keep iff hash >= thresh
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_inv_keep;
+};
+
+template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int A4 = BM * LOTUS_BK / 4 / 256, B4 = BN * LOTUS_BK / 4 / 256;  // float4 per thread
+  static_assert(A4 >= 1 && B4 >= 1, "tile too small");
+  __shared__ float As[LdsTile<BM, A_KC>::kFloats];
+  __shared__ float Bs[LdsTile<BN, B_KC>::kFloats];
+
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.klen;
+  const int kend = min(p.K, kbeg + p.klen);
+  const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+
+  float4 ra[A4], rb[B4];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < A4; ++t) {
+      const int f = tid + t * 256;
+      if (A_KC) {
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
+      } else {
+        const int kr = f / (BM / 4), iq = f % (BM / 4);
+        ra[t] = load4_guard(p.A, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < B4; ++t) {
+      const int f = tid + t * 256;
+      if (B_KC) {
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
+      } else {
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        rb[t] = load4_guard(p.B, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
+      }
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int t = 0; t < A4; ++t) {
+      const int f = tid + t * 256;
+      const float v[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w};
+      if (A_KC) {
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[LdsTile<BM, true>::idx(row, kq * 4 + e)] = v[e];
+      } else {
+        const int kr = f / (BM / 4), iq = f % (BM / 4);
+        *reinterpret_cast<float4*>(&As[kr * BM + iq * 4]) = ra[t];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < B4; ++t) {
+      const int f = tid + t * 256;
+      const float v[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w};
+      if (B_KC) {
+        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
+      } else {
+        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        *reinterpret_cast<float4*>(&Bs[kr * BN + jq * 4]) = rb[t];
+      }
+    }
+  };
+
+  if (kbeg < kend) {
+    gload(kbeg);
+    lstore();
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += LOTUS_BK) {
+      const bool more = k0 + LOTUS_BK < kend;
+      if (more) gload(k0 + LOTUS_BK);
+      mma_slab<BM, BN, A_KC, B_KC, SUM_A>(As, Bs, wr0, wc0, acc, asum);
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+
+  // ---- epilogue
+  float* __restrict__ C = p.C + (long)blockIdx.z * p.part_stride;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int col = n0 + acc_col(wc0, tn);
+      if (col >= p.N) continue;
+      const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + acc_row(wr0, tm, r);
+        if (row >= p.M) continue;
+        const long o = (long)row * p.ldc + col;
+        float v = acc[tm][tn][r] + bv;
+        if (p.pre) p.pre[o] = v;
+        v = act_f(v, p.act);
+        if (p.mulpre) v *= act_grad_f(p.mulpre[o], p.dact);
+        if (p.drop_thresh) v *= dropout_scale(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep);
+        if (p.residual) v += p.residual[o];
+        C[o] = v;
+      }
+    }
+  if (SUM_A) {
+    if (p.bias_part && blockIdx.x == 0 && (wave & 1) == 0) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        float s = asum[tm] + __shfl_xor(asum[tm], 32, 64);
+        const int i = m0 + wr0 + tm * 32 + (tid & 31);
+        if ((tid & 32) == 0 && i < p.M) p.bias_part[(long)blockIdx.z * p.M + i] = s;
+      }
+    }
+  }
+}
+
+// out[e] = sum_z part[z * stride + e]
+__global__ void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long n, long stride,
+                                    int nz, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += part[(long)z * stride + i];
+  out[i] = accumulate ? out[i] + s : s;
+}
+
+int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st) {
+  if (n <= 0) return LOTUS_OK;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_reduce_parts");
+  return LOTUS_OK;
+}
+
+static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
+
+template <bool A_KC, bool B_KC, bool SUM_A>
+static int launch_gemm(GemmP& p, int nz, hipStream_t st) {
+  const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+  const bool small_n = p.N <= 64;
+  dim3 block(256);
+  if (!small_n && blocks128 * nz >= 192) {
+    dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+  } else if (small_n && (long)cdiv(p.M, 128) * nz >= 192) {
+    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
+    hipLaunchKernelGGL((gemm_kernel<128, 64, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+  } else {
+    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
+    hipLaunchKernelGGL((gemm_kernel<64, 64, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+  }
+  LOTUS_LAUNCH_CHECK("lotus_gemm");
+  return LOTUS_OK;
+}
+
+static void set_drop(GemmP& p, float drop_p, unsigned long long seed) {
+  p.drop_seed = seed;
+  if (drop_p > 0.f) {
+    p.drop_thresh = (unsigned)(drop_p * 4294967296.0);
+    if (p.drop_thresh == 0) p.drop_thresh = 1;
+    p.drop_inv_keep = 1.f / (1.f - drop_p);
+  } else {
+    p.drop_thresh = 0;
+    p.drop_inv_keep = 1.f;
+  }
+}
+
+extern "C" {
+
+// y = dropout(act(x w^T + bias)) + residual ; pre (optional) receives x w^T + bias.
+int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                     float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
+                     void* stream) {
+  LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
+  if (M == 0) return LOTUS_OK;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = x; p.B = w; p.C = y; p.M = M; p.N = N; p.K = K;
+  p.lda = K; p.ldb = K; p.ldc = N;
+  p.bias = bias; p.residual = residual; p.pre = pre; p.act = act;
+  p.klen = cdiv(K, LOTUS_BK) * LOTUS_BK;
+  p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K);
+  set_drop(p, drop_p, drop_seed);
+  return launch_gemm<true, true, false>(p, 1, (hipStream_t)stream);
+}
+
+// dx = (dy w) * act'(pre) * dropmask + add.   dy [M,N], w [N,K], dx/pre/add [M,K].
+// `pre`/`act`/`drop_*` describe the layer that PRODUCED this layer's input (its pre-activation,
+// activation and output dropout), so the chain rule through it is fused into this epilogue.
+int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* stream) {
+  LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
+  if (M == 0) return LOTUS_OK;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.B = w; p.C = dx; p.M = M; p.N = K; p.K = N;
+  p.lda = N; p.ldb = K; p.ldc = K;
+  p.act = LOTUS_ACT_NONE;
+  p.mulpre = pre; p.dact = act; p.residual = add;
+  p.klen = cdiv(N, LOTUS_BK) * LOTUS_BK;
+  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K);
+  set_drop(p, drop_p, drop_seed);
+  return launch_gemm<true, false, false>(p, 1, (hipStream_t)stream);
+}
+
+size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
+  // worst case 64 splits of [N][K] + [N]
+  int nz = 1;
+  const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
+  while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
+  return (size_t)nz * ((size_t)N * K + N) * sizeof(float);
+}
+
+// dw (+)= dy^T x ; db (+)= colsum(dy).   dy [M,N], x [M,K], dw [N,K], db [N] (optional).
+int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int nz = 1;
+  const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
+  while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
+  const size_t need = (size_t)nz * ((size_t)N * K + N) * sizeof(float);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= need, "lotus_linear_wgrad: workspace too small (%zu < %zu)",
+                  workspace_bytes, need);
+  float* part = (float*)workspace;
+  float* bpart = part + (size_t)nz * N * K;
+  GemmP p;
+  memset(&p, 0, sizeof(p));
+  p.A = dy; p.B = x; p.C = part; p.M = N; p.N = K; p.K = M;
+  p.lda = N; p.ldb = K; p.ldc = K;
+  p.klen = cdiv(cdiv(M, nz), LOTUS_BK) * LOTUS_BK;
+  if (p.klen == 0) p.klen = LOTUS_BK;
+  p.part_stride = (long)N * K;
+  p.bias_part = db ? bpart : nullptr;
+  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K);
+  set_drop(p, 0.f, 0);
+  int rc = launch_gemm<false, false, true>(p, nz, st);
+  if (rc) return rc;
+  const long n = (long)N * K;
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, dw, n, n, nz, accumulate);
+  if (db)
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, bpart, db, (long)N, (long)N, nz,
+                       accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_linear_wgrad");
+  return LOTUS_OK;
+}
+
+}  // extern "C"

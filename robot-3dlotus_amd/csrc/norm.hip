@@ -1,0 +1,508 @@
+// lotus-hip: LayerNorm and BatchNorm1d(+GELU) forward/backward — HBM-bound row/column
+// reductions (nn.LayerNorm call sites PointTransformerV3/model.py:624-645, model_ca.py:114-124;
+// nn.BatchNorm1d(eps=1e-3, momentum=0.01) model_ca.py:226 at the stem, every pooling and every
+// unpooling branch).  One pass over the activations per kernel, float4 accesses, no atomics;
+// column reductions go through per-block partials that a second tiny kernel sums in fixed order.
+#include "common.h"
+
+// --------------------------------------------------------------------------------- LayerNorm
+// A row is owned by LPR lanes (16/32/64); lane holds float4 #(l + j * LPR), j < NV <= 4.
+struct LnP {
+  const float* x;
+  const float* res;  // optional residual added AFTER the norm: y = LN(x) + res
+  const float* gamma;
+  const float* beta;
+  float* y;
+  float* mean;
+  float* rstd;
+  int M, C, LPR, NV;
+  float eps;
+};
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int o = lpr >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
+  const int rpb = 256 / p.LPR;
+  const int row = blockIdx.x * rpb + threadIdx.x / p.LPR;
+  const int l = threadIdx.x % p.LPR;
+  const bool valid = row < p.M;
+  const int c4 = p.C / 4;
+  float4 v[4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int q = l + j * p.LPR;
+    if (valid && j < p.NV && q < c4) {
+      v[j] = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
+      s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+  }
+  const float mean = group_sum(s, p.LPR) / p.C;
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = l + j * p.LPR;
+    if (valid && j < p.NV && q < c4) {
+      const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+      ss += a * a + b * b + c * c + d * d;
+    }
+  }
+  const float rstd = rsqrtf(group_sum(ss, p.LPR) / p.C + p.eps);
+  if (!valid) return;
+  if (l == 0) {
+    if (p.mean) p.mean[row] = mean;
+    if (p.rstd) p.rstd[row] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = l + j * p.LPR;
+    if (j < p.NV && q < c4) {
+      const float4 g = reinterpret_cast<const float4*>(p.gamma)[q];
+      const float4 b = reinterpret_cast<const float4*>(p.beta)[q];
+      float4 o;
+      o.x = (v[j].x - mean) * rstd * g.x + b.x;
+      o.y = (v[j].y - mean) * rstd * g.y + b.y;
+      o.z = (v[j].z - mean) * rstd * g.z + b.z;
+      o.w = (v[j].w - mean) * rstd * g.w + b.w;
+      if (p.res) {
+        const float4 r = reinterpret_cast<const float4*>(p.res + (long)row * p.C)[q];
+        o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+      }
+      reinterpret_cast<float4*>(p.y + (long)row * p.C)[q] = o;
+    }
+  }
+}
+
+struct LnBwdP {
+  const float* dy;
+  const float* x;
+  const float* mean;
+  const float* rstd;
+  const float* gamma;
+  const float* add;  // optional: dx += add
+  float* dx;
+  float* part;  // [gridDim.x][2][C]  (dgamma, dbeta partials)
+  int M, C, LPR, NV;
+};
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+  extern __shared__ float red[];  // [rpb][2][C]
+  const int rpb = 256 / p.LPR;
+  const int rslot = threadIdx.x / p.LPR, l = threadIdx.x % p.LPR;
+  const int c4 = p.C / 4;
+  float4 pg[4], pb[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pg[j] = pb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int row0 = blockIdx.x * rpb; row0 < p.M; row0 += gridDim.x * rpb) {
+    const int row = row0 + rslot;
+    const bool valid = row < p.M;
+    const float mean = valid ? p.mean[row] : 0.f, rstd = valid ? p.rstd[row] : 0.f;
+    float4 xh[4], g[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = l + j * p.LPR;
+      xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid && j < p.NV && q < c4) {
+        const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
+        const float4 dv = reinterpret_cast<const float4*>(p.dy + (long)row * p.C)[q];
+        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
+        xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        pg[j].x += dv.x * xh[j].x; pg[j].y += dv.y * xh[j].y; pg[j].z += dv.z * xh[j].z; pg[j].w += dv.w * xh[j].w;
+        pb[j].x += dv.x; pb[j].y += dv.y; pb[j].z += dv.z; pb[j].w += dv.w;
+        g[j] = make_float4(dv.x * gm.x, dv.y * gm.y, dv.z * gm.z, dv.w * gm.w);
+        s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+        s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
+      }
+    }
+    s1 = group_sum(s1, p.LPR) / p.C;
+    s2 = group_sum(s2, p.LPR) / p.C;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = l + j * p.LPR;
+      if (valid && j < p.NV && q < c4) {
+        float4 o;
+        o.x = rstd * (g[j].x - s1 - xh[j].x * s2);
+        o.y = rstd * (g[j].y - s1 - xh[j].y * s2);
+        o.z = rstd * (g[j].z - s1 - xh[j].z * s2);
+        o.w = rstd * (g[j].w - s1 - xh[j].w * s2);
+        if (p.add) {
+          const float4 a = reinterpret_cast<const float4*>(p.add + (long)row * p.C)[q];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        reinterpret_cast<float4*>(p.dx + (long)row * p.C)[q] = o;
+      }
+    }
+  }
+  // block reduction of the column partials
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = l + j * p.LPR;
+    if (j < p.NV && q < c4) {
+      reinterpret_cast<float4*>(red + (long)(rslot * 2 + 0) * p.C)[q] = pg[j];
+      reinterpret_cast<float4*>(red + (long)(rslot * 2 + 1) * p.C)[q] = pb[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
+    const int which = c / p.C, col = c % p.C;
+    float s = 0.f;
+    for (int r = 0; r < rpb; ++r) s += red[(long)(r * 2 + which) * p.C + col];
+    p.part[((long)blockIdx.x * 2 + which) * p.C + col] = s;
+  }
+}
+
+// out[which][c] (+)= sum_b part[b][which][c]
+__global__ void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1,
+                                      int nb, int C, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= 2 * C) return;
+  const int which = c / C, col = c % C;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[((long)b * 2 + which) * C + col];
+  float* o = which ? o1 : o0;
+  if (o) o[col] = accumulate ? o[col] + s : s;
+}
+
+static int ln_geometry(int C, int* LPR, int* NV) {
+  if (C % 4) return -1;
+  const int c4 = C / 4;
+  int lpr = 64;
+  if (c4 <= 16) lpr = 16;
+  else if (c4 <= 32) lpr = 32;
+  const int nv = (c4 + lpr - 1) / lpr;
+  if (nv > 4) return -1;
+  *LPR = lpr;
+  *NV = nv;
+  return 0;
+}
+
+// --------------------------------------------------------------------------------- BatchNorm
+// Column statistics in double: per-block partial (sum, sumsq) -> fixed-order reduction.
+struct BnStatP {
+  const float* x;     // [M][C]
+  const float* dy;    // backward: dy (stats of dz, dz*xhat), else null
+  const float* mean;  // backward
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  double* part;  // [gridDim.x][2][C]
+  int M, C, act;
+};
+
+__global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
+  extern __shared__ double dred[];  // [rslots][2][C]
+  const int c4 = p.C / 4;
+  const int tpr = c4 < 256 ? c4 : 256;  // threads per row
+  const int rslots = 256 / tpr;
+  const int rslot = threadIdx.x / tpr, l = threadIdx.x % tpr;
+  const bool live = rslot < rslots;
+  for (int q0 = 0; q0 < c4; q0 += tpr) {
+    const int q = q0 + l;
+    double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (live && q < c4) {
+      float4 mu, is, gm, bt;
+      if (p.dy) {
+        mu = reinterpret_cast<const float4*>(p.mean)[q];
+        is = reinterpret_cast<const float4*>(p.invstd)[q];
+        gm = reinterpret_cast<const float4*>(p.gamma)[q];
+        bt = reinterpret_cast<const float4*>(p.beta)[q];
+      }
+      for (int row = blockIdx.x * rslots + rslot; row < p.M; row += gridDim.x * rslots) {
+        const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (!p.dy) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += xs[e];
+            s1[e] += (double)xs[e] * xs[e];
+          }
+        } else {
+          const float4 dv = reinterpret_cast<const float4*>(p.dy + (long)row * p.C)[q];
+          const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+          const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+          const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (xs[e] - m4[e]) * i4[e];
+            const float dz = ds[e] * act_grad_f(xh * g4[e] + b4[e], p.act);
+            s0[e] += dz;
+            s1[e] += (double)dz * xh;
+          }
+        }
+      }
+    }
+    if (live && q < c4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dred[(long)(rslot * 2 + 0) * p.C + q * 4 + e] = s0[e];
+        dred[(long)(rslot * 2 + 1) * p.C + q * 4 + e] = s1[e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * p.C; c += 256) {
+    const int which = c / p.C, col = c % p.C;
+    double s = 0;
+    for (int r = 0; r < rslots; ++r) s += dred[(long)(r * 2 + which) * p.C + col];
+    p.part[((long)blockIdx.x * 2 + which) * p.C + col] = s;
+  }
+}
+
+__global__ void bn_part_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums, int nb, int C,
+                                      int M) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0) sums[2 * C] = (double)M;  // local row count travels with the sums (SyncBN all-reduce)
+  if (c >= 2 * C) return;
+  double s = 0;
+  for (int b = 0; b < nb; ++b) s += part[(long)b * 2 * C + c];
+  sums[c] = s;
+}
+
+// sums = (sum x, sum x^2, count), already all-reduced across ranks when SyncBN.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, int C, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double count = sums[2 * C];
+  const double m = sums[c] / count;
+  double var = sums[C + c] / count - m * m;
+  if (var < 0) var = 0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* __restrict__ rv, float* mean,
+                                     float* invstd, int C, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+
+struct BnApplyP {
+  const float* x;
+  const float* dy;  // backward when non-null
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  const double* sums;  // backward (train): (sum dz, sum dz*xhat); null in eval mode
+  float* y;            // forward output or dx
+  float* dgamma;       // backward: written by block 0
+  float* dbeta;
+  long total4;  // M * C / 4
+  int C, act, accumulate;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
+  const int c4 = p.C / 4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total4; i += (long)gridDim.x * 256) {
+    const int q = (int)(i % c4);
+    const float4 xv = reinterpret_cast<const float4*>(p.x)[i];
+    const float4 mu = reinterpret_cast<const float4*>(p.mean)[q];
+    const float4 is = reinterpret_cast<const float4*>(p.invstd)[q];
+    const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
+    const float4 bt = reinterpret_cast<const float4*>(p.beta)[q];
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, m4[4] = {mu.x, mu.y, mu.z, mu.w};
+    const float i4[4] = {is.x, is.y, is.z, is.w}, g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+    float o[4];
+    if (!p.dy) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = act_f((xs[e] - m4[e]) * i4[e] * g4[e] + b4[e], p.act);
+    } else {
+      const float4 dv = reinterpret_cast<const float4*>(p.dy)[i];
+      const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xh = (xs[e] - m4[e]) * i4[e];
+        const float dz = ds[e] * act_grad_f(xh * g4[e] + b4[e], p.act);
+        if (p.sums) {
+          const double count = p.sums[2 * p.C];
+          const float mdz = (float)(p.sums[q * 4 + e] / count);
+          const float mdx = (float)(p.sums[p.C + q * 4 + e] / count);
+          o[e] = g4[e] * i4[e] * (dz - mdz - xh * mdx);
+        } else {
+          o[e] = g4[e] * i4[e] * dz;
+        }
+      }
+    }
+    reinterpret_cast<float4*>(p.y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+  if (p.dy && p.dgamma && blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      const float dg = (float)p.sums[p.C + c], db = (float)p.sums[c];
+      p.dgamma[c] = p.accumulate ? p.dgamma[c] + dg : dg;
+      p.dbeta[c] = p.accumulate ? p.dbeta[c] + db : db;
+    }
+  }
+}
+
+static int bn_grid(int M, int C) {
+  const int c4 = C / 4;
+  const int tpr = c4 < 256 ? c4 : 256;
+  const int rslots = 256 / tpr;
+  int g = cdiv(M, rslots * 16);
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return g;
+}
+static size_t bn_dyn_lds(int C) {
+  const int c4 = C / 4;
+  const int tpr = c4 < 256 ? c4 : 256;
+  return (size_t)(256 / tpr) * 2 * C * sizeof(double);
+}
+
+extern "C" {
+
+// y = LayerNorm(x; gamma, beta, eps) (+ res).  mean/rstd [M] saved for backward (optional).
+int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                        float* mean, float* rstd, int M, int C, float eps, void* stream) {
+  LnP p;
+  p.x = x; p.res = res; p.gamma = gamma; p.beta = beta; p.y = y; p.mean = mean; p.rstd = rstd;
+  p.M = M; p.C = C; p.eps = eps;
+  LOTUS_CHECK_ARG(x && gamma && beta && y && M >= 0, "lotus_layernorm_fwd: bad arguments");
+  LOTUS_CHECK_ARG(ln_geometry(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_fwd: unsupported C=%d", C);
+  if (M == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 256 / p.LPR)), dim3(256), 0, (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_layernorm_fwd");
+  return LOTUS_OK;
+}
+
+size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)512 * 2 * C * sizeof(float); }
+
+// dx = LN'(dy) (+ add); dgamma/dbeta (+)= column sums.
+int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+  LnBwdP p;
+  p.dy = dy; p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.add = add; p.dx = dx;
+  p.part = (float*)workspace; p.M = M; p.C = C;
+  LOTUS_CHECK_ARG(dy && x && mean && rstd && gamma && dx && M >= 0, "lotus_layernorm_bwd: bad arguments");
+  LOTUS_CHECK_ARG(ln_geometry(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_bwd: unsupported C=%d", C);
+  const int rpb = 256 / p.LPR;
+  int grid = cdiv(M > 0 ? M : 1, rpb * 8);
+  if (grid > 512) grid = 512;
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(float),
+                  "lotus_layernorm_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * 2 * C * sizeof(float), st, p);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, dgamma, dbeta, grid, C,
+                     accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd");
+  return LOTUS_OK;
+}
+
+size_t lotus_batchnorm_workspace(int M, int C) { return (size_t)512 * 2 * C * sizeof(double); }
+
+// Forward statistics: sums[2*C+1] (double) = (sum x, sum x^2, M) over the M local rows.
+int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  LOTUS_CHECK_ARG(x && sums && C % 4 == 0 && M >= 0, "lotus_batchnorm_stats: bad arguments (C=%d)", C);
+  const int grid = bn_grid(M, C);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(double),
+                  "lotus_batchnorm_stats: workspace too small");
+  BnStatP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.part = (double*)workspace; p.M = M; p.C = C;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
+  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_stats");
+  return LOTUS_OK;
+}
+
+// mean/invstd from (possibly all-reduced) sums[2*C+1]; updates running stats if given.
+int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, float* running_mean,
+                             float* running_var, int C, float eps, float momentum, void* stream) {
+  LOTUS_CHECK_ARG(sums && mean && invstd, "lotus_batchnorm_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
+                     invstd, running_mean, running_var, C, eps, momentum);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_finalize");
+  return LOTUS_OK;
+}
+
+int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
+                               float eps, void* stream) {
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, mean, invstd, C, eps);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_eval_stats");
+  return LOTUS_OK;
+}
+
+// y = act((x - mean) * invstd * gamma + beta)
+int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float* y, int M, int C, int act, void* stream) {
+  LOTUS_CHECK_ARG(x && y && C % 4 == 0, "lotus_batchnorm_apply: bad arguments");
+  if (M == 0) return LOTUS_OK;
+  BnApplyP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.y = y;
+  p.total4 = (long)M * C / 4; p.C = C; p.act = act;
+  int grid = cdiv(p.total4, 256 * 4);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_apply");
+  return LOTUS_OK;
+}
+
+// Backward statistics: sums = (sum dz, sum dz * xhat), dz = dy * act'(z).
+int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, double* sums, int M, int C, int act,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  LOTUS_CHECK_ARG(dy && x && sums && C % 4 == 0, "lotus_batchnorm_bwd_stats: bad arguments");
+  const int grid = bn_grid(M, C);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(double),
+                  "lotus_batchnorm_bwd_stats: workspace too small");
+  BnStatP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.part = (double*)workspace; p.M = M; p.C = C; p.act = act;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
+  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats");
+  return LOTUS_OK;
+}
+
+// dx from dy; train = 1 uses batch statistics (sums[2*C+1] incl. the row count, all-reduced when SyncBN),
+// train = 0 (eval) treats mean/invstd as constants.  dgamma/dbeta (+)= from sums.
+int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const double* sums, float* dx, float* dgamma,
+                              float* dbeta, int M, int C, int act, int train, int accumulate, void* stream) {
+  LOTUS_CHECK_ARG(dy && x && dx && sums && C % 4 == 0, "lotus_batchnorm_bwd_apply: bad arguments");
+  BnApplyP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.sums = sums; p.y = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.total4 = (long)M * C / 4; p.C = C; p.act = act; p.accumulate = accumulate;
+  int grid = cdiv(p.total4 > 0 ? p.total4 : 1, 256 * 4);
+  if (grid > 2048) grid = 2048;
+  hipStream_t st = (hipStream_t)stream;
+  if (!train) {
+    // eval: dx = gamma * invstd * dz ; dgamma/dbeta still come from sums
+    BnApplyP q = p;
+    q.sums = nullptr;
+    q.dgamma = nullptr;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, q);
+    BnApplyP g = p;
+    g.total4 = 0;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(1), dim3(256), 0, st, g);
+  } else {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, p);
+  }
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_apply");
+  return LOTUS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,359 @@
+// lotus-hip: grid pooling / unpooling, the gripper-action head reductions and the losses —
+// HBM-bound segmented kernels (SerializedPooling model.py:760-766, SerializedUnpooling :817-828,
+// ActionHead simple_policy_ptv3.py:113-157, compute_loss :308-373).  Segments are CSR ranges
+// produced by the front-end, so every reduction is an ordered loop: no atomics, deterministic.
+#include "common.h"
+
+// ---------------------------------------------------------------- segment max over cluster members
+// y[c][:] = max_{i in [seg[c], seg[c+1])} x[members[i]][:]   ; arg = winning parent row
+__global__ void pool_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ members,
+                                    const int* __restrict__ seg, int nc, int C, float* __restrict__ y,
+                                    int* __restrict__ arg) {
+  const int c4 = C / 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nc * c4) return;
+  const int c = (int)(gid / c4), q = (int)(gid % c4);
+  const int a = seg[c], b = seg[c + 1];
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int bi[4] = {-1, -1, -1, -1};
+  for (int i = a; i < b; ++i) {
+    const int p = members[i];
+    const float4 v = reinterpret_cast<const float4*>(x + (long)p * C)[q];
+    const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (vs[e] > best[e]) {
+        best[e] = vs[e];
+        bi[e] = p;
+      }
+  }
+  reinterpret_cast<float4*>(y + (long)c * C)[q] = make_float4(best[0], best[1], best[2], best[3]);
+  reinterpret_cast<int4*>(arg + (long)c * C)[q] = make_int4(bi[0], bi[1], bi[2], bi[3]);
+}
+
+// dx[p][:] = (arg[cluster[p]][:] == p) ? dy[cluster[p]][:] : 0
+__global__ void pool_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                    const int* __restrict__ cluster, int n, int C, float* __restrict__ dx) {
+  const int c4 = C / 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c4) return;
+  const int p = (int)(gid / c4), q = (int)(gid % c4);
+  const int c = cluster[p];
+  const float4 g = reinterpret_cast<const float4*>(dy + (long)c * C)[q];
+  const int4 a = reinterpret_cast<const int4*>(arg + (long)c * C)[q];
+  reinterpret_cast<float4*>(dx + (long)p * C)[q] =
+      make_float4(a.x == p ? g.x : 0.f, a.y == p ? g.y : 0.f, a.z == p ? g.z : 0.f, a.w == p ? g.w : 0.f);
+}
+
+// x[p][:] = skip[p][:] + up[cluster[p]][:]
+__global__ void unpool_fwd_kernel(const float* __restrict__ skip, const float* __restrict__ up,
+                                  const int* __restrict__ cluster, int n, int C, float* __restrict__ x) {
+  const int c4 = C / 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c4) return;
+  const int p = (int)(gid / c4), q = (int)(gid % c4);
+  const float4 s = reinterpret_cast<const float4*>(skip + (long)p * C)[q];
+  const float4 u = reinterpret_cast<const float4*>(up + (long)cluster[p] * C)[q];
+  reinterpret_cast<float4*>(x + (long)p * C)[q] = make_float4(s.x + u.x, s.y + u.y, s.z + u.z, s.w + u.w);
+}
+
+// dup[c][:] = sum over members of dx
+__global__ void unpool_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ members,
+                                  const int* __restrict__ seg, int nc, int C, float* __restrict__ dup) {
+  const int c4 = C / 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)nc * c4) return;
+  const int c = (int)(gid / c4), q = (int)(gid % c4);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = seg[c]; i < seg[c + 1]; ++i) {
+    const float4 v = reinterpret_cast<const float4*>(dx + (long)members[i] * C)[q];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  reinterpret_cast<float4*>(dup + (long)c * C)[q] = s;
+}
+
+// ---------------------------------------------------------------- per-cloud max over contiguous rows
+// grid (B, C/32); block 256 = 32 columns x 8 row lanes
+__global__ __launch_bounds__(256) void cloud_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ off,
+                                                            int C, float* __restrict__ y, int* __restrict__ arg) {
+  __shared__ float bv[8][32];
+  __shared__ int bi[8][32];
+  const int b = blockIdx.x, col = blockIdx.y * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+  float best = -INFINITY;
+  int idx = -1;
+  if (col < C)
+    for (int r = off[b] + ry; r < off[b + 1]; r += 8) {
+      const float v = x[(long)r * C + col];
+      if (v > best) {
+        best = v;
+        idx = r;
+      }
+    }
+  bv[ry][threadIdx.x & 31] = best;
+  bi[ry][threadIdx.x & 31] = idx;
+  __syncthreads();
+  if (ry == 0 && col < C) {
+    for (int k = 1; k < 8; ++k) {
+      const float v = bv[k][threadIdx.x];
+      const int i = bi[k][threadIdx.x];
+      if (v > best || (v == best && i >= 0 && i < idx)) {
+        best = v;
+        idx = i;
+      }
+    }
+    y[(long)b * C + col] = best;
+    arg[(long)b * C + col] = idx;
+  }
+}
+
+__global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
+                                     const int* __restrict__ batch, int n, int C, const float* __restrict__ add,
+                                     float* __restrict__ dx) {
+  const int c4 = C / 4;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * c4) return;
+  const int p = (int)(gid / c4), q = (int)(gid % c4);
+  const int b = batch[p];
+  const float4 g = reinterpret_cast<const float4*>(dy + (long)b * C)[q];
+  const int4 a = reinterpret_cast<const int4*>(arg + (long)b * C)[q];
+  float4 o = make_float4(a.x == p ? g.x : 0.f, a.y == p ? g.y : 0.f, a.z == p ? g.z : 0.f, a.w == p ? g.w : 0.f);
+  if (add) {
+    const float4 v = reinterpret_cast<const float4*>(add + (long)p * C)[q];
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+  }
+  reinterpret_cast<float4*>(dx + (long)p * C)[q] = o;
+}
+
+// ---------------------------------------------------------------- losses (simple_policy_ptv3.py:308-373)
+// Position: per cloud b and axis c, soft-target cross entropy over all (point, bin) logits.
+// xt[n][3*nb] logits (n, c, bin); tgt: cloud b at tgt_off = 3*nb*off[b], laid out [3][n_b*nb].
+__global__ __launch_bounds__(256) void pos_ce_fwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+                                                         const int* __restrict__ off, int nb,
+                                                         float* __restrict__ stats /*[B*3][4]: loss,lse,tsum,-*/) {
+  __shared__ float red[8];
+  const int b = blockIdx.x, c = blockIdx.y;
+  const int n0 = off[b], nn = off[b + 1] - n0;
+  const long L = (long)nn * nb;
+  const float* tb = tgt + (long)3 * nb * n0 + (long)c * L;
+  auto logit = [&](long e) { return xt[(long)(n0 + e / nb) * (3 * nb) + c * nb + (e % nb)]; };
+  float m = -INFINITY;
+  for (long e = threadIdx.x; e < L; e += 256) m = fmaxf(m, logit(e));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  double se = 0, stx = 0, st = 0;
+  for (long e = threadIdx.x; e < L; e += 256) {
+    const float x = logit(e), t = tb[e];
+    se += expf(x - m);
+    stx += (double)t * x;
+    st += t;
+  }
+  float v[3] = {(float)se, (float)stx, (float)st};
+  float tot[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = wave_sum(v[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    __syncthreads();
+    tot[k] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float lse = m + logf(tot[0]);
+    float* s = stats + (long)(b * 3 + c) * 4;
+    s[0] = lse * tot[2] - tot[1];
+    s[1] = lse;
+    s[2] = tot[2];
+    s[3] = 0.f;
+  }
+}
+
+// Rotation CE + openness BCE on ae[B][nrot*3 + 1]; gt[B][ga] with rot bins at 3..5 and open at ga-1.
+// losses[4] = pos, rot, open, total.  dae = (d rot / d ae | d open / d ae) column-wise (rot logits and the
+// open logit are disjoint columns), unscaled by the upstream gradient.
+__global__ __launch_bounds__(256) void small_loss_kernel(const float* __restrict__ ae, const float* __restrict__ gt,
+                                                         const float* __restrict__ pos_stats, int B, int nrot, int ga,
+                                                         float pos_w, float rot_w, float* __restrict__ losses,
+                                                         float* __restrict__ dae) {
+  __shared__ float acc[3];
+  const int W = nrot * 3 + 1;
+  if (threadIdx.x < 3) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  float rot = 0.f, opn = 0.f, pos = 0.f;
+  for (int i = threadIdx.x; i < B * 3; i += 256) {
+    const int b = i / 3, a = i % 3;
+    const float* row = ae + (long)b * W;
+    float m = -INFINITY;
+    for (int k = 0; k < nrot; ++k) m = fmaxf(m, row[k * 3 + a]);
+    float se = 0.f;
+    for (int k = 0; k < nrot; ++k) se += expf(row[k * 3 + a] - m);
+    const float lse = m + logf(se);
+    const int tk = (int)gt[(long)b * ga + 3 + a];
+    rot += lse - row[tk * 3 + a];
+    if (dae)
+      for (int k = 0; k < nrot; ++k)
+        dae[(long)b * W + k * 3 + a] = (expf(row[k * 3 + a] - lse) - (k == tk ? 1.f : 0.f)) / (B * 3);
+    pos += pos_stats[(long)i * 4];
+  }
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float x = ae[(long)b * W + W - 1], t = gt[(long)b * ga + ga - 1];
+    opn += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    if (dae) dae[(long)b * W + W - 1] = (1.f / (1.f + expf(-x)) - t) / B;
+  }
+  __shared__ float red[3][4];
+  float v3[3] = {pos, rot, opn};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = wave_sum(v3[k]);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 0; k < 3; ++k) acc[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+    const float lp = acc[0] / (3.f * B), lr = acc[1] / (3.f * B), lo = acc[2] / B;
+    losses[0] = lp; losses[1] = lr; losses[2] = lo; losses[3] = pos_w * lp + rot_w * lr + lo;
+  }
+}
+
+// dxt[n][c][bin] = coef * (softmax * tsum - t) / (3B), coef = g[0] + pos_w * g[3] (device scalars)
+__global__ void pos_ce_bwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+                                  const int* __restrict__ off, const int* __restrict__ batch,
+                                  const float* __restrict__ stats, const float* __restrict__ gl, float pos_w, int B,
+                                  int n, int nb, float* __restrict__ dxt) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)n * 3 * nb;
+  if (gid >= total) return;
+  const int p = (int)(gid / (3 * nb)), rem = (int)(gid % (3 * nb)), c = rem / nb, bin = rem % nb;
+  const int b = batch[p];
+  const int n0 = off[b], nn = off[b + 1] - n0;
+  const float t = tgt[(long)3 * nb * n0 + (long)c * nn * nb + (long)(p - n0) * nb + bin];
+  const float* s = stats + (long)(b * 3 + c) * 4;
+  const float coef = (gl[0] + pos_w * gl[3]) / (3.f * B);
+  dxt[gid] = coef * (expf(xt[gid] - s[1]) * s[2] - t);
+}
+
+// dae_out = dae_saved * (upstream weight of its column): rot columns g[1] + rot_w * g[3], open column g[2] + g[3]
+__global__ void ae_grad_kernel(const float* __restrict__ x, const float* __restrict__ gl, float rot_w, int W, long n,
+                               float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool open_col = (i % W) == W - 1;
+  y[i] = x[i] * (open_col ? gl[2] + gl[3] : gl[1] + rot_w * gl[3]);
+}
+
+// elementwise helpers ---------------------------------------------------------------------------
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+__global__ void dropout_mask_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+                                    unsigned long long seed, unsigned thresh, float inv_keep) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = x[i] * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep);
+}
+
+extern "C" {
+
+int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,
+                       void* stream) {
+  LOTUS_CHECK_ARG(x && members && seg && y && arg && C % 4 == 0, "lotus_pool_max_fwd: bad arguments");
+  if (nc == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     members, seg, nc, C, y, arg);
+  LOTUS_LAUNCH_CHECK("lotus_pool_max_fwd");
+  return LOTUS_OK;
+}
+int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int n, int C, float* dx, void* stream) {
+  LOTUS_CHECK_ARG(dy && arg && cluster && dx && C % 4 == 0, "lotus_pool_max_bwd: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
+                     cluster, n, C, dx);
+  LOTUS_LAUNCH_CHECK("lotus_pool_max_bwd");
+  return LOTUS_OK;
+}
+int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream) {
+  LOTUS_CHECK_ARG(skip && up && cluster && x && C % 4 == 0, "lotus_unpool_fwd: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(unpool_fwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, skip, up,
+                     cluster, n, C, x);
+  LOTUS_LAUNCH_CHECK("lotus_unpool_fwd");
+  return LOTUS_OK;
+}
+int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream) {
+  LOTUS_CHECK_ARG(dx && members && seg && dup && C % 4 == 0, "lotus_unpool_bwd: bad arguments");
+  if (nc == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(unpool_bwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dx,
+                     members, seg, nc, C, dup);
+  LOTUS_LAUNCH_CHECK("lotus_unpool_bwd");
+  return LOTUS_OK;
+}
+// per-cloud max over the contiguous row ranges [off[b], off[b+1])
+int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream) {
+  LOTUS_CHECK_ARG(x && off && y && arg && B > 0, "lotus_cloud_max_fwd: bad arguments");
+  hipLaunchKernelGGL(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, x, off, C, y, arg);
+  LOTUS_LAUNCH_CHECK("lotus_cloud_max_fwd");
+  return LOTUS_OK;
+}
+int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
+                        void* stream) {
+  LOTUS_CHECK_ARG(dy && arg && batch && dx && C % 4 == 0, "lotus_cloud_max_bwd: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  hipLaunchKernelGGL(cloud_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
+                     batch, n, C, add, dx);
+  LOTUS_LAUNCH_CHECK("lotus_cloud_max_bwd");
+  return LOTUS_OK;
+}
+
+// losses[4] = (pos, rot, open, total); pos_stats [B*3][4] and dae [B][nrot*3+1] are saved for backward.
+int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
+                   int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
+                   void* stream) {
+  LOTUS_CHECK_ARG(xt && ae && tgt && gt && off && losses && pos_stats && B > 0, "lotus_loss_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(pos_ce_fwd_kernel, dim3(B, 3), dim3(256), 0, st, xt, tgt, off, nb, pos_stats);
+  hipLaunchKernelGGL(small_loss_kernel, dim3(1), dim3(256), 0, st, ae, gt, pos_stats, B, nrot, ga, pos_w, rot_w, losses, dae);
+  LOTUS_LAUNCH_CHECK("lotus_loss_fwd");
+  return LOTUS_OK;
+}
+// dxt [n][3*nb] and dae_out [B][nrot*3+1] from the upstream gradient of the 4 losses (gl, device).
+int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                   const float* dae_saved, const float* gl, float pos_w, float rot_w, int B, int n, int nb, int nrot,
+                   float* dxt, float* dae_out, void* stream) {
+  LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && dae_saved && gl && dxt && dae_out, "lotus_loss_bwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)n * 3 * nb;
+  hipLaunchKernelGGL(pos_ce_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xt, tgt, off, batch, pos_stats, gl,
+                     pos_w, B, n, nb, dxt);
+  const int W = nrot * 3 + 1;
+  hipLaunchKernelGGL(ae_grad_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, st, dae_saved, gl, rot_w, W,
+                     (long)B * W, dae_out);
+  LOTUS_LAUNCH_CHECK("lotus_loss_bwd");
+  return LOTUS_OK;
+}
+
+int lotus_add(const float* a, const float* b, float* y, long n, void* stream) {
+  LOTUS_CHECK_ARG(a && b && y && n % 4 == 0, "lotus_add: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  int g = cdiv(n / 4, 256);
+  hipLaunchKernelGGL(add_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 4);
+  LOTUS_LAUNCH_CHECK("lotus_add");
+  return LOTUS_OK;
+}
+// y = x * dropmask(seed, p) / (1 - p): forward dropout and its backward (same mask from the same seed)
+int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream) {
+  LOTUS_CHECK_ARG(x && y && p >= 0.f && p < 1.f, "lotus_dropout: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  unsigned th = (unsigned)(p * 4294967296.0);
+  if (p > 0.f && th == 0) th = 1;
+  int g = cdiv(n, 256);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
+                     1.f / (1.f - p));
+  LOTUS_LAUNCH_CHECK("lotus_dropout");
+  return LOTUS_OK;
+}
+
+}  // extern "C"

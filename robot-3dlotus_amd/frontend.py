@@ -1,0 +1,192 @@
+"""Host side of the integer front-end: one call builds every index table of a forward pass.
+
+Mirrors, for all levels at once, what the reference computes piecemeal with dozens of host
+synchronisations: `Point.serialization` + `Point.sparsify` (PointTransformerV3/model.py:83-176), the
+index part of every `SerializedPooling.forward` (:713-772), `get_padding_and_inverse` (:410-466) and
+spconv's neighbour lookup.  The device pipeline (csrc/front_end.hip) runs without a host sync; ONE
+small device->host copy at the end returns the per-level point counts, after which the exactly
+sized neighbour / patch / tile tables are built.
+"""
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import call, query, WS
+
+ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
+
+
+class Level:
+    """Index tables of one resolution level (device tensors unless noted)."""
+    __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
+                 "nbr125", "gidx", "owner", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
+                 "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
+                 "coord", "parent")
+
+
+def draw_order_perms(n_levels, shuffle=True):
+    """The reference draws torch.randperm(4) from the global CPU generator once at input and once per
+    pooling (model.py:130-134, :750-754), also in eval mode (SURVEY.md Trap 4).  Drawing the same
+    number of permutations in the same order keeps seeded runs comparable."""
+    if not shuffle:
+        return [list(range(4)) for _ in range(n_levels)]
+    return [torch.randperm(4).tolist() for _ in range(n_levels)]
+
+
+class FrontEnd:
+    def __init__(self, n_levels, patch_size=128, grid_size=0.01, orders=ORDERS):
+        self.n_levels = n_levels
+        self.K = patch_size
+        self.grid_size = float(np.float32(grid_size))
+        self.order_ids = [ORDERS.index(o) for o in orders]
+        assert len(self.order_ids) == 4, "the HIP front-end is built for the 4-curve configuration"
+        self.depth_bound = 16  # tightened to the observed depth after the first batch
+
+    @torch.no_grad()
+    def build(self, pc_fts, counts, ctx_counts, perms, need_coord=False):
+        """pc_fts: f32 [N, >=3] CUDA (xyz = first three columns).  counts / ctx_counts: python
+        lists (points / instruction tokens per cloud).  perms: n_levels permutations of range(4)."""
+        dev = pc_fts.device
+        N, B, Lv = int(pc_fts.shape[0]), len(counts), self.n_levels
+        assert N == sum(counts) and pc_fts.stride(1) == 1
+        ld = pc_fts.stride(0)
+        i32 = dict(dtype=torch.int32, device=dev)
+        # meta: [0:8] state, [8:8+Lv] n per level, then per-level per-cloud counts
+        meta = torch.zeros(8 + Lv + Lv * B, **i32)
+        state, n_dev = meta[0:8], meta[8:8 + Lv]
+        cnts = meta[8 + Lv:].view(Lv, B)
+        counts_t = torch.tensor(counts, dtype=torch.int32)
+        n_dev[0:1].copy_(torch.tensor([N], dtype=torch.int32), non_blocking=True)
+        cnts[0].copy_(counts_t, non_blocking=True)
+        batch0 = torch.repeat_interleave(torch.arange(B, **i32), counts_t.to(dev), output_size=N)
+
+        bbits = max(1, (B - 1).bit_length())
+        ws_sort = WS.get(query("lotus_fe_sort_workspace", N), dev, slot=1)
+        scratch = torch.empty(8, **i32)
+        gmax = scratch[4:5]
+        raw = []
+        grid = torch.empty(N, 3, **i32)
+        call("lotus_fe_grid", pc_fts, ld, N, self.grid_size, grid, gmax, scratch)
+        code = torch.empty(4, N, dtype=torch.int64, device=dev)
+        perm0 = (np.asarray(self.order_ids, dtype=np.int32)[np.asarray(perms[0])]).astype(np.int32)
+        call("lotus_fe_encode", grid, batch0, N, gmax, perm0.ctypes.data, self.depth_bound, state, code, N)
+        batch = batch0
+        for s in range(Lv):
+            skeys = torch.empty(4, N, dtype=torch.int64, device=dev)
+            order = torch.empty(4, N, **i32)
+            inverse = torch.empty(4, N, **i32)
+            key_bits = max(1, 3 * max(self.depth_bound - s, 0) + bbits)
+            call("lotus_fe_sort", code, N, n_dev[s:s + 1], N, key_bits, skeys, order, inverse, ws_sort, ws_sort.numel())
+            raw.append(dict(grid=grid, batch=batch, code=code, order=order, inverse=inverse, skeys=skeys))
+            if s + 1 < Lv:
+                cluster = torch.empty(N, **i32)
+                seg = torch.empty(N + 1, **i32)
+                ccode = torch.empty(4, N, dtype=torch.int64, device=dev)
+                cgrid = torch.empty(N, 3, **i32)
+                cbatch = torch.empty(N, **i32)
+                perm = np.asarray(perms[s + 1], dtype=np.int32)
+                call("lotus_fe_pool", code, skeys, order, grid, batch, n_dev[s:s + 1], N, perm.ctypes.data, B, cluster,
+                     seg, n_dev[s + 1:s + 2], ccode, cgrid, cbatch, cnts[s + 1])
+                raw[-1].update(cluster=cluster, seg=seg)
+                grid, batch, code = cgrid, cbatch, ccode
+
+        meta_h = meta.cpu().numpy()  # <- the one synchronisation of the front-end
+        if meta_h[0] & 1:
+            depth = int(meta_h[1])
+            if depth > 16:
+                raise ValueError(f"serialisation depth {depth} > 16 (model.py:110)")
+            self.depth_bound = 16
+            return self.build(pc_fts, counts, ctx_counts, perms, need_coord)
+        depth0 = int(meta_h[1])
+        self.depth_bound = max(depth0, 1)
+        if depth0 < Lv - 1:
+            raise NotImplementedError("cloud extent below 2^(levels-1) voxels: pooling_depth 0 path not built")
+        ns = meta_h[8:8 + Lv].tolist()
+        cnt_h = meta_h[8 + Lv:].reshape(Lv, B)
+
+        # ---- exact-size tables per level
+        levels = []
+        host_tabs, host_slices = [], []
+        K = self.K
+
+        def push(arr):
+            arr = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+            start = sum(a.size for a in host_tabs)
+            host_tabs.append(arr)
+            return (start, arr.size)
+
+        ctx_off = np.concatenate([[0], np.cumsum(ctx_counts)]).astype(np.int64)
+        plans = []
+        for s in range(Lv):
+            c = cnt_h[s].astype(np.int64)
+            off = np.concatenate([[0], np.cumsum(c)])
+            cpad = np.where(c > K, (c + K - 1) // K * K, c)
+            offp = np.concatenate([[0], np.cumsum(cpad)])
+            tiles, blocks = [], []
+            for b in range(B):
+                if c[b] == 0:
+                    continue
+                if c[b] <= K:
+                    segs = [(offp[b], c[b])]
+                else:
+                    segs = [(offp[b] + i * K, K) for i in range(int(cpad[b] // K))]
+                for st, ln in segs:
+                    blocks.append((len(tiles), 1, 1, 0, st, ln))
+                    tiles.append((st, ln, st, ln))
+            ca_tiles, ca_blocks = [], []
+            max_t = int(max(1, max((c[b] + 127) // 128 for b in range(B))))
+            G = min(8, max_t)
+            for b in range(B):
+                base = len(ca_tiles)
+                nt = int((c[b] + 127) // 128)
+                for i in range(nt):
+                    ca_tiles.append((off[b] + i * 128, min(128, c[b] - i * 128), ctx_off[b], ctx_counts[b]))
+                for g in range(G):
+                    ca_blocks.append((base + g, max(0, (nt - g + G - 1) // G), G, g, ctx_off[b], ctx_counts[b]))
+            plans.append(dict(off=push(off), offp=push(offp), tiles=push(tiles), blocks=push(blocks),
+                              ca_tiles=push(ca_tiles), ca_blocks=push(ca_blocks), n_tiles=len(tiles),
+                              n_ca_tiles=len(ca_tiles), n_ca_blocks=len(ca_blocks), G=G, npad=int(offp[-1]),
+                              off_host=off))
+        tabs = torch.from_numpy(np.concatenate(host_tabs)).to(dev)
+
+        def view(sl, cols=None):
+            t = tabs[sl[0]:sl[0] + sl[1]]
+            return t.view(-1, cols) if cols else t
+
+        ws_n = WS.get(query("lotus_fe_neighbours_workspace", ns[0]), dev, slot=1)
+        for s in range(Lv):
+            n, r, pl = ns[s], raw[s], plans[s]
+            lv = Level()
+            lv.n, lv.counts, lv.depth = n, cnt_h[s].tolist(), depth0 - s
+            lv.off, lv.off_host = view(pl["off"]), pl["off_host"]
+            lv.grid, lv.batch = r["grid"][:n], r["batch"][:n]
+            lv.code, lv.order, lv.inverse = r["code"][:, :n], r["order"][:, :n], r["inverse"][:, :n]
+            lv.nbr27 = torch.empty(27, n, **i32)
+            call("lotus_fe_neighbours", lv.grid, lv.batch, n, 3, lv.nbr27, ws_n, ws_n.numel())
+            lv.nbr125 = None
+            if s == 0:
+                lv.nbr125 = torch.empty(125, n, **i32)
+                call("lotus_fe_neighbours", lv.grid, lv.batch, n, 5, lv.nbr125, ws_n, ws_n.numel())
+            lv.npad = pl["npad"]
+            lv.gidx = torch.empty(lv.npad, **i32)
+            lv.owner = torch.empty(lv.npad, **i32)
+            call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner)
+            lv.self_tiles, lv.self_blocks = view(pl["tiles"], 4), view(pl["blocks"], 6)
+            lv.n_self_tiles = pl["n_tiles"]
+            lv.ca_tiles, lv.ca_blocks = view(pl["ca_tiles"], 4), view(pl["ca_blocks"], 6)
+            lv.n_ca_tiles, lv.n_ca_blocks, lv.ca_groups = pl["n_ca_tiles"], pl["n_ca_blocks"], pl["G"]
+            lv.cluster = lv.seg_start = lv.members = lv.coord = lv.parent = None
+            if s > 0:
+                pr = raw[s - 1]
+                lv.cluster = pr["cluster"][:ns[s - 1]]   # child id of every parent point
+                lv.seg_start = pr["seg"][:n + 1]          # CSR of the children into members
+                lv.members = pr["order"][0, :ns[s - 1]]   # parent rows sorted by parent code[0]
+                lv.parent = levels[s - 1]
+            levels.append(lv)
+        if need_coord:
+            levels[0].coord = pc_fts[:, :3]
+            for s in range(1, Lv):
+                lv = levels[s]
+                lv.coord = torch.empty(lv.n, 3, dtype=torch.float32, device=dev)
+                call("lotus_fe_pool_coord", levels[s - 1].coord.contiguous(), lv.members, lv.seg_start, lv.n, lv.coord)
+        return levels

@@ -1,0 +1,471 @@
+"""Autograd operators over the C-ABI (csrc/liblotus_hip.so).
+
+One `torch.autograd.Function` per sub-block of the reference model, each with a hand-written
+backward that chains the HIP kernels (fused epilogues, no temporaries beyond what backward needs):
+
+  CpeFn        x + LN(Linear(SubMConv3d(xs)))                      Block.cpe    model.py:615-625,660-662
+  SelfAttnFn   x + proj(patch_attention(qkv(LN(x))))               Block.attn   model.py:664-667,468-557
+  FfnFn        x + fc2(GELU(fc1(LN(x))))                           Block.mlp / CABlock.mlp
+  CrossAttnFn  x + proj(cross_attention(q(LN(x)), kv(context)))    CABlock.attn model_ca.py:135-140
+  StemFn / PoolFn / UnpoolFn / HeadLossFn                          Embedding, SerializedPooling,
+                                                                   SerializedUnpooling, ActionHead+loss
+PyTorch provides device memory, the stream and the autograd graph; all arithmetic is in the kernels.
+"""
+import torch
+
+from ._capi import call, query, WS
+
+ACT_NONE, ACT_GELU, ACT_LEAKY = 0, 1, 2
+BN_EPS, BN_MOMENTUM = 1e-3, 0.01
+
+
+def _ws(nbytes, dev):
+    return WS.get(nbytes, dev, slot=0)
+
+
+def _empty_like_rows(x, cols):
+    return torch.empty(x.shape[0], cols, dtype=torch.float32, device=x.device)
+
+
+# ------------------------------------------------------------------------------------ primitives
+def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0, seed=0):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    pre = torch.empty_like(y) if save_pre else None
+    call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed))
+    return y, pre
+
+
+def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
+    M, N = dy.shape
+    K = w.shape[1]
+    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed))
+    return dx
+
+
+def linear_wgrad(dy, x, need_bias=True):
+    M, N = dy.shape
+    K = x.shape[1]
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_bias else None
+    nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
+    ws = _ws(nbytes, dy.device)
+    call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
+    return dw, db
+
+
+def ln_fwd(x, g, b, res=None, eps=1e-5, save=True):
+    M, C = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save else None
+    call("lotus_layernorm_fwd", x, res, g, b, y, mean, rstd, M, C, float(eps))
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, mean, rstd, g, add=None):
+    M, C = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    nbytes = query("lotus_layernorm_bwd_workspace", M, C)
+    ws = _ws(nbytes, x.device)
+    call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, dg, db, M, C, 0, ws, ws.numel())
+    return dx, dg, db
+
+
+def conv_fwd(x, w, b, nbr, rowidx, add=None):
+    n, cin = x.shape
+    cout, T = w.shape[0], nbr.shape[0]
+    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+    call("lotus_subm_conv", 0, x, w, b, add, y, nbr, rowidx, n, T, cin, cout)
+    return y
+
+
+def conv_dgrad(dy, w, nbr, rowidx, add=None):
+    n, cout = dy.shape
+    cin, T = w.shape[-1], nbr.shape[0]
+    dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
+    call("lotus_subm_conv", 1, dy, w, None, add, dx, nbr, rowidx, n, T, cin, cout)
+    return dx
+
+
+def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
+    n, cout = dy.shape
+    cin, T = x.shape[1], nbr.shape[0]
+    dw = torch.empty(w_shape, dtype=torch.float32, device=dy.device)
+    db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_bias else None
+    nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
+    ws = _ws(nbytes, dy.device)
+    call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
+    return dw, db
+
+
+def dropout(x, p, seed):
+    if p <= 0.0:
+        return x
+    y = torch.empty_like(x)
+    call("lotus_dropout", x, y, x.numel(), float(p), int(seed))
+    return y
+
+
+def add(a, b):
+    y = torch.empty_like(a)
+    call("lotus_add", a, b, y, a.numel())
+    return y
+
+
+class BnState:
+    """Batch statistics hook: `reduce(sums)` all-reduces the fp64 vector (sum, sumsq, count) across
+    ranks when SyncBatchNorm semantics are wanted (train_simple_policy.py:116-117); None = local."""
+    reduce = None
+
+
+def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS):
+    M, C = x.shape
+    dev = x.device
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    if training:
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        ws = _ws(query("lotus_batchnorm_workspace", M, C), dev)
+        call("lotus_batchnorm_stats", x, sums, M, C, ws, ws.numel())
+        if BnState.reduce is not None:
+            BnState.reduce(sums)
+        call("lotus_batchnorm_finalize", sums, mean, invstd, rmean, rvar, C, float(eps), float(momentum))
+    else:
+        call("lotus_batchnorm_eval_stats", rmean, rvar, mean, invstd, C, float(eps))
+    y = torch.empty_like(x)
+    call("lotus_batchnorm_apply", x, mean, invstd, g, b, y, M, C, act)
+    return y, mean, invstd
+
+
+def bn_bwd(dy, x, mean, invstd, g, b, training, act):
+    M, C = x.shape
+    dev = x.device
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+    ws = _ws(query("lotus_batchnorm_workspace", M, C), dev)
+    call("lotus_batchnorm_bwd_stats", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel())
+    # dgamma / dbeta are the LOCAL sums (gradient averaging across ranks is the reducer's job);
+    # dx uses the statistics of the whole (all-rank) batch
+    dg = sums[C:2 * C].float()
+    db = sums[:C].float()
+    if training and BnState.reduce is not None:
+        BnState.reduce(sums)
+    dx = torch.empty_like(x)
+    call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, None, None, M, C, act,
+         1 if training else 0, 0)
+    return dx, dg, db
+
+
+def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d):
+    call("lotus_attention_fwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles,
+         qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6)
+
+
+def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
+                  dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d):
+    dev = q.device
+    grads = [torch.empty(d, dtype=torch.float32, device=dev) for _ in range(4)]
+    ws = _ws(query("lotus_attention_bwd_workspace", nblocks, H), dev)
+    call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
+         qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
+         part_stride, atomic, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, ws, ws.numel())
+    return grads
+
+
+# ------------------------------------------------------------------------------------ sub-blocks
+class CpeFn(torch.autograd.Function):
+    """x1 = x + LN(Linear(SubMConv3d_3(xs))).  In the encoder xs is x; in the decoder xs is the
+    stale proj_skip branch (SURVEY.md Trap 3), hence two tensor inputs."""
+
+    @staticmethod
+    def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl):
+        same = xs is x
+        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0])
+        l, _ = linear_fwd(c, lw, lb)
+        y, mean, rstd = ln_fwd(l, g, b, res=x)
+        ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd)
+        ctx.lvl, ctx.same = lvl, same
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, cw, lw, g, c, l, mean, rstd = ctx.saved_tensors
+        lvl = ctx.lvl
+        dy = dy.contiguous()
+        dl, dg, db = ln_bwd(dy, l, mean, rstd, g)
+        dlw, dlb = linear_wgrad(dl, c)
+        dc = linear_dgrad(dl, lw)
+        dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
+        if ctx.same:  # d x = dy (residual) + conv dgrad
+            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy)
+            return dx, None, dcw, dcb, dlw, dlb, dg, db, None
+        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0])
+        return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None
+
+
+class FfnFn(torch.autograd.Function):
+    """y = x + drop(fc2(drop(GELU(fc1(LN(x))))))   (MLP, model.py:577-583; pre-norm residual)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed):
+        n, mean, rstd = ln_fwd(x, g, b)
+        a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
+        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=seed + 1)
+        ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
+        ctx.drop = (drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
+        p, seed = ctx.drop
+        dy = dy.contiguous()
+        dz2 = dropout(dy, p, seed + 1)
+        dw2, db2 = linear_wgrad(dz2, a)
+        dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
+        dw1, db1 = linear_wgrad(dh, n)
+        dn = linear_dgrad(dh, w1)
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
+        return dx, dg, db, dw1, db1, dw2, db2, None, None
+
+
+class SelfAttnFn(torch.autograd.Function):
+    """y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (SerializedAttention flash path)."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed):
+        N, C = x.shape
+        d = C // H
+        n, mean, rstd = ln_fwd(x, g, b)
+        qkv, _ = linear_fwd(n, wqkv, bqkv)
+        att = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
+        attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
+                      lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d)
+        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
+        ctx.meta = (lvl, H, d, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
+        lvl, H, d, p, seed = ctx.meta
+        N, C = x.shape
+        dy = dy.contiguous()
+        dz = dropout(dy, p, seed)
+        dwp, dbp = linear_wgrad(dz, att)
+        datt = linear_dgrad(dz, wp)
+        dqkv = torch.zeros(N, 3 * C, dtype=torch.float32, device=x.device)  # borrowed rows accumulate
+        gq, bq, gk, bk = attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner,
+                                       lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, (qnw, qnb), (knw, knb), att,
+                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d)
+        dwqkv, dbqkv = linear_wgrad(dqkv, n)
+        dn = linear_dgrad(dqkv, wqkv)
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
+        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None
+
+
+class CrossAttnFn(torch.autograd.Function):
+    """y = x + drop(proj(CrossAttention(q(LN(x)), kv(context))))   (model_ca.py:46-101, :135-140)."""
+
+    @staticmethod
+    def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed):
+        N, C = x.shape
+        d = C // H
+        n, mean, rstd = ln_fwd(x, g, b)
+        q, _ = linear_fwd(n, wq, bq)
+        kv, _ = linear_fwd(context, wkv, bkv)
+        att = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
+        attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
+                      att, lse, H, d)
+        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
+        ctx.meta = (lvl, H, d, drop_p, seed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd = ctx.saved_tensors
+        lvl, H, d, p, seed = ctx.meta
+        N, C = x.shape
+        dev = x.device
+        dy = dy.contiguous()
+        dz = dropout(dy, p, seed)
+        dwp, dbp = linear_wgrad(dz, att)
+        datt = linear_dgrad(dz, wp)
+        dq = torch.empty(N, C, dtype=torch.float32, device=dev)
+        G, L = lvl.ca_groups, kv.shape[0]
+        dkv_part = torch.empty(G, L, 2 * C, dtype=torch.float32, device=dev)
+        gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
+                                         lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
+                                         2 * C, 0, C, L * 2 * C, 0, H, d)
+        dkv = dkv_part[0] if G == 1 else dkv_part.sum(0)
+        dwkv, dbkv = linear_wgrad(dkv, context)
+        dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
+        dwq, dbq = linear_wgrad(dq, n)
+        dn = linear_dgrad(dq, wq)
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
+        return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None
+
+
+class StemFn(torch.autograd.Function):
+    """Embedding: GELU(BN(SubMConv3d_5(x)))   (model.py:844-861; conv has no bias)."""
+
+    @staticmethod
+    def forward(ctx, x, cw, g, b, rmean, rvar, lvl, training):
+        c = conv_fwd(x, cw, None, lvl.nbr125, lvl.order[0])
+        y, mean, invstd = bn_fwd(c, g, b, rmean, rvar, training, ACT_GELU)
+        ctx.save_for_backward(x, cw, g, b, c, mean, invstd)
+        ctx.meta = (lvl, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, cw, g, b, c, mean, invstd = ctx.saved_tensors
+        lvl, training = ctx.meta
+        dc, dg, db = bn_bwd(dy.contiguous(), c, mean, invstd, g, b, training, ACT_GELU)
+        dcw, _ = conv_wgrad(dc, x, cw.shape, lvl.nbr125, need_bias=False)
+        return None, dcw, dg, db, None, None, None, None
+
+
+class PoolFn(torch.autograd.Function):
+    """SerializedPooling: GELU(BN(segment_max(Linear(x))))   (model.py:760-790)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, g, b, rmean, rvar, child, training):
+        proj, _ = linear_fwd(x, w, bias)
+        C = w.shape[0]
+        pooled = torch.empty(child.n, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(child.n, C, dtype=torch.int32, device=x.device)
+        call("lotus_pool_max_fwd", proj, child.members, child.seg_start, child.n, C, pooled, arg)
+        y, mean, invstd = bn_fwd(pooled, g, b, rmean, rvar, training, ACT_GELU)
+        ctx.save_for_backward(x, w, g, b, pooled, arg, mean, invstd)
+        ctx.meta = (child, training)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, g, b, pooled, arg, mean, invstd = ctx.saved_tensors
+        child, training = ctx.meta
+        C = w.shape[0]
+        dpool, dg, db = bn_bwd(dy.contiguous(), pooled, mean, invstd, g, b, training, ACT_GELU)
+        dproj = torch.empty(x.shape[0], C, dtype=torch.float32, device=x.device)
+        call("lotus_pool_max_bwd", dpool, arg, child.cluster, x.shape[0], C, dproj)
+        dw, dbias = linear_wgrad(dproj, x)
+        dx = linear_dgrad(dproj, w)
+        return dx, dw, dbias, dg, db, None, None, None, None
+
+
+class UnpoolFn(torch.autograd.Function):
+    """SerializedUnpooling: skip = GELU(BN(Linear_skip(parent))), up = GELU(BN(Linear(point)));
+    returns (skip + up[cluster], skip)   (model.py:817-828).  `skip` alone feeds the decoder CPE conv."""
+
+    @staticmethod
+    def forward(ctx, xc, xp, wu, bu, gu, betau, rmu, rvu, ws_, bs, gs, betas, rms, rvs, child, training):
+        lu, _ = linear_fwd(xc, wu, bu)
+        up, mu, iu = bn_fwd(lu, gu, betau, rmu, rvu, training, ACT_GELU)
+        ls, _ = linear_fwd(xp, ws_, bs)
+        skip, ms, is_ = bn_fwd(ls, gs, betas, rms, rvs, training, ACT_GELU)
+        x = torch.empty_like(skip)
+        call("lotus_unpool_fwd", skip, up, child.cluster, skip.shape[0], skip.shape[1], x)
+        ctx.save_for_backward(xc, xp, wu, gu, betau, ws_, gs, betas, lu, ls, mu, iu, ms, is_)
+        ctx.meta = (child, training)
+        return x, skip
+
+    @staticmethod
+    def backward(ctx, dx, dskip):
+        xc, xp, wu, gu, betau, ws_, gs, betas, lu, ls, mu, iu, ms, is_ = ctx.saved_tensors
+        child, training = ctx.meta
+        C = wu.shape[0]
+        dx = dx.contiguous()
+        dup = torch.empty(child.n, C, dtype=torch.float32, device=dx.device)
+        call("lotus_unpool_bwd", dx, child.members, child.seg_start, child.n, C, dup)
+        dlu, dgu, dbetau = bn_bwd(dup, lu, mu, iu, gu, betau, training, ACT_GELU)
+        dwu, dbu = linear_wgrad(dlu, xc)
+        dxc = linear_dgrad(dlu, wu)
+        dsk = add(dx, dskip.contiguous()) if dskip is not None else dx
+        dls, dgs, dbetas = bn_bwd(dsk, ls, ms, is_, gs, betas, training, ACT_GELU)
+        dws, dbs = linear_wgrad(dls, xp)
+        dxp = linear_dgrad(dls, ws_)
+        return dxc, dxp, dwu, dbu, dgu, dbetau, None, None, dws, dbs, dgs, dbetas, None, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """Plain nn.Linear (txt_fc, simple_policy_ptv3.py:387,414)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        y, _ = linear_fwd(x, w, b)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dw, db = linear_wgrad(dy, x)
+        dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
+        return dx, dw, db
+
+
+class HeadLossFn(torch.autograd.Function):
+    """ActionHead (heatmap_disc / max / euler_disc) + compute_loss, simple_policy_ptv3.py:113-157,
+    :308-373.  Returns (losses[4] = pos, rot, open, total; xt [N, 3*2*pos_bins]; ae [B, 217])."""
+
+    @staticmethod
+    def forward(ctx, x, hw0, hb0, hw3, hb3, aw0, ab0, aw3, ab3, lvl, tgt, gt, pos_w, rot_w, drop_p, seed, with_loss):
+        dev = x.device
+        N, C = x.shape
+        B = len(lvl.counts)
+        h, hpre = linear_fwd(x, hw0, hb0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=seed)
+        xt, _ = linear_fwd(h, hw3, hb3)
+        pc = torch.empty(B, C, dtype=torch.float32, device=dev)
+        arg = torch.empty(B, C, dtype=torch.int32, device=dev)
+        call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg)
+        a, apre = linear_fwd(pc, aw0, ab0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=seed + 1)
+        ae, _ = linear_fwd(a, aw3, ab3)
+        losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        nb = xt.shape[1] // 3
+        nrot = (ae.shape[1] - 1) // 3
+        stats = torch.empty(B * 3, 4, dtype=torch.float32, device=dev)
+        dae = torch.empty_like(ae)
+        if with_loss:
+            call("lotus_loss_fwd", xt, ae, tgt, gt, lvl.off, B, nb, nrot, gt.shape[1], float(pos_w), float(rot_w),
+                 losses, stats, dae)
+        ctx.save_for_backward(x, hw0, hw3, aw0, aw3, h, hpre, xt, pc, arg, a, apre, stats, dae, tgt)
+        ctx.meta = (lvl, pos_w, rot_w, drop_p, seed, with_loss, nb, nrot)
+        ctx.mark_non_differentiable(xt, ae)
+        return losses, xt, ae
+
+    @staticmethod
+    def backward(ctx, gl, _gxt, _gae):
+        x, hw0, hw3, aw0, aw3, h, hpre, xt, pc, arg, a, apre, stats, dae, tgt = ctx.saved_tensors
+        lvl, pos_w, rot_w, p, seed, with_loss, nb, nrot = ctx.meta
+        assert with_loss, "backward through the head requires compute_loss=True"
+        dev = x.device
+        N, C = x.shape
+        B = len(lvl.counts)
+        gl = gl.contiguous()
+        dxt = torch.empty_like(xt)
+        dae_o = torch.empty_like(dae)
+        call("lotus_loss_bwd", xt, tgt, lvl.off, lvl.batch, stats, dae, gl, float(pos_w), float(rot_w), B, N, nb, nrot,
+             dxt, dae_o)
+        # action branch (B rows)
+        daw3, dab3 = linear_wgrad(dae_o, a)
+        dapre = linear_dgrad(dae_o, aw3, pre=apre, act=ACT_LEAKY, drop_p=p, seed=seed + 1)
+        daw0, dab0 = linear_wgrad(dapre, pc)
+        dpc = linear_dgrad(dapre, aw0)
+        # heatmap branch (N rows)
+        dhw3, dhb3 = linear_wgrad(dxt, h)
+        dhpre = linear_dgrad(dxt, hw3, pre=hpre, act=ACT_LEAKY, drop_p=p, seed=seed)
+        dhw0, dhb0 = linear_wgrad(dhpre, x)
+        dxh = linear_dgrad(dhpre, hw0)
+        dx = torch.empty_like(x)
+        call("lotus_cloud_max_bwd", dpc, arg, lvl.batch, N, C, dxh, dx)
+        return (dx, dhw0, dhb0, dhw3, dhb3, daw0, dab0, daw3, dab3) + (None,) * 8

@@ -1,0 +1,156 @@
+"""SimplePolicyPTV3CA — drop-in for `genrobo3d/models/simple_policy_ptv3.py:376-431` on MI355X.
+
+Module surface kept from the reference: `cls(config.MODEL)`,
+`forward(batch, compute_loss=False, **kwargs)` returning `final_pred_actions` or
+`(final_pred_actions, losses{pos,rot,open,total})`, kwarg `compute_final_action`, properties
+`num_parameters` / `num_trainable_parameters`, and the 460-entry state_dict (Appendix B).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import to_cfg
+from .ptv3 import PointTransformerV3CA
+
+_PTV3_KEYS = ("in_channels", "order", "stride", "enc_depths", "enc_channels", "enc_num_head", "enc_patch_size",
+              "dec_depths", "dec_channels", "dec_num_head", "dec_patch_size", "mlp_ratio", "qkv_bias", "qk_scale",
+              "qk_norm", "attn_drop", "proj_drop", "drop_path", "pre_norm", "shuffle_orders", "enable_rpe",
+              "enable_flash", "upcast_attention", "upcast_softmax", "cls_mode", "pdnorm_bn", "pdnorm_ln",
+              "pdnorm_decouple", "pdnorm_adaptive", "pdnorm_affine", "pdnorm_conditions", "pdnorm_only_decoder",
+              "add_coords_in_attn", "scaled_cosine_attn", "ctx_channels", "pdnorm_context_channels")
+
+
+class BaseModel(nn.Module):
+    """genrobo3d/models/base.py:10-49"""
+
+    @property
+    def num_parameters(self):
+        ps = list(self.parameters())
+        return sum(int(np.prod(p.size())) for p in ps), len(ps)
+
+    @property
+    def num_trainable_parameters(self):
+        ps = [p for p in self.parameters() if p.requires_grad]
+        return sum(int(np.prod(p.size())) for p in ps), len(ps)
+
+    def prepare_batch(self, batch):
+        device = next(self.parameters()).device
+        for k, v in batch.items():
+            if isinstance(v, torch.Tensor):
+                batch[k] = v.to(device)
+        return batch
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, nn.Embedding):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+
+
+class ActionHead(nn.Module):
+    """Parameter layout of simple_policy_ptv3.py:19-68 for (max, heatmap_disc, euler_disc)."""
+
+    def __init__(self, reduce, pos_pred_type, rot_pred_type, hidden_size, dim_actions, dropout=0, voxel_size=0.01,
+                 euler_resolution=5, ptv3_config=None, pos_bins=50):
+        super().__init__()
+        if (reduce, pos_pred_type, rot_pred_type) != ("max", "heatmap_disc", "euler_disc"):
+            raise NotImplementedError("lotus-hip builds the published head: reduce=max, heatmap_disc, euler_disc")
+        self.euler_resolution, self.euler_bins, self.pos_bins = euler_resolution, 360 // euler_resolution, pos_bins
+        self.dropout = float(dropout)
+        self.heatmap_mlp = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.LeakyReLU(0.02), nn.Dropout(dropout),
+                                         nn.Linear(hidden_size, 3 * pos_bins * 2))
+        self.action_mlp = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.LeakyReLU(0.02), nn.Dropout(dropout),
+                                        nn.Linear(hidden_size, self.euler_bins * 3 + 1))
+
+
+class SimplePolicyPTV3CA(BaseModel):
+    def __init__(self, config):
+        super().__init__()
+        config = to_cfg(config)
+        self.config = config
+        p3 = {k: v for k, v in config.ptv3_config.items() if k in _PTV3_KEYS}
+        self.ptv3_model = PointTransformerV3CA(**p3)
+        act = config.action_config
+        if act.use_ee_pose or act.use_step_id:
+            raise NotImplementedError("use_ee_pose / use_step_id context tokens are not built (unused by v1)")
+        self.txt_fc = nn.Linear(act.txt_ft_size, act.context_channels)
+        self.act_proj_head = ActionHead(act.reduce, act.pos_pred_type, act.rot_pred_type,
+                                        config.ptv3_config.dec_channels[0], act.dim_actions, dropout=act.dropout,
+                                        voxel_size=act.voxel_size, pos_bins=act.pos_bins)
+        self.apply(self._init_weights)
+        self._step = 0
+
+    # -- reference API ---------------------------------------------------------------------
+    def prepare_ptv3_batch(self, batch):
+        """simple_policy_ptv3.py:403-431 (context = txt_fc(txt_embeds), one segment per cloud)."""
+        ctx = ops.LinearFn.apply(batch["txt_embeds"].contiguous(), self.txt_fc.weight, self.txt_fc.bias)
+        return {"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
+                "offset": batch["offset"], "feat": batch["pc_fts"], "context": ctx,
+                "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])}
+
+    def forward(self, batch, compute_loss=False, **kwargs):
+        batch = self.prepare_batch(batch)
+        dev = batch["pc_fts"].device
+        if dev.type != "cuda":
+            raise RuntimeError("lotus-hip runs on a HIP device only (no CPU fallback); move the model and batch to cuda")
+        act, head = self.config.action_config, self.act_proj_head
+        outs = self.ptv3_model(self.prepare_ptv3_batch(batch), return_dec_layers=True)
+        last = outs[-1]
+        lvl = last.level
+        B = len(lvl.counts)
+        gt = batch["gt_actions"].float().contiguous() if "gt_actions" in batch else None
+        tgt = None
+        with_loss = bool(compute_loss)
+        if with_loss:
+            dp = batch["disc_pos_probs"]
+            tgt = dp if isinstance(dp, torch.Tensor) else torch.cat([t.reshape(-1) for t in dp]).to(dev)
+            tgt = tgt.float().contiguous()
+        self._step += 1
+        hm, am = head.heatmap_mlp, head.action_mlp
+        p = head.dropout if self.training else 0.0
+        lc = self.config.loss_config
+        dummy = last.feat.new_zeros(1)
+        losses, xt, ae = ops.HeadLossFn.apply(
+            last.feat, hm[0].weight, hm[0].bias, hm[3].weight, hm[3].bias, am[0].weight, am[0].bias, am[3].weight,
+            am[3].bias, lvl, tgt if with_loss else dummy, gt if gt is not None else dummy.view(1, 1),
+            float(lc.pos_weight), float(lc.rot_weight), p, (self._step << 24) + 7, with_loss)
+        nb = 2 * head.pos_bins
+        pred_pos = xt.view(-1, 3, nb).permute(1, 0, 2)          # (3, N, 2*pos_bins) like the reference
+        pred_rot = ae[:, :head.euler_bins * 3].view(B, head.euler_bins, 3)
+        pred_open = ae[:, -1]
+        self.last_pred = (pred_pos, pred_rot, pred_open)
+
+        if kwargs.get("compute_final_action", True):
+            pos = self._decode_pos(xt, last.coord, lvl, nb, act)
+        else:
+            pos = gt[..., :3]
+        # euler_disc decode, simple_policy_ptv3.py:292-296 (float64 on purpose)
+        from scipy.spatial.transform import Rotation as R
+        rot_bins = torch.argmax(pred_rot, 1).cpu().numpy()
+        quat = np.stack([R.from_euler("xyz", x * head.euler_resolution - 180, degrees=True).as_quat() for x in rot_bins], 0)
+        final = torch.cat([pos.double(), torch.from_numpy(quat).to(dev), pred_open.detach().double().unsqueeze(-1)], -1)
+        if compute_loss:
+            return final, {"pos": losses[0], "rot": losses[1], "open": losses[2], "total": losses[3]}
+        return final
+
+    @torch.no_grad()
+    def _decode_pos(self, xt, coord, lvl, nb, act):
+        """get_best_pos_from_disc_pos(best='max'), utils/action_position_utils.py:48-64: per cloud and
+        axis, arg-max over (point, bin) -> coordinate + bin shift."""
+        shift = (torch.arange(-nb // 2, nb // 2, device=xt.device) * act.pos_bin_size).float()
+        out = []
+        for b, (a, e) in enumerate(zip(lvl.off_host[:-1], lvl.off_host[1:])):
+            lg = xt[a:e].view(-1, 3, nb).permute(1, 0, 2).reshape(3, -1)
+            idx = lg.argmax(-1)
+            pt, bn = idx // nb, idx % nb
+            out.append(coord[a:e][pt, torch.arange(3, device=xt.device)] + shift[bn])
+        return torch.stack(out, 0)
+
+
+MODEL_FACTORY = {"SimplePolicyPTV3CA": SimplePolicyPTV3CA}

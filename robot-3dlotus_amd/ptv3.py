@@ -1,0 +1,257 @@
+"""PointTransformerV3CA backbone as a drop-in `nn.Module` over the HIP operators.
+
+Same constructor arguments, `forward(data_dict, return_dec_layers)` contract and parameter names
+as `genrobo3d/models/PointTransformerV3/model_ca.py:155-412` (state_dict layout: SURVEY.md
+Appendix B).  The torch sub-modules (nn.Linear, nn.LayerNorm, nn.BatchNorm1d) are used purely as
+parameter containers — so checkpoints, `SyncBatchNorm.convert_sync_batchnorm` and DDP see the
+usual structure — while every forward/backward computation goes through robot_3dlotus_amd.ops.
+
+Only the configuration family of the published models is built (flash path, qk_norm, no RPE / PDNorm /
+cls_mode); other options raise NotImplementedError rather than silently computing something else.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .frontend import FrontEnd, draw_order_perms
+
+
+class SubMConv3d(nn.Module):
+    """Parameter container with spconv's layout: weight (Cout, k, k, k, Cin), optional bias."""
+
+    def __init__(self, cin, cout, k, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, k, k, k, cin))
+        bound = 1.0 / (cin * k ** 3) ** 0.5
+        nn.init.uniform_(self.weight, -bound, bound)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+        else:
+            self.register_parameter("bias", None)
+
+
+def _bn(c):
+    return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c, h):
+        super().__init__()
+        self.qkv = nn.Linear(c, 3 * c)
+        self.proj = nn.Linear(c, c)
+        self.q_norm = nn.LayerNorm(c // h, eps=1e-6)
+        self.k_norm = nn.LayerNorm(c // h, eps=1e-6)
+
+
+class _CrossAttn(nn.Module):
+    def __init__(self, c, h, ctx):
+        super().__init__()
+        self.q = nn.Linear(c, c)
+        self.kv = nn.Linear(ctx, 2 * c)
+        self.proj = nn.Linear(c, c)
+        self.q_norm = nn.LayerNorm(c // h, eps=1e-6)
+        self.k_norm = nn.LayerNorm(c // h, eps=1e-6)
+
+
+class _MLP(nn.Module):
+    def __init__(self, c, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(c, hidden)
+        self.fc2 = nn.Linear(hidden, c)
+
+
+class Block(nn.Module):
+    """model.py:586-680"""
+
+    def __init__(self, c, h, mlp_ratio):
+        super().__init__()
+        self.num_heads = h
+        self.cpe = nn.Sequential(SubMConv3d(c, c, 3, bias=True), nn.Linear(c, c), nn.LayerNorm(c))
+        self.norm1 = nn.Sequential(nn.LayerNorm(c))
+        self.attn = _Attn(c, h)
+        self.norm2 = nn.Sequential(nn.LayerNorm(c))
+        self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
+
+    def run(self, x, xs, lvl, drop_p, seed):
+        c0, c1, c2 = self.cpe[0], self.cpe[1], self.cpe[2]
+        x = ops.CpeFn.apply(x, xs, c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias, lvl)
+        a, n1 = self.attn, self.norm1[0]
+        x = ops.SelfAttnFn.apply(x, n1.weight, n1.bias, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.q_norm.bias,
+                                 a.k_norm.weight, a.k_norm.bias, a.proj.weight, a.proj.bias, lvl, self.num_heads,
+                                 drop_p, seed)
+        m, n2 = self.mlp[0], self.norm2[0]
+        return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
+                               seed + 2)
+
+
+class CABlock(nn.Module):
+    """model_ca.py:104-152"""
+
+    def __init__(self, c, h, ctx, mlp_ratio):
+        super().__init__()
+        self.num_heads = h
+        self.norm1 = nn.Sequential(nn.LayerNorm(c))
+        self.attn = _CrossAttn(c, h, ctx)
+        self.norm2 = nn.Sequential(nn.LayerNorm(c))
+        self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
+
+    def run(self, x, context, lvl, drop_p, seed):
+        a, n1 = self.attn, self.norm1[0]
+        x = ops.CrossAttnFn.apply(x, context, n1.weight, n1.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
+                                  a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight,
+                                  a.proj.bias, lvl, self.num_heads, drop_p, seed)
+        m, n2 = self.mlp[0], self.norm2[0]
+        return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
+                               seed + 2)
+
+
+class _Down(nn.Module):
+    """SerializedPooling parameters, model.py:707-711"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.proj = nn.Linear(cin, cout)
+        self.norm = nn.Sequential(_bn(cout))
+
+
+class _Up(nn.Module):
+    """SerializedUnpooling parameters, model.py:804-813"""
+
+    def __init__(self, cin, cskip, cout):
+        super().__init__()
+        self.proj = nn.Sequential(nn.Linear(cin, cout), _bn(cout))
+        self.proj_skip = nn.Sequential(nn.Linear(cskip, cout), _bn(cout))
+
+
+class _Stem(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv = SubMConv3d(cin, cout, 5, bias=False)
+        self.norm = _bn(cout)
+
+
+class _Embedding(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.stem = _Stem(cin, cout)
+
+
+class PointDict(dict):
+    """EasyDict stand-in for the reference's `_pack_point_dict` (model.py:1065-1070)."""
+    __getattr__ = dict.__getitem__
+
+
+def _tick(bn, training):
+    if training:
+        bn.num_batches_tracked.add_(1)
+
+
+class PointTransformerV3CA(nn.Module):
+    def __init__(self, in_channels=6, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2, 2, 2),
+                 enc_depths=(2, 2, 2, 6, 2), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+                 enc_patch_size=(1024,) * 5, dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+                 dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024,) * 4, mlp_ratio=4, ctx_channels=256,
+                 qkv_bias=True, qk_scale=None, qk_norm=False, attn_drop=0.0, proj_drop=0.0, drop_path=0.3,
+                 pre_norm=True, shuffle_orders=True, enable_rpe=False, enable_flash=True, upcast_attention=False,
+                 upcast_softmax=False, cls_mode=False, pdnorm_bn=False, pdnorm_ln=False, pdnorm_decouple=True,
+                 pdnorm_adaptive=False, pdnorm_context_channels=256, pdnorm_affine=True,
+                 pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D"), pdnorm_only_decoder=False,
+                 add_coords_in_attn=False, scaled_cosine_attn=False):
+        super().__init__()
+        unsupported = dict(pdnorm_bn=pdnorm_bn, pdnorm_ln=pdnorm_ln, enable_rpe=enable_rpe, cls_mode=cls_mode,
+                           scaled_cosine_attn=scaled_cosine_attn, not_flash=not enable_flash, not_qk_norm=not qk_norm,
+                           not_pre_norm=not pre_norm, no_qkv_bias=not qkv_bias, qk_scale=qk_scale is not None,
+                           add_coords=add_coords_in_attn not in (False, "none", None), drop_path=drop_path > 0,
+                           depth_gt_1=any(d != 1 for d in list(enc_depths) + list(dec_depths)),
+                           stride_ne_2=any(s != 2 for s in stride),
+                           patch_ne_128=any(p > 128 for p in list(enc_patch_size) + list(dec_patch_size)))
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"lotus-hip builds the published 3D-LOTUS configuration family only; unsupported: {bad}")
+        if len(set(enc_patch_size) | set(dec_patch_size)) != 1:
+            raise NotImplementedError("all patch sizes must be equal")
+        self.num_stages = len(enc_depths)
+        self.order = list(order)
+        self.shuffle_orders = shuffle_orders
+        self.proj_drop, self.attn_drop = float(proj_drop), float(attn_drop)
+        self.enc_channels, self.dec_channels = list(enc_channels), list(dec_channels) + [enc_channels[-1]]
+        self.frontend = FrontEnd(self.num_stages, patch_size=enc_patch_size[0], orders=self.order)
+
+        self.embedding = _Embedding(in_channels, enc_channels[0])
+        self.enc = nn.Sequential()
+        for s in range(self.num_stages):
+            enc = nn.Sequential()
+            if s > 0:
+                enc.add_module("down", _Down(enc_channels[s - 1], enc_channels[s]))
+            enc.add_module("block0", Block(enc_channels[s], enc_num_head[s], mlp_ratio))
+            enc.add_module("ca_block0", CABlock(enc_channels[s], enc_num_head[s], ctx_channels, mlp_ratio))
+            self.enc.add_module(f"enc{s}", enc)
+        self.dec = nn.Sequential()
+        dc = self.dec_channels
+        for s in reversed(range(self.num_stages - 1)):
+            dec = nn.Sequential()
+            dec.add_module("up", _Up(dc[s + 1], enc_channels[s], dc[s]))
+            dec.add_module("block0", Block(dc[s], dec_num_head[s], mlp_ratio))
+            dec.add_module("ca_block0", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
+            self.dec.add_module(f"dec{s}", dec)
+        self._step = 0
+        self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
+
+    def _pack(self, feat, lvl):
+        return PointDict(feat=feat, coord=lvl.coord, offset=lvl.off[1:].long(), level=lvl)
+
+    def forward(self, data_dict, return_dec_layers=False):
+        """data_dict keys as in the reference: coord / feat / offset / context / context_offset
+        (+ grid_size).  Extra host-side hints `counts` / `context_counts` (python lists) avoid two
+        device->host copies.  Returns the list [enc_last, dec..] of {feat, coord, offset} when
+        return_dec_layers, else the last dict (model_ca.py:383-412)."""
+        feat = data_dict["feat"].contiguous()
+        counts = data_dict.get("counts")
+        if counts is None:
+            off = data_dict["offset"].tolist()
+            counts = [b - a for a, b in zip([0] + off[:-1], off)]
+        ctx_counts = data_dict.get("context_counts")
+        if ctx_counts is None:
+            off = data_dict["context_offset"].tolist()
+            ctx_counts = [b - a for a, b in zip([0] + off[:-1], off)]
+        context = data_dict["context"].contiguous()
+        perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
+        coord = data_dict["coord"]
+        src = feat if (coord.data_ptr() == feat.data_ptr() and feat.shape[1] >= 3) else coord.contiguous()
+        self.frontend.grid_size = float(torch.tensor(float(data_dict.get("grid_size", 0.01)), dtype=torch.float32).item())
+        levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
+        training = self.training
+        p = self.proj_drop if training else 0.0
+        self._step += 1
+        seed = (self._step << 24)
+
+        st = self.embedding.stem
+        _tick(st.norm, training)
+        x = ops.StemFn.apply(feat, st.conv.weight, st.norm.weight, st.norm.bias, st.norm.running_mean,
+                             st.norm.running_var, levels[0], training)
+        skips = []
+        for s in range(self.num_stages):
+            enc, lvl = self.enc[s], levels[s]
+            seed += 64
+            if s > 0:
+                d, bn = enc.down, enc.down.norm[0]
+                _tick(bn, training)
+                x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                     lvl, training)
+            x = enc.block0.run(x, x, lvl, p, seed)
+            x = enc.ca_block0.run(x, context, lvl, p, seed + 8)
+            skips.append(x)
+        outs = [self._pack(x, levels[-1])]
+        for i, s in enumerate(reversed(range(self.num_stages - 1))):
+            dec, lvl, child = self.dec[i], levels[s], levels[s + 1]
+            seed += 64
+            u, us = dec.up.proj, dec.up.proj_skip
+            _tick(u[1], training)
+            _tick(us[1], training)
+            x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
+                                         u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
+                                         us[1].running_mean, us[1].running_var, child, training)
+            x = dec.block0.run(x, skip, lvl, p, seed)
+            x = dec.ca_block0.run(x, context, lvl, p, seed + 8)
+            outs.append(self._pack(x, lvl))
+        return outs if return_dec_layers else outs[-1]

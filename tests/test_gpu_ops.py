@@ -1,0 +1,298 @@
+"""GPU unit tests of every HIP kernel family against plain PyTorch fp32/fp64 formulations of the
+same op (and the oracle's conv / attention restatements).  Tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import front_end as fe  # noqa: E402
+from oracle import model as om  # noqa: E402
+
+
+def _ops():
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import ops
+
+    return ops
+
+
+def _close(a, b, tol, msg=""):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{msg}: max err {err:.3e} > {tol:.1e} * {scale:.3g}"
+
+
+# ------------------------------------------------------------------------------------ linear
+@pytest.mark.parametrize("M,N,K", [(65536, 64, 64), (1000, 192, 64), (441, 768, 768), (3000, 256, 1024), (190, 512, 256),
+                                   (65536, 90, 128), (16, 217, 128), (7, 128, 128), (4097, 128, 512)])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_linear_fwd(M, N, K, act):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    x, w, b, r = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    y, pre = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), residual=r.cuda(), act=act, save_pre=True)
+    ref_pre = x.double() @ w.double().t() + b.double()
+    ref = {0: lambda t: t, 1: lambda t: F.gelu(t), 2: lambda t: F.leaky_relu(t, 0.02)}[act](ref_pre) + r.double()
+    _close(pre, ref_pre, 2e-6, "pre")
+    _close(y, ref, 2e-6, "y")
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 64), (1000, 64, 192), (441, 3072, 768), (65536, 90, 128), (16, 217, 128)])
+def test_linear_dgrad_wgrad(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x, w, dy = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(M, N, generator=g)
+    pre, addt = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    dx = ops.linear_dgrad(dy.cuda(), w.cuda(), pre=pre.cuda(), add=addt.cuda(), act=1)
+    xr = pre.double().requires_grad_(True)
+    (gr,) = torch.autograd.grad(F.gelu(xr).sum(), xr)
+    _close(dx, (dy.double() @ w.double()) * gr + addt.double(), 2e-6, "dgrad")
+    dx0 = ops.linear_dgrad(dy.cuda(), w.cuda())
+    _close(dx0, dy.double() @ w.double(), 2e-6, "dgrad plain")
+    dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
+    _close(dw, dy.double().t() @ x.double(), 3e-6, "wgrad")
+    _close(db, dy.double().sum(0), 3e-6, "bgrad")
+    dw2, _ = ops.linear_wgrad(dy.cuda(), x.cuda())
+    assert torch.equal(dw, dw2), "wgrad must be deterministic"
+
+
+def test_linear_dropout_statistics_and_replay():
+    ops = _ops()
+    x = torch.ones(4096, 64).cuda()
+    w = torch.eye(64).cuda()
+    y, _ = ops.linear_fwd(x, w, None, drop_p=0.1, seed=1234)
+    keep = (y != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    assert torch.allclose(y[y != 0], torch.tensor(1 / 0.9).cuda())
+    y2, _ = ops.linear_fwd(x, w, None, drop_p=0.1, seed=1234)
+    assert torch.equal(y, y2)
+    assert torch.equal(ops.dropout(x, 0.1, 1234), y), "standalone mask must replay the fused epilogue mask"
+    y3, _ = ops.linear_fwd(x, w, None, drop_p=0.1, seed=1235)
+    assert not torch.equal(y, y3)
+
+
+# ------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("M,C", [(65536, 64), (1000, 128), (777, 256), (441, 512), (300, 768)])
+def test_layernorm(M, C):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    x, r, dy = torch.randn(M, C, generator=g) * 2 + 0.5, torch.randn(M, C, generator=g), torch.randn(M, C, generator=g)
+    gam, bet, addt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(M, C, generator=g)
+    y, mean, rstd = ops.ln_fwd(x.cuda(), gam.cuda(), bet.cuda(), res=r.cuda())
+    xd = x.double().requires_grad_(True)
+    gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = F.layer_norm(xd, (C,), gd, bd, 1e-5)
+    _close(y, ref + r.double(), 3e-6, "ln fwd")
+    ref.backward(dy.double())
+    dx, dg, db = ops.ln_bwd(dy.cuda(), x.cuda(), mean, rstd, gam.cuda(), add=addt.cuda())
+    _close(dx, xd.grad + addt.double(), 5e-6, "ln dx")
+    _close(dg, gd.grad, 5e-6, "ln dgamma")
+    _close(db, bd.grad, 5e-6, "ln dbeta")
+
+
+@pytest.mark.parametrize("M,C", [(65536, 64), (6921, 256), (37, 768)])
+@pytest.mark.parametrize("training", [True, False])
+def test_batchnorm_gelu(M, C, training):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + M)
+    x, dy = torch.randn(M, C, generator=g) * 1.7 + 0.3, torch.randn(M, C, generator=g)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_d, rv_d = rm.clone().cuda(), rv.clone().cuda()
+    y, mean, invstd = ops.bn_fwd(x.cuda(), gam.cuda(), bet.cuda(), rm_d, rv_d, training, 1)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm2, rv2 = rm.double().clone(), rv.double().clone()
+    ref = F.gelu(F.batch_norm(xd, rm2, rv2, gd, bd, training, 0.01, 1e-3))
+    _close(y, ref, 3e-6, "bn fwd")
+    if training:
+        _close(rm_d, rm2, 1e-6, "running mean")
+        _close(rv_d, rv2, 1e-6, "running var")
+    ref.backward(dy.double())
+    dx, dg, db = ops.bn_bwd(dy.cuda(), x.cuda(), mean, invstd, gam.cuda(), bet.cuda(), training, 1)
+    _close(dx, xd.grad, 1e-5, "bn dx")
+    _close(dg, gd.grad, 1e-5, "bn dgamma")
+    _close(db, bd.grad, 1e-5, "bn dbeta")
+
+
+# ------------------------------------------------------------------------------------ sparse conv
+def _cloud_levels(B, n, seed, n_levels=2):
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.synth_batch(B, n, ragged=True, seed=seed)
+    perms = [[0, 1, 2, 3]] * n_levels
+    ref = fe.build_all_levels(batch["pc_fts"][:, :3].numpy(), batch["npoints_in_batch"], n_levels, perms=perms)
+    got = FrontEnd(n_levels).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], perms)
+    return batch, ref, got
+
+
+@pytest.mark.parametrize("cin,cout,k", [(64, 64, 3), (128, 128, 3), (7, 64, 5), (256, 128, 3)])
+def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
+    ops = _ops()
+    batch, ref, got = _cloud_levels(3, 1500, seed=cin + k)
+    n = got[0].n
+    g = torch.Generator().manual_seed(cin * cout)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, k, k, k, cin, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    dy = torch.randn(n, cout, generator=g)
+    nbr_ref = torch.from_numpy(ref[0]["nbr27" if k == 3 else "nbr125"]).long()
+    nbr = got[0].nbr27 if k == 3 else got[0].nbr125
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yref = om.subm_conv(xd, nbr_ref, wd, bd)
+    y = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0])
+    _close(y, yref, 3e-6, "conv fwd")
+    yref.backward(dy.double())
+    if cin == cout:
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, got[0].order[0])
+        _close(dx, xd.grad, 3e-6, "conv dgrad")
+    dw, db = ops.conv_wgrad(dy.cuda(), x.cuda(), w.shape, nbr)
+    _close(dw, wd.grad, 5e-6, "conv wgrad")
+    _close(db, bd.grad, 5e-6, "conv bgrad")
+    if cin != cout and k == 3:
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, None)
+        _close(dx, xd.grad, 3e-6, "conv dgrad (cin != cout, natural row order)")
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("C,H", [(64, 2), (128, 4), (768, 32)])
+def test_patch_attention_fwd_bwd(C, H):
+    ops = _ops()
+    batch, ref, got = _cloud_levels(3, 300, seed=C)
+    lv, r = got[0], ref[0]
+    n, d = lv.n, C // H
+    g = torch.Generator().manual_seed(C)
+    qkv = torch.randn(n, 3 * C, generator=g) * 1.5
+    qn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    kn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    dout = torch.randn(n, C, generator=g)
+    lvl = dict(order_t=torch.from_numpy(r["order"]), inverse_t=torch.from_numpy(r["inverse"]),
+               pad_t=torch.from_numpy(r["pad"]), unpad_t=torch.from_numpy(r["unpad"]), cu_seqlens=r["cu_seqlens"])
+    qd = qkv.double().requires_grad_(True)
+    pr = [t.double().requires_grad_(True) for t in (*qn, *kn)]
+    oref = om.patch_attention(qd, lvl, 0, H, pr[0], pr[1], pr[2], pr[3], 128)
+    oref.backward(dout.double())
+    dev = lambda t: t.cuda()  # noqa: E731
+    qc = dev(qkv)
+    qnc, knc = tuple(map(dev, qn)), tuple(map(dev, kn))
+    att = torch.empty(n, C, device="cuda")
+    lse = torch.empty(lv.npad, H, device="cuda")
+    ops.attention_fwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.n_self_tiles,
+                      qnc, knc, att, lse, H, d)
+    _close(att, oref, 5e-6, "attn fwd")
+    dqkv = torch.zeros(n, 3 * C, device="cuda")
+    gr = ops.attention_bwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.self_blocks,
+                           lv.n_self_tiles, qnc, knc, att, dev(dout), lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d)
+    _close(dqkv, qd.grad, 2e-5, "attn dqkv")
+    for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
+        _close(a, b.grad, 5e-5, name)
+
+
+@pytest.mark.parametrize("C,H", [(64, 2), (768, 32)])
+def test_cross_attention_fwd_bwd(C, H):
+    ops = _ops()
+    batch, ref, got = _cloud_levels(3, 700, seed=C + 1)
+    lv = got[0]
+    n, d = lv.n, C // H
+    counts, ctx_counts = batch["npoints_in_batch"], batch["txt_lens"]
+    L = sum(ctx_counts)
+    g = torch.Generator().manual_seed(C + 5)
+    q, kv = torch.randn(n, C, generator=g) * 1.5, torch.randn(L, 2 * C, generator=g) * 1.5
+    qn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    kn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    dout = torch.randn(n, C, generator=g)
+    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    pr = [t.double().requires_grad_(True) for t in (*qn, *kn)]
+    oref = om.cross_attention(qd, kvd, counts, ctx_counts, H, pr[0], pr[1], pr[2], pr[3])
+    oref.backward(dout.double())
+    qc, kvc = q.cuda(), kv.cuda()
+    qnc, knc = tuple(t.cuda() for t in qn), tuple(t.cuda() for t in kn)
+    att = torch.empty(n, C, device="cuda")
+    lse = torch.empty(n, H, device="cuda")
+    ops.attention_fwd(qc, C, 0, kvc, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.n_ca_tiles, qnc, knc, att, lse, H, d)
+    _close(att, oref, 5e-6, "xattn fwd")
+    dq = torch.empty(n, C, device="cuda")
+    G = lv.ca_groups
+    dkvp = torch.empty(G, L, 2 * C, device="cuda")
+    gr = ops.attention_bwd(qc, C, 0, kvc, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.ca_blocks, lv.n_ca_blocks, qnc,
+                           knc, att, dout.cuda(), lse, dq, C, 0, dkvp, 2 * C, 0, C, L * 2 * C, 0, H, d)
+    _close(dq, qd.grad, 2e-5, "xattn dq")
+    _close(dkvp.sum(0), kvd.grad, 2e-5, "xattn dkv")
+    for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
+        _close(a, b.grad, 5e-5, name)
+
+
+# ------------------------------------------------------------------------------------ pool / head / loss
+def test_pool_unpool():
+    ops = _ops()
+    from robot_3dlotus_amd._capi import call
+
+    batch, ref, got = _cloud_levels(2, 900, seed=3)
+    parent, child = got[0], got[1]
+    C = 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(parent.n, C, generator=g)
+    cl = torch.from_numpy(ref[1]["cluster"])
+    yref = torch.zeros(child.n, C).scatter_reduce(0, cl.view(-1, 1).expand(-1, C), x, "amax", include_self=False)
+    y = torch.empty(child.n, C, device="cuda")
+    arg = torch.empty(child.n, C, dtype=torch.int32, device="cuda")
+    call("lotus_pool_max_fwd", x.cuda(), child.members, child.seg_start, child.n, C, y, arg)
+    assert torch.equal(y.cpu(), yref)
+    assert torch.equal(x[arg.cpu().long(), torch.arange(C)], yref)
+    dy = torch.randn(child.n, C, generator=g)
+    dx = torch.empty(parent.n, C, device="cuda")
+    call("lotus_pool_max_bwd", dy.cuda(), arg, child.cluster, parent.n, C, dx)
+    xr = x.clone().requires_grad_(True)
+    torch.zeros(child.n, C).scatter_reduce(0, cl.view(-1, 1).expand(-1, C), xr, "amax", include_self=False).backward(dy)
+    assert torch.equal(dx.cpu(), xr.grad)
+    up = torch.randn(child.n, C, generator=g)
+    o = torch.empty(parent.n, C, device="cuda")
+    call("lotus_unpool_fwd", x.cuda(), up.cuda(), child.cluster, parent.n, C, o)
+    assert torch.equal(o.cpu(), x + up[cl])
+    dup = torch.empty(child.n, C, device="cuda")
+    call("lotus_unpool_bwd", x.cuda(), child.members, child.seg_start, child.n, C, dup)
+    _close(dup, torch.zeros(child.n, C).index_add(0, cl, x), 2e-6, "unpool bwd")
+
+
+def test_head_and_losses():
+    ops = _ops()
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.synth_batch(3, 500, ragged=True, seed=8)
+    lv = FrontEnd(2).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], [[0, 1, 2, 3]] * 2)[0]
+    counts = batch["npoints_in_batch"]
+    N, C, B = lv.n, 128, len(counts)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(N, C, generator=g)
+    ws = [torch.randn(C, C, generator=g) / 11, torch.randn(C, generator=g) * 0.1, torch.randn(90, C, generator=g) / 11,
+          torch.randn(90, generator=g) * 0.1, torch.randn(C, C, generator=g) / 11, torch.randn(C, generator=g) * 0.1,
+          torch.randn(217, C, generator=g) / 11, torch.randn(217, generator=g) * 0.1]
+    gt = batch["gt_actions"]
+    tgt = torch.cat([t.reshape(-1) for t in batch["disc_pos_probs"]])
+    xd = x.double().requires_grad_(True)
+    wd = [w.double().requires_grad_(True) for w in ws]
+    h = F.leaky_relu(F.linear(xd, wd[0], wd[1]), 0.02)
+    xt = F.linear(h, wd[2], wd[3]).view(-1, 3, 30).permute(1, 0, 2)
+    pcs = torch.stack([t.max(0)[0] for t in torch.split(xd, counts)], 0)
+    ae = F.linear(F.leaky_relu(F.linear(pcs, wd[4], wd[5]), 0.02), wd[6], wd[7])
+    pos = sum(F.cross_entropy(lg.reshape(3, -1), tg.double()) for lg, tg in zip(torch.split(xt, counts, 1), batch["disc_pos_probs"])) / B
+    rot = F.cross_entropy(ae[:, :216].reshape(-1, 72, 3), gt[:, 3:6].long())
+    opn = F.binary_cross_entropy_with_logits(ae[:, -1], gt[:, -1].double())
+    total = pos + rot + opn
+    total.backward()
+    xc = x.cuda().requires_grad_(True)
+    wc = [w.cuda().requires_grad_(True) for w in ws]
+    losses, xt_g, ae_g = ops.HeadLossFn.apply(xc, *wc, lv, tgt.cuda(), gt.cuda(), 1.0, 1.0, 0.0, 0, True)
+    _close(losses, torch.stack([pos, rot, opn, total]), 3e-6, "losses")
+    _close(ae_g, ae, 3e-6, "ae")
+    losses[3].backward()
+    _close(xc.grad, xd.grad, 1e-5, "head dx")
+    for i, (a, b) in enumerate(zip(wc, wd)):
+        _close(a.grad, b.grad, 1e-5, f"head param {i}")
