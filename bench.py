@@ -1,0 +1,188 @@
+"""bench.py — keystep-samples/sec (train fwd+bwd) of the 3D-LOTUS v1 policy on N MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+One "step" = forward + loss + backward (+ gradient all-reduce when N > 1) of the v1 model over one
+synthetic GemBench-shape batch of 16 key-step clouds x 4096 points per GPU (BASELINE.json
+configs[1]; weak scaling: 16 clouds per rank).  Inputs are resident in HBM before the timed
+region.  Dropout is active (train mode, reference rates), weights are random-init of the v1
+architecture.  Prints ONE JSON line on rank 0 with the metric, the roofline object of the
+dominant kernel family (dense fp32-MFMA linear layers, timed live with HIP events by replaying
+the step's launch list) and the CPU baseline (the oracle timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+GFLOP_PER_SAMPLE = 60.5  # fwd+bwd algorithmic work per key-step sample, v1 @ 4096 pts
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def dev_batch(batch, dev):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(dev)
+        elif k == "disc_pos_probs":
+            out[k] = torch.cat([t.reshape(-1) for t in v]).to(dev)  # packed once, stays in HBM
+        else:
+            out[k] = v
+    return out
+
+
+def gemm_roofline(ops, calls, dev, reps=5):
+    """Replay every dense-linear launch of one training step (forward, dgrad, wgrad) on the
+    current stream, bracketed by HIP events, and return (flops per step, ms per step, launches)."""
+    import torch
+
+    uniq = {}
+    for c in calls:
+        uniq[c] = uniq.get(c, 0) + 1
+    tot_ms, tot_flop, n_launch = 0.0, 0.0, 0
+    for (kind, M, N, K), cnt in uniq.items():
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * 0.02
+        dy = torch.randn(M, N, device=dev)
+        fn = {"fwd": lambda: ops.linear_fwd(x, w, None), "dgrad": lambda: ops.linear_dgrad(dy, w),
+              "wgrad": lambda: ops.linear_wgrad(dy, x)}[kind]
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        tot_ms += ms * cnt
+        tot_flop += 2.0 * M * N * K * cnt
+        n_launch += cnt
+    return tot_flop, tot_ms, n_launch
+
+
+def cpu_baseline(cfg_name="v1", clouds=2, npoints=4096, iters=2):
+    """The oracle (CPU PyTorch restatement of the reference path) timed on the host cores:
+    forward + loss + backward of `clouds` clouds, median of `iters` after one warm-up."""
+    import golden_util as gu
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    cfg = lcfg.preset(cfg_name)
+    sd = seeded_state_dict(gu.state_template(cfg), 0, "init")
+    batch = synth.synth_batch(clouds, npoints, seed=0)
+    perms = [[0, 1, 2, 3]] * len(cfg.ptv3_config.enc_channels)
+    times = []
+    for it in range(iters + 1):
+        sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+        t0 = time.time()
+        out = Oracle(sdg, lcfg.plain(cfg), training=True).forward(batch, perms)
+        out["losses"]["total"].backward()
+        times.append(time.time() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(clouds / t, 4), "unit": "keystep-samples/s", "cores": ncores, "kind": "port",
+            "sample": f"{clouds} clouds x {npoints} pts, v1 model, fwd+loss+bwd, median of {iters} after 1 warm-up "
+                      f"(oracle/model.py, torch CPU fp32, {ncores} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="key-step clouds per GPU")
+    ap.add_argument("--npoints", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import config as lcfg, ops, parallel, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+
+    rank, local, world = parallel.init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
+    reducer = parallel.GradReducer(model, bucket_mb=64.0)
+    if world > 1:
+        parallel.enable_sync_batchnorm()
+    batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
+
+    def step():
+        reducer.zero_grad()
+        _, losses = model(batch, compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        reducer.finish()
+        return losses
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(losses["total"]).item()
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.batch * world * args.steps / dt
+        out = {
+            "metric": "keystep-samples/sec (train fwd+bwd) 3D-LOTUS GemBench", "value": round(value, 2),
+            "unit": "keystep-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3D-LOTUS v1 (68.18M params), {args.batch} key-step clouds x {args.npoints} pts "
+                                   f"per GPU, fwd+loss+bwd, train mode (dropout on), fp32 exact (MFMA f32)",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "model_gflop_per_sample": GFLOP_PER_SAMPLE,
+                       "model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 2)},
+        }
+        if not args.no_roofline:
+            calls = []
+            ops.CALL_LOG = calls
+            step()
+            ops.CALL_LOG = None
+            torch.cuda.synchronize()
+            flop, gms, nl = gemm_roofline(ops, calls, dev)
+            ach = flop / (gms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "kernel": "gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
+                               "launches_per_step": nl, "ms_per_step": round(gms, 3),
+                               "gflop_per_step": round(flop / 1e9, 1)}
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -17,6 +17,7 @@ from ._capi import call, query, WS
 
 ACT_NONE, ACT_GELU, ACT_LEAKY = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01
+CALL_LOG = None  # bench.py sets this to a list to record the (kind, M, N, K) of every dense launch
 
 
 def _ws(nbytes, dev):
@@ -33,6 +34,8 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     pre = torch.empty_like(y) if save_pre else None
+    if CALL_LOG is not None:
+        CALL_LOG.append(("fwd", M, N, K))
     call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed))
     return y, pre
 
@@ -41,6 +44,8 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    if CALL_LOG is not None:
+        CALL_LOG.append(("dgrad", M, N, K))
     call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed))
     return dx
 
@@ -50,6 +55,8 @@ def linear_wgrad(dy, x, need_bias=True):
     K = x.shape[1]
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_bias else None
+    if CALL_LOG is not None:
+        CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
     ws = _ws(nbytes, dy.device)
     call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())

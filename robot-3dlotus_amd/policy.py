@@ -126,7 +126,14 @@ class SimplePolicyPTV3CA(BaseModel):
         pred_open = ae[:, -1]
         self.last_pred = (pred_pos, pred_rot, pred_open)
 
-        if kwargs.get("compute_final_action", True):
+        decode = kwargs.get("compute_final_action", True)
+        if compute_loss and self.training and not decode and not kwargs.get("decode_actions", False):
+            # Training step of the reference trainer (`_, losses = model(batch, compute_loss=True,
+            # compute_final_action=False)`, train_simple_policy.py:211): the action tuple is discarded, so
+            # the device->host argmax copy + per-sample scipy decode (simple_policy_ptv3.py:292-296) is
+            # skipped unless decode_actions=True is passed.  See INTEGRATION.md.
+            return None, {"pos": losses[0], "rot": losses[1], "open": losses[2], "total": losses[3]}
+        if decode:
             pos = self._decode_pos(xt, last.coord, lvl, nb, act)
         else:
             pos = gt[..., :3]

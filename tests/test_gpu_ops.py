@@ -50,12 +50,13 @@ def test_linear_dgrad_wgrad(M, N, K):
     dx = ops.linear_dgrad(dy.cuda(), w.cuda(), pre=pre.cuda(), add=addt.cuda(), act=1)
     xr = pre.double().requires_grad_(True)
     (gr,) = torch.autograd.grad(F.gelu(xr).sum(), xr)
-    _close(dx, (dy.double() @ w.double()) * gr + addt.double(), 2e-6, "dgrad")
+    tol_n, tol_m = 4e-7 * N ** 0.5 + 1e-6, 4e-7 * M ** 0.5 + 1e-6   # fp32 accumulation over N / M terms
+    _close(dx, (dy.double() @ w.double()) * gr + addt.double(), tol_n, "dgrad")
     dx0 = ops.linear_dgrad(dy.cuda(), w.cuda())
-    _close(dx0, dy.double() @ w.double(), 2e-6, "dgrad plain")
+    _close(dx0, dy.double() @ w.double(), tol_n, "dgrad plain")
     dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
-    _close(dw, dy.double().t() @ x.double(), 3e-6, "wgrad")
-    _close(db, dy.double().sum(0), 3e-6, "bgrad")
+    _close(dw, dy.double().t() @ x.double(), tol_m, "wgrad")
+    _close(db, dy.double().sum(0), tol_m, "bgrad")
     dw2, _ = ops.linear_wgrad(dy.cuda(), x.cuda())
     assert torch.equal(dw, dw2), "wgrad must be deterministic"
 
@@ -225,7 +226,8 @@ def test_cross_attention_fwd_bwd(C, H):
     _close(dq, qd.grad, 2e-5, "xattn dq")
     _close(dkvp.sum(0), kvd.grad, 2e-5, "xattn dkv")
     for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
-        _close(a, b.grad, 5e-5, name)
+        # dkn_b is mathematically zero (softmax is shift-invariant per query): pure fp32 cancellation noise
+        _close(a, b.grad, 5e-4 if name == "dkn_b" else 5e-5, name)
 
 
 # ------------------------------------------------------------------------------------ pool / head / loss
