@@ -1,0 +1,121 @@
+"""CPU tests of the host-side logic: config presets, state_dict layout, synthetic batches,
+cloud sharding and the data-parallel gradient reducer (world_size 2 over gloo)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+import robot_3dlotus_amd  # noqa: F401
+from oracle import front_end as fe
+from robot_3dlotus_amd import config as lcfg, parallel, synth
+from robot_3dlotus_amd.policy import MODEL_FACTORY, SimplePolicyPTV3CA
+
+
+def test_v1_preset_matches_published_overrides():
+    c = lcfg.preset("v1")
+    assert c.model_class == "SimplePolicyPTV3CA" and MODEL_FACTORY[c.model_class] is SimplePolicyPTV3CA
+    p, a = c.ptv3_config, c.action_config
+    assert p.enc_channels == [64, 128, 256, 512, 768] and p.dec_channels == [128, 128, 256, 512]
+    assert p.enc_depths == [1] * 5 and p.qk_norm is True and p.enable_flash is True and p.in_channels == 7
+    assert a.pos_pred_type == "heatmap_disc" and a.rot_pred_type == "euler_disc" and a.pos_bins == 15
+    assert a.dropout == 0.2 and p.proj_drop == 0.1 and p.drop_path == 0.0 and a.use_ee_pose is False
+
+
+def test_override_parser_follows_yacs_list_semantics():
+    c = lcfg.load_model_config(None, ["MODEL.ptv3_config.enc_depths", "[1, 1]", "action_config.pos_bins", "7",
+                                      "ptv3_config.pdnorm_conditions", "null", "action_config.reduce", "max"])
+    assert c.ptv3_config.enc_depths == [1, 1] and c.action_config.pos_bins == 7
+    assert c.ptv3_config.pdnorm_conditions is None and c.action_config.reduce == "max"
+
+
+@pytest.mark.parametrize("variant,nparams,nentries", [("v1", 68177587, 460), ("tiny", 947827, 157)])
+def test_module_state_dict_layout(variant, nparams, nentries):
+    cfg = lcfg.preset(variant)
+    m = SimplePolicyPTV3CA(cfg)
+    sd, t = m.state_dict(), gu.state_template(cfg)
+    assert set(sd) == set(t) and len(sd) == nentries
+    assert all(tuple(sd[k].shape) == tuple(t[k].shape) for k in t)
+    assert m.num_parameters[0] == nparams == m.num_trainable_parameters[0]
+    # weight-decay grouping of the reference keys on these substrings (optim/misc.py:15)
+    nodecay = [n for n, _ in m.named_parameters() if any(s in n for s in ("bias", "LayerNorm.bias", "LayerNorm.weight"))]
+    assert all(n.endswith("bias") for n in nodecay)
+
+
+def test_unsupported_configurations_raise():
+    with pytest.raises(NotImplementedError):
+        SimplePolicyPTV3CA(lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["ptv3_config.enable_flash", "False"]))
+    with pytest.raises(NotImplementedError):
+        SimplePolicyPTV3CA(lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["action_config.use_ee_pose", "True"]))
+
+
+def test_synthetic_batch_schema_and_voxel_uniqueness():
+    b = synth.synth_batch(5, 1000, ragged=True, seed=3)
+    n = b["npoints_in_batch"]
+    assert b["pc_fts"].shape == (sum(n), 7) and b["offset"].tolist() == np.cumsum(n).tolist()
+    assert b["txt_embeds"].shape == (sum(b["txt_lens"]), 512) and b["gt_actions"].shape == (5, 7)
+    assert all(p.shape == (3, k * 30) for p, k in zip(b["disc_pos_probs"], n))
+    g = fe.grid_coord(b["pc_fts"][:, :3].numpy())
+    key = np.concatenate([fe.offset2batch(n)[:, None], g], 1)
+    assert len(np.unique(key, axis=0)) == len(key), "synthetic clouds must stay voxel-unique after re-gridding"
+
+
+def test_shard_clouds_balances_points():
+    counts = [4096, 100, 3000, 2900, 50, 4000, 3500, 1200]
+    sh = parallel.shard_clouds(counts, 4)
+    assert sorted(i for s in sh for i in s) == list(range(8))
+    loads = [sum(counts[i] for i in s) for s in sh]
+    assert max(loads) - min(loads) < 2000
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, _, w = parallel.init_distributed(backend="gloo")
+    torch.manual_seed(rank)  # different init per rank -> the broadcast must equalise
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    red = parallel.GradReducer(net, bucket_mb=0.0002)  # tiny buckets -> several async all-reduces
+    assert len(red.buckets) >= 2
+    gsum = None
+    for step in range(2):
+        red.zero_grad()
+        g = torch.Generator().manual_seed(100 + rank + 10 * step)
+        x = torch.randn(5, 8, generator=g)
+        net(x).square().sum().backward()
+        red.finish()
+        gsum = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+    # reference: average of the per-rank gradients computed serially
+    torch.manual_seed(0)
+    ref_net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    acc = None
+    for rr in range(world):
+        ref_net.zero_grad()
+        g = torch.Generator().manual_seed(100 + rr + 10)
+        ref_net(torch.randn(5, 8, generator=g)).square().sum().backward()
+        v = torch.cat([p.grad.flatten() for p in ref_net.parameters()])
+        acc = v if acc is None else acc + v
+    ok = torch.allclose(gsum, acc / world, atol=1e-6)
+    # SyncBN statistics hook: (sum, sumsq, count) vector is summed in place
+    parallel.enable_sync_batchnorm()
+    from robot_3dlotus_amd import ops
+    s = torch.tensor([1.0 + rank, 2.0, 10.0], dtype=torch.float64)
+    ops.BnState.reduce(s)
+    ok = ok and s.tolist() == [3.0, 4.0, 20.0]
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
