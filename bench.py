@@ -40,7 +40,7 @@ def dev_batch(batch, dev):
     return out
 
 
-def gemm_roofline(ops, calls, dev, reps=5):
+def gemm_roofline(ops, calls, dev, reps=5, report=None):
     """Replay every dense-linear launch of one training step (forward, dgrad, wgrad) on the
     current stream, bracketed by HIP events, and return (flops per step, ms per step, launches)."""
     import torch
@@ -66,6 +66,8 @@ def gemm_roofline(ops, calls, dev, reps=5):
         tot_ms += ms * cnt
         tot_flop += 2.0 * M * N * K * cnt
         n_launch += cnt
+        if report is not None:
+            report.append((ms * cnt, kind, M, N, K, cnt, ms, 2e-9 * M * N * K / ms))
     return tot_flop, tot_ms, n_launch
 
 
@@ -105,6 +107,7 @@ def main():
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     args = ap.parse_args()
 
     import robot_3dlotus_amd  # noqa: F401
@@ -117,16 +120,21 @@ def main():
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
-    reducer = parallel.GradReducer(model, bucket_mb=64.0)
-    if world > 1:
+    reducer = None
+    if world > 1:  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
+        reducer = parallel.GradReducer(model, bucket_mb=64.0)
         parallel.enable_sync_batchnorm()
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
 
     def step():
-        reducer.zero_grad()
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            model.zero_grad(set_to_none=True)
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
         losses["total"].backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         return losses
 
     for _ in range(args.warmup):
@@ -169,7 +177,13 @@ def main():
             step()
             ops.CALL_LOG = None
             torch.cuda.synchronize()
-            flop, gms, nl = gemm_roofline(ops, calls, dev)
+            rep = [] if args.gemm_report else None
+            flop, gms, nl = gemm_roofline(ops, calls, dev, report=rep)
+            if rep is not None:
+                with open(args.gemm_report, "w") as f:
+                    f.write("total_ms kind M N K count ms_each TFLOPs\n")
+                    for r in sorted(rep, reverse=True):
+                        f.write("%.3f %s %d %d %d %d %.4f %.1f\n" % r)
             ach = flop / (gms * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,

@@ -426,15 +426,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
 }
 
-// out4[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
-__global__ void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1, float* o2, float* o3,
-                                      int nb, int d, int accumulate) {
-  const int which = threadIdx.x >> 5, j = threadIdx.x & 31;
-  if (j >= d) return;
+// out[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
+// one block per `which`; 8 row lanes x 32 columns, fixed-order tree -> deterministic
+__global__ __launch_bounds__(256) void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1,
+                                                             float* o2, float* o3, int nb, int d, int accumulate) {
+  __shared__ float red[8][32];
+  const int which = blockIdx.x, j = threadIdx.x & 31, r = threadIdx.x >> 5;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[((long)b * 4 + which) * 32 + j];
-  float* o = which == 0 ? o0 : which == 1 ? o1 : which == 2 ? o2 : o3;
-  o[j] = accumulate ? o[j] + s : s;
+  for (int b = r; b < nb; b += 8) s += part[((long)b * 4 + which) * 32 + j];
+  red[r][j] = s;
+  __syncthreads();
+  if (r == 0 && j < d) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += red[k][j];
+    float* o = which == 0 ? o0 : which == 1 ? o1 : which == 2 ? o2 : o3;
+    o[j] = accumulate ? o[j] + t : t;
+  }
 }
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
@@ -493,7 +500,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   const size_t sm = attn_smem_bytes(true);
   (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblocks, H), dim3(256), sm, st, p);
-  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(1), dim3(128), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
+  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(4), dim3(256), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
                      nblocks * H, d, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_attention_bwd");
   return LOTUS_OK;

@@ -14,6 +14,8 @@
 #include "mma.h"
 
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);
+int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
+                         const int* nbr, const int* rowidx, int n, int T, int cin, int cout, hipStream_t st, int* rc);
 
 struct ConvP {
   const float* x;   // [n][KD] gathered operand (features, or dy for dgrad)
@@ -180,7 +182,8 @@ struct ConvWgP {
   const float* x;   // [n][cin]
   const int* nbr;   // [T][n]
   float* part;      // [nsplit][cout][T][cin]
-  float* bias_part; // [nsplit][cout] or null
+  float* bias_part; // slice z at bias_part + z * part_stride, or null
+  long part_stride; // floats between split slabs
   int n, T, cin, cout, chunk;  // chunk = points per split (<= WG_MAX_PAIRS)
 };
 #define WG_MAX_PAIRS 2048
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
       }
     }
   }
-  float* part = p.part + (long)blockIdx.z * p.cout * p.T * p.cin;
+  float* part = p.part + (long)blockIdx.z * p.part_stride;
   const int col = ci0 + acc_col(wc0, 0);
   if (col < p.cin) {
 #pragma unroll
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
   if (p.bias_part && t == p.T / 2 && ci0 == 0 && (wave & 1) == 0) {
     const float s = asum[0] + __shfl_xor(asum[0], 32, 64);
     const int i = co0 + wr0 + (tid & 31);
-    if ((tid & 32) == 0 && i < p.cout) p.bias_part[(long)blockIdx.z * p.cout + i] = s;
+    if ((tid & 32) == 0 && i < p.cout) p.bias_part[(long)blockIdx.z * p.part_stride + i] = s;
   }
 }
 
@@ -287,6 +290,10 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* bias,
                     const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
   if (n == 0) return LOTUS_OK;
+  {
+    int rc = 0;  // pair-compacted fast path (conv_pairs.hip) for the 3^3 CPE convolutions
+    if (lotus_conv_pairs_try(mode, x, w, bias, add, y, nbr, rowidx, n, T, cin, cout, (hipStream_t)stream, &rc)) return rc;
+  }
   ConvP p;
   memset(&p, 0, sizeof(p));
   p.x = x; p.w = w; p.y = y; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
@@ -336,16 +343,24 @@ int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db,
   const size_t wsz = (size_t)cout * T * cin;
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)nsplit * (wsz + cout) * sizeof(float),
                   "lotus_subm_conv_wgrad: workspace too small");
+  const size_t slab = wsz + cout;
+  const bool direct = nsplit == 1 && !accumulate;
   ConvWgP p;
-  p.dy = dy; p.x = x; p.nbr = nbr; p.part = (float*)workspace;
-  p.bias_part = db ? p.part + (size_t)nsplit * wsz : nullptr;
+  p.dy = dy; p.x = x; p.nbr = nbr;
   p.n = n; p.T = T; p.cin = cin; p.cout = cout; p.chunk = WG_MAX_PAIRS;
+  if (direct) {
+    p.part = dw; p.bias_part = db; p.part_stride = 0;
+  } else {
+    p.part = (float*)workspace; p.part_stride = (long)slab;
+    p.bias_part = db ? p.part + wsz : nullptr;
+  }
   dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
   hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv_wgrad");
-  int rc = lotus_reduce_parts(p.part, dw, (long)wsz, (long)wsz, nsplit, accumulate, st);
-  if (rc) return rc;
-  if (db) rc = lotus_reduce_parts(p.bias_part, db, cout, cout, nsplit, accumulate, st);
+  if (direct) return LOTUS_OK;
+  if (db && db == dw + wsz) return lotus_reduce_parts(p.part, dw, (long)slab, (long)slab, nsplit, accumulate, st);
+  int rc = lotus_reduce_parts(p.part, dw, (long)wsz, (long)slab, nsplit, accumulate, st);
+  if (!rc && db) rc = lotus_reduce_parts(p.part + wsz, db, cout, (long)slab, nsplit, accumulate, st);
   return rc;
 }
 

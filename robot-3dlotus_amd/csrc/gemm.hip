@@ -24,7 +24,8 @@ struct GemmP {
   int dact;  // derivative code used with mulpre
   int klen;          // K range per blockIdx.z (multiple of BK)
   long part_stride;  // C += z * part_stride when gridDim.z > 1
-  float* bias_part;  // wgrad: [gridDim.z][M] column sums of dY
+  float* bias_part;  // wgrad: column sums of dY, slice z at bias_part + z * bias_stride
+  long bias_stride;
   int a_vec, b_vec;  // 16-byte vector loads allowed
   // output dropout (applied after act, before residual): keep iff hash >= thresh
   unsigned long long drop_seed;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int tm = 0; tm < TM; ++tm) {
         float s = asum[tm] + __shfl_xor(asum[tm], 32, 64);
         const int i = m0 + wr0 + tm * 32 + (tid & 31);
-        if ((tid & 32) == 0 && i < p.M) p.bias_part[(long)blockIdx.z * p.M + i] = s;
+        if ((tid & 32) == 0 && i < p.M) p.bias_part[(long)blockIdx.z * p.bias_stride + i] = s;
       }
     }
   }
@@ -250,46 +251,50 @@ int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* 
   return launch_gemm<true, false, false>(p, 1, (hipStream_t)stream);
 }
 
-size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
-  // worst case 64 splits of [N][K] + [N]
+static int wgrad_splits(int M, int N, int K) {
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
   while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
-  return (size_t)nz * ((size_t)N * K + N) * sizeof(float);
+  return nz;
+}
+
+size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
+  return (size_t)wgrad_splits(M, N, K) * ((size_t)N * K + N) * sizeof(float);
 }
 
 // dw (+)= dy^T x ; db (+)= colsum(dy).   dy [M,N], x [M,K], dw [N,K], db [N] (optional).
+// When db == dw + N*K (one contiguous [N*K + N] gradient buffer) the split-K partials of both are
+// summed by a single launch; with one split and accumulate == 0 the GEMM writes dw/db directly.
 int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  int nz = 1;
-  const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
-  while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
-  const size_t need = (size_t)nz * ((size_t)N * K + N) * sizeof(float);
-  LOTUS_CHECK_ARG(workspace && workspace_bytes >= need, "lotus_linear_wgrad: workspace too small (%zu < %zu)",
-                  workspace_bytes, need);
+  const int nz = wgrad_splits(M, N, K);
+  const size_t slab = (size_t)N * K + N;
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)nz * slab * sizeof(float),
+                  "lotus_linear_wgrad: workspace too small (%zu < %zu)", workspace_bytes, (size_t)nz * slab * sizeof(float));
+  const bool direct = nz == 1 && !accumulate;
   float* part = (float*)workspace;
-  float* bpart = part + (size_t)nz * N * K;
   GemmP p;
   memset(&p, 0, sizeof(p));
-  p.A = dy; p.B = x; p.C = part; p.M = N; p.N = K; p.K = M;
+  p.A = dy; p.B = x; p.M = N; p.N = K; p.K = M;
   p.lda = N; p.ldb = K; p.ldc = K;
-  p.klen = cdiv(cdiv(M, nz), LOTUS_BK) * LOTUS_BK;
-  if (p.klen == 0) p.klen = LOTUS_BK;
-  p.part_stride = (long)N * K;
-  p.bias_part = db ? bpart : nullptr;
+  p.klen = cdiv(cdiv(M > 0 ? M : 1, nz), LOTUS_BK) * LOTUS_BK;
   p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K);
   set_drop(p, 0.f, 0);
+  if (direct) {
+    p.C = dw; p.bias_part = db;
+  } else {
+    p.C = part; p.part_stride = (long)slab;
+    p.bias_part = db ? part + (size_t)N * K : nullptr; p.bias_stride = (long)slab;
+  }
   int rc = launch_gemm<false, false, true>(p, nz, st);
-  if (rc) return rc;
+  if (rc || direct) return rc;
   const long n = (long)N * K;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, dw, n, n, nz, accumulate);
-  if (db)
-    hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, bpart, db, (long)N, (long)N, nz,
-                       accumulate);
-  LOTUS_LAUNCH_CHECK("lotus_linear_wgrad");
-  return LOTUS_OK;
+  if (db && db == dw + n) return lotus_reduce_parts(part, dw, (long)slab, (long)slab, nz, accumulate, st);
+  rc = lotus_reduce_parts(part, dw, n, (long)slab, nz, accumulate, st);
+  if (!rc && db) rc = lotus_reduce_parts(part + n, db, (long)N, (long)slab, nz, accumulate, st);
+  return rc;
 }
 
 }  // extern "C"

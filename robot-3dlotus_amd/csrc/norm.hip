@@ -156,16 +156,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   }
 }
 
-// out[which][c] (+)= sum_b part[b][which][c]
-__global__ void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0, float* __restrict__ o1,
-                                      int nb, int C, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= 2 * C) return;
-  const int which = c / C, col = c % C;
+// out[which][c] (+)= sum_b part[b][which][c]; block = 32 columns x 8 row lanes, fixed-order tree
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0,
+                                                             float* __restrict__ o1, int nb, int C, int accumulate) {
+  __shared__ float red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[((long)b * 2 + which) * C + col];
-  float* o = which ? o1 : o0;
-  if (o) o[col] = accumulate ? o[col] + s : s;
+  if (c < 2 * C)
+    for (int b = r; b < nb; b += 8) s += part[(long)b * 2 * C + c];
+  red[r][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r == 0 && c < 2 * C) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    const int which = c / C, col = c % C;
+    float* o = which ? o1 : o0;
+    if (o) o[col] = accumulate ? o[col] + t : t;
+  }
 }
 
 static int ln_geometry(int C, int* LPR, int* NV) {
@@ -253,14 +260,21 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
   }
 }
 
-__global__ void bn_part_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums, int nb, int C,
-                                      int M) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0) sums[2 * C] = (double)M;  // local row count travels with the sums (SyncBN all-reduce)
-  if (c >= 2 * C) return;
+__global__ __launch_bounds__(256) void bn_part_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                                             int nb, int C, int M) {
+  __shared__ double red[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+  if (blockIdx.x == 0 && threadIdx.x == 0) sums[2 * C] = (double)M;  // local row count travels with the sums
   double s = 0;
-  for (int b = 0; b < nb; ++b) s += part[(long)b * 2 * C + c];
-  sums[c] = s;
+  if (c < 2 * C)
+    for (int b = r; b < nb; b += 8) s += part[(long)b * 2 * C + c];
+  red[r][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r == 0 && c < 2 * C) {
+    double t = 0;
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    sums[c] = t;
+  }
 }
 
 // sums = (sum x, sum x^2, count), already all-reduced across ranks when SyncBN.
@@ -397,7 +411,7 @@ int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
                   "lotus_layernorm_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * 2 * C * sizeof(float), st, p);
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, dgamma, dbeta, grid, C,
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, dgamma, dbeta, grid, C,
                      accumulate);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd");
   return LOTUS_OK;
@@ -417,7 +431,7 @@ int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* work
   p.x = x; p.part = (double*)workspace; p.M = M; p.C = C;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
-  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_stats");
   return LOTUS_OK;
 }
@@ -470,7 +484,7 @@ int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean
   p.part = (double*)workspace; p.M = M; p.C = C; p.act = act;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
-  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats");
   return LOTUS_OK;
 }

@@ -53,8 +53,9 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
 def linear_wgrad(dy, x, need_bias=True):
     M, N = dy.shape
     K = x.shape[1]
-    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    db = torch.empty(N, dtype=torch.float32, device=dy.device) if need_bias else None
+    buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
+    dw = buf[:N * K].view(N, K)              # one contiguous gradient slab -> a single split-K reduce launch
+    db = buf[N * K:] if need_bias else None
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
@@ -102,8 +103,10 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None):
 def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     n, cout = dy.shape
     cin, T = x.shape[1], nbr.shape[0]
-    dw = torch.empty(w_shape, dtype=torch.float32, device=dy.device)
-    db = torch.empty(cout, dtype=torch.float32, device=dy.device) if need_bias else None
+    nw = cout * T * cin
+    buf = torch.empty(nw + (cout if need_bias else 0), dtype=torch.float32, device=dy.device)
+    dw = buf[:nw].view(w_shape)
+    db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
     ws = _ws(nbytes, dy.device)
     call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
