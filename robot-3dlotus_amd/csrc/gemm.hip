@@ -33,13 +33,18 @@ struct GemmP {
   float drop_inv_keep;
 };
 
-template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A>
+// FAST: operands are 16-byte aligned with ld % 4 == 0 and the contiguous extents are multiples of 4,
+// so every global access is an unconditional float4 (rows / columns beyond the edge are clamped to a
+// valid address; k beyond the split range is zeroed by a select).  !FAST keeps per-element guards
+// (odd widths such as the 90- and 217-wide head layers).
+template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * LOTUS_BK / 4 / 256, B4 = BN * LOTUS_BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
-  __shared__ float As[LdsTile<BM, A_KC>::kFloats];
-  __shared__ float Bs[LdsTile<BN, B_KC>::kFloats];
+  constexpr int AF = LdsTile<BM, A_KC>::kFloats, BF = LdsTile<BN, B_KC>::kFloats;
+  __shared__ __attribute__((aligned(16))) float As[2 * AF];
+  __shared__ __attribute__((aligned(16))) float Bs[2 * BF];
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -59,16 +64,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
   float4 ra[A4], rb[B4];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int k0) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
       if (A_KC) {
         const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
-        ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
+        if (FAST) {
+          const int k = k0 + kq * 4;
+          const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4));
+          ra[t] = k < kend ? v : z4;
+        } else {
+          ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
+        }
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
-        ra[t] = load4_guard(p.A, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
+        if (FAST) {
+          const int k = k0 + kr;
+          const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
+          ra[t] = k < kend ? v : z4;
+        } else {
+          ra[t] = load4_guard(p.A, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
+        }
       }
     }
 #pragma unroll
@@ -76,14 +94,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int f = tid + t * 256;
       if (B_KC) {
         const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
-        rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
+        if (FAST) {
+          const int k = k0 + kq * 4;
+          const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4));
+          rb[t] = k < kend ? v : z4;
+        } else {
+          rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
+        }
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
-        rb[t] = load4_guard(p.B, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
+        if (FAST) {
+          const int k = k0 + kr;
+          const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
+          rb[t] = k < kend ? v : z4;
+        } else {
+          rb[t] = load4_guard(p.B, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
+        }
       }
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](float* Ad, float* Bd) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
@@ -91,10 +121,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       if (A_KC) {
         const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) As[LdsTile<BM, true>::idx(row, kq * 4 + e)] = v[e];
+        for (int e = 0; e < 4; ++e) Ad[LdsTile<BM, true>::idx(row, kq * 4 + e)] = v[e];
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
-        *reinterpret_cast<float4*>(&As[kr * BM + iq * 4]) = ra[t];
+        *reinterpret_cast<float4*>(&Ad[kr * BM + iq * 4]) = ra[t];
       }
     }
 #pragma unroll
@@ -104,27 +134,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       if (B_KC) {
         const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Bs[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
+        for (int e = 0; e < 4; ++e) Bd[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[kr * BN + jq * 4]) = rb[t];
+        *reinterpret_cast<float4*>(&Bd[kr * BN + jq * 4]) = rb[t];
       }
     }
   };
 
+  // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs
   if (kbeg < kend) {
     gload(kbeg);
-    lstore();
+    lstore(As, Bs);
     __syncthreads();
+    int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += LOTUS_BK) {
-      const bool more = k0 + LOTUS_BK < kend;
-      if (more) gload(k0 + LOTUS_BK);
-      mma_slab<BM, BN, A_KC, B_KC, SUM_A>(As, Bs, wr0, wc0, acc, asum);
+      gload(k0 + LOTUS_BK);  // past-the-end prefetch is clamped / zeroed and never consumed
+      mma_slab<BM, BN, A_KC, B_KC, SUM_A>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      cur ^= 1;
+      lstore(As + cur * AF, Bs + cur * BF);
       __syncthreads();
-      if (more) {
-        lstore();
-        __syncthreads();
-      }
     }
   }
 
@@ -182,23 +211,33 @@ int lotus_reduce_parts(const float* part, float* out, long n, long stride, int n
 
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
-template <bool A_KC, bool B_KC, bool SUM_A>
-static int launch_gemm(GemmP& p, int nz, hipStream_t st) {
+template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
+static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
   const bool small_n = p.N <= 64;
   dim3 block(256);
   if (!small_n && blocks128 * nz >= 192) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else if (small_n && (long)cdiv(p.M, 128) * nz >= 192) {
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
-    hipLaunchKernelGGL((gemm_kernel<128, 64, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<128, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else {
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    hipLaunchKernelGGL((gemm_kernel<64, 64, A_KC, B_KC, SUM_A>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_gemm");
   return LOTUS_OK;
+}
+
+template <bool A_KC, bool B_KC, bool SUM_A>
+static int launch_gemm(GemmP& p, int nz, hipStream_t st) {
+  // FAST needs float4-safe extents on both operands: the contiguous dimension must be a multiple of 4
+  // (K for k-contiguous operands, M / N otherwise) and at least 4 wide
+  const bool a_ok = p.a_vec && (A_KC ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4));
+  const bool b_ok = p.b_vec && (B_KC ? (p.K % 4 == 0 && p.K >= 4) : (p.N % 4 == 0 && p.N >= 4));
+  if (a_ok && b_ok && p.M >= 1 && p.N >= 1 && p.K >= 1) return launch_gemm_t<A_KC, B_KC, SUM_A, true>(p, nz, st);
+  return launch_gemm_t<A_KC, B_KC, SUM_A, false>(p, nz, st);
 }
 
 static void set_drop(GemmP& p, float drop_p, unsigned long long seed) {
