@@ -89,9 +89,14 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
 
 /* ---- submanifold sparse convolution (spconv.SubMConv3d, model.py:615-622, :844-853) -------- */
 /* mode 0 fwd: y[n][cout] = sum_t W[:,t,:] x[nbr[t][.]] + bias (+ add); mode 1 dgrad: x = dy, y = dx.
- * w is (cout, k, k, k, cin) row-major; rowidx (optional) = processing order of the rows. */
-int lotus_subm_conv(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
-                    const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* stream);
+ * w is (cout, k, k, k, cin) row-major; rowidx (optional) = processing order of the rows.  w_t
+ * (optional, from lotus_conv_weight_transpose) and workspace (optional) enable the pair-compacted,
+ * tap-split fast path for the 3^3 convolutions. */
+size_t lotus_subm_conv_workspace(int n, int cin, int cout);
+int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream);
+int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
+                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+                    size_t workspace_bytes, void* stream);
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout);
 int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
                           int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,

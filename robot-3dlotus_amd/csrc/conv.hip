@@ -14,8 +14,11 @@
 #include "mma.h"
 
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);
-int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
-                         const int* nbr, const int* rowidx, int n, int T, int cin, int cout, hipStream_t st, int* rc);
+int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
+                         float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+                         size_t workspace_bytes, hipStream_t st, int* rc);
+size_t lotus_conv_pairs_workspace(int n, int ND);
+int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, hipStream_t st);
 
 struct ConvP {
   const float* x;   // [n][KD] gathered operand (features, or dy for dgrad)
@@ -285,14 +288,29 @@ static size_t conv_dyn_lds(int T, int BM) { return (size_t)(T * BM + 2 * T) * si
 
 extern "C" {
 
+size_t lotus_subm_conv_workspace(int n, int cin, int cout) {
+  const size_t a = lotus_conv_pairs_workspace(n, cout), b = lotus_conv_pairs_workspace(n, cin);
+  return a > b ? a : b;
+}
+
+// w_t [cin][T][cout] = transpose of w [cout][T][cin] (coalesced weight fragments for mode 0)
+int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream) {
+  LOTUS_CHECK_ARG(w && w_t && cout > 0 && T > 0 && cin > 0, "lotus_conv_weight_transpose: bad arguments");
+  return lotus_conv_weight_transpose_impl(w, w_t, cout, T, cin, (hipStream_t)stream);
+}
+
 // mode 0: fwd  (x [n][cin]  -> y [n][cout]);  mode 1: dgrad (x = dy [n][cout] -> y = dx [n][cin]).
-int lotus_subm_conv(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
-                    const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* stream) {
+// w_t (optional, mode 0) and workspace (optional) enable the pair-compacted tap-split fast path.
+int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
+                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+                    size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
   if (n == 0) return LOTUS_OK;
   {
     int rc = 0;  // pair-compacted fast path (conv_pairs.hip) for the 3^3 CPE convolutions
-    if (lotus_conv_pairs_try(mode, x, w, bias, add, y, nbr, rowidx, n, T, cin, cout, (hipStream_t)stream, &rc)) return rc;
+    if (lotus_conv_pairs_try(mode, x, w, w_t, bias, add, y, nbr, rowidx, n, T, cin, cout, workspace, workspace_bytes,
+                             (hipStream_t)stream, &rc))
+      return rc;
   }
   ConvP p;
   memset(&p, 0, sizeof(p));

@@ -15,16 +15,20 @@
 
 struct ConvP2 {
   const float* x;    // [n][KD]
-  const float* w;    // [cout][T][cin]
-  float* y;          // [n][ND]
+  const float* w;    // B operand: element (k, tap, j) at w[k * wld + tap * tapw + j]  (j contiguous)
+  float* y;          // [n][ND]  (or partial slabs [nz][n][ND] when tap-split)
   const float* bias;
   const float* add;
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] or null
-  int n, T, cin, cout, KD, ND, mirror;
+  long wld;
+  int tapw;
+  int n, T, KD, ND, mirror;
+  int tpz;           // taps per blockIdx.z
+  long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
 };
 
-template <int NCS, int BM, bool FWD>
+template <int NCS, int BM>
 __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   constexpr int NRT = 4 / NCS;          // row tiles per block
   constexpr int KC = NCS == 4 ? 32 : 16;  // reduction chunk staged per iteration
@@ -48,6 +52,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   const int gt = tid - rt * GT;  // thread index inside the row tile's gather team
   const int n0 = blockIdx.x * NW;
   const int m0 = (blockIdx.y * NRT + rt) * BM;
+  const int t_beg = blockIdx.z * p.tpz, t_end = min(p.T, t_beg + p.tpz);
 
   for (int i = tid; i < NRT * BM * NW; i += 256) out_s[i] = 0.f;
   for (int r = gt; r < BM; r += GT) {
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   }
   __syncthreads();
   // per-tap ordered compaction of the active pairs of this row tile (wave ballot + popcount)
-  for (int t = cs; t < p.T; t += NCS) {
+  for (int t = t_beg + cs; t < t_end; t += NCS) {
     int base = 0;
     for (int r0 = 0; r0 < BM; r0 += 64) {
       const int r = r0 + lane;
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   __syncthreads();
   if (gt == 0) {
     int c = 0;
-    for (int t = 0; t < p.T; ++t)
+    for (int t = t_beg; t < t_end; ++t)
       if (cnt_s[rt * MAXT + t] > 0) act_s[rt * MAXT + c++] = t;
     nact_s[rt] = c;
   }
@@ -85,7 +90,6 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   int max_iters = 0;
 #pragma unroll
   for (int q = 0; q < NRT; ++q) max_iters = max(max_iters, nact_s[q] * nkc);
-  const long wld = (long)p.T * p.cin;
 
   f32x16 acc[TG];
 #pragma unroll
@@ -109,18 +113,10 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
       if (row < cnt) ga[q] = *reinterpret_cast<const float4*>(p.x + (long)src_s[(rt * MAXT + t) * BM + row] * p.KD + k0 + kq * 4);
     }
     const int tw = p.mirror ? (p.T - 1 - t) : t;
-    if (FWD) {  // B(k, j) = w[n0 + cs*32 + j][tw][k0 + k]  : contiguous run of KC/2 floats per lane
-      const float* wp = p.w + (long)(n0 + cs * 32 + l31) * wld + (long)tw * p.cin + k0 + hh * (KC / 2);
+    // B(k, j): lanes j read consecutive floats (coalesced 128 B per half-wave and k)
+    const float* wp = p.w + (long)(k0 + hh * (KC / 2)) * p.wld + (long)tw * p.tapw + n0 + cs * 32 + l31;
 #pragma unroll
-      for (int s4 = 0; s4 < KC / 8; ++s4) {
-        const float4 v = *reinterpret_cast<const float4*>(wp + s4 * 4);
-        bnxt[s4 * 4 + 0] = v.x; bnxt[s4 * 4 + 1] = v.y; bnxt[s4 * 4 + 2] = v.z; bnxt[s4 * 4 + 3] = v.w;
-      }
-    } else {    // B(k, j) = w[k0 + k][tw][n0 + cs*32 + j]
-      const float* wp = p.w + (long)(k0 + hh * (KC / 2)) * wld + (long)tw * p.cin + n0 + cs * 32 + l31;
-#pragma unroll
-      for (int s = 0; s < KC / 2; ++s) bnxt[s] = wp[(long)s * wld];
-    }
+    for (int s = 0; s < KC / 2; ++s) bnxt[s] = wp[(long)s * p.wld];
   };
   auto stage = [&](int buf) {  // gathered registers -> LDS image [BM][KC+1]
     float* dst = my_a + buf * BM * (KC + 1);
@@ -178,23 +174,65 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
     }
     __syncthreads();
   }
-  // epilogue: coalesced row stores
+  // epilogue: coalesced row stores (final result, or this tap group's partial slab)
+  const bool final_out = p.part_stride == 0;
+  float* yo = p.y + (long)blockIdx.z * p.part_stride;
   for (int i = gt; i < BM * (NW / 4); i += GT) {
     const int r = i / (NW / 4), c4 = i % (NW / 4);
     const int pr = prow_s[rt * BM + r];
     if (pr < 0) continue;
     float4 v = *reinterpret_cast<const float4*>(out_s + (rt * BM + r) * NW + c4 * 4);
     const int col = n0 + c4 * 4;
-    if (p.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
-      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
-    }
     const long o = (long)pr * p.ND + col;
-    if (p.add) {
-      const float4 a = *reinterpret_cast<const float4*>(p.add + o);
-      v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+    if (final_out) {
+      if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (p.add) {
+        const float4 a = *reinterpret_cast<const float4*>(p.add + o);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
     }
-    *reinterpret_cast<float4*>(p.y + o) = v;
+    *reinterpret_cast<float4*>(yo + o) = v;
+  }
+}
+
+// y = sum_z part[z] + bias + add   (fixed order -> deterministic)
+__global__ void conv_part_reduce_kernel(const float* __restrict__ part, long stride, int nz, const float* __restrict__ bias,
+                                        const float* __restrict__ add, float* __restrict__ y, long total4, int nd4) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(part)[i];
+    for (int z = 1; z < nz; ++z) {
+      const float4 v = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (bias) {
+      const float4 b = reinterpret_cast<const float4*>(bias)[i % nd4];
+      s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+    }
+    if (add) {
+      const float4 a = reinterpret_cast<const float4*>(add)[i];
+      s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    reinterpret_cast<float4*>(y)[i] = s;
+  }
+}
+
+// wt[ci][t][co] = w[co][t][ci]   (32x32 LDS tile transpose per tap)
+__global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int T,
+                                                      int cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < cout && ci < cin) ? w[((long)co * T + t) * cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < cin && co < cout) wt[((long)ci * T + t) * cout + co] = tile[tx][r];
   }
 }
 
@@ -205,33 +243,62 @@ static size_t pairs_smem() {
          (size_t)NRT * MAXT * BM;
 }
 
-template <int NCS, int BM, bool FWD>
-static int launch_pairs(const ConvP2& p, hipStream_t st) {
+static int tap_splits(int n, int ND) {
+  const long base = (long)cdiv(n, 128) * (ND <= 64 ? 1 : ND / 128);
+  int nz = 1;
+  while (nz < 9 && base * nz < 384) nz = nz == 1 ? 3 : 9;  // 27 taps -> 1, 3 or 9 groups
+  return nz;
+}
+
+template <int NCS, int BM>
+static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
   constexpr int NRT = 4 / NCS;
   const size_t sm = pairs_smem<NCS, BM>();
-  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, BM, FWD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  dim3 grid(p.ND / (32 * NCS), cdiv(p.n, BM * NRT));
-  hipLaunchKernelGGL((conv_pairs_kernel<NCS, BM, FWD>), grid, dim3(256), sm, st, p);
+  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  dim3 grid(p.ND / (32 * NCS), cdiv(p.n, BM * NRT), nz);
+  hipLaunchKernelGGL((conv_pairs_kernel<NCS, BM>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
 
-// returns 1 if the pair-compacted path handled the call, 0 if the shape is not eligible
-int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* bias, const float* add, float* y,
-                         const int* nbr, const int* rowidx, int n, int T, int cin, int cout, hipStream_t st, int* rc) {
+size_t lotus_conv_pairs_workspace(int n, int ND) {
+  const int nz = tap_splits(n, ND);
+  return nz > 1 ? (size_t)nz * n * ND * sizeof(float) : 0;
+}
+
+int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, hipStream_t st) {
+  hipLaunchKernelGGL(conv_wt_kernel, dim3(cdiv(cin, 32), cdiv(cout, 32), T), dim3(256), 0, st, w, wt, cout, T, cin);
+  LOTUS_LAUNCH_CHECK("lotus_conv_weight_transpose");
+  return LOTUS_OK;
+}
+
+// returns 1 if the pair-compacted path handled the call, 0 if the shape is not eligible.
+// mode 0 needs the transposed weights w_t [cin][T][cout]; mode 1 uses w [cout][T][cin] directly.
+int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
+                         float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+                         size_t workspace_bytes, hipStream_t st, int* rc) {
   const int KD = mode == 0 ? cin : cout, ND = mode == 0 ? cout : cin;
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
+  if (mode == 0 && !w_t) return 0;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16) return 0;
+  const int nz = tap_splits(n, ND);
+  if (nz > 1 && (!workspace || workspace_bytes < (size_t)nz * n * ND * sizeof(float))) return 0;
   ConvP2 p;
-  p.x = x; p.w = w; p.y = y; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
-  p.n = n; p.T = T; p.cin = cin; p.cout = cout; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
-  const bool small = (long)cdiv(n, 128) * cdiv(ND, 128) < 400;  // fewer than ~1.5 blocks per CU: use smaller row tiles
-  if (ND == 64) {
-    *rc = mode == 0 ? launch_pairs<2, 128, true>(p, st) : launch_pairs<2, 128, false>(p, st);
-  } else if (small) {
-    *rc = mode == 0 ? launch_pairs<4, 64, true>(p, st) : launch_pairs<4, 64, false>(p, st);
-  } else {
-    *rc = mode == 0 ? launch_pairs<4, 128, true>(p, st) : launch_pairs<4, 128, false>(p, st);
+  p.x = x; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
+  p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
+  if (mode == 0) { p.w = w_t; p.wld = (long)T * cout; p.tapw = cout; }
+  else           { p.w = w;   p.wld = (long)T * cin;  p.tapw = cin; }
+  p.tpz = cdiv(T, nz);
+  p.y = nz > 1 ? (float*)workspace : y;
+  p.part_stride = nz > 1 ? (long)n * ND : 0;
+  *rc = ND == 64 ? launch_pairs<2, 128>(p, nz, st) : launch_pairs<4, 128>(p, nz, st);
+  if (*rc == 0 && nz > 1) {
+    const long total4 = (long)n * ND / 4;
+    int g = cdiv(total4, 256);
+    hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, (const float*)workspace,
+                       (long)n * ND, nz, bias, add, y, total4, ND / 4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { lotus_set_error("conv_part_reduce: %s", hipGetErrorString(e)); *rc = LOTUS_E_LAUNCH; }
   }
   return 1;
 }

@@ -84,11 +84,26 @@ def ln_bwd(dy, x, mean, rstd, g, add=None):
     return dx, dg, db
 
 
-def conv_fwd(x, w, b, nbr, rowidx, add=None):
+def conv_weight_t(w):
+    """[cout, k,k,k, cin] -> [cin, T, cout] copy (coalesced weight fragments for the forward conv)."""
+    cout, cin = w.shape[0], w.shape[-1]
+    T = w.numel() // (cout * cin)
+    wt = torch.empty(cin, T, cout, dtype=torch.float32, device=w.device)
+    call("lotus_conv_weight_transpose", w, wt, cout, T, cin)
+    return wt
+
+
+def _conv_ws(n, cin, cout, dev):
+    nbytes = query("lotus_subm_conv_workspace", n, cin, cout)
+    return WS.get(nbytes, dev, slot=2) if nbytes else None
+
+
+def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None):
     n, cin = x.shape
     cout, T = w.shape[0], nbr.shape[0]
     y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
-    call("lotus_subm_conv", 0, x, w, b, add, y, nbr, rowidx, n, T, cin, cout)
+    ws = _conv_ws(n, cin, cout, x.device) if T == 27 else None
+    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, ws, ws.numel() if ws is not None else 0)
     return y
 
 
@@ -96,7 +111,9 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None):
     n, cout = dy.shape
     cin, T = w.shape[-1], nbr.shape[0]
     dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
-    call("lotus_subm_conv", 1, dy, w, None, add, dx, nbr, rowidx, n, T, cin, cout)
+    ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
+    call("lotus_subm_conv", 1, dy, w, None, None, add, dx, nbr, rowidx, n, T, cin, cout, ws,
+         ws.numel() if ws is not None else 0)
     return dx
 
 
@@ -194,7 +211,7 @@ class CpeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl):
         same = xs is x
-        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0])
+        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=conv_weight_t(cw))
         l, _ = linear_fwd(c, lw, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
         ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd)

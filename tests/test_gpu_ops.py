@@ -149,6 +149,9 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
     yref = om.subm_conv(xd, nbr_ref, wd, bd)
     y = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0])
     _close(y, yref, 3e-6, "conv fwd")
+    if k == 3:
+        y2 = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0], w_t=ops.conv_weight_t(w.cuda()))
+        _close(y2, yref, 3e-6, "conv fwd (pair-compacted, transposed weights)")
     yref.backward(dy.double())
     if cin == cout:
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, got[0].order[0])
