@@ -76,12 +76,14 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
 /* nn.Linear (+GELU/LeakyReLU, +Dropout, +residual): y = dropout(act(x w^T + bias)) + residual;
  * `pre` (optional) receives x w^T + bias.  Call sites: model.py:386-387,572-574,623,707,804-805;
  * model_ca.py:27-31; simple_policy_ptv3.py:40-68,387. */
+size_t lotus_linear_workspace(int M, int N, int K); /* optional split-K scratch for fwd / dgrad */
 int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                      float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 /* dx = (dy w) * act'(pre) * dropmask + add : chain rule through the producer of this layer's input */
 int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
-                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* stream);
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* workspace,
+                       size_t workspace_bytes, void* stream);
 size_t lotus_linear_wgrad_workspace(int M, int N, int K);
 /* dw (+)= dy^T x, db (+)= colsum(dy); deterministic split-K */
 int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,

@@ -43,8 +43,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int A4 = BM * LOTUS_BK / 4 / 256, B4 = BN * LOTUS_BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
   constexpr int AF = LdsTile<BM, A_KC>::kFloats, BF = LdsTile<BN, B_KC>::kFloats;
-  __shared__ __attribute__((aligned(16))) float As[2 * AF];
-  __shared__ __attribute__((aligned(16))) float Bs[2 * BF];
+  constexpr int WN = BN / 2, SLD = WN + 4;  // epilogue staging: per wave [32][WN + 4]
+  constexpr int LDSF = (2 * AF + 2 * BF) > (4 * 32 * SLD) ? (2 * AF + 2 * BF) : (4 * 32 * SLD);
+  __shared__ __attribute__((aligned(16))) float smem[LDSF];
+  float* As = smem;
+  float* Bs = smem + 2 * AF;
 
   const int tid = threadIdx.x, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -159,27 +162,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   // ---- epilogue
   float* __restrict__ C = p.C + (long)blockIdx.z * p.part_stride;
+  if (FAST) {
+    // Stage each wave's 32 x WN sub-tile through LDS and leave as float4 rows: 16 B per lane loads of
+    // residual / pre-activation and 16 B stores (4 B-per-lane stores ran at ~1 TB/s, 4x below HBM).
+    float* st = smem + wave * (32 * SLD);
+    const int l31 = tid & 31, hh = (tid >> 5) & 1, lane = tid & 63;
+    constexpr int LPR = WN / 4;         // lanes per row
+    constexpr int RPI = 64 / LPR;       // rows per wave-instruction
+    __syncthreads();                    // every wave is done with the operand images
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm)
+    for (int tm = 0; tm < TM; ++tm) {
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int col = n0 + acc_col(wc0, tn);
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + acc_row(wr0, tm, r);
-        if (row >= p.M) continue;
-        const long o = (long)row * p.ldc + col;
-        float v = acc[tm][tn][r] + bv;
-        if (p.pre) p.pre[o] = v;
-        v = act_f(v, p.act);
-        if (p.mulpre) v *= act_grad_f(p.mulpre[o], p.dact);
-        if (p.drop_thresh) v *= dropout_scale(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep);
-        if (p.residual) v += p.residual[o];
-        C[o] = v;
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + 4 * hh) * SLD + tn * 32 + l31] = acc[tm][tn][r];
+      __syncthreads();
+      const int c4 = lane % LPR;
+      const int col = n0 + wc0 + c4 * 4;
+      if (col < p.N) {
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int rl = it * RPI + lane / LPR;
+          const int row = m0 + wr0 + tm * 32 + rl;
+          if (row < p.M) {
+            const long o = (long)row * p.ldc + col;
+            const float4 a4 = *reinterpret_cast<const float4*>(st + rl * SLD + c4 * 4);
+            float v[4] = {a4.x + bv.x, a4.y + bv.y, a4.z + bv.z, a4.w + bv.w};
+            if (p.pre) *reinterpret_cast<float4*>(p.pre + o) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.act != LOTUS_ACT_NONE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+            }
+            if (p.mulpre) {
+              const float4 m4 = *reinterpret_cast<const float4*>(p.mulpre + o);
+              const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
+            }
+            if (p.drop_thresh) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
+            }
+            if (p.residual) {
+              const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
+              v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
       }
+      __syncthreads();
     }
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const int col = n0 + acc_col(wc0, tn);
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + acc_row(wr0, tm, r);
+          if (row >= p.M) continue;
+          const long o = (long)row * p.ldc + col;
+          float v = acc[tm][tn][r] + bv;
+          if (p.pre) p.pre[o] = v;
+          v = act_f(v, p.act);
+          if (p.mulpre) v *= act_grad_f(p.mulpre[o], p.dact);
+          if (p.drop_thresh) v *= dropout_scale(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep);
+          if (p.residual) v += p.residual[o];
+          C[o] = v;
+        }
+      }
+  }
   if (SUM_A) {
     if (p.bias_part && blockIdx.x == 0 && (wave & 1) == 0) {
 #pragma unroll
@@ -192,19 +250,40 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 }
 
-// out[e] = sum_z part[z * stride + e]
-__global__ void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long n, long stride,
-                                    int nz, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int z = 0; z < nz; ++z) s += part[(long)z * stride + i];
-  out[i] = accumulate ? out[i] + s : s;
+// out[e] = sum_z part[z * stride + e].  Block = 16 float4 columns x 16 z-lanes: coalesced 256-byte row
+// segments per z, 16 independent partial sums per column, fixed-order LDS tree -> deterministic.
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+                                                           long stride, int nz, int accumulate) {
+  __shared__ float4 red[16][16];
+  const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const long e = ((long)blockIdx.x * 16 + q) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e + 3 < n) {
+    for (int z = zl; z < nz; z += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long)z * stride + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  } else if (e < n) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int z = zl; z < nz; z += 16)
+      for (int k = 0; k < 4 && e + k < n; ++k) t[k] += part[(long)z * stride + e + k];
+    s = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  red[zl][q] = s;
+  __syncthreads();
+  if (zl == 0 && e < n) {
+    float4 t = red[0][q];
+    for (int k = 1; k < 16; ++k) {
+      t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w;
+    }
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int k = 0; k < 4 && e + k < n; ++k) out[e + k] = accumulate ? out[e + k] + tv[k] : tv[k];
+  }
 }
 
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st) {
   if (n <= 0) return LOTUS_OK;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_reduce_parts");
   return LOTUS_OK;
 }
@@ -236,7 +315,10 @@ static int launch_gemm(GemmP& p, int nz, hipStream_t st) {
   // (K for k-contiguous operands, M / N otherwise) and at least 4 wide
   const bool a_ok = p.a_vec && (A_KC ? (p.K % 4 == 0 && p.K >= 4) : (p.M % 4 == 0 && p.M >= 4));
   const bool b_ok = p.b_vec && (B_KC ? (p.K % 4 == 0 && p.K >= 4) : (p.N % 4 == 0 && p.N >= 4));
-  if (a_ok && b_ok && p.M >= 1 && p.N >= 1 && p.K >= 1) return launch_gemm_t<A_KC, B_KC, SUM_A, true>(p, nz, st);
+  const bool c_ok = p.N % 4 == 0 && p.ldc % 4 == 0 && p.part_stride % 4 == 0 && vec_ok(p.C, p.ldc) &&
+                    (!p.bias || ((uintptr_t)p.bias) % 16 == 0) && (!p.residual || ((uintptr_t)p.residual) % 16 == 0) &&
+                    (!p.pre || ((uintptr_t)p.pre) % 16 == 0) && (!p.mulpre || ((uintptr_t)p.mulpre) % 16 == 0);
+  if (a_ok && b_ok && c_ok) return launch_gemm_t<A_KC, B_KC, SUM_A, true>(p, nz, st);
   return launch_gemm_t<A_KC, B_KC, SUM_A, false>(p, nz, st);
 }
 
@@ -252,12 +334,84 @@ static void set_drop(GemmP& p, float drop_p, unsigned long long seed) {
   }
 }
 
+// sum of split-K partials + the full epilogue (bias, pre, act, act', dropout, residual), float4 wide
+__global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, long stride, int nz) {
+  const int n4 = p.N / 4;
+  const long total4 = (long)p.M * n4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i / n4), col = (int)(i % n4) * 4;
+    const long o = (long)row * p.ldc + col;
+    float4 s4 = *reinterpret_cast<const float4*>(part + o);
+    for (int z = 1; z < nz; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (long)z * stride + o);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    float v[4] = {s4.x, s4.y, s4.z, s4.w};
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.pre) *reinterpret_cast<float4*>(p.pre + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+    if (p.mulpre) {
+      const float4 m4 = *reinterpret_cast<const float4*>(p.mulpre + o);
+      const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
+    }
+    if (p.drop_thresh) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
+    }
+    if (p.residual) {
+      const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
+      v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+    }
+    *reinterpret_cast<float4*>(p.C + o) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+// Few output tiles but a long reduction (deep levels: M = 361..1450, K up to 3072): split K over
+// blockIdx.z into a workspace and finish with splitk_epilogue_kernel.  Returns the split count.
+static int fwd_splits(int M, int N, int K) {
+  const long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
+  int nz = 1;
+  while (nz < 16 && blocks * nz < 512 && K / (nz * 2) >= 128) nz *= 2;
+  return nz;
+}
+
+template <bool A_KC, bool B_KC>
+static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const int nz = (p.N % 4 == 0 && p.ldc == p.N) ? fwd_splits(p.M, p.N, p.K) : 1;
+  const size_t need = (size_t)nz * p.M * p.N * sizeof(float);
+  if (nz == 1 || !workspace || workspace_bytes < need || ((uintptr_t)workspace) % 16) return launch_gemm<A_KC, B_KC, false>(p, 1, st);
+  GemmP q = p;
+  q.C = (float*)workspace; q.part_stride = (long)p.M * p.N;
+  q.bias = nullptr; q.residual = nullptr; q.pre = nullptr; q.mulpre = nullptr; q.act = LOTUS_ACT_NONE; q.drop_thresh = 0;
+  q.klen = cdiv(cdiv(p.K, nz), LOTUS_BK) * LOTUS_BK;
+  int rc = launch_gemm<A_KC, B_KC, false>(q, nz, st);
+  if (rc) return rc;
+  const long total4 = (long)p.M * p.N / 4;
+  int g = cdiv(total4, 256);
+  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, p, (const float*)workspace,
+                     (long)p.M * p.N, nz);
+  LOTUS_LAUNCH_CHECK("lotus_gemm(split-K epilogue)");
+  return LOTUS_OK;
+}
+
 extern "C" {
 
 // y = dropout(act(x w^T + bias)) + residual ; pre (optional) receives x w^T + bias.
+size_t lotus_linear_workspace(int M, int N, int K) {
+  const int a = fwd_splits(M, N, K), b = fwd_splits(M, K, N);
+  const size_t wa = a > 1 ? (size_t)a * M * N * sizeof(float) : 0, wb = b > 1 ? (size_t)b * M * K * sizeof(float) : 0;
+  return wa > wb ? wa : wb;
+}
+
 int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                      float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
-                     void* stream) {
+                     void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
   if (M == 0) return LOTUS_OK;
   GemmP p;
@@ -268,14 +422,15 @@ int lotus_linear_fwd(const float* x, const float* w, const float* bias, const fl
   p.klen = cdiv(K, LOTUS_BK) * LOTUS_BK;
   p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K);
   set_drop(p, drop_p, drop_seed);
-  return launch_gemm<true, true, false>(p, 1, (hipStream_t)stream);
+  return run_gemm_splitk<true, true>(p, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // dx = (dy w) * act'(pre) * dropmask + add.   dy [M,N], w [N,K], dx/pre/add [M,K].
 // `pre`/`act`/`drop_*` describe the layer that PRODUCED this layer's input (its pre-activation,
 // activation and output dropout), so the chain rule through it is fused into this epilogue.
 int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
-                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* stream) {
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* workspace,
+                       size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
   if (M == 0) return LOTUS_OK;
   GemmP p;
@@ -287,12 +442,13 @@ int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* 
   p.klen = cdiv(N, LOTUS_BK) * LOTUS_BK;
   p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K);
   set_drop(p, drop_p, drop_seed);
-  return launch_gemm<true, false, false>(p, 1, (hipStream_t)stream);
+  return run_gemm_splitk<true, false>(p, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 static int wgrad_splits(int M, int N, int K) {
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
+  // both operands are streamed exactly once: keep >= ~6 blocks per CU in flight (Little's law)
   while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
   return nz;
 }

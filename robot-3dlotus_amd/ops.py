@@ -36,7 +36,9 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
     pre = torch.empty_like(y) if save_pre else None
     if CALL_LOG is not None:
         CALL_LOG.append(("fwd", M, N, K))
-    call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed))
+    nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
+    ws = _ws(nb, x.device) if nb else None
+    call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed), ws, nb)
     return y, pre
 
 
@@ -46,7 +48,9 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
     if CALL_LOG is not None:
         CALL_LOG.append(("dgrad", M, N, K))
-    call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed))
+    nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
+    ws = _ws(nb, dy.device) if nb else None
+    call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed), ws, nb)
     return dx
 
 
