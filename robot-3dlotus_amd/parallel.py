@@ -25,8 +25,9 @@ def init_distributed(backend=None):
         return 0, 0, 1
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = os.environ.get("LOTUS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
+        local = local % torch.cuda.device_count()  # (gloo smoke runs may put several ranks on one device)
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, init_method="env://")
