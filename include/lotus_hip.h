@@ -135,11 +135,13 @@ int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean
 /* flash_attn_varlen_qkvpacked_func (model.py:543-549) and flash_attn_varlen_kvpacked_func
  * (model_ca.py:62-66) with the preceding q_norm/k_norm LayerNorm(d, eps) (model.py:532-533,
  * model_ca.py:52-53), in fp32.  tiles: int32 [ntiles][4] = q_start, q_len, k_start, k_len (<= 128).
- * Row r of q lives at q + r*q_ld + q_off + h*d; k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d. */
+ * Row r of q lives at q + r*q_ld + q_off + h*d; k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d.
+ * drop_p / drop_seed: dropout on the probabilities (flash-attn dropout_p), regenerated in backward. */
 int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
-                        long out_ld, float* lse, int H, int d, float scale, float eps, void* stream);
+                        long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
+                        unsigned long long drop_seed, void* stream);
 size_t lotus_attention_bwd_workspace(int nblocks, int H);
 /* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len */
 int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
@@ -148,7 +150,8 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
-                        int H, int d, float scale, float eps, void* workspace, size_t workspace_bytes, void* stream);
+                        int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pooling, head, losses ---------------------------------------------------------------- */
 /* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */

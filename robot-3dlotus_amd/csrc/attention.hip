@@ -36,7 +36,18 @@ struct AttnP {
   int atomic_out;            // 1: atomicAdd into dq/dkv (self-attention with borrowed rows)
   int H, d;
   float scale, eps;
+  // dropout on the attention probabilities (flash-attn dropout_p, model.py:547 / model_ca.py:64)
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_inv_keep;
 };
+
+// keep/scale factor of probability (tile, head, row, col); 1 when dropout is off
+__device__ __forceinline__ float pmask(const AttnP& p, int tile, int h, int row, int col) {
+  if (!p.drop_thresh) return 1.f;
+  const unsigned long long idx = ((((unsigned long long)tile * p.H + h) * AT + row) * AT) + col;
+  return dropout_scale(p.drop_seed, idx, p.drop_thresh, p.drop_inv_keep);
+}
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
@@ -190,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     sum += __shfl_xor(sum, 1, 64);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     if (row < q_len) {
-      for (int c = c0; c < c1; ++c) srow[c] *= inv;
+      for (int c = c0; c < c1; ++c) srow[c] *= inv * pmask(p, blockIdx.x, h, row, c);
       for (int c = max(c1, c0); c < c0 + 64; ++c) srow[c] = 0.f;  // keys beyond k_len
       if (half == 0 && p.lse) p.lse[(long)(q_start + row) * p.H + h] = m + logf(sum);
     }
@@ -337,7 +348,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
     const int qend = (q_len + 1) & ~1;
     if (r0 < k_len) {
       for (int kk = 0; kk < qend; kk += 2)
-        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31], s.dO[(kk + hh) * ALD + l31], acc_dv, 0, 0, 0);
+        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31] * pmask(p, tile, h, kk + hh, r0 + l31),
+                                                      s.dO[(kk + hh) * ALD + l31], acc_dv, 0, 0, 0);
     }
     // dP = dO V^T  (wave owns query rows)
     f32x16 dp[4];
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
           for (int r = 0; r < 16; ++r) {
             const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float* sp = s.S + row * SLD + t * 32 + l31;
-            *sp = p.scale * (*sp) * (dp[t][r] - s.Dv[row]);
+            *sp = p.scale * (*sp) * (dp[t][r] * pmask(p, tile, h, row, t * 32 + l31) - s.Dv[row]);
           }
         }
     }
@@ -444,6 +456,17 @@ __global__ __launch_bounds__(256) void attn_ln_reduce_kernel(const float* __rest
   }
 }
 
+static void set_attn_drop(AttnP& p, float drop_p, unsigned long long seed) {
+  p.drop_seed = seed;
+  p.drop_thresh = 0;
+  p.drop_inv_keep = 1.f;
+  if (drop_p > 0.f) {
+    p.drop_thresh = (unsigned)(drop_p * 4294967296.0);
+    if (p.drop_thresh == 0) p.drop_thresh = 1;
+    p.drop_inv_keep = 1.f / (1.f - drop_p);
+  }
+}
+
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
 
 extern "C" {
@@ -453,7 +476,8 @@ extern "C" {
 int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
-                        long out_ld, float* lse, int H, int d, float scale, float eps, void* stream) {
+                        long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
+                        unsigned long long drop_seed, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && out && check_geom(H, d) == 0, "lotus_attention_fwd: bad arguments (H=%d d=%d)", H, d);
   if (ntiles == 0) return LOTUS_OK;
   AttnP p;
@@ -462,6 +486,7 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.qidx = qidx; p.kidx = kidx; p.owner = owner; p.tiles = tiles;
   p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
+  set_attn_drop(p, drop_p, drop_seed);
   const size_t sm = attn_smem_bytes(false);
   (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
@@ -480,7 +505,8 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
-                        int H, int d, float scale, float eps, void* workspace, size_t workspace_bytes, void* stream) {
+                        int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
                   "lotus_attention_bwd: bad arguments");
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_attention_bwd_workspace(nblocks, H),
@@ -496,6 +522,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.dkv = dkv; p.dkv_ld = dkv_ld; p.dk_off = dk_off; p.dv_off = dv_off; p.dkv_part_stride = dkv_part_stride;
   p.atomic_out = atomic_out; p.ln_part = (float*)workspace;
   p.H = H; p.d = d; p.scale = scale; p.eps = eps;
+  set_attn_drop(p, drop_p, drop_seed);
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = attn_smem_bytes(true);
   (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);

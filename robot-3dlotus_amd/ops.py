@@ -191,19 +191,21 @@ def bn_bwd(dy, x, mean, invstd, g, b, training, act):
     return dx, dg, db
 
 
-def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d):
+def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d,
+                  drop_p=0.0, seed=0):
     call("lotus_attention_fwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles,
-         qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6)
+         qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6, float(drop_p), int(seed))
 
 
 def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
-                  dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d):
+                  dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d, drop_p=0.0, seed=0):
     dev = q.device
     grads = [torch.empty(d, dtype=torch.float32, device=dev) for _ in range(4)]
     ws = _ws(query("lotus_attention_bwd_workspace", nblocks, H), dev)
     call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
          qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
-         part_stride, atomic, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, ws, ws.numel())
+         part_stride, atomic, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
+         int(seed), ws, ws.numel())
     return grads
 
 
@@ -268,7 +270,7 @@ class SelfAttnFn(torch.autograd.Function):
     """y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (SerializedAttention flash path)."""
 
     @staticmethod
-    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed):
+    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
         N, C = x.shape
         d = C // H
         n, mean, rstd = ln_fwd(x, g, b)
@@ -276,16 +278,16 @@ class SelfAttnFn(torch.autograd.Function):
         att = torch.empty(N, C, dtype=torch.float32, device=x.device)
         lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
         attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
-                      lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d)
+                      lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, seed + 1)
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
-        ctx.meta = (lvl, H, d, drop_p, seed)
+        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
-        lvl, H, d, p, seed = ctx.meta
+        lvl, H, d, p, seed, attn_p = ctx.meta
         N, C = x.shape
         dy = dy.contiguous()
         dz = dropout(dy, p, seed)
@@ -294,18 +296,18 @@ class SelfAttnFn(torch.autograd.Function):
         dqkv = torch.zeros(N, 3 * C, dtype=torch.float32, device=x.device)  # borrowed rows accumulate
         gq, bq, gk, bk = attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner,
                                        lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, (qnw, qnb), (knw, knb), att,
-                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d)
+                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d, attn_p, seed + 1)
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
         dn = linear_dgrad(dqkv, wqkv)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None
+        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):
     """y = x + drop(proj(CrossAttention(q(LN(x)), kv(context))))   (model_ca.py:46-101, :135-140)."""
 
     @staticmethod
-    def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed):
+    def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
         N, C = x.shape
         d = C // H
         n, mean, rstd = ln_fwd(x, g, b)
@@ -314,16 +316,16 @@ class CrossAttnFn(torch.autograd.Function):
         att = torch.empty(N, C, dtype=torch.float32, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
-                      att, lse, H, d)
+                      att, lse, H, d, attn_p, seed + 1)
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
-        ctx.meta = (lvl, H, d, drop_p, seed)
+        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd = ctx.saved_tensors
-        lvl, H, d, p, seed = ctx.meta
+        lvl, H, d, p, seed, attn_p = ctx.meta
         N, C = x.shape
         dev = x.device
         dy = dy.contiguous()
@@ -335,14 +337,14 @@ class CrossAttnFn(torch.autograd.Function):
         dkv_part = torch.empty(G, L, 2 * C, dtype=torch.float32, device=dev)
         gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
                                          lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
-                                         2 * C, 0, C, L * 2 * C, 0, H, d)
+                                         2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, seed + 1)
         dkv = dkv_part[0] if G == 1 else dkv_part.sum(0)
         dwkv, dbkv = linear_wgrad(dkv, context)
         dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
         dwq, dbq = linear_wgrad(dq, n)
         dn = linear_dgrad(dq, wq)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None
+        return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None, None
 
 
 class StemFn(torch.autograd.Function):

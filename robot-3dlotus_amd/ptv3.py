@@ -72,13 +72,13 @@ class Block(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, xs, lvl, drop_p, seed):
+    def run(self, x, xs, lvl, drop_p, seed, attn_p=0.0):
         c0, c1, c2 = self.cpe[0], self.cpe[1], self.cpe[2]
         x = ops.CpeFn.apply(x, xs, c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias, lvl)
         a, n1 = self.attn, self.norm1[0]
         x = ops.SelfAttnFn.apply(x, n1.weight, n1.bias, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.q_norm.bias,
                                  a.k_norm.weight, a.k_norm.bias, a.proj.weight, a.proj.bias, lvl, self.num_heads,
-                                 drop_p, seed)
+                                 drop_p, seed, attn_p)
         m, n2 = self.mlp[0], self.norm2[0]
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
                                seed + 2)
@@ -95,11 +95,11 @@ class CABlock(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, context, lvl, drop_p, seed):
+    def run(self, x, context, lvl, drop_p, seed, attn_p=0.0):
         a, n1 = self.attn, self.norm1[0]
         x = ops.CrossAttnFn.apply(x, context, n1.weight, n1.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
                                   a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight,
-                                  a.proj.bias, lvl, self.num_heads, drop_p, seed)
+                                  a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p)
         m, n2 = self.mlp[0], self.norm2[0]
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
                                seed + 2)
@@ -222,6 +222,7 @@ class PointTransformerV3CA(nn.Module):
         levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
         training = self.training
         p = self.proj_drop if training else 0.0
+        pa = self.attn_drop if training else 0.0
         self._step += 1
         seed = (self._step << 24)
 
@@ -238,8 +239,8 @@ class PointTransformerV3CA(nn.Module):
                 _tick(bn, training)
                 x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      lvl, training)
-            x = enc.block0.run(x, x, lvl, p, seed)
-            x = enc.ca_block0.run(x, context, lvl, p, seed + 8)
+            x = enc.block0.run(x, x, lvl, p, seed, pa)
+            x = enc.ca_block0.run(x, context, lvl, p, seed + 8, pa)
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
@@ -251,7 +252,7 @@ class PointTransformerV3CA(nn.Module):
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
                                          us[1].running_mean, us[1].running_var, child, training)
-            x = dec.block0.run(x, skip, lvl, p, seed)
-            x = dec.ca_block0.run(x, context, lvl, p, seed + 8)
+            x = dec.block0.run(x, skip, lvl, p, seed, pa)
+            x = dec.ca_block0.run(x, context, lvl, p, seed + 8, pa)
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]

@@ -22,7 +22,7 @@ def _build(cfg, sd, train):
     m.load_state_dict(sd, strict=True)
     m = m.cuda()
     m.train(train)
-    m.ptv3_model.proj_drop = 0.0      # fixtures are dropout-free
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0      # fixtures are dropout-free
     m.act_proj_head.dropout = 0.0
     return m
 

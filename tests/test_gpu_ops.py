@@ -301,3 +301,48 @@ def test_head_and_losses():
     _close(xc.grad, xd.grad, 1e-5, "head dx")
     for i, (a, b) in enumerate(zip(wc, wd)):
         _close(a.grad, b.grad, 1e-5, f"head param {i}")
+
+
+def test_attention_dropout_mask_is_consistent_between_fwd_and_bwd():
+    """attn_drop (flash-attn dropout_p): the counter-based mask must be the same in forward and backward.
+    Checked through (i) E[sum_k P~] = 1, (ii) the adjoint identity <dO, P~ dV_dir> = <dV, dV_dir> (out is linear
+    in V), (iii) a central-difference directional derivative w.r.t. q."""
+    ops = _ops()
+    batch, ref, got = _cloud_levels(2, 300, seed=11)
+    lv = got[0]
+    C, H, p_drop, seed = 64, 2, 0.3, 99
+    n, d = lv.n, C // H
+    g = torch.Generator().manual_seed(1)
+    qkv = (torch.randn(n, 3 * C, generator=g)).cuda()
+    qn = (torch.ones(d).cuda(), torch.zeros(d).cuda())
+
+    def fwd(t):
+        att = torch.empty(n, C, device="cuda")
+        lse = torch.empty(lv.npad, H, device="cuda")
+        ops.attention_fwd(t, 3 * C, 0, t, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.n_self_tiles,
+                          qn, qn, att, lse, H, d, p_drop, seed)
+        return att, lse
+
+    ones = qkv.clone()
+    ones[:, 2 * C:] = 1.0
+    att1, _ = fwd(ones)
+    assert abs(att1.mean().item() - 1.0) < 0.02 and att1.std().item() > 0.01
+    att, lse = fwd(qkv)
+    att_b, _ = fwd(qkv)
+    assert torch.equal(att, att_b)
+    dout = torch.randn(n, C, generator=g).cuda()
+    dqkv = torch.zeros(n, 3 * C, device="cuda")
+    ops.attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.self_blocks,
+                      lv.n_self_tiles, qn, qn, att, dout, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d, p_drop, seed)
+    u = torch.randn(n, 3 * C, generator=g).cuda()
+    uv = torch.zeros_like(u)
+    uv[:, 2 * C:] = u[:, 2 * C:]
+    lhs = ((fwd(qkv + uv)[0] - att) * dout).double().sum().item()
+    rhs = (dqkv * uv).double().sum().item()
+    assert abs(lhs - rhs) <= 2e-4 * max(1.0, abs(rhs)), (lhs, rhs)
+    uq = torch.zeros_like(u)
+    uq[:, :2 * C] = u[:, :2 * C]
+    eps = 1e-2
+    num = (((fwd(qkv + eps * uq)[0] - fwd(qkv - eps * uq)[0]) / (2 * eps)) * dout).double().sum().item()
+    ana = (dqkv * uq).double().sum().item()
+    assert abs(num - ana) <= 3e-2 * max(1.0, abs(ana)), (num, ana)

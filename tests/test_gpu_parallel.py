@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
         m = SimplePolicyPTV3CA(cfg)
         m.load_state_dict(sd)
         m = m.cuda().train()
-        m.ptv3_model.proj_drop = 0.0
+        m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0
         m.act_proj_head.dropout = 0.0
         m.ptv3_model.order_perms = perms
         return m
