@@ -12,6 +12,7 @@
 // into MFMA B fragments (k is permuted identically on both operands: lane-half h takes
 // k = h*KC/2 + s, so every lane reads a contiguous run).
 #include "mma.h"
+#include <stdlib.h>
 
 struct ConvP2 {
   const float* x;    // [n][KD]
@@ -26,154 +27,252 @@ struct ConvP2 {
   int n, T, KD, ND, mirror;
   int tpz;           // taps per blockIdx.z
   long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
+  long long* clk;    // optional phase timestamps of block (0,0,0) (profiling aid)
+  int dbg;           // ablation switches for profiling (LOTUS_CONV_DBG): 1 no fold, 2 no B reload, 4 no image fill, 8 no MFMA
 };
 
-template <int NCS, int BM>
+// Kernel structure (v2, "resident rows"): the distinct neighbour rows touched by a 128-row tile
+// (its own rows plus a halo, ~2-3x the tile) are hashed into an LDS table whose slot index IS the
+// row's position in an LDS image xs[slot][KC+1].  Per reduction chunk the image is filled ONCE
+// from HBM; every tap then reads its MFMA A fragments straight from the image through the
+// per-pair slot index — no per-tap gather, no per-tap barrier.  (v1 re-gathered rows per
+// (tap, chunk) and spent ~80 % of its time waiting for those loads.)  If a pathological tile
+// overflows the table, its tap range is halved and processed in phases.
+template <int NCS>
+struct PairsCfg {
+  // BM = 64 keeps the block at ~74 KB of LDS so that TWO blocks share a CU (8 waves): the hashing, image
+  // fills and fold latencies of one block hide under the MFMAs of the other (BM = 128 / one block per CU
+  // measured 43 % MFMA utilisation inside the tap loop)
+  static constexpr int BM = 64, NRT = 4 / NCS, KC = NCS == 4 ? 32 : 16, NW = 32 * NCS, MAXT = 27;
+  static constexpr int HT = 256;  // hash slots (= resident rows) per row tile
+  static constexpr size_t bytes() {
+    return (size_t)(NRT * (BM + 1) * NW + NRT * HT * (KC + 1)) * 4 + (size_t)NRT * HT * 4 + (size_t)NRT * MAXT * BM * 2 +
+           (size_t)NRT * MAXT * BM + (size_t)(2 * NRT * MAXT + 8 + NRT * BM) * 4;
+  }
+};
+
+// One (tap, chunk) for NG dense pair groups: A fragments from the resident image through the per-pair
+// slot, B fragment from registers; fully unrolled with a compile-time group count so that the LDS reads
+// and MFMAs software-pipeline (a runtime `g < ng` predicate on LDS-loaded counts is treated as divergent
+// by the compiler and serialises every MFMA behind its own ds_read + waitcnt).
+template <int NG, int KC, int NW>
+__device__ __forceinline__ void tap_compute(const float* __restrict__ xs, const unsigned short* __restrict__ sl,
+                                            const unsigned char* __restrict__ rows, int cnt, const float (&b)[KC / 2],
+                                            float* __restrict__ ob, int l31, int hh, int dbg) {
+  f32x16 acc[NG];
+  int abase[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    abase[g] = (int)sl[min(g * 32 + l31, cnt - 1)] * (KC + 1) + hh * (KC / 2);
+  }
+  if (!(dbg & 8)) {
+#pragma unroll
+    for (int s = 0; s < KC / 2; ++s) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[abase[g] + s], b[s], acc[g], 0, 0, 0);
+    }
+  }
+  if (dbg & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t += acc[g][0] + acc[g][7] + acc[g][15];
+    if (t == 1.2345e30f) ob[0] = t;
+    return;
+  }
+  // fold into the LDS output tile: this wave owns its 32 columns, taps are folded in fixed order
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    int ro[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ro[r] = (int)rows[g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] * NW;  // padded pairs -> dummy row
+    float ov[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ov[r] = ob[ro[r]];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ob[ro[r]] = ov[r] + acc[g][r];
+  }
+}
+
+template <int NCS>
 __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
-  constexpr int NRT = 4 / NCS;          // row tiles per block
-  constexpr int KC = NCS == 4 ? 32 : 16;  // reduction chunk staged per iteration
-  constexpr int NW = 32 * NCS;          // output columns per block
-  constexpr int TG = BM / 32;           // max pair groups per tap
-  constexpr int GT = 64 * NCS;          // gather threads per row tile
-  constexpr int G4 = BM * (KC / 4) / GT;  // float4 gathered per thread per iteration
-  constexpr int MAXT = 27;
+  using Cfg = PairsCfg<NCS>;
+  constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT;
+  constexpr int TG = BM / 32;   // max pair groups per tap
+  constexpr int GT = 64 * NCS;  // threads of one row tile's team
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* out_s = smem;                               // [NRT][BM][NW]
-  float* a_s = out_s + NRT * BM * NW;                // [NRT][2][BM][KC+1]
-  int* src_s = (int*)(a_s + NRT * 2 * BM * (KC + 1));  // [NRT][MAXT][BM]
-  int* cnt_s = src_s + NRT * MAXT * BM;              // [NRT][MAXT]
-  int* act_s = cnt_s + NRT * MAXT;                   // [NRT][MAXT]
-  int* nact_s = act_s + NRT * MAXT;                  // [NRT]
-  int* prow_s = nact_s + 4;                          // [NRT][BM]
-  unsigned char* row_s = (unsigned char*)(prow_s + NRT * BM);  // [NRT][MAXT][BM]
+  float* out_s = smem;                                   // [NRT][BM+1][NW]  (row BM = dummy sink of padded pairs)
+  float* xs_s = out_s + NRT * (BM + 1) * NW;             // [NRT][HT][KC+1]
+  int* hkey_s = (int*)(xs_s + NRT * HT * (KC + 1));      // [NRT][HT] global row id or -1
+  int* cnt_s = hkey_s + NRT * HT;                        // [NRT][MAXT]
+  int* act_s = cnt_s + NRT * MAXT;                       // [NRT][MAXT]
+  int* misc_s = act_s + NRT * MAXT;                      // [8]: nact per rt (0..3), overflow (4)
+  int* prow_s = misc_s + 8;                              // [NRT][BM]
+  unsigned short* slot_s = (unsigned short*)(prow_s + NRT * BM);  // [NRT][MAXT][BM]
+  unsigned char* row_s = (unsigned char*)(slot_s + NRT * MAXT * BM);  // [NRT][MAXT][BM]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1;
   const int rt = wave / NCS, cs = wave % NCS;
-  const int gt = tid - rt * GT;  // thread index inside the row tile's gather team
+  const int gt = tid - rt * GT;
   const int n0 = blockIdx.x * NW;
   const int m0 = (blockIdx.y * NRT + rt) * BM;
-  const int t_beg = blockIdx.z * p.tpz, t_end = min(p.T, t_beg + p.tpz);
+  const int z_beg = blockIdx.z * p.tpz, z_end = min(p.T, z_beg + p.tpz);
+  float* my_xs = xs_s + rt * HT * (KC + 1);
+  int* my_hkey = hkey_s + rt * HT;
 
-  for (int i = tid; i < NRT * BM * NW; i += 256) out_s[i] = 0.f;
+  int clk_i = 0;
+  auto stamp = [&]() {
+    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && clk_i < 64) p.clk[clk_i] = wall_clock64();
+    ++clk_i;
+  };
+  stamp();  // 0 start
+  static_assert(HT * (KC + 1) >= MAXT * BM, "row image must be able to hold the temporary neighbour list");
+  int* src_tmp = (int*)my_xs;  // [taps][BM] neighbour ids, aliased onto the row image (first phase only)
+  for (int i = tid; i < NRT * (BM + 1) * NW; i += 256) out_s[i] = 0.f;
   for (int r = gt; r < BM; r += GT) {
     const int m = m0 + r;
     prow_s[rt * BM + r] = m < p.n ? (p.rowidx ? p.rowidx[m] : m) : -1;
   }
   __syncthreads();
-  // per-tap ordered compaction of the active pairs of this row tile (wave ballot + popcount)
-  for (int t = t_beg + cs; t < t_end; t += NCS) {
+  // neighbour ids of the whole tile with independent (batched) loads -> LDS, then an ordered in-place
+  // compaction of the active output rows of every tap (wave ballot + popcount)
+  {
+    const int total = (z_end - z_beg) * BM;
+#pragma unroll 4
+    for (int i = gt; i < total; i += GT) {
+      const int pr = prow_s[rt * BM + (i % BM)];
+      src_tmp[i] = pr >= 0 ? p.nbr[(long)(z_beg + i / BM) * p.n + pr] : -1;
+    }
+  }
+  __syncthreads();
+  stamp();  // 1 after neighbour loads
+  for (int t = z_beg + cs; t < z_end; t += NCS) {
     int base = 0;
     for (int r0 = 0; r0 < BM; r0 += 64) {
       const int r = r0 + lane;
-      const int pr = r < BM ? prow_s[rt * BM + r] : -1;
-      const int nb = pr >= 0 ? p.nbr[(long)t * p.n + pr] : -1;
+      const int nb = src_tmp[(t - z_beg) * BM + r];
       const unsigned long long b = __ballot(nb >= 0);
       if (nb >= 0) {
         const int k = base + __popcll(b & ((1ull << lane) - 1ull));
-        src_s[(rt * MAXT + t) * BM + k] = nb;
         row_s[(rt * MAXT + t) * BM + k] = (unsigned char)r;
+        src_tmp[(t - z_beg) * BM + k] = nb;  // k <= r: in place; valid until the first image fill
       }
       base += __popcll(b);
     }
     if (lane == 0) cnt_s[rt * MAXT + t] = base;
+    // pad the last group with the dummy sink row so that the fold needs no per-element predicate
+    if (base + lane < ((base + 31) & ~31)) row_s[(rt * MAXT + t) * BM + base + lane] = (unsigned char)BM;
   }
   __syncthreads();
-  if (gt == 0) {
-    int c = 0;
-    for (int t = t_beg; t < t_end; ++t)
-      if (cnt_s[rt * MAXT + t] > 0) act_s[rt * MAXT + c++] = t;
-    nact_s[rt] = c;
-  }
-  __syncthreads();
+  stamp();  // 2 after compaction
+
   const int nkc = p.KD / KC;
-  const int my_iters = nact_s[rt] * nkc;
-  int max_iters = 0;
-#pragma unroll
-  for (int q = 0; q < NRT; ++q) max_iters = max(max_iters, nact_s[q] * nkc);
+  float bst[3][KC / 2];
+  static_assert(BM / 32 == 2, "tap loop is written for <= 2 pair groups per tap");
 
-  f32x16 acc[TG];
-#pragma unroll
-  for (int g = 0; g < TG; ++g)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-
-  float4 ga[G4];
-  float bcur[KC / 2], bnxt[KC / 2];
-  float* my_a = a_s + rt * 2 * BM * (KC + 1);
-
-  auto issue = [&](int it) {  // global loads of iteration `it` into registers (A rows + B fragment)
-    const int t = act_s[rt * MAXT + it / nkc];
-    const int k0 = (it % nkc) * KC;
-    const int cnt = cnt_s[rt * MAXT + t];
-#pragma unroll
-    for (int q = 0; q < G4; ++q) {
-      const int f = gt + q * GT;
-      const int row = f / (KC / 4), kq = f % (KC / 4);
-      ga[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < cnt) ga[q] = *reinterpret_cast<const float4*>(p.x + (long)src_s[(rt * MAXT + t) * BM + row] * p.KD + k0 + kq * 4);
-    }
+  auto load_b = [&](float (&dst)[KC / 2], int t, int kc) {  // weight fragment of (tap, chunk): coalesced 128 B per half-wave and k
     const int tw = p.mirror ? (p.T - 1 - t) : t;
-    // B(k, j): lanes j read consecutive floats (coalesced 128 B per half-wave and k)
-    const float* wp = p.w + (long)(k0 + hh * (KC / 2)) * p.wld + (long)tw * p.tapw + n0 + cs * 32 + l31;
+    const float* wp = p.w + (long)(kc * KC + hh * (KC / 2)) * p.wld + (long)tw * p.tapw + n0 + cs * 32 + l31;
 #pragma unroll
-    for (int s = 0; s < KC / 2; ++s) bnxt[s] = wp[(long)s * p.wld];
-  };
-  auto stage = [&](int buf) {  // gathered registers -> LDS image [BM][KC+1]
-    float* dst = my_a + buf * BM * (KC + 1);
-#pragma unroll
-    for (int q = 0; q < G4; ++q) {
-      const int f = gt + q * GT;
-      const int row = f / (KC / 4), kq = f % (KC / 4);
-      float* o = dst + row * (KC + 1) + kq * 4;
-      o[0] = ga[q].x; o[1] = ga[q].y; o[2] = ga[q].z; o[3] = ga[q].w;
-    }
+    for (int s = 0; s < KC / 2; ++s) dst[s] = wp[(long)s * p.wld];
   };
 
-  if (my_iters > 0) {
-    issue(0);
-    stage(0);
-  }
-#pragma unroll
-  for (int s = 0; s < KC / 2; ++s) bcur[s] = bnxt[s];
-  __syncthreads();
-  for (int it = 0; it < max_iters; ++it) {
-    const bool live = it < my_iters;
-    const bool more = it + 1 < my_iters;
-    if (more) issue(it + 1);
-    if (live) {
-      const int t = act_s[rt * MAXT + it / nkc];
+  int t0 = z_beg, span = z_end - z_beg;
+  bool first_phase = true;
+  while (t0 < z_end) {  // phases over tap ranges (one phase unless a tile overflows the row table)
+    const int t1 = min(z_end, t0 + span);
+    for (int i = gt; i < HT; i += GT) my_hkey[i] = -1;
+    if (tid == 0) misc_s[4] = 0;
+    __syncthreads();
+    // hash every pair's neighbour row into the table; the table position is the LDS row slot
+    for (int t = t0; t < t1; ++t) {
       const int cnt = cnt_s[rt * MAXT + t];
-      const int ng = (cnt + 31) >> 5;
-      const float* ab = my_a + (it & 1) * BM * (KC + 1);
-#pragma unroll
-      for (int s = 0; s < KC / 2; ++s) {
-#pragma unroll
-        for (int g = 0; g < TG; ++g)
-          if (g < ng)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(ab[(g * 32 + l31) * (KC + 1) + hh * (KC / 2) + s], bcur[s], acc[g], 0, 0, 0);
+      for (int k = gt; k < cnt; k += GT) {
+        const int g = first_phase ? src_tmp[(t - z_beg) * BM + k]
+                                  : p.nbr[(long)t * p.n + prow_s[rt * BM + row_s[(rt * MAXT + t) * BM + k]]];
+        unsigned pos = ((unsigned)g * 2654435761u >> 16) % HT;
+        int probes = 0;
+        while (true) {
+          const int old = atomicCAS(&my_hkey[pos], -1, g);
+          if (old == -1 || old == g) break;
+          pos = pos + 1 == HT ? 0 : pos + 1;
+          if (++probes >= HT) { misc_s[4] = 1; break; }
+        }
+        slot_s[(rt * MAXT + t) * BM + k] = (unsigned short)pos;
       }
-      if ((it % nkc) == nkc - 1) {  // tap finished: fold into the LDS output tile (this wave owns its columns)
-        float* ob = out_s + rt * BM * NW + cs * 32 + l31;
-        const unsigned char* rows = row_s + (rt * MAXT + t) * BM;
-#pragma unroll
-        for (int g = 0; g < TG; ++g)
-          if (g < ng) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int idx = g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-              if (idx < cnt) ob[(int)rows[idx] * NW] += acc[g][r];
-              acc[g][r] = 0.f;
-            }
-          }
-      }
-    }
-    if (more) {
-      stage((it + 1) & 1);
-#pragma unroll
-      for (int s = 0; s < KC / 2; ++s) bcur[s] = bnxt[s];
     }
     __syncthreads();
+    if (misc_s[4]) {  // block-uniform: retry with half the taps (a single tap always fits: <= BM rows)
+      __syncthreads();
+      span = max(1, (t1 - t0) / 2);
+      continue;
+    }
+    first_phase = false;  // the image fill below overwrites the temporary neighbour list
+    if (gt == 0) {
+      int c = 0;
+      for (int t = t0; t < t1; ++t)
+        if (cnt_s[rt * MAXT + t] > 0) act_s[rt * MAXT + c++] = t;
+      misc_s[rt] = c;
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(misc_s[rt]);
+    const int vact = lane < nact ? act_s[rt * MAXT + lane] : 0;   // lane j: j-th active tap
+    const int vcnt = cnt_s[rt * MAXT + vact];                     // and its pair count
+    stamp();  // 3 after hashing + active list
+
+    for (int kc = 0; kc < nkc; ++kc) {
+      // fill the resident image with this chunk of every hashed row (one HBM/L2 read per row and chunk);
+      // loads are issued in batches of 8 so their latencies overlap
+      constexpr int FILL = HT * (KC / 4) / GT;
+      static_assert(HT * (KC / 4) % GT == 0 && FILL % 4 == 0, "fill loop shape");
+#pragma unroll
+      for (int b0 = 0; b0 < FILL; b0 += 4) {
+        int gs[4];
+        float4 vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gs[j] = my_hkey[(gt + (b0 + j) * GT) / (KC / 4)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = (gt + (b0 + j) * GT) % (KC / 4);
+          vv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (gs[j] >= 0 && !(p.dbg & 4)) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = gt + (b0 + j) * GT;
+          float* o = my_xs + (i / (KC / 4)) * (KC + 1) + (i % (KC / 4)) * 4;
+          o[0] = vv[j].x; o[1] = vv[j].y; o[2] = vv[j].z; o[3] = vv[j].w;
+        }
+      }
+      // Tap loop, software-pipelined 2 taps deep on the weight fragments (their L2 latency, ~1 us under load,
+      // exceeds one tap's MFMA time): three register stages rotated by a 3x unrolled loop.  Tap ids / pair counts
+      // live in lanes of two VGPRs and are read as scalars with v_readlane (no LDS latency in the loop).
+      if (nact > 0) load_b(bst[0], __builtin_amdgcn_readlane(vact, 0), kc);
+      if (nact > 1) load_b(bst[1], __builtin_amdgcn_readlane(vact, 1), kc);
+      __syncthreads();
+      stamp();  // 4+2kc after image fill
+      float* ob = out_s + rt * (BM + 1) * NW + cs * 32 + l31;
+      auto step = [&](int a, const float (&bc)[KC / 2], float (&bl)[KC / 2]) {
+        if (a + 2 < nact && !(p.dbg & 2)) load_b(bl, __builtin_amdgcn_readlane(vact, a + 2), kc);
+        const int t = __builtin_amdgcn_readlane(vact, a);
+        const int cnt = __builtin_amdgcn_readlane(vcnt, a);
+        const unsigned short* sl = slot_s + (rt * MAXT + t) * BM;
+        const unsigned char* rows = row_s + (rt * MAXT + t) * BM;
+        if (cnt <= 32) tap_compute<1, KC, NW>(my_xs, sl, rows, cnt, bc, ob, l31, hh, p.dbg);
+        else tap_compute<2, KC, NW>(my_xs, sl, rows, cnt, bc, ob, l31, hh, p.dbg);
+      };
+      for (int a = 0; a < nact; a += 3) {
+        step(a, bst[0], bst[2]);
+        if (a + 1 < nact) step(a + 1, bst[1], bst[0]);
+        if (a + 2 < nact) step(a + 2, bst[2], bst[1]);
+      }
+      stamp();  // 5+2kc after the tap loop (wave 0)
+      __syncthreads();
+    }
+    t0 = t1;
   }
+
   // epilogue: coalesced row stores (final result, or this tap group's partial slab)
   const bool final_out = p.part_stride == 0;
   float* yo = p.y + (long)blockIdx.z * p.part_stride;
@@ -181,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
     const int r = i / (NW / 4), c4 = i % (NW / 4);
     const int pr = prow_s[rt * BM + r];
     if (pr < 0) continue;
-    float4 v = *reinterpret_cast<const float4*>(out_s + (rt * BM + r) * NW + c4 * 4);
+    float4 v = *reinterpret_cast<const float4*>(out_s + (rt * (BM + 1) + r) * NW + c4 * 4);
     const int col = n0 + c4 * 4;
     const long o = (long)pr * p.ND + col;
     if (final_out) {
@@ -196,6 +295,8 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
     }
     *reinterpret_cast<float4*>(yo + o) = v;
   }
+  stamp();  // last: after epilogue
+  if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) p.clk[63] = clk_i;
 }
 
 // y = sum_z part[z] + bias + add   (fixed order -> deterministic)
@@ -236,27 +337,27 @@ __global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ 
   }
 }
 
-template <int NCS, int BM>
-static size_t pairs_smem() {
-  constexpr int NRT = 4 / NCS, KC = NCS == 4 ? 32 : 16, NW = 32 * NCS, MAXT = 27;
-  return (size_t)(NRT * BM * NW + NRT * 2 * BM * (KC + 1)) * 4 + (size_t)(NRT * MAXT * BM + 2 * NRT * MAXT + 4 + NRT * BM) * 4 +
-         (size_t)NRT * MAXT * BM;
+static long long* g_conv_clk = nullptr;
+extern "C" int lotus_debug_conv_clock(long long* host64) {
+  if (!g_conv_clk) return -1;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host64, g_conv_clk, 64 * sizeof(long long), hipMemcpyDeviceToHost);
 }
 
 static int tap_splits(int n, int ND) {
-  const long base = (long)cdiv(n, 128) * (ND <= 64 ? 1 : ND / 128);
+  const long base = (long)cdiv(n, 64 * (ND <= 64 ? 2 : 1)) * (ND <= 64 ? 1 : ND / 128);
   int nz = 1;
-  while (nz < 9 && base * nz < 384) nz = nz == 1 ? 3 : 9;  // 27 taps -> 1, 3 or 9 groups
+  while (nz < 9 && base * nz < 768) nz = nz == 1 ? 3 : 9;  // 27 taps -> 1, 3 or 9 groups
   return nz;
 }
 
-template <int NCS, int BM>
+template <int NCS>
 static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
-  constexpr int NRT = 4 / NCS;
-  const size_t sm = pairs_smem<NCS, BM>();
-  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  dim3 grid(p.ND / (32 * NCS), cdiv(p.n, BM * NRT), nz);
-  hipLaunchKernelGGL((conv_pairs_kernel<NCS, BM>), grid, dim3(256), sm, st, p);
+  using Cfg = PairsCfg<NCS>;
+  const size_t sm = Cfg::bytes();
+  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
+  hipLaunchKernelGGL((conv_pairs_kernel<NCS>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
@@ -289,9 +390,18 @@ int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* 
   if (mode == 0) { p.w = w_t; p.wld = (long)T * cout; p.tapw = cout; }
   else           { p.w = w;   p.wld = (long)T * cin;  p.tapw = cin; }
   p.tpz = cdiv(T, nz);
+  {
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("LOTUS_CONV_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+    static long long* clk = nullptr;
+    if (getenv("LOTUS_CONV_CLK") && !clk) (void)hipMalloc(&clk, 64 * sizeof(long long));
+    p.clk = clk;
+    g_conv_clk = clk;
+  }
   p.y = nz > 1 ? (float*)workspace : y;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
-  *rc = ND == 64 ? launch_pairs<2, 128>(p, nz, st) : launch_pairs<4, 128>(p, nz, st);
+  *rc = ND == 64 ? launch_pairs<2>(p, nz, st) : launch_pairs<4>(p, nz, st);
   if (*rc == 0 && nz > 1) {
     const long total4 = (long)n * ND / 4;
     int g = cdiv(total4, 256);
