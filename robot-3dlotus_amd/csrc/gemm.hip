@@ -9,6 +9,7 @@
 // wgrad is deterministic: split-K partials go to a caller-provided workspace and are summed in a
 // fixed order by a second kernel (no float atomics).
 #include "mma.h"
+#include <stdlib.h>
 
 struct GemmP {
   const float* A;
@@ -290,15 +291,26 @@ int lotus_reduce_parts(const float* part, float* out, long n, long stride, int n
 
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
+static int tune_env(const char* name) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
+static int g_force_tile = -1, g_force_nz = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 2: 128x64, 3: 64x64), LOTUS_GEMM_NZ
+
 template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
   const bool small_n = p.N <= 64;
   dim3 block(256);
-  if (!small_n && blocks128 * nz >= 192) {
+  if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
+  int tile = g_force_tile;
+  // measured (tools/gemm_sweep.py): 128x128 tiles only pay with >= 4 blocks per CU; otherwise 64x64 tiles
+  // (more blocks in flight) win, including the N <= 64 layers and every split-K weight gradient
+  if (tile == 0) tile = (!small_n && !SUM_A && blocks128 * nz >= 1024) ? 1 : 3;
+  if (tile == 1) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
     hipLaunchKernelGGL((gemm_kernel<128, 128, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-  } else if (small_n && (long)cdiv(p.M, 128) * nz >= 192) {
+  } else if (tile == 2) {
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
     hipLaunchKernelGGL((gemm_kernel<128, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else {
@@ -375,9 +387,12 @@ __global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, 
 // Few output tiles but a long reduction (deep levels: M = 361..1450, K up to 3072): split K over
 // blockIdx.z into a workspace and finish with splitk_epilogue_kernel.  Returns the split count.
 static int fwd_splits(int M, int N, int K) {
+  if (g_force_nz < 0) g_force_nz = tune_env("LOTUS_GEMM_NZ");
+  if (g_force_nz > 0) return (K / g_force_nz >= 16) ? g_force_nz : 1;
   const long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
   int nz = 1;
-  while (nz < 16 && blocks * nz < 512 && K / (nz * 2) >= 128) nz *= 2;
+  if (blocks < 128)  // split-K only pays for very small output grids with a long reduction
+    while (nz < 16 && blocks * nz < 256 && K / (nz * 2) >= 256) nz *= 2;
   return nz;
 }
 
@@ -446,10 +461,12 @@ int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* 
 }
 
 static int wgrad_splits(int M, int N, int K) {
+  if (g_force_nz < 0) g_force_nz = tune_env("LOTUS_GEMM_NZ");
+  if (g_force_nz > 0) return (M / g_force_nz >= 16) ? g_force_nz : 1;
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
   // both operands are streamed exactly once: keep >= ~6 blocks per CU in flight (Little's law)
-  while (nz < 64 && tiles * nz < 512 && (long)nz * 256 < M) nz *= 2;
+  while (nz < 64 && tiles * nz < 1024 && (long)nz * 128 < M) nz *= 2;
   return nz;
 }
 
