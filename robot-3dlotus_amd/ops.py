@@ -19,6 +19,43 @@ ACT_NONE, ACT_GELU, ACT_LEAKY = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01
 CALL_LOG = None  # bench.py sets this to a list to record the (kind, M, N, K) of every dense launch
 
+# Weight gradients are off the critical path of backward (nothing downstream consumes them before the
+# optimiser / gradient all-reduce) and their kernels are latency-bound streams over dy and x, while the
+# dgrad chain is MFMA-bound: running them on a second HIP stream lets the two overlap on the CUs.
+# enable_side_stream() turns this on; sync_side_stream() must be called before the gradients are read.
+SIDE = None
+
+
+def enable_side_stream(on=True):
+    global SIDE
+    SIDE = torch.cuda.Stream() if on else None
+
+
+def sync_side_stream():
+    if SIDE is not None:
+        torch.cuda.current_stream().wait_stream(SIDE)
+
+
+class _OnSide:
+    """Run a weight-gradient producer on the side stream after the main stream's pending work."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        if SIDE is None:
+            return self
+        SIDE.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(SIDE)
+        self.ctx = torch.cuda.stream(SIDE)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if SIDE is not None:
+            self.ctx.__exit__(*a)
+
 
 def _ws(nbytes, dev):
     return WS.get(nbytes, dev, slot=0)
@@ -63,8 +100,12 @@ def linear_wgrad(dy, x, need_bias=True):
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
-    ws = _ws(nbytes, dy.device)
-    call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
+    with _OnSide(dy, x):
+        buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
+        dw = buf[:N * K].view(N, K)
+        db = buf[N * K:] if need_bias else None
+        ws = WS.get(nbytes, dy.device, slot=3 if SIDE is not None else 0)
+        call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
     return dw, db
 
 
@@ -129,8 +170,12 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     dw = buf[:nw].view(w_shape)
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
-    ws = _ws(nbytes, dy.device)
-    call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
+    with _OnSide(dy, x):
+        buf = torch.empty(nw + (cout if need_bias else 0), dtype=torch.float32, device=dy.device)
+        dw = buf[:nw].view(w_shape)
+        db = buf[nw:] if need_bias else None
+        ws = WS.get(nbytes, dy.device, slot=3 if SIDE is not None else 0)
+        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
     return dw, db
 
 
