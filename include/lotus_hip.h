@@ -62,10 +62,11 @@ int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* ord
 int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_start, int n_child, float* ccoord,
                         void* stream);
 /* SerializedAttention.get_padding_and_inverse, model.py:410-466, composed with order/inverse:
- * gidx[i] = order[pad[i]], owner[i] = (unpad[inverse[gidx[i]]] == i).  off/offp: int32 [B+1]
- * exclusive prefix sums of the per-cloud counts / padded counts. */
+ * gidx[i] = order[pad[i]], owner[i] = (unpad[inverse[gidx[i]]] == i); kext[i] = -1 for owners, else the
+ * compact index e of the borrowed copy, ext_pos[e] = i.  off/offp: int32 [B+1] exclusive prefix sums of
+ * the per-cloud counts / padded counts. */
 int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int K, int npad, int* gidx, int* owner,
-                   void* stream);
+                   int* kext, int* ext_pos, void* stream);
 /* spconv submanifold neighbour lookup (SubMConv3d call sites model.py:615-622, :844-853): tap-major
  * nbr int32 [ksize^3][n], -1 = absent, duplicates -> lowest index (SURVEY.md Trap 5). */
 size_t lotus_fe_neighbours_workspace(int n);
@@ -143,13 +144,15 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
                         unsigned long long drop_seed, void* stream);
 size_t lotus_attention_bwd_workspace(int nblocks, int H);
-/* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len */
+/* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.  kext / ext_pos /
+ * dkv_extra (optional, from lotus_fe_patch): k/v gradients of the borrowed tail-patch copies go to a side
+ * buffer [n_extra][2*H*d] and are added to their point afterwards (no atomics, no zero-fill of dkv). */
 int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, const int* blocks,
                         int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
                         const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
-                        int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
                         void* workspace, size_t workspace_bytes, void* stream);
 
@@ -177,6 +180,11 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
 int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */
 int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+
+/* ---- profiling aids (diagnostic only): phase timestamps (100 MHz wall clock) of block 0 of the last
+ * pair-conv / attention-backward launch when LOTUS_CONV_CLK / LOTUS_ATTN_CLK is set; host64 = int64[64] (host) */
+int lotus_debug_conv_clock(long long* host64);
+int lotus_debug_attn_clock(long long* host64);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
 // LDS plan (floats): Q[128][33] K[128][33] V[128][33] (dO[128][33]) S[128][129]; everything a
 // (tile, head) needs stays on chip between the QK^T, softmax and PV stages.
 #include "common.h"
+#include <stdlib.h>
 
 #define AT 128        // tile rows (queries) and max keys
 #define ALD 33        // row stride of the [128][d<=32] images
@@ -33,13 +34,18 @@ struct AttnP {
   float* dq; long dq_ld; int dq_off;
   float* dkv; long dkv_ld; int dk_off, dv_off; long dkv_part_stride;
   float* ln_part;            // [nblocks * H][4][32]  dgamma_q, dbeta_q, dgamma_k, dbeta_k
-  int atomic_out;            // 1: atomicAdd into dq/dkv (self-attention with borrowed rows)
+  int atomic_out;            // 1: atomicAdd into dq/dkv (kept for generality; unused by the model)
+  const int* kext;           // per k position: -1 = owner row, else row of dkv_extra (borrowed copy of a tail patch)
+  float* dkv_extra;          // [n_extra][dkv_extra_ld] k | v gradients of the borrowed copies
+  long dkv_extra_ld;
   int H, d;
   float scale, eps;
   // dropout on the attention probabilities (flash-attn dropout_p, model.py:547 / model_ca.py:64)
   unsigned long long drop_seed;
   unsigned drop_thresh;
   float drop_inv_keep;
+  int dbg;         // ablation switches (LOTUS_ATTN_DBG): 1 plain P epilogue, 2 no S MFMAs, 4 no affine on operands
+  long long* clk;  // optional phase timestamps of block (0,0) (profiling aid, LOTUS_ATTN_CLK)
 };
 
 // keep/scale factor of probability (tile, head, row, col); 1 when dropout is off
@@ -98,7 +104,7 @@ struct AttnSmem {
   float* Q; float* K; float* V; float* dO; float* S;
   float* qrstd; float* krstd; float* Dv; float* lse;
   float* gq; float* bq; float* gk; float* bk;
-  int* qrow; int* krow; int* qown;
+  int* qrow; int* krow; int* qown; int* kext;
 };
 
 __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
@@ -117,10 +123,11 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.qrow = (int*)p; p += AT;
   s.krow = (int*)p; p += AT;
   s.qown = (int*)p; p += AT;
+  s.kext = (int*)p; p += AT;
   return s;
 }
 static size_t attn_smem_bytes(bool bwd) {
-  return (size_t)((bwd ? 4 : 3) * AT * ALD + AT * SLD + 4 * AT + 4 * 32 + 3 * AT) * sizeof(float);
+  return (size_t)((bwd ? 4 : 3) * AT * ALD + AT * SLD + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
 }
 
 __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
     float sum = 0.f;
     if (row < q_len)
       for (int c = c0; c < c1; ++c) {
-        const float e = expf(srow[c] - m);
+        const float e = __expf(srow[c] - m);
         srow[c] = e;
         sum += e;
       }
@@ -225,13 +232,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
 // ------------------------------------------------------------------------------------ backward
 __device__ __forceinline__ void store_rows(const float* img, float* base, long ld, int coff, const int* rows_s,
-                                           const int* own_s, int len, int d, int atomic) {
+                                           const int* own_s, int len, int d, int atomic, const int* ext_s = nullptr,
+                                           float* ext_base = nullptr, long ext_ld = 0, int ext_coff = 0) {
   const int sub = threadIdx.x & 7;
   for (int r = threadIdx.x >> 3; r < len; r += 32) {
     if (own_s && !own_s[r]) continue;
     if (sub * 4 >= d) continue;
     const float* v = img + r * ALD + sub * 4;
     float* o = base + (long)rows_s[r] * ld + coff + sub * 4;
+    if (ext_s && ext_s[r] >= 0) o = ext_base + (long)ext_s[r] * ext_ld + ext_coff + sub * 4;  // borrowed copy
     if (atomic) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
@@ -263,6 +272,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnSmem s = carve(smem, true);
   __shared__ float lnacc[4][32];
+  __shared__ float colred[2][8][32];
   const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1;
   const int h = blockIdx.y, d = p.d;
   const int* bd = p.blocks + blockIdx.x * 6;
@@ -270,8 +280,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   const int k_start = bd[4], k_len = bd[5];
   const int r0 = wave * 32;
   const int ktiles = (k_len + 31) / 32;
+  int clk_i = 0;
+  auto stamp = [&]() {
+    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && clk_i < 40) p.clk[clk_i] = wall_clock64();
+    ++clk_i;
+  };
+  stamp();
 
-  if (tid < AT) s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+  if (tid < AT) {
+    s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+    s.kext[tid] = (tid < k_len && p.kext) ? p.kext[k_start + tid] : -1;
+  }
   if (tid < 4 * 32) lnacc[tid >> 5][tid & 31] = 0.f;
   load_affine(p, s);
   __syncthreads();
@@ -280,6 +299,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   __syncthreads();
   if (tid >= AT) ln_rows<false>(s.K, s.krstd, tid - AT, k_len, d, p.eps, nullptr, nullptr);
   __syncthreads();
+  stamp();  // 1: K/V loaded + K LN
 
   f32x16 acc_dv = zero16(), acc_dk = zero16();
   const float gk_l = s.gk[l31], bk_l = s.bk[l31], gq_l = s.gq[l31], bq_l = s.bq[l31];
@@ -316,12 +336,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
     __syncthreads();
     if (tid < AT) ln_rows<false>(s.Q, s.qrstd, tid, q_len, d, p.eps, nullptr, nullptr);
     __syncthreads();
+    stamp();  // 2: Q/dO/O loaded, D, Q LN
 
     // P = exp(scale * Qn Kn^T - lse), zero outside the valid (q_len, k_len) rectangle
     if (r0 < q_len) {
       f32x16 acc[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) acc[t] = zero16();
+      if (!(p.dbg & 2)) {
+        if (p.dbg & 4) {
+          for (int kk = 0; kk < d; kk += 2) {
+            const int k = kk + hh;
+            const float a = s.Q[(r0 + l31) * ALD + k];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + k], acc[t], 0, 0, 0);
+          }
+        } else {
       for (int kk = 0; kk < d; kk += 2) {
         const int k = kk + hh;
         const float a = s.Q[(r0 + l31) * ALD + k] * s.gq[k] + s.bq[k];
@@ -330,6 +361,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
           if (t < ktiles)
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + k] * s.gk[k] + s.bk[k], acc[t], 0, 0, 0);
       }
+        }
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -337,18 +370,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
           const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
           const int col = t * 32 + l31;
           const bool ok = t < ktiles && row < q_len && col < k_len;
-          s.S[row * SLD + col] = ok ? expf(acc[t][r] * p.scale - s.lse[row]) : 0.f;
+          // the sign bit carries the dropout mask (P >= 0): +P kept, -P dropped -> one hash per element
+          if (p.dbg & 1) { s.S[row * SLD + col] = acc[t][r]; continue; }
+          const float pv = ok ? __expf(acc[t][r] * p.scale - s.lse[row]) : 0.f;
+          s.S[row * SLD + col] = (p.drop_thresh && pmask(p, tile, h, row, col) == 0.f) ? -pv : pv;
         }
       }
     } else {
       for (int i = l31 + 32 * hh; i < 32 * AT; i += 64) s.S[(r0 + i / AT) * SLD + (i % AT)] = 0.f;
     }
     __syncthreads();
+    stamp();  // 3: P
     // dV += P^T dO   (wave owns key rows r0..r0+31)
     const int qend = (q_len + 1) & ~1;
     if (r0 < k_len) {
       for (int kk = 0; kk < qend; kk += 2)
-        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31] * pmask(p, tile, h, kk + hh, r0 + l31),
+        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(s.S[(kk + hh) * SLD + r0 + l31], 0.f) * p.drop_inv_keep,
                                                       s.dO[(kk + hh) * ALD + l31], acc_dv, 0, 0, 0);
     }
     // dP = dO V^T  (wave owns query rows)
@@ -364,6 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
       }
     }
     __syncthreads();
+    stamp();  // 4: dV, dP
     // dS = scale * P * (dP - D), in place over P
     if (r0 < q_len) {
 #pragma unroll
@@ -373,11 +411,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
           for (int r = 0; r < 16; ++r) {
             const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             float* sp = s.S + row * SLD + t * 32 + l31;
-            *sp = p.scale * (*sp) * (dp[t][r] * pmask(p, tile, h, row, t * 32 + l31) - s.Dv[row]);
+            const float sv = *sp;  // +P kept / -P dropped
+            *sp = p.scale * fabsf(sv) * ((sv > 0.f ? dp[t][r] * p.drop_inv_keep : 0.f) - s.Dv[row]);
           }
         }
     }
     __syncthreads();
+    stamp();  // 5: dS
     // dKn += dS^T Qn  (wave owns key rows) ; dQn = dS Kn (wave owns query rows)
     if (r0 < k_len) {
       for (int kk = 0; kk < qend; kk += 2)
@@ -392,6 +432,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
                                                       s.K[(kk + hh) * ALD + l31] * gk_l + bk_l, acc_dq, 0, 0, 0);
     }
     __syncthreads();  // dO image is free now: reuse it for dQn
+    stamp();  // 6: dK, dQ
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -399,18 +440,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
     }
     __syncthreads();
     // q_norm affine gradients (column pass), then LN backward (row pass), then store
+    {  // column sums over the tile's rows with all 256 threads: 8 row slices x 32 columns, then an 8-way tree
+      const int j = tid & 31, part = tid >> 5;
+      float ag = 0.f, ab = 0.f;
+      if (j < d)
+        for (int r = part * 16; r < min(q_len, part * 16 + 16); ++r) {
+          const float g = s.dO[r * ALD + j];
+          ag += g * s.Q[r * ALD + j];
+          ab += g;
+        }
+      colred[0][part][j] = ag;
+      colred[1][part][j] = ab;
+    }
+    __syncthreads();
     if (tid < 64) {
       const int which = tid >> 5, j = tid & 31;  // 0: dgamma_q, 1: dbeta_q
       float a = 0.f;
-      if (j < d)
-        for (int r = 0; r < q_len; ++r) a += which == 0 ? s.dO[r * ALD + j] * s.Q[r * ALD + j] : s.dO[r * ALD + j];
+      for (int k = 0; k < 8; ++k) a += colred[which][k][j];
       lnacc[which][j] += a;
     }
-    __syncthreads();
     if (tid < AT) ln_rows_bwd(s.dO, s.Q, s.qrstd, tid, q_len, d, s.gq);
     __syncthreads();
     store_rows(s.dO, p.dq, p.dq_ld, p.dq_off + h * d, s.qrow, s.qown, q_len, d, 0);  // one owner per row
     __syncthreads();
+    stamp();  // 7: q-norm grads, LN bwd, dq stored
   }
 
   // ---- K / V gradients of this block
@@ -422,20 +475,35 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
     s.dO[row * ALD + l31] = (l31 < d) ? acc_dk[r] : 0.f;
   }
   __syncthreads();
-  if (tid >= 64 && tid < 128) {
-    const int which = (tid - 64) >> 5, j = tid & 31;  // 2: dgamma_k, 3: dbeta_k
-    float a = 0.f;
+  {
+    const int j = tid & 31, part = tid >> 5;
+    float ag = 0.f, ab = 0.f;
     if (j < d)
-      for (int r = 0; r < k_len; ++r) a += which == 0 ? s.dO[r * ALD + j] * s.K[r * ALD + j] : s.dO[r * ALD + j];
-    lnacc[2 + which][j] = a;
+      for (int r = part * 16; r < min(k_len, part * 16 + 16); ++r) {
+        const float g = s.dO[r * ALD + j];
+        ag += g * s.K[r * ALD + j];
+        ab += g;
+      }
+    colred[0][part][j] = ag;
+    colred[1][part][j] = ab;
   }
   __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, j = tid & 31;  // 2: dgamma_k, 3: dbeta_k
+    float a = 0.f;
+    for (int k = 0; k < 8; ++k) a += colred[which][k][j];
+    lnacc[2 + which][j] = a;
+  }
   if (tid < AT) ln_rows_bwd(s.dO, s.K, s.krstd, tid, k_len, d, s.gk);
   __syncthreads();
   float* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
-  store_rows(s.dO, dkv, p.dkv_ld, p.dk_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out);
-  store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out);
+  store_rows(s.dO, dkv, p.dkv_ld, p.dk_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
+             p.dkv_extra, p.dkv_extra_ld, h * d);
+  store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
+             p.dkv_extra, p.dkv_extra_ld, p.dv_off - p.dk_off + h * d);
   if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
+  stamp();  // 8: k side done
+  if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.clk[63] = clk_i;
 }
 
 // out[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
@@ -465,6 +533,28 @@ static void set_attn_drop(AttnP& p, float drop_p, unsigned long long seed) {
     if (p.drop_thresh == 0) p.drop_thresh = 1;
     p.drop_inv_keep = 1.f / (1.f - drop_p);
   }
+}
+
+// dqkv[point][k|v columns] += extra[e]  for every borrowed copy e (each point is borrowed at most once)
+__global__ void attn_extra_fixup_kernel(const float* __restrict__ extra, long extra_ld, const int* __restrict__ ext_pos,
+                                        const int* __restrict__ kidx, int n_extra, int w4, float* __restrict__ dkv,
+                                        long dkv_ld, int dk_off) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n_extra * w4) return;
+  const int e = (int)(gid / w4), c = (int)(gid % w4) * 4;
+  const int point = kidx[ext_pos[e]];
+  const float4 a = *reinterpret_cast<const float4*>(extra + (long)e * extra_ld + c);
+  float4* o = reinterpret_cast<float4*>(dkv + (long)point * dkv_ld + dk_off + c);
+  float4 v = *o;
+  v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  *o = v;
+}
+
+static long long* g_attn_clk = nullptr;
+extern "C" int lotus_debug_attn_clock(long long* host64) {
+  if (!g_attn_clk) return -1;
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host64, g_attn_clk, 64 * sizeof(long long), hipMemcpyDeviceToHost);
 }
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
@@ -504,7 +594,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
                         const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
-                        int atomic_out, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
                         void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
@@ -521,12 +611,29 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.dq = dq; p.dq_ld = dq_ld; p.dq_off = dq_off;
   p.dkv = dkv; p.dkv_ld = dkv_ld; p.dk_off = dk_off; p.dv_off = dv_off; p.dkv_part_stride = dkv_part_stride;
   p.atomic_out = atomic_out; p.ln_part = (float*)workspace;
+  p.kext = kext; p.dkv_extra = (kext && n_extra > 0) ? dkv_extra : nullptr; p.dkv_extra_ld = 2L * H * d;
+  LOTUS_CHECK_ARG(!(kext && n_extra > 0) || (dkv_extra && ext_pos && dv_off - dk_off == H * d),
+                  "lotus_attention_bwd: borrowed-row buffer needs dkv_extra, ext_pos and adjacent k|v column blocks");
   p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
+  {
+    static long long* clk = nullptr;
+    if (getenv("LOTUS_ATTN_CLK") && !clk) (void)hipMalloc(&clk, 64 * sizeof(long long));
+    p.clk = clk;
+    g_attn_clk = clk;
+    static int dbg = -1;
+    if (dbg < 0) { const char* e = getenv("LOTUS_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
+    p.dbg = dbg;
+  }
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = attn_smem_bytes(true);
   (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblocks, H), dim3(256), sm, st, p);
+  if (p.dkv_extra) {
+    const int w4 = 2 * H * d / 4;
+    hipLaunchKernelGGL(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,
+                       ext_pos, kidx, n_extra, w4, dkv, dkv_ld, dk_off);
+  }
   hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(4), dim3(256), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
                      nblocks * H, d, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_attention_bwd");

@@ -64,11 +64,15 @@ __device__ __forceinline__ float act_grad_f(float pre, int act) {
 // Counter-based dropout mask: keep iff hash(seed, idx) >= p * 2^32.  Stateless so the backward
 // pass regenerates the identical mask from (seed, element index).
 __device__ __forceinline__ uint32_t lotus_hash32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (uint32_t)(z >> 32);
+  // murmur3-style 32-bit finaliser over (index, seed): 3 multiplies, ~8 VALU ops (a 64-bit splitmix costs ~25)
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)seed;
+  x ^= (uint32_t)(idx >> 32) * 0x7FEB352Du + (uint32_t)(seed >> 32);
+  x ^= x >> 16;
+  x *= 0x85EBCA6Bu;
+  x ^= x >> 13;
+  x *= 0xC2B2AE35u;
+  x ^= x >> 16;
+  return x;
 }
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
   return lotus_hash32(seed, idx) >= thresh ? inv_keep : 0.f;

@@ -291,7 +291,7 @@ __global__ void fe_pool_child_kernel(const long long* __restrict__ pcode, long p
 // off / offp: exclusive prefix sums of the per-cloud counts / padded counts (B+1 entries, device).
 __global__ void fe_patch_kernel(const int* __restrict__ order, const int* __restrict__ off,
                                 const int* __restrict__ offp, int B, int K, int npad, int* __restrict__ gidx,
-                                int* __restrict__ owner) {
+                                int* __restrict__ owner, int* __restrict__ kext, int* __restrict__ ext_pos) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npad) return;
   int lo = 0, hi = B;  // find cloud c with offp[c] <= i < offp[c+1]
@@ -305,6 +305,11 @@ __global__ void fe_patch_kernel(const int* __restrict__ order, const int* __rest
   const int src = l < ncnt ? l : l - K;  // the tail patch borrows the K - r points preceding it
   gidx[i] = order[off[c] + src];
   owner[i] = l < ncnt;
+  if (kext) {
+    const int e = l < ncnt ? -1 : (offp[c] - off[c]) + (l - ncnt);  // compact index of the borrowed copy
+    kext[i] = e;
+    if (e >= 0) ext_pos[e] = i;
+  }
 }
 
 // ---------------------------------------------------------------- neighbour tables (spconv semantics)
@@ -473,11 +478,11 @@ int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_s
 
 // Patch gather table for SerializedAttention: gidx[npad], owner[npad].  off/offp: int32 [B+1] device.
 int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int K, int npad, int* gidx, int* owner,
-                   void* stream) {
+                   int* kext, int* ext_pos, void* stream) {
   LOTUS_CHECK_ARG(order && off && offp && gidx && owner && B > 0 && K > 0, "lotus_fe_patch: bad arguments");
   if (npad == 0) return LOTUS_OK;
   hipLaunchKernelGGL(fe_patch_kernel, dim3(cdiv(npad, 256)), dim3(256), 0, (hipStream_t)stream, order, off, offp, B, K,
-                     npad, gidx, owner);
+                     npad, gidx, owner, kext, ext_pos);
   LOTUS_LAUNCH_CHECK("lotus_fe_patch");
   return LOTUS_OK;
 }

@@ -19,7 +19,7 @@ ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
 class Level:
     """Index tables of one resolution level (device tensors unless noted)."""
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
-                 "nbr125", "gidx", "owner", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
+                 "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
                  "coord", "parent")
 
@@ -170,7 +170,11 @@ class FrontEnd:
             lv.npad = pl["npad"]
             lv.gidx = torch.empty(lv.npad, **i32)
             lv.owner = torch.empty(lv.npad, **i32)
-            call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner)
+            lv.kext = torch.empty(lv.npad, **i32)
+            lv.n_extra = lv.npad - n
+            lv.ext_pos = torch.empty(max(lv.n_extra, 1), **i32)
+            call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner, lv.kext,
+                 lv.ext_pos)
             lv.self_tiles, lv.self_blocks = view(pl["tiles"], 4), view(pl["blocks"], 6)
             lv.n_self_tiles = pl["n_tiles"]
             lv.ca_tiles, lv.ca_blocks = view(pl["ca_tiles"], 4), view(pl["ca_blocks"], 6)

@@ -243,13 +243,14 @@ def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, ti
 
 
 def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
-                  dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d, drop_p=0.0, seed=0):
+                  dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d, drop_p=0.0, seed=0,
+                  kext=None, ext_pos=None, n_extra=0, dkv_extra=None):
     dev = q.device
     grads = [torch.empty(d, dtype=torch.float32, device=dev) for _ in range(4)]
     ws = _ws(query("lotus_attention_bwd_workspace", nblocks, H), dev)
     call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
          qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
-         part_stride, atomic, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
+         part_stride, atomic, kext, ext_pos, n_extra, dkv_extra, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
          int(seed), ws, ws.numel())
     return grads
 
@@ -338,10 +339,14 @@ class SelfAttnFn(torch.autograd.Function):
         dz = dropout(dy, p, seed)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
-        dqkv = torch.zeros(N, 3 * C, dtype=torch.float32, device=x.device)  # borrowed rows accumulate
+        # every (point, q|k|v column) is written exactly once by its owner position; the k/v gradients of the
+        # borrowed tail-patch copies go to a small side buffer and are added afterwards (no atomics, no memset)
+        dqkv = torch.empty(N, 3 * C, dtype=torch.float32, device=x.device)
+        extra = torch.empty(max(lvl.n_extra, 1), 2 * C, dtype=torch.float32, device=x.device)
         gq, bq, gk, bk = attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner,
                                        lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, (qnw, qnb), (knw, knb), att,
-                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d, attn_p, seed + 1)
+                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, attn_p, seed + 1,
+                                       lvl.kext, lvl.ext_pos, lvl.n_extra, extra)
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
         dn = linear_dgrad(dqkv, wqkv)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)

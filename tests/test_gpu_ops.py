@@ -190,9 +190,11 @@ def test_patch_attention_fwd_bwd(C, H):
     ops.attention_fwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.n_self_tiles,
                       qnc, knc, att, lse, H, d)
     _close(att, oref, 5e-6, "attn fwd")
-    dqkv = torch.zeros(n, 3 * C, device="cuda")
+    dqkv = torch.empty(n, 3 * C, device="cuda")
+    extra = torch.empty(max(lv.n_extra, 1), 2 * C, device="cuda")
     gr = ops.attention_bwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.self_blocks,
-                           lv.n_self_tiles, qnc, knc, att, dev(dout), lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d)
+                           lv.n_self_tiles, qnc, knc, att, dev(dout), lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, 0.0, 0,
+                           lv.kext, lv.ext_pos, lv.n_extra, extra)
     _close(dqkv, qd.grad, 2e-5, "attn dqkv")
     for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
         _close(a, b.grad, 5e-5, name)
@@ -331,9 +333,11 @@ def test_attention_dropout_mask_is_consistent_between_fwd_and_bwd():
     att_b, _ = fwd(qkv)
     assert torch.equal(att, att_b)
     dout = torch.randn(n, C, generator=g).cuda()
-    dqkv = torch.zeros(n, 3 * C, device="cuda")
+    dqkv = torch.empty(n, 3 * C, device="cuda")
+    extra = torch.empty(max(lv.n_extra, 1), 2 * C, device="cuda")
     ops.attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.self_blocks,
-                      lv.n_self_tiles, qn, qn, att, dout, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 1, H, d, p_drop, seed)
+                      lv.n_self_tiles, qn, qn, att, dout, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, p_drop, seed,
+                      lv.kext, lv.ext_pos, lv.n_extra, extra)
     u = torch.randn(n, 3 * C, generator=g).cuda()
     uv = torch.zeros_like(u)
     uv[:, 2 * C:] = u[:, 2 * C:]
