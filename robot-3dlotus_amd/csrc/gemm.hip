@@ -38,12 +38,17 @@ struct GemmP {
 // so every global access is an unconditional float4 (rows / columns beyond the edge are clamped to a
 // valid address; k beyond the split range is zeroed by a select).  !FAST keeps per-element guards
 // (odd widths such as the 90- and 217-wide head layers).
-template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A, bool FAST>
+// value-wise select (a pointer select between the loaded vector and a zero constant goes through scratch)
+__device__ __forceinline__ float4 zsel(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int A4 = BM * LOTUS_BK / 4 / 256, B4 = BN * LOTUS_BK / 4 / 256;  // float4 per thread
+  constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
-  constexpr int AF = LdsTile<BM, A_KC>::kFloats, BF = LdsTile<BN, B_KC>::kFloats;
+  constexpr int AF = LdsTile<BM, A_KC, BK>::kFloats, BF = LdsTile<BN, B_KC, BK>::kFloats;
   constexpr int WN = BN / 2, SLD = WN + 4;  // epilogue staging: per wave [32][WN + 4]
   constexpr int LDSF = (2 * AF + 2 * BF) > (4 * 32 * SLD) ? (2 * AF + 2 * BF) : (4 * 32 * SLD);
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
@@ -68,17 +73,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
   float4 ra[A4], rb[B4];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto gload = [&](int k0) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
       if (A_KC) {
-        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4));
-          ra[t] = k < kend ? v : z4;
+          ra[t] = zsel(k < kend, v);
         } else {
           ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
         }
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (FAST) {
           const int k = k0 + kr;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
-          ra[t] = k < kend ? v : z4;
+          ra[t] = zsel(k < kend, v);
         } else {
           ra[t] = load4_guard(p.A, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
         }
@@ -97,11 +101,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int t = 0; t < B4; ++t) {
       const int f = tid + t * 256;
       if (B_KC) {
-        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4));
-          rb[t] = k < kend ? v : z4;
+          rb[t] = zsel(k < kend, v);
         } else {
           rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
         }
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         if (FAST) {
           const int k = k0 + kr;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
-          rb[t] = k < kend ? v : z4;
+          rb[t] = zsel(k < kend, v);
         } else {
           rb[t] = load4_guard(p.B, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
         }
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int f = tid + t * 256;
       const float v[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w};
       if (A_KC) {
-        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        const int row = f / (BK / 4), kq = f % (BK / 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Ad[LdsTile<BM, true>::idx(row, kq * 4 + e)] = v[e];
+        for (int e = 0; e < 4; ++e) Ad[LdsTile<BM, true, BK>::idx(row, kq * 4 + e)] = v[e];
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
         *reinterpret_cast<float4*>(&Ad[kr * BM + iq * 4]) = ra[t];
@@ -136,9 +140,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const int f = tid + t * 256;
       const float v[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w};
       if (B_KC) {
-        const int row = f / (LOTUS_BK / 4), kq = f % (LOTUS_BK / 4);
+        const int row = f / (BK / 4), kq = f % (BK / 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Bd[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
+        for (int e = 0; e < 4; ++e) Bd[LdsTile<BN, true, BK>::idx(row, kq * 4 + e)] = v[e];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
         *reinterpret_cast<float4*>(&Bd[kr * BN + jq * 4]) = rb[t];
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     lstore(As, Bs);
     __syncthreads();
     int cur = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += LOTUS_BK) {
-      gload(k0 + LOTUS_BK);  // past-the-end prefetch is clamped / zeroed and never consumed
-      mma_slab<BM, BN, A_KC, B_KC, SUM_A>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      gload(k0 + BK);  // past-the-end prefetch is clamped / zeroed and never consumed
+      mma_slab<BM, BN, A_KC, B_KC, SUM_A, BK>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       cur ^= 1;
       lstore(As + cur * AF, Bs + cur * BF);
       __syncthreads();
@@ -295,27 +299,38 @@ static int tune_env(const char* name) {
   const char* e = getenv(name);
   return e ? atoi(e) : 0;
 }
-static int g_force_tile = -1, g_force_nz = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 2: 128x64, 3: 64x64), LOTUS_GEMM_NZ
+static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 3: 64x64), LOTUS_GEMM_NZ, LOTUS_GEMM_BK
+#define GEMM_KALIGN 64  // split-K ranges are multiples of the largest slab depth
 
 template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+  const long blocks64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
   const bool small_n = p.N <= 64;
   dim3 block(256);
   if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
+  if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
   int tile = g_force_tile;
   // measured (tools/gemm_sweep.py): 128x128 tiles only pay with >= 4 blocks per CU; otherwise 64x64 tiles
   // (more blocks in flight) win, including the N <= 64 layers and every split-K weight gradient
   if (tile == 0) tile = (!small_n && !SUM_A && blocks128 * nz >= 1024) ? 1 : 3;
   if (tile == 1) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-  } else if (tile == 2) {
-    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
-    hipLaunchKernelGGL((gemm_kernel<128, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else {
+    // slab depth (tools/gemm_sweep.py): with <= 2 blocks per CU nothing else hides the global-load latency,
+    // so run deep slabs (4x the MFMA work and bytes in flight per barrier); large grids keep BK = 16 for
+    // occupancy; the streamed weight-gradient operands like BK = 32
+    int bk = g_force_bk;
+    if (!bk) bk = SUM_A ? 32 : (blocks64 * nz <= 512 ? 64 : (blocks64 * nz <= 2048 ? 32 : 16));
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    hipLaunchKernelGGL((gemm_kernel<64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    if (bk == 64) {
+      hipLaunchKernelGGL((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    } else if (bk == 32) {
+      hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    } else {
+      hipLaunchKernelGGL((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    }
   }
   LOTUS_LAUNCH_CHECK("lotus_gemm");
   return LOTUS_OK;
@@ -391,8 +406,8 @@ static int fwd_splits(int M, int N, int K) {
   if (g_force_nz > 0) return (K / g_force_nz >= 16) ? g_force_nz : 1;
   const long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
   int nz = 1;
-  if (blocks < 128)  // split-K only pays for very small output grids with a long reduction
-    while (nz < 16 && blocks * nz < 256 && K / (nz * 2) >= 256) nz *= 2;
+  // fewer than 2 blocks per CU and a long reduction: split K until ~2 blocks per CU, >= 384 deep each
+  while (nz < 16 && blocks * nz < 512 && K / (nz * 2) >= 384) nz *= 2;
   return nz;
 }
 
@@ -404,7 +419,7 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, hi
   GemmP q = p;
   q.C = (float*)workspace; q.part_stride = (long)p.M * p.N;
   q.bias = nullptr; q.residual = nullptr; q.pre = nullptr; q.mulpre = nullptr; q.act = LOTUS_ACT_NONE; q.drop_thresh = 0;
-  q.klen = cdiv(cdiv(p.K, nz), LOTUS_BK) * LOTUS_BK;
+  q.klen = cdiv(cdiv(p.K, nz), GEMM_KALIGN) * GEMM_KALIGN;
   int rc = launch_gemm<A_KC, B_KC, false>(q, nz, st);
   if (rc) return rc;
   const long total4 = (long)p.M * p.N / 4;
@@ -434,7 +449,7 @@ int lotus_linear_fwd(const float* x, const float* w, const float* bias, const fl
   p.A = x; p.B = w; p.C = y; p.M = M; p.N = N; p.K = K;
   p.lda = K; p.ldb = K; p.ldc = N;
   p.bias = bias; p.residual = residual; p.pre = pre; p.act = act;
-  p.klen = cdiv(K, LOTUS_BK) * LOTUS_BK;
+  p.klen = cdiv(K, GEMM_KALIGN) * GEMM_KALIGN;
   p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K);
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, true>(p, workspace, workspace_bytes, (hipStream_t)stream);
@@ -454,7 +469,7 @@ int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* 
   p.lda = N; p.ldb = K; p.ldc = K;
   p.act = LOTUS_ACT_NONE;
   p.mulpre = pre; p.dact = act; p.residual = add;
-  p.klen = cdiv(N, LOTUS_BK) * LOTUS_BK;
+  p.klen = cdiv(N, GEMM_KALIGN) * GEMM_KALIGN;
   p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K);
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, false>(p, workspace, workspace_bytes, (hipStream_t)stream);
@@ -465,8 +480,9 @@ static int wgrad_splits(int M, int N, int K) {
   if (g_force_nz > 0) return (M / g_force_nz >= 16) ? g_force_nz : 1;
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
-  // both operands are streamed exactly once: keep >= ~6 blocks per CU in flight (Little's law)
-  while (nz < 64 && tiles * nz < 1024 && (long)nz * 128 < M) nz *= 2;
+  if (tiles >= 128 && M < 1024) return 1;  // deep levels: the second (reduce) launch costs more than it hides
+  // both operands are streamed exactly once: keep ~4 blocks per CU in flight (Little's law), >= 128 rows each
+  while (nz < 256 && tiles * nz < 1024 && M / (nz * 2) >= 128) nz *= 2;
   return nz;
 }
 
@@ -491,7 +507,7 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
   memset(&p, 0, sizeof(p));
   p.A = dy; p.B = x; p.M = N; p.N = K; p.K = M;
   p.lda = N; p.ldb = K; p.ldc = K;
-  p.klen = cdiv(cdiv(M > 0 ? M : 1, nz), LOTUS_BK) * LOTUS_BK;
+  p.klen = cdiv(cdiv(M > 0 ? M : 1, nz), GEMM_KALIGN) * GEMM_KALIGN;
   p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K);
   set_drop(p, 0.f, 0);
   if (direct) {

@@ -16,10 +16,10 @@
 // LDS images.  "KC" = the operand is k-contiguous in global memory (rows of K): image [R][BK+1]
 // (odd stride -> conflict-free ds_read_b32 across 32 rows).  Otherwise the operand is contiguous
 // along its non-reduction index: image [BK][R] (lanes read consecutive floats).
-template <int R, bool KC>
+template <int R, bool KC, int BK = LOTUS_BK>
 struct LdsTile {
-  static constexpr int kStride = KC ? (LOTUS_BK + 1) : R;
-  static constexpr int kFloats = KC ? R * (LOTUS_BK + 1) : LOTUS_BK * R;
+  static constexpr int kStride = KC ? (BK + 1) : R;
+  static constexpr int kFloats = KC ? R * (BK + 1) : BK * R;
   __device__ static __forceinline__ int idx(int r, int k) { return KC ? r * kStride + k : k * kStride + r; }
 };
 
@@ -42,19 +42,19 @@ __device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, lo
 }
 
 // One BK slab of MFMAs for this wave.  acc[tm][tn] += A(32 rows) x B(32 cols).
-template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A>
+template <int BM, int BN, bool A_KC, bool B_KC, bool SUM_A, int BK = LOTUS_BK>
 __device__ __forceinline__ void mma_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wr0,
                                          int wc0, f32x16 (&acc)[BM / 64][BN / 64], float (&asum)[BM / 64],
                                          unsigned tm_mask = 0xffffffffu) {
   constexpr int TM = BM / 64, TN = BN / 64;
   const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
 #pragma unroll
-  for (int kk = 0; kk < LOTUS_BK; kk += 2) {
+  for (int kk = 0; kk < BK; kk += 2) {
     float a[TM], b[TN];
 #pragma unroll
-    for (int tm = 0; tm < TM; ++tm) a[tm] = As[LdsTile<BM, A_KC>::idx(wr0 + tm * 32 + l31, kk + h)];
+    for (int tm = 0; tm < TM; ++tm) a[tm] = As[LdsTile<BM, A_KC, BK>::idx(wr0 + tm * 32 + l31, kk + h)];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[LdsTile<BN, B_KC>::idx(wc0 + tn * 32 + l31, kk + h)];
+    for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[LdsTile<BN, B_KC, BK>::idx(wc0 + tn * 32 + l31, kk + h)];
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       if (SUM_A) asum[tm] += a[tm];

@@ -1,6 +1,6 @@
-"""Diagnostic: for every dense-layer shape of one training step, time the GEMM under forced tile /
-split-K configurations (LOTUS_GEMM_TILE / LOTUS_GEMM_NZ are read once per process, so each config is a
-child process).  Usage: python tools/gemm_sweep.py  -> prints the best config per (kind, M, N, K)."""
+"""Diagnostic: for every dense-layer shape of one training step (tools/gemm_shapes.json, from `bench.py --gemm-report`), time the GEMM under forced tile / slab-depth / split-K configurations
+(LOTUS_GEMM_TILE / LOTUS_GEMM_BK / LOTUS_GEMM_NZ are read once per process, so each config is a child
+process).  Writes gpurun_out/gemm_sweep.json: {"kind M N K": {"count": c, "tile,bk,nz": us, ...}}."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,33 +17,26 @@ def child():
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): fn()
+        for _ in range(8): fn()
         e1.record(); e1.synchronize()
-        out[f"{kind} {M} {N} {K}"] = e0.elapsed_time(e1) / 5 * 1e3
+        out[f"{kind} {M} {N} {K}"] = e0.elapsed_time(e1) / 8 * 1e3
     print("RESULT " + json.dumps(out))
 
 if os.environ.get("SHAPES"):
     child(); sys.exit(0)
 
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-shapes = json.load(open(os.path.join(ROOT, "tools", "gemm_shapes.json")))
-res = {}
-TILES = (0,) if os.environ.get('AUTO_ONLY') else (0, 1, 2, 3)
-NZS = (0,) if os.environ.get('AUTO_ONLY') else (0, 1, 2, 4, 8, 16, 32, 64)
-for tile in TILES:
-    for nz in NZS:
-        env = dict(os.environ, SHAPES=json.dumps(shapes), LOTUS_GEMM_TILE=str(tile), LOTUS_GEMM_NZ=str(nz))
-        r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
-        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        if not line:
-            print("config failed", tile, nz, r.stderr[-300:]); continue
-        for k, v in json.loads(line[0][7:]).items():
-            res.setdefault(k, {})[(tile, nz)] = v
-tot_auto = tot_best = 0
-for k, d in sorted(res.items(), key=lambda kv: -kv[1][(0, 0)]):
-    best = min(d, key=d.get)
-    cnt = next(c for (kk, *_), c in [((f"{s[0]} {s[1]} {s[2]} {s[3]}",), 1) for s in shapes] if kk == k)
-    tot_auto += d[(0, 0)]; tot_best += d[best]
-    print(f"{k:28s} auto {d[(0,0)]:8.1f} us   best {d[best]:8.1f} us  tile={best[0]} nz={best[1]}   " +
-          " ".join(f"t{t}z{z}:{d[(t,z)]:.0f}" for (t, z) in sorted(d) if d[(t, z)] < 1.15 * d[best] and (t, z) != best))
-print("sum auto", tot_auto, "sum best", tot_best)
+rows = json.load(open(os.path.join(ROOT, "tools", "gemm_shapes.json")))  # [kind, M, N, K, count] of one v1 step
+shapes = [tuple(r[:4]) for r in rows]
+res = {f"{r[0]} {r[1]} {r[2]} {r[3]}": {"count": r[4]} for r in rows}
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+configs = [(0, 0, 0)] + [(1, 16, nz) for nz in (1, 2, 4)] + [(3, bk, nz) for bk in (16, 32, 64) for nz in (1, 2, 4, 8, 16, 32, 64, 128)]
+for tile, bk, nz in configs:
+    env = dict(os.environ, SHAPES=json.dumps(shapes), LOTUS_GEMM_TILE=str(tile), LOTUS_GEMM_NZ=str(nz), LOTUS_GEMM_BK=str(bk))
+    r = subprocess.run([sys.executable, __file__], env=env, capture_output=True, text=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    if not line:
+        print("config failed", tile, bk, nz, r.stderr[-300:]); continue
+    for k, v in json.loads(line[0][7:]).items():
+        res[k][f"{tile},{bk},{nz}"] = v
+    print("done", tile, bk, nz, flush=True)
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "gemm_sweep.json"), "w"))
