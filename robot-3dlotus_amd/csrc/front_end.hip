@@ -147,31 +147,29 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const long long* __restric
     for (int dgt = lane; dgt < 256; dgt += 64) hist[((long)slot * 256 + dgt) * ntiles_max + tile] = h[wave][dgt];
 }
 
-// exclusive scan of hist[slot][digit][tile] (digit-major) by one block per slot
+// exclusive scan of hist[slot][digit][tile] (digit-major) by one block per slot: every thread scans a
+// contiguous chunk serially, one block-wide scan of the chunk totals, then the chunk is rewritten
 __global__ __launch_bounds__(1024) void rs_scan_kernel(int* __restrict__ hist, int ntiles_max) {
   __shared__ int wsum[16];
-  __shared__ int carry_s;
   int* h = hist + (long)blockIdx.x * 256 * ntiles_max;
   const int total = 256 * ntiles_max;
-  if (threadIdx.x == 0) carry_s = 0;
+  const int chunk = (total + 1023) / 1024;
+  const int i0 = threadIdx.x * chunk, i1 = min(total, i0 + chunk);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += h[i];
+  int x = s;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if ((threadIdx.x & 63) >= o) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
   __syncthreads();
-  for (int base = 0; base < total; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < total ? h[i] : 0;
-    int x = v;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if ((threadIdx.x & 63) >= o) x += y;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    const int carry = carry_s;
-    if (i < total) h[i] = carry + woff + x - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
-    __syncthreads();
+  int run = x - s;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
+  for (int i = i0; i < i1; ++i) {
+    const int v = h[i];
+    h[i] = run;
+    run += v;
   }
 }
 
@@ -228,41 +226,62 @@ __global__ void fe_inverse_kernel(const int* __restrict__ order, int* __restrict
 // Parent points sorted by code[0] (sorted keys `skey`, permutation `order0`).  Cluster id of a
 // parent = rank of (code[0] >> 3) among the distinct values; children are therefore stored in
 // ascending parent-cell order, exactly like torch.unique(sorted=True).
+// cluster heads (first element of every run of equal parent keys) counted per 1024-element block
+__global__ __launch_bounds__(1024) void fe_pool_count_kernel(const long long* __restrict__ skey,
+                                                             const int* __restrict__ n_ptr, int* __restrict__ blk) {
+  __shared__ int wsum[16];
+  const int n = *n_ptr;
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int head = 0;
+  if (i < n) head = (i == 0) || ((skey[i] >> 3) != (skey[i - 1] >> 3));
+  const int c = __popcll(__ballot(head));
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    blk[blockIdx.x] = t;
+  }
+}
+
 __global__ __launch_bounds__(1024) void fe_pool_scan_kernel(const long long* __restrict__ skey,
                                                             const int* __restrict__ order0,
-                                                            const int* __restrict__ n_ptr, int* __restrict__ cluster,
-                                                            int* __restrict__ seg_start, int* __restrict__ n_child) {
+                                                            const int* __restrict__ n_ptr, const int* __restrict__ blk,
+                                                            int* __restrict__ cluster, int* __restrict__ seg_start,
+                                                            int* __restrict__ n_child) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int n = *n_ptr;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + threadIdx.x;
-    int head = 0;
-    if (i < n) head = (i == 0) || ((skey[i] >> 3) != (skey[i - 1] >> 3));
-    int x = head;
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(x, o, 64);
-      if ((threadIdx.x & 63) >= o) x += y;
-    }
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
-    const int carry = carry_s;
-    const int id = carry + woff + x - 1;  // inclusive scan - 1
-    if (i < n) {
-      cluster[order0[i]] = id;
-      if (head) seg_start[id] = i;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) carry_s = carry + woff + x;
-    __syncthreads();
+  if (threadIdx.x < 64) {  // heads in all preceding blocks (gridDim.x <= a few hundred)
+    int t = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 64) t += blk[b];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (threadIdx.x == 0) carry_s = t;
   }
-  if (threadIdx.x == 0) {
-    *n_child = carry_s;
-    seg_start[carry_s] = n;
+  const int i = blockIdx.x * 1024 + threadIdx.x;
+  int head = 0;
+  if (i < n) head = (i == 0) || ((skey[i] >> 3) != (skey[i - 1] >> 3));
+  int x = head;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if ((threadIdx.x & 63) >= o) x += y;
+  }
+  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) woff += wsum[w];
+  const int id = carry_s + woff + x - 1;  // inclusive scan - 1
+  if (i < n) {
+    cluster[order0[i]] = id;
+    if (head) seg_start[id] = i;
+    if (i == n - 1) {
+      *n_child = id + 1;
+      seg_start[id + 1] = n;
+    }
+  }
+  if (n == 0 && i == 0) {
+    *n_child = 0;
+    seg_start[0] = 0;
   }
 }
 
@@ -283,7 +302,14 @@ __global__ void fe_pool_child_kernel(const long long* __restrict__ pcode, long p
   for (int a = 0; a < 3; ++a) cgrid[(long)c * 3 + a] = pgrid[(long)head * 3 + a] >> pooling_depth;
   const int b = pbatch[head];
   cbatch[c] = b;
-  atomicAdd(&ccounts[b], 1);
+  // children are sorted by cloud, so a wave nearly always holds one cloud: one atomic per wave
+  const int b0 = __shfl(b, __ffsll((long long)__ballot(1)) - 1, 64);
+  const unsigned long long same = __ballot(b == b0);
+  if (same == __ballot(1)) {
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)same) - 1) atomicAdd(&ccounts[b0], __popcll(same));
+  } else {
+    atomicAdd(&ccounts[b], 1);
+  }
 }
 
 // ---------------------------------------------------------------- patch tables (model.py:410-466)
@@ -460,7 +486,12 @@ int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* ord
   hipStream_t st = (hipStream_t)stream;
   int4 pm = make_int4(perm4[0], perm4[1], perm4[2], perm4[3]);
   (void)hipMemsetAsync(ccounts, 0, (size_t)nbatch * sizeof(int), st);
-  hipLaunchKernelGGL(fe_pool_scan_kernel, dim3(1), dim3(1024), 0, st, skey0, order0, n_ptr, cluster, seg_start, n_child);
+  // cbatch doubles as the per-block head-count scratch until fe_pool_child_kernel overwrites it
+  const int nblk = cdiv(n_max, 1024);
+  LOTUS_CHECK_ARG(nblk <= n_max, "lotus_fe_pool: n_max too small");
+  hipLaunchKernelGGL(fe_pool_count_kernel, dim3(nblk), dim3(1024), 0, st, skey0, n_ptr, cbatch);
+  hipLaunchKernelGGL(fe_pool_scan_kernel, dim3(nblk), dim3(1024), 0, st, skey0, order0, n_ptr, (const int*)cbatch, cluster,
+                     seg_start, n_child);
   hipLaunchKernelGGL(fe_pool_child_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, pcode, (long)n_max, order0,
                      seg_start, pgrid, pbatch, n_child, pm, ccode, (long)n_max, cgrid, cbatch, ccounts, 1);
   LOTUS_LAUNCH_CHECK("lotus_fe_pool");

@@ -74,28 +74,29 @@ __global__ void unpool_bwd_kernel(const float* __restrict__ dx, const int* __res
 
 // ---------------------------------------------------------------- per-cloud max over contiguous rows
 // grid (B, C/32); block 256 = 32 columns x 8 row lanes
-__global__ __launch_bounds__(256) void cloud_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ off,
-                                                            int C, float* __restrict__ y, int* __restrict__ arg) {
-  __shared__ float bv[8][32];
-  __shared__ int bi[8][32];
-  const int b = blockIdx.x, col = blockIdx.y * 32 + (threadIdx.x & 31), ry = threadIdx.x >> 5;
+__global__ __launch_bounds__(1024) void cloud_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ off,
+                                                             int C, float* __restrict__ y, int* __restrict__ arg) {
+  __shared__ float bv[32][33];
+  __shared__ int bi[32][33];
+  const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int b = blockIdx.x, col = blockIdx.y * 32 + cl;
   float best = -INFINITY;
   int idx = -1;
   if (col < C)
-    for (int r = off[b] + ry; r < off[b + 1]; r += 8) {
+    for (int r = off[b] + ry; r < off[b + 1]; r += 32) {
       const float v = x[(long)r * C + col];
       if (v > best) {
         best = v;
         idx = r;
       }
     }
-  bv[ry][threadIdx.x & 31] = best;
-  bi[ry][threadIdx.x & 31] = idx;
+  bv[ry][cl] = best;
+  bi[ry][cl] = idx;
   __syncthreads();
   if (ry == 0 && col < C) {
-    for (int k = 1; k < 8; ++k) {
-      const float v = bv[k][threadIdx.x];
-      const int i = bi[k][threadIdx.x];
+    for (int k = 1; k < 32; ++k) {
+      const float v = bv[k][cl];
+      const int i = bi[k][cl];
       if (v > best || (v == best && i >= 0 && i < idx)) {
         best = v;
         idx = i;
@@ -127,29 +128,34 @@ __global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __
 // ---------------------------------------------------------------- losses (simple_policy_ptv3.py:308-373)
 // Position: per cloud b and axis c, soft-target cross entropy over all (point, bin) logits.
 // xt[n][3*nb] logits (n, c, bin); tgt: cloud b at tgt_off = 3*nb*off[b], laid out [3][n_b*nb].
-__global__ __launch_bounds__(256) void pos_ce_fwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
-                                                         const int* __restrict__ off, int nb,
-                                                         float* __restrict__ stats /*[B*3][4]: loss,lse,tsum,-*/) {
-  __shared__ float red[8];
+__global__ __launch_bounds__(1024) void pos_ce_fwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+                                                          const int* __restrict__ off, int nb,
+                                                          float* __restrict__ stats /*[B*3][4]: loss,lse,tsum,-*/) {
+  __shared__ float red[16];
   const int b = blockIdx.x, c = blockIdx.y;
   const int n0 = off[b], nn = off[b + 1] - n0;
-  const long L = (long)nn * nb;
-  const float* tb = tgt + (long)3 * nb * n0 + (long)c * L;
-  auto logit = [&](long e) { return xt[(long)(n0 + e / nb) * (3 * nb) + c * nb + (e % nb)]; };
+  const float* tb = tgt + (long)3 * nb * n0 + (long)c * nn * nb;
+  const float* xb = xt + (long)n0 * (3 * nb) + c * nb;
+  // lanes 0..31 of a half-wave walk the bins of one point; 32 points per block step
+  const int j0 = threadIdx.x & 31, g = threadIdx.x >> 5;
   float m = -INFINITY;
-  for (long e = threadIdx.x; e < L; e += 256) m = fmaxf(m, logit(e));
+  for (int p = g; p < nn; p += 32)
+    for (int j = j0; j < nb; j += 32) m = fmaxf(m, xb[(long)p * (3 * nb) + j]);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
   __syncthreads();
   double se = 0, stx = 0, st = 0;
-  for (long e = threadIdx.x; e < L; e += 256) {
-    const float x = logit(e), t = tb[e];
-    se += expf(x - m);
-    stx += (double)t * x;
-    st += t;
-  }
+  for (int p = g; p < nn; p += 32)
+    for (int j = j0; j < nb; j += 32) {
+      const float x = xb[(long)p * (3 * nb) + j], t = tb[(long)p * nb + j];
+      se += expf(x - m);
+      stx += (double)t * x;
+      st += t;
+    }
   float v[3] = {(float)se, (float)stx, (float)st};
   float tot[3];
 #pragma unroll
@@ -157,7 +163,10 @@ __global__ __launch_bounds__(256) void pos_ce_fwd_kernel(const float* __restrict
     const float w = wave_sum(v[k]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    tot[k] = red[0] + red[1] + red[2] + red[3];
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q];
+    tot[k] = t;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -294,7 +303,7 @@ int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc
 // per-cloud max over the contiguous row ranges [off[b], off[b+1])
 int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream) {
   LOTUS_CHECK_ARG(x && off && y && arg && B > 0, "lotus_cloud_max_fwd: bad arguments");
-  hipLaunchKernelGGL(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, x, off, C, y, arg);
+  hipLaunchKernelGGL(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, x, off, C, y, arg);
   LOTUS_LAUNCH_CHECK("lotus_cloud_max_fwd");
   return LOTUS_OK;
 }
@@ -314,7 +323,7 @@ int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const flo
                    void* stream) {
   LOTUS_CHECK_ARG(xt && ae && tgt && gt && off && losses && pos_stats && B > 0, "lotus_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pos_ce_fwd_kernel, dim3(B, 3), dim3(256), 0, st, xt, tgt, off, nb, pos_stats);
+  hipLaunchKernelGGL(pos_ce_fwd_kernel, dim3(B, 3), dim3(1024), 0, st, xt, tgt, off, nb, pos_stats);
   hipLaunchKernelGGL(small_loss_kernel, dim3(1), dim3(256), 0, st, ae, gt, pos_stats, B, nrot, ga, pos_w, rot_w, losses, dae);
   LOTUS_LAUNCH_CHECK("lotus_loss_fwd");
   return LOTUS_OK;
