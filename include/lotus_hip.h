@@ -169,7 +169,9 @@ int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, 
 int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
                         void* stream);
 /* compute_loss (heatmap_disc / euler_disc), simple_policy_ptv3.py:322-373: losses[4] = pos, rot,
- * open, total.  xt [n][3*nb]; ae [B][nrot*3+1]; tgt = concatenated disc_pos_probs; gt [B][ga]. */
+ * open, total.  xt [n][3*nb]; ae [B][nrot*3+1]; tgt = concatenated disc_pos_probs; gt [B][ga].
+ * pos_stats: lotus_loss_stats_floats(B) floats (statistics [B*3][4] followed by slice partials). */
+size_t lotus_loss_stats_floats(int B);
 int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
                    int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
                    void* stream);

@@ -147,29 +147,55 @@ __global__ __launch_bounds__(256) void rs_hist_kernel(const long long* __restric
     for (int dgt = lane; dgt < 256; dgt += 64) hist[((long)slot * 256 + dgt) * ntiles_max + tile] = h[wave][dgt];
 }
 
-// exclusive scan of hist[slot][digit][tile] (digit-major) by one block per slot: every thread scans a
-// contiguous chunk serially, one block-wide scan of the chunk totals, then the chunk is rewritten
+// exclusive scan of hist[slot][digit][tile] (digit-major) by one block per slot.  Segments of 16384 counters
+// are staged through LDS with coalesced loads / stores; every thread scans its 16 consecutive counters in LDS
+// (row stride 17 -> conflict-free), one block-wide scan of the thread totals per segment.
+#define RS_SCAN_SEG 16384
 __global__ __launch_bounds__(1024) void rs_scan_kernel(int* __restrict__ hist, int ntiles_max) {
+  __shared__ int buf[1024 * 17];
   __shared__ int wsum[16];
   int* h = hist + (long)blockIdx.x * 256 * ntiles_max;
   const int total = 256 * ntiles_max;
-  const int chunk = (total + 1023) / 1024;
-  const int i0 = threadIdx.x * chunk, i1 = min(total, i0 + chunk);
-  int s = 0;
-  for (int i = i0; i < i1; ++i) s += h[i];
-  int x = s;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(x, o, 64);
-    if ((threadIdx.x & 63) >= o) x += y;
-  }
-  if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-  __syncthreads();
-  int run = x - s;
-  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += wsum[w];
-  for (int i = i0; i < i1; ++i) {
-    const int v = h[i];
-    h[i] = run;
-    run += v;
+  int carry = 0;
+  for (int base = 0; base < total; base += RS_SCAN_SEG) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = k * 1024 + threadIdx.x;  // element within the segment
+      buf[(e >> 4) * 17 + (e & 15)] = base + e < total ? h[base + e] : 0;
+    }
+    __syncthreads();
+    int* mine = buf + threadIdx.x * 17;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += mine[k];
+    int x = s;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(x, o, 64);
+      if ((threadIdx.x & 63) >= o) x += y;
+    }
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int run = carry + x - s, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int v = wsum[w];
+      if (w < (int)(threadIdx.x >> 6)) run += v;
+      tot += v;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int v = mine[k];
+      mine[k] = run;
+      run += v;
+    }
+    carry += tot;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int e = k * 1024 + threadIdx.x;
+      if (base + e < total) h[base + e] = buf[(e >> 4) * 17 + (e & 15)];
+    }
+    __syncthreads();
   }
 }
 

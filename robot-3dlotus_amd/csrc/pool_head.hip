@@ -128,28 +128,29 @@ __global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __
 // ---------------------------------------------------------------- losses (simple_policy_ptv3.py:308-373)
 // Position: per cloud b and axis c, soft-target cross entropy over all (point, bin) logits.
 // xt[n][3*nb] logits (n, c, bin); tgt: cloud b at tgt_off = 3*nb*off[b], laid out [3][n_b*nb].
-__global__ __launch_bounds__(1024) void pos_ce_fwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+#define POS_CE_SPLITS 32
+// slice s of cloud b, axis c: partial (max, sum exp(x - max), sum t x, sum t) of the heatmap cross-entropy
+__global__ __launch_bounds__(256) void pos_ce_part_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
                                                           const int* __restrict__ off, int nb,
-                                                          float* __restrict__ stats /*[B*3][4]: loss,lse,tsum,-*/) {
-  __shared__ float red[16];
-  const int b = blockIdx.x, c = blockIdx.y;
+                                                          float* __restrict__ part /*[B*3][SPLITS][4]*/) {
+  __shared__ float red[4];
+  const int s = blockIdx.x, bc = blockIdx.y, b = bc / 3, c = bc % 3;
   const int n0 = off[b], nn = off[b + 1] - n0;
+  const int p0 = (int)((long)nn * s / POS_CE_SPLITS), p1 = (int)((long)nn * (s + 1) / POS_CE_SPLITS);
   const float* tb = tgt + (long)3 * nb * n0 + (long)c * nn * nb;
   const float* xb = xt + (long)n0 * (3 * nb) + c * nb;
-  // lanes 0..31 of a half-wave walk the bins of one point; 32 points per block step
+  // lanes 0..31 of a half-wave walk the bins of one point; 8 points per block step
   const int j0 = threadIdx.x & 31, g = threadIdx.x >> 5;
   float m = -INFINITY;
-  for (int p = g; p < nn; p += 32)
+  for (int p = p0 + g; p < p1; p += 8)
     for (int j = j0; j < nb; j += 32) m = fmaxf(m, xb[(long)p * (3 * nb) + j]);
   m = wave_max(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  m = red[0];
-#pragma unroll
-  for (int w = 1; w < 16; ++w) m = fmaxf(m, red[w]);
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
   double se = 0, stx = 0, st = 0;
-  for (int p = g; p < nn; p += 32)
+  for (int p = p0 + g; p < p1; p += 8)
     for (int j = j0; j < nb; j += 32) {
       const float x = xb[(long)p * (3 * nb) + j], t = tb[(long)p * nb + j];
       se += expf(x - m);
@@ -163,19 +164,34 @@ __global__ __launch_bounds__(1024) void pos_ce_fwd_kernel(const float* __restric
     const float w = wave_sum(v[k]);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
     __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t += red[q];
-    tot[k] = t;
+    tot[k] = ((red[0] + red[1]) + red[2]) + red[3];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float lse = m + logf(tot[0]);
-    float* s = stats + (long)(b * 3 + c) * 4;
-    s[0] = lse * tot[2] - tot[1];
-    s[1] = lse;
-    s[2] = tot[2];
-    s[3] = 0.f;
+    float* o = part + ((long)bc * POS_CE_SPLITS + s) * 4;
+    o[0] = m; o[1] = tot[0]; o[2] = tot[1]; o[3] = tot[2];
+  }
+}
+
+// fixed-order merge of the slices: stats[bc] = (loss, lse, tsum, -)
+__global__ __launch_bounds__(64) void pos_ce_merge_kernel(const float* __restrict__ part, float* __restrict__ stats) {
+  const int bc = blockIdx.x, s = threadIdx.x;
+  float m = -INFINITY, se = 0.f, stx = 0.f, st = 0.f;
+  if (s < POS_CE_SPLITS) {
+    const float* o = part + ((long)bc * POS_CE_SPLITS + s) * 4;
+    m = o[0]; se = o[1]; stx = o[2]; st = o[3];
+  }
+  const float M = wave_max(m);
+  se = wave_sum(m > -INFINITY ? se * expf(m - M) : 0.f);
+  stx = wave_sum(stx);
+  st = wave_sum(st);
+  if (s == 0) {
+    const float lse = M + logf(se);
+    float* o = stats + (long)bc * 4;
+    o[0] = lse * st - stx;
+    o[1] = lse;
+    o[2] = st;
+    o[3] = 0.f;
   }
 }
 
@@ -317,13 +333,19 @@ int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n
   return LOTUS_OK;
 }
 
-// losses[4] = (pos, rot, open, total); pos_stats [B*3][4] and dae [B][nrot*3+1] are saved for backward.
+// floats the caller must provide as pos_stats: [B*3][4] statistics + the slice partials behind them
+size_t lotus_loss_stats_floats(int B) { return (size_t)B * 3 * 4 * (1 + POS_CE_SPLITS); }
+
+// losses[4] = (pos, rot, open, total); pos_stats (lotus_loss_stats_floats(B) floats; the leading [B*3][4] are
+// what backward reads) and dae [B][nrot*3+1] are saved for backward.
 int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
                    int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
                    void* stream) {
   LOTUS_CHECK_ARG(xt && ae && tgt && gt && off && losses && pos_stats && B > 0, "lotus_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pos_ce_fwd_kernel, dim3(B, 3), dim3(1024), 0, st, xt, tgt, off, nb, pos_stats);
+  float* part = pos_stats + (size_t)B * 3 * 4;  // slice partials live behind the per-(cloud, axis) stats
+  hipLaunchKernelGGL(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
+  hipLaunchKernelGGL(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
   hipLaunchKernelGGL(small_loss_kernel, dim3(1), dim3(256), 0, st, ae, gt, pos_stats, B, nrot, ga, pos_w, rot_w, losses, dae);
   LOTUS_LAUNCH_CHECK("lotus_loss_fwd");
   return LOTUS_OK;

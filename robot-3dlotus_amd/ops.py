@@ -516,7 +516,7 @@ class HeadLossFn(torch.autograd.Function):
         losses = torch.zeros(4, dtype=torch.float32, device=dev)
         nb = xt.shape[1] // 3
         nrot = (ae.shape[1] - 1) // 3
-        stats = torch.empty(B * 3, 4, dtype=torch.float32, device=dev)
+        stats = torch.empty(query("lotus_loss_stats_floats", B), dtype=torch.float32, device=dev)
         dae = torch.empty_like(ae)
         if with_loss:
             call("lotus_loss_fwd", xt, ae, tgt, gt, lvl.off, B, nb, nrot, gt.shape[1], float(pos_w), float(rot_w),
