@@ -148,8 +148,6 @@ def main():
         reducer = parallel.GradReducer(model, bucket_mb=64.0)
         parallel.enable_sync_batchnorm()
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
-    if os.environ.get("LOTUS_SIDE_STREAM", "0") == "1":  # experimental: weight gradients on a second stream (+3.5 % at N=1)
-        ops.enable_side_stream()
 
     def step():
         if reducer is not None:
@@ -158,7 +156,6 @@ def main():
             model.zero_grad(set_to_none=True)
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
         losses["total"].backward()
-        ops.sync_side_stream()
         if reducer is not None:
             reducer.finish()
         return losses

@@ -11,6 +11,8 @@ backward that chains the HIP kernels (fused epilogues, no temporaries beyond wha
                                                                    SerializedUnpooling, ActionHead+loss
 PyTorch provides device memory, the stream and the autograd graph; all arithmetic is in the kernels.
 """
+import os
+
 import torch
 
 from ._capi import call, query, WS
@@ -22,13 +24,32 @@ CALL_LOG = None  # bench.py sets this to a list to record the (kind, M, N, K) of
 # Weight gradients are off the critical path of backward (nothing downstream consumes them before the
 # optimiser / gradient all-reduce) and their kernels are latency-bound streams over dy and x, while the
 # dgrad chain is MFMA-bound: running them on a second HIP stream lets the two overlap on the CUs.
-# enable_side_stream() turns this on; sync_side_stream() must be called before the gradients are read.
+# Fork/join per autograd node: the side stream waits for the main stream before each weight-gradient launch
+# and every backward() ends with the main stream waiting for the side stream (`_joined`), so whatever
+# consumes the returned gradients (accumulation, the GradReducer hooks, the optimiser) is ordered after them.
+# On by default; LOTUS_SIDE_STREAM=0 (or enable_side_stream(False)) keeps everything on one stream.
 SIDE = None
+_SIDE_ON = os.environ.get("LOTUS_SIDE_STREAM", "1") != "0"
 
 
 def enable_side_stream(on=True):
+    global SIDE, _SIDE_ON
+    _SIDE_ON = bool(on)
+    if not on:
+        sync_side_stream()
+        SIDE = None
+
+
+_IN_NODE = 0  # > 0 while a `_joined` backward is running: only then is the join guaranteed
+
+
+def _side():
     global SIDE
-    SIDE = torch.cuda.Stream() if on else None
+    if not _SIDE_ON or _IN_NODE == 0:
+        return None
+    if SIDE is None:
+        SIDE = torch.cuda.Stream()
+    return SIDE
 
 
 def sync_side_stream():
@@ -37,24 +58,34 @@ def sync_side_stream():
 
 
 class _OnSide:
-    """Run a weight-gradient producer on the side stream after the main stream's pending work."""
-
-    def __init__(self, *tensors):
-        self.tensors = tensors
+    """Run a weight-gradient producer on the side stream after the main stream's pending work.  Outputs are
+    allocated by the caller on the main stream; the per-node join makes that safe for the caching allocator."""
 
     def __enter__(self):
-        if SIDE is None:
+        self.side = _side()
+        if self.side is None:
             return self
-        SIDE.wait_stream(torch.cuda.current_stream())
-        for t in self.tensors:
-            t.record_stream(SIDE)
-        self.ctx = torch.cuda.stream(SIDE)
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
 
     def __exit__(self, *a):
-        if SIDE is not None:
+        if self.side is not None:
             self.ctx.__exit__(*a)
+
+
+def _joined(fn):
+    """backward() decorator: join the side stream before the gradients leave the node."""
+    def wrapped(ctx, *grads):
+        global _IN_NODE
+        _IN_NODE += 1
+        try:
+            return fn(ctx, *grads)
+        finally:
+            _IN_NODE -= 1
+            sync_side_stream()
+    return staticmethod(wrapped)
 
 
 def _ws(nbytes, dev):
@@ -100,11 +131,8 @@ def linear_wgrad(dy, x, need_bias=True):
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
-    with _OnSide(dy, x):
-        buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
-        dw = buf[:N * K].view(N, K)
-        db = buf[N * K:] if need_bias else None
-        ws = WS.get(nbytes, dy.device, slot=3 if SIDE is not None else 0)
+    with _OnSide():
+        ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
         call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
     return dw, db
 
@@ -170,11 +198,8 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     dw = buf[:nw].view(w_shape)
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
-    with _OnSide(dy, x):
-        buf = torch.empty(nw + (cout if need_bias else 0), dtype=torch.float32, device=dy.device)
-        dw = buf[:nw].view(w_shape)
-        db = buf[nw:] if need_bias else None
-        ws = WS.get(nbytes, dy.device, slot=3 if SIDE is not None else 0)
+    with _OnSide():
+        ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
         call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
     return dw, db
 
@@ -270,7 +295,7 @@ class CpeFn(torch.autograd.Function):
         ctx.lvl, ctx.same = lvl, same
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         xs, cw, lw, g, c, l, mean, rstd = ctx.saved_tensors
         lvl = ctx.lvl
@@ -298,7 +323,7 @@ class FfnFn(torch.autograd.Function):
         ctx.drop = (drop_p, seed)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
         p, seed = ctx.drop
@@ -330,7 +355,7 @@ class SelfAttnFn(torch.autograd.Function):
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
         lvl, H, d, p, seed, attn_p = ctx.meta
@@ -372,7 +397,7 @@ class CrossAttnFn(torch.autograd.Function):
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd = ctx.saved_tensors
         lvl, H, d, p, seed, attn_p = ctx.meta
@@ -408,7 +433,7 @@ class StemFn(torch.autograd.Function):
         ctx.meta = (lvl, training)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, cw, g, b, c, mean, invstd = ctx.saved_tensors
         lvl, training = ctx.meta
@@ -432,7 +457,7 @@ class PoolFn(torch.autograd.Function):
         ctx.meta = (child, training)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, w, g, b, pooled, arg, mean, invstd = ctx.saved_tensors
         child, training = ctx.meta
@@ -461,7 +486,7 @@ class UnpoolFn(torch.autograd.Function):
         ctx.meta = (child, training)
         return x, skip
 
-    @staticmethod
+    @_joined
     def backward(ctx, dx, dskip):
         xc, xp, wu, gu, betau, ws_, gs, betas, lu, ls, mu, iu, ms, is_ = ctx.saved_tensors
         child, training = ctx.meta
@@ -488,7 +513,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
@@ -526,7 +551,7 @@ class HeadLossFn(torch.autograd.Function):
         ctx.mark_non_differentiable(xt, ae)
         return losses, xt, ae
 
-    @staticmethod
+    @_joined
     def backward(ctx, gl, _gxt, _gae):
         x, hw0, hw3, aw0, aw3, h, hpre, xt, pc, arg, a, apre, stats, dae, tgt = ctx.saved_tensors
         lvl, pos_w, rot_w, p, seed, with_loss, nb, nrot = ctx.meta
