@@ -45,70 +45,30 @@ struct PairsCfg {
   // measured 43 % MFMA utilisation inside the tap loop)
   static constexpr int BM = 64, NRT = 4 / NCS, KC = NCS == 4 ? 32 : 16, NW = 32 * NCS, MAXT = 27;
   static constexpr int HT = 256;  // hash slots (= resident rows) per row tile
+  // image row stride: 16-byte rows read with ds_read_b128 where the LDS budget allows (NCS = 2 sits exactly at
+  // two blocks per CU with the odd stride)
+  static constexpr bool AVEC = NCS == 4;
+  static constexpr int XLD = AVEC ? KC + 4 : KC + 1;
   static constexpr size_t bytes() {
-    return (size_t)(NRT * (BM + 1) * NW + NRT * HT * (KC + 1)) * 4 + (size_t)NRT * HT * 4 + (size_t)NRT * MAXT * BM * 2 +
-           (size_t)NRT * MAXT * BM + (size_t)(2 * NRT * MAXT + 8 + NRT * BM) * 4;
+    return (size_t)(NRT * (BM + 1) * NW + NRT * HT * XLD) * 4 + (size_t)NRT * HT * 4 + (size_t)NRT * MAXT * BM * 2 +
+           (size_t)NRT * MAXT * BM + (size_t)(NRT * MAXT + NRT * 64 + 16 + NRT * BM) * 4;
   }
 };
 
-// One (tap, chunk) for NG dense pair groups: A fragments from the resident image through the per-pair
-// slot, B fragment from registers; fully unrolled with a compile-time group count so that the LDS reads
-// and MFMAs software-pipeline (a runtime `g < ng` predicate on LDS-loaded counts is treated as divergent
-// by the compiler and serialises every MFMA behind its own ds_read + waitcnt).
-template <int NG, int KC, int NW>
-__device__ __forceinline__ void tap_compute(const float* __restrict__ xs, const unsigned short* __restrict__ sl,
-                                            const unsigned char* __restrict__ rows, int cnt, const float (&b)[KC / 2],
-                                            float* __restrict__ ob, int l31, int hh, int dbg) {
-  f32x16 acc[NG];
-  int abase[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
-    abase[g] = (int)sl[min(g * 32 + l31, cnt - 1)] * (KC + 1) + hh * (KC / 2);
-  }
-  if (!(dbg & 8)) {
-#pragma unroll
-    for (int s = 0; s < KC / 2; ++s) {
-#pragma unroll
-      for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[abase[g] + s], b[s], acc[g], 0, 0, 0);
-    }
-  }
-  if (dbg & 1) {
-    float t = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) t += acc[g][0] + acc[g][7] + acc[g][15];
-    if (t == 1.2345e30f) ob[0] = t;
-    return;
-  }
-  // fold into the LDS output tile: this wave owns its 32 columns, taps are folded in fixed order
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    int ro[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ro[r] = (int)rows[g * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh] * NW;  // padded pairs -> dummy row
-    float ov[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ov[r] = ob[ro[r]];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ob[ro[r]] = ov[r] + acc[g][r];
-  }
-}
-
 template <int NCS>
-__global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
+__global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   using Cfg = PairsCfg<NCS>;
-  constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT;
+  constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT, XLD = Cfg::XLD;
   constexpr int TG = BM / 32;   // max pair groups per tap
   constexpr int GT = 64 * NCS;  // threads of one row tile's team
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* out_s = smem;                                   // [NRT][BM+1][NW]  (row BM = dummy sink of padded pairs)
   float* xs_s = out_s + NRT * (BM + 1) * NW;             // [NRT][HT][KC+1]
-  int* hkey_s = (int*)(xs_s + NRT * HT * (KC + 1));      // [NRT][HT] global row id or -1
+  int* hkey_s = (int*)(xs_s + NRT * HT * XLD);      // [NRT][HT] global row id or -1
   int* cnt_s = hkey_s + NRT * HT;                        // [NRT][MAXT]
-  int* act_s = cnt_s + NRT * MAXT;                       // [NRT][MAXT]
-  int* misc_s = act_s + NRT * MAXT;                      // [8]: nact per rt (0..3), overflow (4)
-  int* prow_s = misc_s + 8;                              // [NRT][BM]
+  int* grp_s = cnt_s + NRT * MAXT;                       // [NRT][64] pair groups: tap | offset << 8 | pairs << 16
+  int* misc_s = grp_s + NRT * 64;                        // [16]: groups per rt (0..3), overflow (4), dummy row ids (8..15)
+  int* prow_s = misc_s + 16;                             // [NRT][BM]
   unsigned short* slot_s = (unsigned short*)(prow_s + NRT * BM);  // [NRT][MAXT][BM]
   unsigned char* row_s = (unsigned char*)(slot_s + NRT * MAXT * BM);  // [NRT][MAXT][BM]
 
@@ -118,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
   const int n0 = blockIdx.x * NW;
   const int m0 = (blockIdx.y * NRT + rt) * BM;
   const int z_beg = blockIdx.z * p.tpz, z_end = min(p.T, z_beg + p.tpz);
-  float* my_xs = xs_s + rt * HT * (KC + 1);
+  float* my_xs = xs_s + rt * HT * XLD;
   int* my_hkey = hkey_s + rt * HT;
 
   int clk_i = 0;
@@ -127,9 +87,10 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
     ++clk_i;
   };
   stamp();  // 0 start
-  static_assert(HT * (KC + 1) >= MAXT * BM, "row image must be able to hold the temporary neighbour list");
+  static_assert(HT * XLD >= MAXT * BM, "row image must be able to hold the temporary neighbour list");
   int* src_tmp = (int*)my_xs;  // [taps][BM] neighbour ids, aliased onto the row image (first phase only)
   for (int i = tid; i < NRT * (BM + 1) * NW; i += 256) out_s[i] = 0.f;
+  if (tid < 8) misc_s[8 + tid] = BM * 0x01010101;  // 32 row ids that all name the dummy sink row
   for (int r = gt; r < BM; r += GT) {
     const int m = m0 + r;
     prow_s[rt * BM + r] = m < p.n ? (p.rowidx ? p.rowidx[m] : m) : -1;
@@ -169,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
 
   const int nkc = p.KD / KC;
   float bst[3][KC / 2];
-  static_assert(BM / 32 == 2, "tap loop is written for <= 2 pair groups per tap");
+  static_assert(2 * MAXT <= 64, "the group list must fit the lanes of one VGPR");
 
   auto load_b = [&](float (&dst)[KC / 2], int t, int kc) {  // weight fragment of (tap, chunk): coalesced 128 B per half-wave and k
     const int tw = p.mirror ? (p.T - 1 - t) : t;
@@ -185,22 +146,22 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
     for (int i = gt; i < HT; i += GT) my_hkey[i] = -1;
     if (tid == 0) misc_s[4] = 0;
     __syncthreads();
-    // hash every pair's neighbour row into the table; the table position is the LDS row slot
-    for (int t = t0; t < t1; ++t) {
-      const int cnt = cnt_s[rt * MAXT + t];
-      for (int k = gt; k < cnt; k += GT) {
-        const int g = first_phase ? src_tmp[(t - z_beg) * BM + k]
-                                  : p.nbr[(long)t * p.n + prow_s[rt * BM + row_s[(rt * MAXT + t) * BM + k]]];
-        unsigned pos = ((unsigned)g * 2654435761u >> 16) % HT;
-        int probes = 0;
-        while (true) {
-          const int old = atomicCAS(&my_hkey[pos], -1, g);
-          if (old == -1 || old == g) break;
-          pos = pos + 1 == HT ? 0 : pos + 1;
-          if (++probes >= HT) { misc_s[4] = 1; break; }
-        }
-        slot_s[(rt * MAXT + t) * BM + k] = (unsigned short)pos;
+    // hash every pair's neighbour row into the table; the table position is the LDS row slot.  One flat loop
+    // over (tap, pair) so that the LDS round trips of different pairs overlap.
+    for (int i = gt; i < (t1 - t0) * BM; i += GT) {
+      const int t = t0 + i / BM, k = i % BM;
+      if (k >= cnt_s[rt * MAXT + t]) continue;
+      const int g = first_phase ? src_tmp[(t - z_beg) * BM + k]
+                                : p.nbr[(long)t * p.n + prow_s[rt * BM + row_s[(rt * MAXT + t) * BM + k]]];
+      unsigned pos = ((unsigned)g * 2654435761u >> 16) % HT;
+      int probes = 0;
+      while (true) {
+        const int old = atomicCAS(&my_hkey[pos], -1, g);
+        if (old == -1 || old == g) break;
+        pos = pos + 1 == HT ? 0 : pos + 1;
+        if (++probes >= HT) { misc_s[4] = 1; break; }
       }
+      slot_s[(rt * MAXT + t) * BM + k] = (unsigned short)pos;
     }
     __syncthreads();
     if (misc_s[4]) {  // block-uniform: retry with half the taps (a single tap always fits: <= BM rows)
@@ -209,67 +170,171 @@ __global__ __launch_bounds__(256) void conv_pairs_kernel(ConvP2 p) {
       continue;
     }
     first_phase = false;  // the image fill below overwrites the temporary neighbour list
-    if (gt == 0) {
+    if (gt == 0) {  // work list: dense groups of <= 32 pairs, taps in fixed order
       int c = 0;
-      for (int t = t0; t < t1; ++t)
-        if (cnt_s[rt * MAXT + t] > 0) act_s[rt * MAXT + c++] = t;
+      for (int t = t0; t < t1; ++t) {
+        const int cnt = cnt_s[rt * MAXT + t];
+        for (int o = 0; o < cnt; o += 32) grp_s[rt * 64 + c++] = t | (o << 8) | (min(32, cnt - o) << 16);
+      }
       misc_s[rt] = c;
     }
     __syncthreads();
-    const int nact = __builtin_amdgcn_readfirstlane(misc_s[rt]);
-    const int vact = lane < nact ? act_s[rt * MAXT + lane] : 0;   // lane j: j-th active tap
-    const int vcnt = cnt_s[rt * MAXT + vact];                     // and its pair count
-    stamp();  // 3 after hashing + active list
+    const int ngr = __builtin_amdgcn_readfirstlane(misc_s[rt]);
+    const int vgrp = grp_s[rt * 64 + min(lane, max(ngr - 1, 0))];  // lane j: j-th group (read as a scalar with v_readlane)
+    stamp();  // 3 after hashing + work list
 
-    for (int kc = 0; kc < nkc; ++kc) {
-      // fill the resident image with this chunk of every hashed row (one HBM/L2 read per row and chunk);
-      // loads are issued in batches of 8 so their latencies overlap
-      constexpr int FILL = HT * (KC / 4) / GT;
-      static_assert(HT * (KC / 4) % GT == 0 && FILL % 4 == 0, "fill loop shape");
+    // Resident image: chunk kc + 1 is fetched into registers while the groups of chunk kc run (one HBM/L2 read
+    // per row and chunk, its latency under the MFMAs) and written to LDS between the two barriers ending the chunk.
+    constexpr int FILL = HT * (KC / 4) / GT;
+    static_assert(HT * (KC / 4) % GT == 0, "fill loop shape");
+    float4 vv[FILL];
+    auto issue_fill = [&](int kc) {
+      int gs[FILL];
 #pragma unroll
-      for (int b0 = 0; b0 < FILL; b0 += 4) {
-        int gs[4];
-        float4 vv[4];
+      for (int j = 0; j < FILL; ++j) gs[j] = my_hkey[(gt + j * GT) / (KC / 4)];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) gs[j] = my_hkey[(gt + (b0 + j) * GT) / (KC / 4)];
+      for (int j = 0; j < FILL; ++j) {
+        const int q = (gt + j * GT) % (KC / 4);
+        vv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gs[j] >= 0 && !(p.dbg & 4)) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
+      }
+    };
+    auto store_fill = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = (gt + (b0 + j) * GT) % (KC / 4);
-          vv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (gs[j] >= 0 && !(p.dbg & 4)) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int i = gt + (b0 + j) * GT;
-          float* o = my_xs + (i / (KC / 4)) * (KC + 1) + (i % (KC / 4)) * 4;
+      for (int j = 0; j < FILL; ++j) {
+        const int i = gt + j * GT;
+        float* o = my_xs + (i / (KC / 4)) * XLD + (i % (KC / 4)) * 4;
+        if (Cfg::AVEC) {
+          *reinterpret_cast<float4*>(o) = vv[j];
+        } else {
           o[0] = vv[j].x; o[1] = vv[j].y; o[2] = vv[j].z; o[3] = vv[j].w;
         }
       }
-      // Tap loop, software-pipelined 2 taps deep on the weight fragments (their L2 latency, ~1 us under load,
-      // exceeds one tap's MFMA time): three register stages rotated by a 3x unrolled loop.  Tap ids / pair counts
-      // live in lanes of two VGPRs and are read as scalars with v_readlane (no LDS latency in the loop).
-      if (nact > 0) load_b(bst[0], __builtin_amdgcn_readlane(vact, 0), kc);
-      if (nact > 1) load_b(bst[1], __builtin_amdgcn_readlane(vact, 1), kc);
-      __syncthreads();
-      stamp();  // 4+2kc after image fill
-      float* ob = out_s + rt * (BM + 1) * NW + cs * 32 + l31;
-      auto step = [&](int a, const float (&bc)[KC / 2], float (&bl)[KC / 2]) {
-        if (a + 2 < nact && !(p.dbg & 2)) load_b(bl, __builtin_amdgcn_readlane(vact, a + 2), kc);
-        const int t = __builtin_amdgcn_readlane(vact, a);
-        const int cnt = __builtin_amdgcn_readlane(vcnt, a);
-        const unsigned short* sl = slot_s + (rt * MAXT + t) * BM;
-        const unsigned char* rows = row_s + (rt * MAXT + t) * BM;
-        if (cnt <= 32) tap_compute<1, KC, NW>(my_xs, sl, rows, cnt, bc, ob, l31, hh, p.dbg);
-        else tap_compute<2, KC, NW>(my_xs, sl, rows, cnt, bc, ob, l31, hh, p.dbg);
-      };
-      for (int a = 0; a < nact; a += 3) {
-        step(a, bst[0], bst[2]);
-        if (a + 1 < nact) step(a + 1, bst[1], bst[0]);
-        if (a + 2 < nact) step(a + 2, bst[2], bst[1]);
+    };
+    issue_fill(0);
+    store_fill();
+    float* ob = out_s + rt * (BM + 1) * NW + cs * 32 + l31;
+    constexpr int KS = KC / 2;  // MFMAs (k-steps) per group and chunk
+    // image offset of this lane's A fragment run for group word gw: pair (offset + min(lane, pairs - 1)), k half hh
+    auto a_base = [&](int gw) {
+      const int t = gw & 255, off = (gw >> 8) & 255, cn = gw >> 16;
+      return (int)slot_s[(rt * MAXT + t) * BM + off + min(l31, cn - 1)] * XLD + hh * KS;
+    };
+    auto read_a = [&](float (&dst)[KS], int ab) {  // this lane's run of KS consecutive k of one image row
+      if (Cfg::AVEC) {
+#pragma unroll
+        for (int s4 = 0; s4 < KS / 4; ++s4) {
+          const float4 v4 = *reinterpret_cast<const float4*>(my_xs + ab + s4 * 4);
+          dst[s4 * 4] = v4.x; dst[s4 * 4 + 1] = v4.y; dst[s4 * 4 + 2] = v4.z; dst[s4 * 4 + 3] = v4.w;
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) dst[s2] = my_xs[ab + s2];
       }
-      stamp();  // 5+2kc after the tap loop (wave 0)
-      __syncthreads();
+    };
+    // Flat (chunk, group) pipeline, one basic block per step, software-pipelined by hand (sched_barrier pins the
+    // interleave) and continuous across chunk boundaries:
+    //   weights  : fragments of step i + 2 are requested from L2 (three register stages)
+    //   A        : fragments of step i + 1 are read from the image while step i multiplies (two stages; restarted
+    //              after the image swap at a chunk boundary)
+    //   fold     : the accumulators of step i - 1 are added into the LDS output tile under the MFMAs of step i
+    //              (two accumulator sets); the wave owns its 32 columns and folds in fixed order
+    // Group words live in the lanes of one VGPR and are read as scalars with v_readlane.
+    const int nsteps = nkc * ngr;
+    __syncthreads();
+    stamp();  // 4 image of chunk 0 visible
+    if (ngr == 0) {  // nothing to multiply in this phase: keep the block's barrier sequence
+      if (nkc > 1) issue_fill(1);
+      for (int kc = 1; kc < nkc; ++kc) {
+        __syncthreads();
+        store_fill();
+        if (kc + 1 < nkc) issue_fill(kc + 1);
+        __syncthreads();
+      }
+    } else {
+      f32x16 accs[2];
+      float afr[2][KS];
+      const unsigned char* prows = (const unsigned char*)(misc_s + 8);  // pending fold: none yet -> dummy sink
+      int g_cur = 0, kc_cur = 0;  // position of the running step
+      int g_b = 0, kc_b = 0;      // position of the weight prefetch (two steps ahead)
+      auto adv = [&](int& g, int& kc) {
+        if (++g == ngr) { g = 0; ++kc; }
+      };
+      load_b(bst[0], __builtin_amdgcn_readlane(vgrp, 0) & 255, 0);
+      adv(g_b, kc_b);
+      load_b(bst[1], __builtin_amdgcn_readlane(vgrp, g_b) & 255, min(kc_b, nkc - 1));
+      adv(g_b, kc_b);
+      if (nkc > 1) issue_fill(1);  // after the first weight loads: vmcnt retires in order
+      read_a(afr[0], a_base(__builtin_amdgcn_readlane(vgrp, 0)));
+      int abase_n = a_base(__builtin_amdgcn_readlane(vgrp, min(1, ngr - 1)));
+      auto step = [&](const float (&bc)[KS], float (&bl)[KS], f32x16& ac, const f32x16& ap, float (&A)[KS], float (&An)[KS]) {
+        if (g_cur == 0 && kc_cur > 0) {  // chunk boundary (block-uniform count: nkc - 1 per wave)
+          __syncthreads();               // every wave is done with the old image
+          store_fill();
+          if (kc_cur + 1 < nkc) issue_fill(kc_cur + 1);
+          __syncthreads();
+          read_a(A, a_base(__builtin_amdgcn_readlane(vgrp, 0)));
+        }
+        const int gw = __builtin_amdgcn_readlane(vgrp, g_cur);
+        const int gwb = __builtin_amdgcn_readlane(vgrp, g_b);
+        load_b(bl, gwb & 255, min(kc_b, nkc - 1));
+        const bool next_in_chunk = g_cur + 1 < ngr;
+        const int gwn2 = __builtin_amdgcn_readlane(vgrp, g_cur + 2 < ngr ? g_cur + 2 : (g_cur + 2 - ngr) % ngr);
+        constexpr int Q1 = KS / 8, Q2 = KS / 4, Q3 = 5 * KS / 8;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ac[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < Q1; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = *reinterpret_cast<const unsigned*>(prows + 8 * q + 4 * hh);
+#pragma unroll
+        for (int s2 = Q1; s2 < Q2; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        int ro[16];
+        float ov[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ro[r] = (int)((pk[r >> 2] >> (8 * (r & 3))) & 255u) * NW;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ov[r] = ob[ro[r]];
+        if (next_in_chunk) read_a(An, abase_n);
+        const int ab2 = a_base(gwn2);
+#pragma unroll
+        for (int s2 = Q2; s2 < Q3; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[ro[r]] = ov[r] + ap[r];
+#pragma unroll
+        for (int s2 = Q3; s2 < KS; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        abase_n = ab2;
+        prows = row_s + (rt * MAXT + (gw & 255)) * BM + ((gw >> 8) & 255);
+        adv(g_cur, kc_cur);
+        adv(g_b, kc_b);
+      };
+      for (int i = 0; i < nsteps; i += 6) {
+        step(bst[0], bst[2], accs[0], accs[1], afr[0], afr[1]);
+        if (i + 1 < nsteps) step(bst[1], bst[0], accs[1], accs[0], afr[1], afr[0]);
+        if (i + 2 < nsteps) step(bst[2], bst[1], accs[0], accs[1], afr[0], afr[1]);
+        if (i + 3 < nsteps) step(bst[0], bst[2], accs[1], accs[0], afr[1], afr[0]);
+        if (i + 4 < nsteps) step(bst[1], bst[0], accs[0], accs[1], afr[0], afr[1]);
+        if (i + 5 < nsteps) step(bst[2], bst[1], accs[1], accs[0], afr[1], afr[0]);
+      }
+      {  // fold of the last step (its accumulator set has the parity of nsteps - 1)
+        unsigned pk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = *reinterpret_cast<const unsigned*>(prows + 8 * q + 4 * hh);
+        const bool odd = (nsteps - 1) & 1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ro = (int)((pk[r >> 2] >> (8 * (r & 3))) & 255u) * NW;
+          ob[ro] += odd ? accs[1][r] : accs[0][r];
+        }
+      }
     }
+    stamp();  // 5 after the pipeline (wave 0)
+    __syncthreads();
     t0 = t1;
   }
 
@@ -354,7 +419,9 @@ static int tap_splits(int n, int ND) {
 template <int NCS>
 static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
   using Cfg = PairsCfg<NCS>;
-  const size_t sm = Cfg::bytes();
+  static int pad = -1;
+  if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
+  const size_t sm = Cfg::bytes() + (size_t)pad;
   (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
   hipLaunchKernelGGL((conv_pairs_kernel<NCS>), grid, dim3(256), sm, st, p);
