@@ -149,12 +149,16 @@ def main():
         parallel.enable_sync_batchnorm()
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
 
+    params = [p for p in model.parameters() if p.requires_grad]
+
     def step():
         if reducer is not None:
             reducer.zero_grad()
         else:
-            model.zero_grad(set_to_none=True)
+            for p in params:  # model.zero_grad(set_to_none=True) without the module-tree walk (2 ms of host time)
+                p.grad = None
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
+        model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
         losses["total"].backward()
         if reducer is not None:
             reducer.finish()

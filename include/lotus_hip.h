@@ -113,6 +113,9 @@ size_t lotus_layernorm_bwd_workspace(int M, int C);
 int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
                         void* workspace, size_t workspace_bytes, void* stream);
+/* second half of the above when it was called with dgamma == NULL: reduce the column partials left in workspace */
+int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamma, float* dbeta, int accumulate,
+                               void* stream);
 /* nn.BatchNorm1d(eps=1e-3, momentum=0.01) (+GELU), model_ca.py:226: statistics are exposed as
  * double sums[2*C+1] = (sum, sumsq, row count) so that a caller can all-reduce them across ranks (SyncBatchNorm,
  * train_simple_policy.py:116-117) between _stats and _finalize. */

@@ -88,14 +88,22 @@ def _conv(a):
     return a
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_dev = torch.cuda.current_device
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream (the raw-handle query is ~20x cheaper than building a
+    torch.cuda.Stream object, and this runs once per kernel launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_dev())
     return torch.cuda.current_stream().cuda_stream
 
 
 def call(name, *args):
     """Call an int-returning entry point; tensors -> device pointers; appends the current stream."""
-    L = lib()
-    rc = L.fn[name](*[_conv(a) for a in args], stream_ptr())
+    L = _LIB or lib()
+    rc = L.fn[name](*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream_ptr())
     if rc != 0:
         raise LotusError(f"{name} failed ({rc}): {L.last_error()}")
 

@@ -156,19 +156,27 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   }
 }
 
-// out[which][c] (+)= sum_b part[b][which][c]; block = 32 columns x 8 row lanes, fixed-order tree
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0,
-                                                             float* __restrict__ o1, int nb, int C, int accumulate) {
-  __shared__ float red[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r = threadIdx.x >> 5;
+// out[which][c] (+)= sum_b part[b][which][c]; block = 32 columns x 32 row lanes, fixed-order tree
+__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ o0,
+                                                              float* __restrict__ o1, int nb, int C, int accumulate) {
+  __shared__ float red[32][33];
+  const int cl = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float s = 0.f;
-  if (c < 2 * C)
-    for (int b = r; b < nb; b += 8) s += part[(long)b * 2 * C + c];
-  red[r][threadIdx.x & 31] = s;
+  if (c < 2 * C) {
+    int b = r;
+    for (; b + 96 < nb; b += 128) {  // four independent loads in flight
+      const float v0 = part[(long)b * 2 * C + c], v1 = part[(long)(b + 32) * 2 * C + c];
+      const float v2 = part[(long)(b + 64) * 2 * C + c], v3 = part[(long)(b + 96) * 2 * C + c];
+      s += (v0 + v1) + (v2 + v3);
+    }
+    for (; b < nb; b += 32) s += part[(long)b * 2 * C + c];
+  }
+  red[r][cl] = s;
   __syncthreads();
   if (r == 0 && c < 2 * C) {
     float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    for (int k = 0; k < 32; ++k) t += red[k][cl];
     const int which = c / C, col = c % C;
     float* o = which ? o1 : o0;
     if (o) o[col] = accumulate ? o[col] + t : t;
@@ -393,9 +401,16 @@ int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, co
   return LOTUS_OK;
 }
 
-size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)512 * 2 * C * sizeof(float); }
+#define LN_BWD_MAX_GRID 1024
+static int ln_bwd_grid(int M, int rpb) {
+  int grid = cdiv(M > 0 ? M : 1, rpb * 4);  // >= 4 row groups per block, <= 4 blocks per CU
+  return grid > LN_BWD_MAX_GRID ? LN_BWD_MAX_GRID : grid;
+}
+size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)LN_BWD_MAX_GRID * 2 * C * sizeof(float); }
 
-// dx = LN'(dy) (+ add); dgamma/dbeta (+)= column sums.
+// dx = LN'(dy) (+ add); dgamma/dbeta (+)= column sums.  With dgamma == NULL only dx is produced and the
+// per-block column partials stay in `workspace` for lotus_layernorm_bwd_params (which a caller may run on
+// another stream: the parameter gradients are off the critical path of backward).
 int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
                         void* workspace, size_t workspace_bytes, void* stream) {
@@ -405,15 +420,29 @@ int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
   LOTUS_CHECK_ARG(dy && x && mean && rstd && gamma && dx && M >= 0, "lotus_layernorm_bwd: bad arguments");
   LOTUS_CHECK_ARG(ln_geometry(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_bwd: unsupported C=%d", C);
   const int rpb = 256 / p.LPR;
-  int grid = cdiv(M > 0 ? M : 1, rpb * 8);
-  if (grid > 512) grid = 512;
+  const int grid = ln_bwd_grid(M, rpb);
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(float),
                   "lotus_layernorm_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * 2 * C * sizeof(float), st, p);
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, dgamma, dbeta, grid, C,
-                     accumulate);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, st, p.part, dgamma, dbeta, grid, C,
+                       accumulate);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd");
+  return LOTUS_OK;
+}
+
+// dgamma/dbeta (+)= the column partials a preceding lotus_layernorm_bwd(dgamma = NULL) of the same (M, C) left in
+// `workspace`; fixed summation order.
+int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamma, float* dbeta, int accumulate,
+                               void* stream) {
+  int lpr, nv;
+  LOTUS_CHECK_ARG(workspace && dgamma && dbeta && M >= 0, "lotus_layernorm_bwd_params: bad arguments");
+  LOTUS_CHECK_ARG(ln_geometry(C, &lpr, &nv) == 0, "lotus_layernorm_bwd_params: unsupported C=%d", C);
+  const int grid = ln_bwd_grid(M, 256 / lpr);
+  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream,
+                     (const float*)workspace, dgamma, dbeta, grid, C, accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd_params");
   return LOTUS_OK;
 }
 

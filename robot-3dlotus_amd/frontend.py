@@ -46,6 +46,26 @@ class FrontEnd:
     def build(self, pc_fts, counts, ctx_counts, perms, need_coord=False):
         """pc_fts: f32 [N, >=3] CUDA (xyz = first three columns).  counts / ctx_counts: python
         lists (points / instruction tokens per cloud).  perms: n_levels permutations of range(4)."""
+        return self.finish(self.launch(pc_fts, counts, perms), ctx_counts, need_coord)
+
+    @torch.no_grad()
+    def launch(self, pc_fts, counts, perms, stream=None):
+        """First half of build(): enqueue the sync-free device pipeline (grid coordinates, codes, sorts,
+        pooling of every level) and the asynchronous device->host copy of the per-level counts.  With
+        `stream` (a side stream) the work is ordered after everything already enqueued on the current stream
+        and runs concurrently with whatever the current stream gets next — the input-dependent integer part of
+        the NEXT batch can be prefetched under the backward pass of the current one.  finish() completes it."""
+        cur = torch.cuda.current_stream()
+        if stream is not None:
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                pend = self._launch(pc_fts, counts, perms, ws_slot=5)
+        else:
+            pend = self._launch(pc_fts, counts, perms, ws_slot=1)
+        pend["stream"] = stream
+        return pend
+
+    def _launch(self, pc_fts, counts, perms, ws_slot):
         dev = pc_fts.device
         N, B, Lv = int(pc_fts.shape[0]), len(counts), self.n_levels
         assert N == sum(counts) and pc_fts.stride(1) == 1
@@ -61,10 +81,11 @@ class FrontEnd:
         batch0 = torch.repeat_interleave(torch.arange(B, **i32), counts_t.to(dev), output_size=N)
 
         bbits = max(1, (B - 1).bit_length())
-        ws_sort = WS.get(query("lotus_fe_sort_workspace", N), dev, slot=1)
+        ws_sort = WS.get(query("lotus_fe_sort_workspace", N), dev, slot=ws_slot)
         scratch = torch.empty(8, **i32)
         gmax = scratch[4:5]
         raw = []
+        keep = [meta, batch0, scratch]
         grid = torch.empty(N, 3, **i32)
         call("lotus_fe_grid", pc_fts, ld, N, self.grid_size, grid, gmax, scratch)
         code = torch.empty(4, N, dtype=torch.int64, device=dev)
@@ -89,8 +110,31 @@ class FrontEnd:
                      seg, n_dev[s + 1:s + 2], ccode, cgrid, cbatch, cnts[s + 1])
                 raw[-1].update(cluster=cluster, seg=seg)
                 grid, batch, code = cgrid, cbatch, ccode
+        for r in raw:
+            keep.extend(v for v in r.values() if isinstance(v, torch.Tensor))
+        meta_h = torch.empty(meta.shape, dtype=torch.int32, pin_memory=True)
+        meta_h.copy_(meta, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(raw=raw, meta_h=meta_h, event=ev, keep=keep, pc_fts=pc_fts, counts=list(counts), perms=perms,
+                    depth_bound=self.depth_bound)
 
-        meta_h = meta.cpu().numpy()  # <- the one synchronisation of the front-end
+    @torch.no_grad()
+    def finish(self, pend, ctx_counts, need_coord=False):
+        """Second half of build(): wait for the counts (the one host synchronisation of the front-end; free when
+        launch() ran ahead on a side stream), then build the exactly sized neighbour / patch / tile tables on the
+        current stream."""
+        pc_fts, counts, perms, raw = pend["pc_fts"], pend["counts"], pend["perms"], pend["raw"]
+        dev = pc_fts.device
+        N, B, Lv = int(pc_fts.shape[0]), len(counts), self.n_levels
+        i32 = dict(dtype=torch.int32, device=dev)
+        pend["event"].synchronize()
+        if pend["stream"] is not None:  # tables were allocated on the side stream and are consumed here
+            cur = torch.cuda.current_stream()
+            cur.wait_event(pend["event"])
+            for t in pend["keep"]:
+                t.record_stream(cur)
+        meta_h = pend["meta_h"].numpy()
         if meta_h[0] & 1:
             depth = int(meta_h[1])
             if depth > 16:

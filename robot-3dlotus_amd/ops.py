@@ -152,8 +152,16 @@ def ln_bwd(dy, x, mean, rstd, g, add=None):
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
     nbytes = query("lotus_layernorm_bwd_workspace", M, C)
-    ws = _ws(nbytes, x.device)
-    call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, dg, db, M, C, 0, ws, ws.numel())
+    if _side() is None:
+        ws = _ws(nbytes, x.device)
+        call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, dg, db, M, C, 0, ws, ws.numel())
+        return dx, dg, db
+    # dx on the main stream; the parameter-gradient reduction of the column partials (own workspace slot, joined
+    # at the end of the node like every other weight gradient) on the side stream
+    ws = WS.get(nbytes, x.device, slot=4)
+    call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, None, None, M, C, 0, ws, ws.numel())
+    with _OnSide():
+        call("lotus_layernorm_bwd_params", ws, M, C, dg, db, 0)
     return dx, dg, db
 
 

@@ -94,6 +94,18 @@ class SimplePolicyPTV3CA(BaseModel):
                 "offset": batch["offset"], "feat": batch["pc_fts"], "context": ctx,
                 "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])}
 
+    @torch.no_grad()
+    def prefetch(self, batch):
+        """Optional input-pipeline hook (not in the reference): start the integer front-end of `batch` on a side
+        stream.  Call it for the NEXT batch right after the forward of the current one; the following
+        forward(batch) must get the same dict.  Purely an overlap device — results are identical."""
+        batch = self.prepare_batch(batch)
+        if not batch["pc_fts"].is_contiguous():
+            batch["pc_fts"] = batch["pc_fts"].contiguous()
+        self.ptv3_model.prefetch({"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
+                                  "offset": batch["offset"], "feat": batch["pc_fts"],
+                                  "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
+
     def forward(self, batch, compute_loss=False, **kwargs):
         batch = self.prepare_batch(batch)
         dev = batch["pc_fts"].device

@@ -9,6 +9,7 @@ usual structure — while every forward/backward computation goes through robot_
 Only the configuration family of the published models is built (flash path, qk_norm, no RPE / PDNorm /
 cls_mode); other options raise NotImplementedError rather than silently computing something else.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -196,16 +197,15 @@ class PointTransformerV3CA(nn.Module):
             self.dec.add_module(f"dec{s}", dec)
         self._step = 0
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
+        self._pending, self._fe_stream = None, None  # prefetch() state
 
     def _pack(self, feat, lvl):
         return PointDict(feat=feat, coord=lvl.coord, offset=lvl.off[1:].long(), level=lvl)
 
-    def forward(self, data_dict, return_dec_layers=False):
-        """data_dict keys as in the reference: coord / feat / offset / context / context_offset
-        (+ grid_size).  Extra host-side hints `counts` / `context_counts` (python lists) avoid two
-        device->host copies.  Returns the list [enc_last, dec..] of {feat, coord, offset} when
-        return_dec_layers, else the last dict (model_ca.py:383-412)."""
-        feat = data_dict["feat"].contiguous()
+    def _front_inputs(self, data_dict):
+        feat = data_dict["feat"]
+        if not feat.is_contiguous():
+            feat = feat.contiguous()
         counts = data_dict.get("counts")
         if counts is None:
             off = data_dict["offset"].tolist()
@@ -214,12 +214,42 @@ class PointTransformerV3CA(nn.Module):
         if ctx_counts is None:
             off = data_dict["context_offset"].tolist()
             ctx_counts = [b - a for a, b in zip([0] + off[:-1], off)]
-        context = data_dict["context"].contiguous()
-        perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
+        context = data_dict.get("context")
+        if context is not None:
+            context = context.contiguous()
         coord = data_dict["coord"]
         src = feat if (coord.data_ptr() == feat.data_ptr() and feat.shape[1] >= 3) else coord.contiguous()
-        self.frontend.grid_size = float(torch.tensor(float(data_dict.get("grid_size", 0.01)), dtype=torch.float32).item())
-        levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
+        self.frontend.grid_size = float(np.float32(data_dict.get("grid_size", 0.01)))
+        return feat, src, counts, ctx_counts, context
+
+    @torch.no_grad()
+    def prefetch(self, data_dict):
+        """Start the integer front-end (serialisation, sorts, pooling tables) of `data_dict` on a side stream.
+        It depends on the input cloud only, so a trainer can call this for batch i + 1 right after the forward
+        of batch i: the work then hides under the backward pass, and the next forward(data_dict) — which must
+        receive the very same dict — finds its tables without draining the GPU.  The order permutations are drawn
+        here (same count and order of torch.randperm calls as the reference's forward)."""
+        if self._fe_stream is None:
+            self._fe_stream = torch.cuda.Stream()
+        feat, src, counts, ctx_counts, context = self._front_inputs(data_dict)
+        perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
+        data_dict["feat"] = feat  # keep the tensors forward() will look at identical
+        if src is not feat:
+            data_dict["coord"] = src
+        self._pending = self.frontend.launch(src, counts, perms, stream=self._fe_stream)
+
+    def forward(self, data_dict, return_dec_layers=False):
+        """data_dict keys as in the reference: coord / feat / offset / context / context_offset
+        (+ grid_size).  Extra host-side hints `counts` / `context_counts` (python lists) avoid two
+        device->host copies.  Returns the list [enc_last, dec..] of {feat, coord, offset} when
+        return_dec_layers, else the last dict (model_ca.py:383-412)."""
+        feat, src, counts, ctx_counts, context = self._front_inputs(data_dict)
+        pend, self._pending = self._pending, None
+        if pend is not None and pend["pc_fts"] is src and pend["counts"] == list(counts):
+            levels = self.frontend.finish(pend, ctx_counts, need_coord=True)  # prefetched: no pipeline drain
+        else:
+            perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
+            levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
         training = self.training
         p = self.proj_drop if training else 0.0
         pa = self.attn_drop if training else 0.0

@@ -114,3 +114,39 @@ def test_full_size_train_step_properties():
     with torch.no_grad():
         acts = m(batch, compute_loss=False)
     assert acts.shape == (16, 8) and acts.dtype == torch.float64
+
+
+def test_prefetch_is_bit_identical():
+    """policy.prefetch() (front-end of the next batch on a side stream) only moves work in time: losses,
+    logits and gradients must equal the synchronous path bit for bit, over several pipelined steps."""
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 3, "scaled")
+    perms = [[2, 0, 3, 1], [1, 3, 0, 2]]
+    batches = [_dev_batch(synth.synth_batch(3, 700, ragged=True, seed=s)) for s in (5, 6, 7)]
+
+    def run(prefetch):
+        m = _build(cfg, sd, True)
+        m.ptv3_model.order_perms = perms
+        out = []
+        if prefetch:
+            m.prefetch(batches[0])
+        for i, b in enumerate(batches):
+            m.zero_grad(set_to_none=True)
+            _, losses = m(b, compute_loss=True, compute_final_action=False)
+            if prefetch and i + 1 < len(batches):
+                m.prefetch(batches[i + 1])
+            losses["total"].backward()
+            out.append((losses["total"].detach().clone(), m.last_pred[0].detach().clone(),
+                        [p.grad.detach().clone() for p in m.parameters()]))
+        torch.cuda.synchronize()
+        return out
+
+    a, b = run(False), run(True)
+    for (la, xa, ga), (lb, xb, gb) in zip(a, b):
+        assert torch.equal(la, lb) and torch.equal(xa, xb)
+        for u, v in zip(ga, gb):
+            assert torch.equal(u, v)
