@@ -75,10 +75,14 @@ class FrontEnd:
         meta = torch.zeros(8 + Lv + Lv * B, **i32)
         state, n_dev = meta[0:8], meta[8:8 + Lv]
         cnts = meta[8 + Lv:].view(Lv, B)
-        counts_t = torch.tensor(counts, dtype=torch.int32)
-        n_dev[0:1].copy_(torch.tensor([N], dtype=torch.int32), non_blocking=True)
-        cnts[0].copy_(counts_t, non_blocking=True)
-        batch0 = torch.repeat_interleave(torch.arange(B, **i32), counts_t.to(dev), output_size=N)
+        # host -> device through pinned memory: a pageable copy would make the host wait for the whole queue
+        hc = torch.empty(B + 1, dtype=torch.int32, pin_memory=True)
+        hc[0] = N
+        hc[1:] = torch.as_tensor(counts, dtype=torch.int32)
+        dc = hc.to(dev, non_blocking=True)
+        n_dev[0:1].copy_(dc[0:1])
+        cnts[0].copy_(dc[1:])
+        batch0 = torch.repeat_interleave(torch.arange(B, **i32), dc[1:], output_size=N)
 
         bbits = max(1, (B - 1).bit_length())
         ws_sort = WS.get(query("lotus_fe_sort_workspace", N), dev, slot=ws_slot)
@@ -191,7 +195,10 @@ class FrontEnd:
                               ca_tiles=push(ca_tiles), ca_blocks=push(ca_blocks), n_tiles=len(tiles),
                               n_ca_tiles=len(ca_tiles), n_ca_blocks=len(ca_blocks), G=G, npad=int(offp[-1]),
                               off_host=off))
-        tabs = torch.from_numpy(np.concatenate(host_tabs)).to(dev)
+        ntab = sum(a.size for a in host_tabs)
+        tabs_h = torch.empty(ntab, dtype=torch.int32, pin_memory=True)  # pinned: the upload must not drain the queue
+        np.concatenate(host_tabs, out=tabs_h.numpy())
+        tabs = tabs_h.to(dev, non_blocking=True)
 
         def view(sl, cols=None):
             t = tabs[sl[0]:sl[0] + sl[1]]

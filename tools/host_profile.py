@@ -10,9 +10,11 @@ import bench
 dev = torch.device("cuda", 0)
 model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
 batch = bench.dev_batch(synth.synth_batch(16, 4096, seed=0), dev)
+params = list(model.parameters())
 def step():
-    model.zero_grad(set_to_none=True)
+    for p in params: p.grad = None
     _, losses = model(batch, compute_loss=True, compute_final_action=False)
+    model.prefetch(batch)
     losses["total"].backward()
 for _ in range(5): step()
 torch.cuda.synchronize()
