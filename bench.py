@@ -150,6 +150,10 @@ def main():
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
 
     params = [p for p in model.parameters() if p.requires_grad]
+    if reducer is None:
+        # gradients are dropped (set to None) before every step and nothing reads them during backward:
+        # the weight-gradient stream only has to be joined once, at the end of the backward pass
+        ops.set_wgrad_join("end")
 
     def step():
         if reducer is not None:

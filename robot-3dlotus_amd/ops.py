@@ -28,8 +28,25 @@ CALL_LOG = None  # bench.py sets this to a list to record the (kind, M, N, K) of
 # and every backward() ends with the main stream waiting for the side stream (`_joined`), so whatever
 # consumes the returned gradients (accumulation, the GradReducer hooks, the optimiser) is ordered after them.
 # On by default; LOTUS_SIDE_STREAM=0 (or enable_side_stream(False)) keeps everything on one stream.
+#
+# set_wgrad_join("end") defers the join to ONE wait at the end of the backward pass (an autograd engine
+# callback): the weight-gradient kernels of a node may then still be running while the main stream is
+# several nodes further down the dgrad chain.  Valid when nothing reads a parameter gradient during
+# backward — i.e. `.grad is None` on entry (zero_grad(set_to_none=True): autograd adopts the tensor without
+# touching it) and no per-parameter hooks; the GradReducer (hooks) and gradient accumulation need the
+# default "node".  Tensors the side stream reads are marked with record_stream so the caching allocator does
+# not hand their memory to the main stream early.
 SIDE = None
 _SIDE_ON = os.environ.get("LOTUS_SIDE_STREAM", "1") != "0"
+_JOIN = "node"
+_END_CB_PENDING = False
+
+
+def set_wgrad_join(mode):
+    global _JOIN
+    assert mode in ("node", "end")
+    sync_side_stream()
+    _JOIN = mode
 
 
 def enable_side_stream(on=True):
@@ -59,13 +76,20 @@ def sync_side_stream():
 
 class _OnSide:
     """Run a weight-gradient producer on the side stream after the main stream's pending work.  Outputs are
-    allocated by the caller on the main stream; the per-node join makes that safe for the caching allocator."""
+    allocated by the caller on the main stream (they stay alive until after the join); `reads` are the tensors
+    the side-stream kernels consume."""
+
+    def __init__(self, *reads):
+        self.reads = reads
 
     def __enter__(self):
         self.side = _side()
         if self.side is None:
             return self
         self.side.wait_stream(torch.cuda.current_stream())
+        if _JOIN == "end":  # no join at the end of the node: the allocator must know about the second reader
+            for t in self.reads:
+                t.record_stream(self.side)
         self.ctx = torch.cuda.stream(self.side)
         self.ctx.__enter__()
         return self
@@ -75,16 +99,27 @@ class _OnSide:
             self.ctx.__exit__(*a)
 
 
+def _end_of_backward():
+    global _END_CB_PENDING
+    _END_CB_PENDING = False
+    sync_side_stream()
+
+
 def _joined(fn):
-    """backward() decorator: join the side stream before the gradients leave the node."""
+    """backward() decorator: join the side stream before the gradients leave the node ("node"), or once at the
+    end of the backward pass ("end")."""
     def wrapped(ctx, *grads):
-        global _IN_NODE
+        global _IN_NODE, _END_CB_PENDING
         _IN_NODE += 1
         try:
+            if _JOIN == "end" and _SIDE_ON and not _END_CB_PENDING:
+                _END_CB_PENDING = True
+                torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
             return fn(ctx, *grads)
         finally:
             _IN_NODE -= 1
-            sync_side_stream()
+            if _JOIN == "node":
+                sync_side_stream()
     return staticmethod(wrapped)
 
 
@@ -131,7 +166,7 @@ def linear_wgrad(dy, x, need_bias=True):
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
-    with _OnSide():
+    with _OnSide(dy, x):
         ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
         call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
     return dw, db
@@ -158,9 +193,10 @@ def ln_bwd(dy, x, mean, rstd, g, add=None):
         return dx, dg, db
     # dx on the main stream; the parameter-gradient reduction of the column partials (own workspace slot, joined
     # at the end of the node like every other weight gradient) on the side stream
-    ws = WS.get(nbytes, x.device, slot=4)
+    # ("end" join: the partials must outlive an unknown amount of main-stream progress -> a fresh buffer)
+    ws = WS.get(nbytes, x.device, slot=4) if _JOIN == "node" else torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, None, None, M, C, 0, ws, ws.numel())
-    with _OnSide():
+    with _OnSide(ws):
         call("lotus_layernorm_bwd_params", ws, M, C, dg, db, 0)
     return dx, dg, db
 
@@ -206,7 +242,7 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     dw = buf[:nw].view(w_shape)
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
-    with _OnSide():
+    with _OnSide(dy, x, nbr):
         ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
         call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
     return dw, db

@@ -150,3 +150,37 @@ def test_prefetch_is_bit_identical():
         assert torch.equal(la, lb) and torch.equal(xa, xb)
         for u, v in zip(ga, gb):
             assert torch.equal(u, v)
+
+
+def test_deferred_wgrad_join_is_bit_identical():
+    """ops.set_wgrad_join("end") (one join of the weight-gradient stream per backward pass instead of one per
+    autograd node) must not change a single bit of the gradients."""
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 4, "scaled")
+    batches = [_dev_batch(synth.synth_batch(4, 900, ragged=True, seed=s)) for s in (11, 12, 13)]
+
+    def run(mode):
+        ops.set_wgrad_join(mode)
+        try:
+            m = _build(cfg, sd, True)
+            m.ptv3_model.order_perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
+            out = []
+            for b in batches:
+                for p in m.parameters():
+                    p.grad = None
+                _, losses = m(b, compute_loss=True, compute_final_action=False)
+                losses["total"].backward()
+                out.append([p.grad.detach().clone() for p in m.parameters()])
+            torch.cuda.synchronize()
+            return out
+        finally:
+            ops.set_wgrad_join("node")
+
+    a, b = run("node"), run("end")
+    for ga, gb in zip(a, b):
+        for u, v in zip(ga, gb):
+            assert torch.equal(u, v)
