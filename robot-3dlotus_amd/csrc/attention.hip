@@ -507,18 +507,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
 }
 
 // out[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
-// one block per `which`; 8 row lanes x 32 columns, fixed-order tree -> deterministic
-__global__ __launch_bounds__(256) void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1,
-                                                             float* o2, float* o3, int nb, int d, int accumulate) {
-  __shared__ float red[8][32];
+// one block per `which`; 32 row lanes x 32 columns, four loads in flight per lane, fixed-order tree -> deterministic
+__global__ __launch_bounds__(1024) void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1,
+                                                              float* o2, float* o3, int nb, int d, int accumulate) {
+  __shared__ float red[32][33];
   const int which = blockIdx.x, j = threadIdx.x & 31, r = threadIdx.x >> 5;
   float s = 0.f;
-  for (int b = r; b < nb; b += 8) s += part[((long)b * 4 + which) * 32 + j];
+  int b = r;
+  for (; b + 96 < nb; b += 128) {
+    const float v0 = part[((long)b * 4 + which) * 32 + j], v1 = part[((long)(b + 32) * 4 + which) * 32 + j];
+    const float v2 = part[((long)(b + 64) * 4 + which) * 32 + j], v3 = part[((long)(b + 96) * 4 + which) * 32 + j];
+    s += (v0 + v1) + (v2 + v3);
+  }
+  for (; b < nb; b += 32) s += part[((long)b * 4 + which) * 32 + j];
   red[r][j] = s;
   __syncthreads();
   if (r == 0 && j < d) {
     float t = 0.f;
-    for (int k = 0; k < 8; ++k) t += red[k][j];
+    for (int k = 0; k < 32; ++k) t += red[k][j];
     float* o = which == 0 ? o0 : which == 1 ? o1 : which == 2 ? o2 : o3;
     o[j] = accumulate ? o[j] + t : t;
   }
@@ -634,7 +640,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
     hipLaunchKernelGGL(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,
                        ext_pos, kidx, n_extra, w4, dkv, dkv_ld, dk_off);
   }
-  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(4), dim3(256), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
+  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(4), dim3(1024), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
                      nblocks * H, d, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_attention_bwd");
   return LOTUS_OK;

@@ -295,13 +295,17 @@ def bn_bwd(dy, x, mean, invstd, g, b, training, act):
     call("lotus_batchnorm_bwd_stats", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel())
     # dgamma / dbeta are the LOCAL sums (gradient averaging across ranks is the reducer's job);
     # dx uses the statistics of the whole (all-rank) batch
-    dg = sums[C:2 * C].float()
-    db = sums[:C].float()
-    if training and BnState.reduce is not None:
-        BnState.reduce(sums)
     dx = torch.empty_like(x)
-    call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, None, None, M, C, act,
-         1 if training else 0, 0)
+    if training and BnState.reduce is not None:
+        dg = sums[C:2 * C].float()
+        db = sums[:C].float()
+        BnState.reduce(sums)
+        call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, None, None, M, C, act, 1, 0)
+    else:  # local statistics: the apply kernel writes the parameter gradients itself
+        dg = torch.empty(C, dtype=torch.float32, device=dev)
+        db = torch.empty(C, dtype=torch.float32, device=dev)
+        call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, dg, db, M, C, act,
+             1 if training else 0, 0)
     return dx, dg, db
 
 

@@ -143,8 +143,7 @@ class PointDict(dict):
 
 
 def _tick(bn, training):
-    if training:
-        bn.num_batches_tracked.add_(1)
+    """num_batches_tracked bookkeeping is batched: one fused launch per forward (see forward())."""
 
 
 class PointTransformerV3CA(nn.Module):
@@ -198,6 +197,7 @@ class PointTransformerV3CA(nn.Module):
         self._step = 0
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
         self._pending, self._fe_stream = None, None  # prefetch() state
+        self._nbt = None
 
     def _pack(self, feat, lvl):
         return PointDict(feat=feat, coord=lvl.coord, offset=lvl.off[1:].long(), level=lvl)
@@ -251,6 +251,10 @@ class PointTransformerV3CA(nn.Module):
             perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
             levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
         training = self.training
+        if training:  # BatchNorm1d.num_batches_tracked += 1 for every norm layer, one fused launch
+            if self._nbt is None:
+                self._nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
+            torch._foreach_add_(self._nbt, 1)
         p = self.proj_drop if training else 0.0
         pa = self.attn_drop if training else 0.0
         self._step += 1
