@@ -114,7 +114,7 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.K = p; p += AT * ALD;
   s.V = p; p += AT * ALD;
   s.dO = p; if (bwd) p += AT * ALD;
-  s.S = p; p += AT * SLD;
+  s.S = p; if (bwd) p += AT * SLD;
   s.qrstd = p; p += AT;
   s.krstd = p; p += AT;
   s.Dv = p; p += AT;
@@ -126,8 +126,8 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.kext = (int*)p; p += AT;
   return s;
 }
-static size_t attn_smem_bytes(bool bwd) {
-  return (size_t)((bwd ? 4 : 3) * AT * ALD + AT * SLD + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
+static size_t attn_smem_bytes(bool bwd) {  // the forward carves the same layout but never touches S
+  return (size_t)((bwd ? 4 : 3) * AT * ALD + (bwd ? AT * SLD : 0) + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
 }
 
 __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
@@ -142,7 +142,13 @@ __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
 }
 
 // ------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+// Scores are computed TRANSPOSED, S^T = K Q^T, so that in the MFMA accumulator layout a lane owns one query
+// (col = lane & 31) and its registers run over the keys (row = (r & 3) + 8 (r >> 2) + 4 hh of key tile t):
+//   * the softmax of a query is a reduction over the lane's own 64 registers plus one exchange with lane ^ 32;
+//   * the probabilities are ALREADY the B fragments of O^T = V^T P^T (k = key: lane-half hh of step (t, r)
+//     supplies exactly the key it holds in register r; the A fragment V[key][dcol] comes from the LDS image);
+// the 128 x 128 score image never exists in LDS (3 row images = 51 KB -> three blocks per CU).
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnSmem s = carve(smem, false);
   const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1;
@@ -166,66 +172,81 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
   __syncthreads();
 
   const int r0 = wave * 32;
+  if (r0 >= q_len) return;
   const int ktiles = (k_len + 31) / 32;
-  // S = scale * Q K^T
-  if (r0 < q_len) {
-    f32x16 acc[4];
+  const int qi = r0 + l31;  // this lane's query
+  f32x16 acc[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = zero16();
-    for (int kk = 0; kk < d; kk += 2) {
-      const float a = s.Q[(r0 + l31) * ALD + kk + hh];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + kk + hh], acc[t], 0, 0, 0);
-    }
+  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  for (int kk = 0; kk < d; kk += 2) {
+    const float bq = s.Q[qi * ALD + kk + hh];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < ktiles) {
+      if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[(t * 32 + l31) * ALD + kk + hh], bq, acc[t], 0, 0, 0);
+  }
+  // softmax over this query's keys: registers of both lane halves
+  float m = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          s.S[row * SLD + t * 32 + l31] = acc[t][r] * p.scale;
-        }
-      }
-  }
-  __syncthreads();
-  // row softmax (2 threads per row)
-  {
-    const int row = tid >> 1, half = tid & 1;
-    const int c0 = half * 64, c1 = min(k_len, c0 + 64);
-    float* srow = s.S + row * SLD;
-    float m = -INFINITY;
-    if (row < q_len)
-      for (int c = c0; c < c1; ++c) m = fmaxf(m, srow[c]);
-    m = fmaxf(m, __shfl_xor(m, 1, 64));
-    float sum = 0.f;
-    if (row < q_len)
-      for (int c = c0; c < c1; ++c) {
-        const float e = __expf(srow[c] - m);
-        srow[c] = e;
-        sum += e;
-      }
-    sum += __shfl_xor(sum, 1, 64);
-    const float inv = sum > 0.f ? 1.f / sum : 0.f;
-    if (row < q_len) {
-      for (int c = c0; c < c1; ++c) srow[c] *= inv * pmask(p, blockIdx.x, h, row, c);
-      for (int c = max(c1, c0); c < c0 + 64; ++c) srow[c] = 0.f;  // keys beyond k_len
-      if (half == 0 && p.lse) p.lse[(long)(q_start + row) * p.H + h] = m + logf(sum);
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float v = key < k_len ? acc[t][r] * p.scale : -INFINITY;
+      acc[t][r] = v;
+      m = fmaxf(m, v);
     }
-  }
-  __syncthreads();
-  // O = P V
-  if (r0 < q_len) {
-    f32x16 acc = zero16();
-    const int kend = (k_len + 1) & ~1;
-    for (int kk = 0; kk < kend; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(r0 + l31) * SLD + kk + hh], s.V[(kk + hh) * ALD + l31], acc, 0, 0, 0);
-    if (l31 < d) {
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = acc[t][r] > -INFINITY ? __expf(acc[t][r] - m) : 0.f;
+      acc[t][r] = e;
+      sum += e;
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = sum > 0.f ? 1.f / sum : 0.f;
+  if (p.drop_thresh) {
+    // same counter hash as pmask(): idx = row_base + key with row_base a multiple of 128, so only the low
+    // word changes with the key and the high-word / seed terms are per-lane constants
+    const unsigned long long rb = (((unsigned long long)blockIdx.x * p.H + h) * AT + qi) * AT;
+    const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+    const unsigned s0 = (unsigned)p.drop_seed;
+    const float keep = inv * p.drop_inv_keep;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < q_len && s.qown[row]) p.out[(long)s.qrow[row] * p.out_ld + h * d + l31] = acc[r];
+        unsigned x = (lo0 + (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh)) * 0x9E3779B1u + s0;
+        x ^= c2;
+        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+        acc[t][r] *= x >= p.drop_thresh ? keep : 0.f;
       }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
+  }
+  if (hh == 0 && qi < q_len && p.lse) p.lse[(long)(q_start + qi) * p.H + h] = m + logf(sum);
+  // O^T[dcol][query] = sum_key V[key][dcol] P[query][key]
+  f32x16 o = zero16();
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < ktiles) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(s.V[key * ALD + l31], acc[t][r], o, 0, 0, 0);
+      }
+    }
+  if (qi < q_len && s.qown[qi]) {
+    float* orow = p.out + (long)s.qrow[qi] * p.out_ld + h * d;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int dc = 8 * q4 + 4 * hh;
+      if (dc < d) *reinterpret_cast<float4*>(orow + dc) = make_float4(o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]);
     }
   }
 }
