@@ -55,6 +55,15 @@ __device__ __forceinline__ float pmask(const AttnP& p, int tile, int h, int row,
   return dropout_scale(p.drop_seed, idx, p.drop_thresh, p.drop_inv_keep);
 }
 
+// lotus_hash32(seed, idx) >= thresh with the index split as (hi, lo): the hi / seed terms are hoisted by the callers
+// (c2 = hi * 0x7FEB352D + seed_hi, s0 = seed_lo), only the low word changes inside a tile
+__device__ __forceinline__ bool keep_lo(unsigned lo, unsigned s0, unsigned c2, unsigned thresh) {
+  unsigned x = lo * 0x9E3779B1u + s0;
+  x ^= c2;
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x >= thresh;
+}
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -114,7 +123,7 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.K = p; p += AT * ALD;
   s.V = p; p += AT * ALD;
   s.dO = p; if (bwd) p += AT * ALD;
-  s.S = p; if (bwd) p += AT * SLD;
+  s.S = nullptr;  // scores live in registers (transposed-accumulator formulation)
   s.qrstd = p; p += AT;
   s.krstd = p; p += AT;
   s.Dv = p; p += AT;
@@ -126,8 +135,8 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.kext = (int*)p; p += AT;
   return s;
 }
-static size_t attn_smem_bytes(bool bwd) {  // the forward carves the same layout but never touches S
-  return (size_t)((bwd ? 4 : 3) * AT * ALD + (bwd ? AT * SLD : 0) + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
+static size_t attn_smem_bytes(bool bwd) {
+  return (size_t)((bwd ? 4 : 3) * AT * ALD + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
 }
 
 __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
@@ -289,7 +298,7 @@ __device__ __forceinline__ void ln_rows_bwd(float* g, const float* xh, const flo
   for (int j = 0; j < d; ++j) gr[j] = rs * (gr[j] * gam[j] - s1 - xr[j] * s2);
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnSmem s = carve(smem, true);
   __shared__ float lnacc[4][32];
@@ -359,105 +368,107 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
     __syncthreads();
     stamp();  // 2: Q/dO/O loaded, D, Q LN
 
-    // P = exp(scale * Qn Kn^T - lse), zero outside the valid (q_len, k_len) rectangle
-    if (r0 < q_len) {
-      f32x16 acc[4];
+    // No score image: P and dS are recomputed in registers in the two accumulator orientations that the
+    // three output products need (each lane owns ONE key, resp. ONE query; its registers run over the other
+    // index, which is exactly the B-fragment layout of the products that reduce over that index).
+    //
+    // ---- orientation A: lane <-> key kj of this wave's 32 keys, registers <-> queries of tile qt
+    //        S[q][kj], dP[q][kj]  ->  dV^T[:, kj] += dO^T Pm ,  dKn^T[:, kj] += Qn^T dS
+    if (r0 < k_len) {
+      const int kj = r0 + l31;
+      // q_norm's affine is folded into the hoisted key fragment: (xq g + b) . kn = xq . (g kn) + b . kn, so the
+      // A operand is the raw normalised row and the bias term is one per-key constant
+      float kb[16], vb[16], c_a = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) acc[t] = zero16();
-      if (!(p.dbg & 2)) {
-        if (p.dbg & 4) {
-          for (int kk = 0; kk < d; kk += 2) {
-            const int k = kk + hh;
-            const float a = s.Q[(r0 + l31) * ALD + k];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + k], acc[t], 0, 0, 0);
-          }
-        } else {
-      for (int kk = 0; kk < d; kk += 2) {
-        const int k = kk + hh;
-        const float a = s.Q[(r0 + l31) * ALD + k] * s.gq[k] + s.bq[k];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (t < ktiles)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.K[(t * 32 + l31) * ALD + k] * s.gk[k] + s.bk[k], acc[t], 0, 0, 0);
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int k = 2 * s2 + hh;
+        const float kn = s.K[kj * ALD + k] * s.gk[k] + s.bk[k];
+        c_a += s.bq[k] * kn;
+        kb[s2] = kn * s.gq[k];
+        vb[s2] = s.V[kj * ALD + k];
       }
+      c_a += __shfl_xor(c_a, 32, 64);
+      // dropout index ((tile * H + h) * 128 + q) * 128 + key: the tile/head part is a multiple of 2^14, so the
+      // (q, key) part only ever touches the low word
+      const unsigned long long tb = ((unsigned long long)tile * p.H + h) * AT * AT;
+      const unsigned lo_a = (unsigned)tb + kj, s0 = (unsigned)p.drop_seed;
+      const unsigned c2 = (unsigned)(tb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+      const int qtiles = (q_len + 31) / 32;
+      for (int qt = 0; qt < qtiles; ++qt) {
+        f32x16 sa = zero16(), dpa = zero16();
+        const float* qrow_p = s.Q + (qt * 32 + l31) * ALD + hh;
+        const float* dorow_p = s.dO + (qt * 32 + l31) * ALD + hh;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow_p[2 * s2], kb[s2], sa, 0, 0, 0);
+          dpa = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow_p[2 * s2], vb[s2], dpa, 0, 0, 0);
         }
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const int col = t * 32 + l31;
-          const bool ok = t < ktiles && row < q_len && col < k_len;
-          // the sign bit carries the dropout mask (P >= 0): +P kept, -P dropped -> one hash per element
-          if (p.dbg & 1) { s.S[row * SLD + col] = acc[t][r]; continue; }
-          const float pv = ok ? __expf(acc[t][r] * p.scale - s.lse[row]) : 0.f;
-          s.S[row * SLD + col] = (p.drop_thresh && pmask(p, tile, h, row, col) == 0.f) ? -pv : pv;
+          const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = qq < q_len && kj < k_len;
+          const float pv = ok ? __expf((sa[r] + c_a) * p.scale - s.lse[qq]) : 0.f;
+          const bool keep = !p.drop_thresh || keep_lo(lo_a + qq * AT, s0, c2, p.drop_thresh);
+          sa[r] = keep ? pv * p.drop_inv_keep : 0.f;                                                   // dropout(P)
+          dpa[r] = p.scale * pv * ((keep ? dpa[r] * p.drop_inv_keep : 0.f) - s.Dv[qq]);                // dS
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.dO[qq * ALD + l31], sa[r], acc_dv, 0, 0, 0);
+          acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Q[qq * ALD + l31] * gq_l + bq_l, dpa[r], acc_dk, 0, 0, 0);
         }
       }
-    } else {
-      for (int i = l31 + 32 * hh; i < 32 * AT; i += 64) s.S[(r0 + i / AT) * SLD + (i % AT)] = 0.f;
     }
-    __syncthreads();
-    stamp();  // 3: P
-    // dV += P^T dO   (wave owns key rows r0..r0+31)
-    const int qend = (q_len + 1) & ~1;
-    if (r0 < k_len) {
-      for (int kk = 0; kk < qend; kk += 2)
-        acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(fmaxf(s.S[(kk + hh) * SLD + r0 + l31], 0.f) * p.drop_inv_keep,
-                                                      s.dO[(kk + hh) * ALD + l31], acc_dv, 0, 0, 0);
-    }
-    // dP = dO V^T  (wave owns query rows)
-    f32x16 dp[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) dp[t] = zero16();
-    if (r0 < q_len) {
-      for (int kk = 0; kk < d; kk += 2) {
-        const float a = s.dO[(r0 + l31) * ALD + kk + hh];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          if (t < ktiles) dp[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, s.V[(t * 32 + l31) * ALD + kk + hh], dp[t], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-    stamp();  // 4: dV, dP
-    // dS = scale * P * (dP - D), in place over P
-    if (r0 < q_len) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < ktiles) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            float* sp = s.S + row * SLD + t * 32 + l31;
-            const float sv = *sp;  // +P kept / -P dropped
-            *sp = p.scale * fabsf(sv) * ((sv > 0.f ? dp[t][r] * p.drop_inv_keep : 0.f) - s.Dv[row]);
-          }
-        }
-    }
-    __syncthreads();
-    stamp();  // 5: dS
-    // dKn += dS^T Qn  (wave owns key rows) ; dQn = dS Kn (wave owns query rows)
-    if (r0 < k_len) {
-      for (int kk = 0; kk < qend; kk += 2)
-        acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(kk + hh) * SLD + r0 + l31],
-                                                      s.Q[(kk + hh) * ALD + l31] * gq_l + bq_l, acc_dk, 0, 0, 0);
-    }
+    // ---- orientation B: lane <-> query qi of this wave's 32 queries, registers <-> keys of tile t
+    //        S^T[k][qi], dP^T[k][qi]  ->  dQn^T[:, qi] += Kn^T dS^T
     f32x16 acc_dq = zero16();
     if (r0 < q_len) {
-      const int kend = (k_len + 1) & ~1;
-      for (int kk = 0; kk < kend; kk += 2)
-        acc_dq = __builtin_amdgcn_mfma_f32_32x32x2f32(s.S[(r0 + l31) * SLD + kk + hh],
-                                                      s.K[(kk + hh) * ALD + l31] * gk_l + bk_l, acc_dq, 0, 0, 0);
+      const int qi = r0 + l31;
+      float qb[16], dob[16], c_b = 0.f;  // k_norm's affine folded into the hoisted query fragment (as above)
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) {
+        const int k = 2 * s2 + hh;
+        const float qn = s.Q[qi * ALD + k] * s.gq[k] + s.bq[k];
+        c_b += s.bk[k] * qn;
+        qb[s2] = qn * s.gk[k];
+        dob[s2] = s.dO[qi * ALD + k];
+      }
+      c_b += __shfl_xor(c_b, 32, 64);
+      const float lse_q = s.lse[qi], d_q = s.Dv[qi];
+      const unsigned long long tb = ((unsigned long long)tile * p.H + h) * AT * AT;
+      const unsigned lo_b = (unsigned)tb + qi * AT, s0 = (unsigned)p.drop_seed;
+      const unsigned c2 = (unsigned)(tb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+      for (int t = 0; t < ktiles; ++t) {
+        f32x16 sb = zero16(), dpb = zero16();
+        const float* krow_p = s.K + (t * 32 + l31) * ALD + hh;
+        const float* vrow_p = s.V + (t * 32 + l31) * ALD + hh;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          sb = __builtin_amdgcn_mfma_f32_32x32x2f32(krow_p[2 * s2], qb[s2], sb, 0, 0, 0);
+          dpb = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow_p[2 * s2], dob[s2], dpb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const bool ok = key < k_len && qi < q_len;
+          const float pv = ok ? __expf((sb[r] + c_b) * p.scale - lse_q) : 0.f;
+          const bool keep = !p.drop_thresh || keep_lo(lo_b + key, s0, c2, p.drop_thresh);
+          sb[r] = p.scale * pv * ((keep ? dpb[r] * p.drop_inv_keep : 0.f) - d_q);                      // dS^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          acc_dq = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[key * ALD + l31] * gk_l + bk_l, sb[r], acc_dq, 0, 0, 0);
+        }
+      }
     }
     __syncthreads();  // dO image is free now: reuse it for dQn
     stamp();  // 6: dK, dQ
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      s.dO[row * ALD + l31] = (r0 < q_len && l31 < d) ? acc_dq[r] : 0.f;
+    for (int r = 0; r < 16; ++r) {  // accumulator is dQn^T: col = query (lane), row = head column
+      const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      s.dO[(r0 + l31) * ALD + dc] = (r0 < q_len && dc < d) ? acc_dq[r] : 0.f;
     }
     __syncthreads();
     // q_norm affine gradients (column pass), then LN backward (row pass), then store
@@ -490,10 +501,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   // ---- K / V gradients of this block
   // dV straight from registers -> V image (V no longer needed), dKn -> dO image
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    s.V[row * ALD + l31] = (l31 < d) ? acc_dv[r] : 0.f;
-    s.dO[row * ALD + l31] = (l31 < d) ? acc_dk[r] : 0.f;
+  for (int r = 0; r < 16; ++r) {  // accumulators are dV^T / dKn^T: col = key (lane), row = head column
+    const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    s.V[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dv[r] : 0.f;
+    s.dO[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dk[r] : 0.f;
   }
   __syncthreads();
   {
