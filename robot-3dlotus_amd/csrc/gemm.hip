@@ -38,6 +38,62 @@ struct GemmP {
 // so every global access is an unconditional float4 (rows / columns beyond the edge are clamped to a
 // valid address; k beyond the split range is zeroed by a select).  !FAST keeps per-element guards
 // (odd widths such as the 90- and 217-wide head layers).
+// LDS images of the GEMM.  k-contiguous operands ("KC"): [R][BK + 4] — rows are 16-byte aligned, a lane's fragment run
+// is read with ds_read_b128 (row stride 36/20/68 floats: the 16 lanes of a b128 group land on distinct 16-byte slots).
+// Operands contiguous along their non-reduction index: [BK][R] (float4 row stores, ds_read_b32 fragment reads).
+// Both operands consume k in the same permuted order: MFMA step s of lane-half h uses k = h * BK/2 + s, so the
+// KC fragments are contiguous runs.
+template <int R, bool KC, int BK>
+struct GTile {
+  static constexpr int kLd = KC ? BK + 4 : R;
+  static constexpr int kFloats = KC ? R * (BK + 4) : BK * R;
+};
+
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A>
+__device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const float* __restrict__ Bs, int wr0, int wc0,
+                                          f32x16 (&acc)[BM / 64][BN / 64], float (&asum)[BM / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64, KS = BK / 2;
+  const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+  float a[TM][KS], b[TN][KS];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    if (A_KC) {
+      const float* row = As + (wr0 + tm * 32 + l31) * GTile<BM, true, BK>::kLd + h * KS;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        a[tm][4 * q] = v.x; a[tm][4 * q + 1] = v.y; a[tm][4 * q + 2] = v.z; a[tm][4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) a[tm][s2] = As[(h * KS + s2) * BM + wr0 + tm * 32 + l31];
+    }
+  }
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    if (B_KC) {
+      const float* row = Bs + (wc0 + tn * 32 + l31) * GTile<BN, true, BK>::kLd + h * KS;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        b[tn][4 * q] = v.x; b[tn][4 * q + 1] = v.y; b[tn][4 * q + 2] = v.z; b[tn][4 * q + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) b[tn][s2] = Bs[(h * KS + s2) * BN + wc0 + tn * 32 + l31];
+    }
+  }
+#pragma unroll
+  for (int s2 = 0; s2 < KS; ++s2) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (SUM_A) asum[tm] += a[tm][s2];
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm][s2], b[tn][s2], acc[tm][tn], 0, 0, 0);
+    }
+  }
+}
+
 // value-wise select (a pointer select between the loaded vector and a zero constant goes through scratch)
 __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -48,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
-  constexpr int AF = LdsTile<BM, A_KC, BK>::kFloats, BF = LdsTile<BN, B_KC, BK>::kFloats;
+  constexpr int AF = GTile<BM, A_KC, BK>::kFloats, BF = GTile<BN, B_KC, BK>::kFloats;
   constexpr int WN = BN / 2, SLD = WN + 4;  // epilogue staging: per wave [32][WN + 4]
   constexpr int LDSF = (2 * AF + 2 * BF) > (4 * 32 * SLD) ? (2 * AF + 2 * BF) : (4 * 32 * SLD);
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
@@ -128,8 +184,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const float v[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w};
       if (A_KC) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Ad[LdsTile<BM, true, BK>::idx(row, kq * 4 + e)] = v[e];
+        *reinterpret_cast<float4*>(&Ad[row * GTile<BM, true, BK>::kLd + kq * 4]) = ra[t];
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
         *reinterpret_cast<float4*>(&Ad[kr * BM + iq * 4]) = ra[t];
@@ -141,8 +196,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const float v[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w};
       if (B_KC) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Bd[LdsTile<BN, true, BK>::idx(row, kq * 4 + e)] = v[e];
+        *reinterpret_cast<float4*>(&Bd[row * GTile<BN, true, BK>::kLd + kq * 4]) = rb[t];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
         *reinterpret_cast<float4*>(&Bd[kr * BN + jq * 4]) = rb[t];
@@ -158,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       gload(k0 + BK);  // past-the-end prefetch is clamped / zeroed and never consumed
-      mma_slab<BM, BN, A_KC, B_KC, SUM_A, BK>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      gemm_slab<BM, BN, BK, A_KC, B_KC, SUM_A>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       cur ^= 1;
       lstore(As + cur * AF, Bs + cur * BF);
       __syncthreads();
