@@ -112,7 +112,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   float* Bs = smem + 2 * AF;
 
   const int tid = threadIdx.x, wave = tid >> 6;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear id, each XCD has its own L2.  Give every
+  // XCD a contiguous run of the row-major tile list so that the column blocks sharing an A row tile (and the
+  // neighbouring row tiles sharing B) hit the same L2 instead of fetching the operand once per XCD.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int nbx = gridDim.x, total = nbx * gridDim.y;
+    const int lin = by * nbx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    by = t / nbx;
+    bx = t - by * nbx;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = blockIdx.z * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
   }
   if (SUM_A) {
-    if (p.bias_part && blockIdx.x == 0 && (wave & 1) == 0) {
+    if (p.bias_part && bx == 0 && (wave & 1) == 0) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
         float s = asum[tm] + __shfl_xor(asum[tm], 32, 64);
