@@ -374,8 +374,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
     //
     // ---- orientation A: lane <-> key kj of this wave's 32 keys, registers <-> queries of tile qt
     //        S[q][kj], dP[q][kj]  ->  dV^T[:, kj] += dO^T Pm ,  dKn^T[:, kj] += Qn^T dS
-    if (r0 < k_len) {
-      const int kj = r0 + l31;
+    // (with a single key tile — cross-attention to <= 32 instruction tokens — all four waves share it and split
+    //  the query tiles instead; their partial dV / dK are summed in wave order at the end of the block)
+    const bool share_k = ktiles == 1;
+    const int rk = share_k ? 0 : r0;
+    if (rk < k_len) {
+      const int kj = rk + l31;
       // q_norm's affine is folded into the hoisted key fragment: (xq g + b) . kn = xq . (g kn) + b . kn, so the
       // A operand is the raw normalised row and the bias term is one per-key constant
       float kb[16], vb[16], c_a = 0.f;
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       const unsigned lo_a = (unsigned)tb + kj, s0 = (unsigned)p.drop_seed;
       const unsigned c2 = (unsigned)(tb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
       const int qtiles = (q_len + 31) / 32;
-      for (int qt = 0; qt < qtiles; ++qt) {
+      for (int qt = share_k ? wave : 0; qt < qtiles; qt += share_k ? 4 : 1) {
         f32x16 sa = zero16(), dpa = zero16();
         const float* qrow_p = s.Q + (qt * 32 + l31) * ALD + hh;
         const float* dorow_p = s.dO + (qt * 32 + l31) * ALD + hh;
@@ -500,13 +504,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
 
   // ---- K / V gradients of this block
   // dV straight from registers -> V image (V no longer needed), dKn -> dO image
+  if (ktiles == 1) {  // shared key tile: rows 0..31 get the four waves' partials in wave order, the rest is zero
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {  // accumulators are dV^T / dKn^T: col = key (lane), row = head column
-    const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
-    s.V[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dv[r] : 0.f;
-    s.dO[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dk[r] : 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          float* pv = s.V + l31 * ALD + dc;
+          float* pk = s.dO + l31 * ALD + dc;
+          if (w == 0) {
+            *pv = (dc < d) ? acc_dv[r] : 0.f;
+            *pk = (dc < d) ? acc_dk[r] : 0.f;
+          } else if (dc < d) {
+            *pv += acc_dv[r];
+            *pk += acc_dk[r];
+          }
+        }
+      } else if (w == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          s.V[(r0 + l31) * ALD + dc] = 0.f;
+          s.dO[(r0 + l31) * ALD + dc] = 0.f;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // accumulators are dV^T / dKn^T: col = key (lane), row = head column
+      const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      s.V[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dv[r] : 0.f;
+      s.dO[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dk[r] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   {
     const int j = tid & 31, part = tid >> 5;
     float ag = 0.f, ab = 0.f;
