@@ -93,7 +93,8 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
 /* ---- submanifold sparse convolution (spconv.SubMConv3d, model.py:615-622, :844-853) -------- */
 /* mode 0 fwd: y[n][cout] = sum_t W[:,t,:] x[nbr[t][.]] + bias (+ add); mode 1 dgrad: x = dy, y = dx.
  * w is (cout, k, k, k, cin) row-major; rowidx (optional) = processing order of the rows.  w_t
- * (optional, from lotus_conv_weight_transpose) and workspace (optional) enable the pair-compacted,
+ * (optional; 2 * cout*T*cin floats written by lotus_conv_weight_transpose: MFMA-fragment-packed copies of w
+ * for both modes, cin and cout multiples of 32) and workspace (optional) enable the pair-compacted,
  * tap-split fast path for the 3^3 convolutions. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
 int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream);

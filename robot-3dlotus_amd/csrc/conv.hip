@@ -293,14 +293,15 @@ size_t lotus_subm_conv_workspace(int n, int cin, int cout) {
   return a > b ? a : b;
 }
 
-// w_t [cin][T][cout] = transpose of w [cout][T][cin] (coalesced weight fragments for mode 0)
+// w_t [2][cout*T*cin]: MFMA-fragment-packed copies of w for the forward and the input-gradient direction
+// (layout: conv_pairs.hip); cin and cout must be multiples of 32
 int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream) {
   LOTUS_CHECK_ARG(w && w_t && cout > 0 && T > 0 && cin > 0, "lotus_conv_weight_transpose: bad arguments");
   return lotus_conv_weight_transpose_impl(w, w_t, cout, T, cin, (hipStream_t)stream);
 }
 
 // mode 0: fwd  (x [n][cin]  -> y [n][cout]);  mode 1: dgrad (x = dy [n][cout] -> y = dx [n][cin]).
-// w_t (optional, mode 0) and workspace (optional) enable the pair-compacted tap-split fast path.
+// w_t (optional) and workspace (optional) enable the pair-compacted tap-split fast path in both modes.
 int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
                     float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
                     size_t workspace_bytes, void* stream) {

@@ -16,14 +16,12 @@
 
 struct ConvP2 {
   const float* x;    // [n][KD]
-  const float* w;    // B operand: element (k, tap, j) at w[k * wld + tap * tapw + j]  (j contiguous)
+  const float* w;    // packed B fragments: element (k, tap, j) at w[((tap * (KD / 4) + k / 4) * ND + j) * 4 + k % 4]
   float* y;          // [n][ND]  (or partial slabs [nz][n][ND] when tap-split)
   const float* bias;
   const float* add;
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] or null
-  long wld;
-  int tapw;
   int n, T, KD, ND, mirror;
   int tpz;           // taps per blockIdx.z
   long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
@@ -132,11 +130,18 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   float bst[3][KC / 2];
   static_assert(2 * MAXT <= 64, "the group list must fit the lanes of one VGPR");
 
-  auto load_b = [&](float (&dst)[KC / 2], int t, int kc) {  // weight fragment of (tap, chunk): coalesced 128 B per half-wave and k
+  auto load_b = [&](float (&dst)[KC / 2], int t, int kc) {  // weight fragment of (tap, chunk): this lane's KC/2 consecutive k
+    // k-quads (4 consecutive k) are the 16-byte unit: quad (kc * KC + hh * KC/2) / 4 + q of column j sits at float4
+    // index quad * ND + j, so a wave instruction reads two contiguous 512-byte runs; 32-bit index from the uniform
+    // base -> scalar-base global loads with one VALU op of address math each
     const int tw = p.mirror ? (p.T - 1 - t) : t;
-    const float* wp = p.w + (long)(kc * KC + hh * (KC / 2)) * p.wld + (long)tw * p.tapw + n0 + cs * 32 + l31;
+    const float4* wp4 = reinterpret_cast<const float4*>(p.w);
+    const unsigned base = (unsigned)((tw * (p.KD / 4) + (kc * KC + hh * (KC / 2)) / 4) * p.ND + n0 + cs * 32 + l31);
 #pragma unroll
-    for (int s = 0; s < KC / 2; ++s) dst[s] = wp[(long)s * p.wld];
+    for (int q = 0; q < KC / 8; ++q) {
+      const float4 v = wp4[base + (unsigned)(q * p.ND)];
+      dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+    }
   };
 
   int t0 = z_beg, span = z_end - z_beg;
@@ -303,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
 #pragma unroll
         for (int s2 = Q2; s2 < Q3; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        // (LDS float atomics — ds_add_f32 — were measured 5x slower than this read / add / write)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ob[ro[r]] = ov[r] + ap[r];
 #pragma unroll
@@ -385,20 +391,30 @@ __global__ void conv_part_reduce_kernel(const float* __restrict__ part, long str
   }
 }
 
-// wt[ci][t][co] = w[co][t][ci]   (32x32 LDS tile transpose per tap)
-__global__ __launch_bounds__(256) void conv_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int T,
-                                                      int cin) {
+// Packed MFMA B fragments of a 3^3 convolution weight w [cout][T][cin], both directions in one buffer:
+//   fwd   (dir 0): (k = cin index,  j = cout index)  value w[j][t][k]
+//   dgrad (dir 1): (k = cout index, j = cin index)   value w[k][t][j]
+// element (k, t, j) of direction dir lives at  dir * cout*T*cin + ((t * (KD / 4) + k / 4) * ND + j) * 4 + k % 4:
+// quads of 4 consecutive k are the 16-byte unit a lane loads, and the 32 columns of a wave's slice are contiguous.
+__global__ __launch_bounds__(256) void conv_wpack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int T,
+                                                         int cin) {
   __shared__ float tile[32][33];
-  const int t = blockIdx.z, co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int t = blockIdx.z % T, dir = blockIdx.z / T;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int r = ty; r < 32; r += 8) {
-    const int co = co0 + r, ci = ci0 + tx;
-    tile[r][tx] = (co < cout && ci < cin) ? w[((long)co * T + t) * cin + ci] : 0.f;
-  }
+  const long half = (long)cout * T * cin;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = w[((long)(co0 + r) * T + t) * cin + ci0 + tx];  // [co][ci]
   __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int ci = ci0 + r, co = co0 + tx;
-    if (ci < cin && co < cout) wt[((long)ci * T + t) * cout + co] = tile[tx][r];
+  // output run of a thread group: 32 columns j x one k-quad (128 floats, contiguous)
+  const int jj = (threadIdx.x >> 2) & 31, k4 = threadIdx.x & 3, qsel = threadIdx.x >> 7;  // 2 quads per pass
+  for (int q = qsel; q < 8; q += 2) {
+    if (dir == 0) {  // k = ci, j = co
+      const int k = ci0 + q * 4 + k4, j = co0 + jj;
+      wp[(((long)t * (cin / 4) + k / 4) * cout + j) * 4 + k4] = tile[jj][q * 4 + k4];
+    } else {         // k = co, j = ci
+      const int k = co0 + q * 4 + k4, j = ci0 + jj;
+      wp[half + (((long)t * (cout / 4) + k / 4) * cin + j) * 4 + k4] = tile[q * 4 + k4][jj];
+    }
   }
 }
 
@@ -434,28 +450,31 @@ size_t lotus_conv_pairs_workspace(int n, int ND) {
   return nz > 1 ? (size_t)nz * n * ND * sizeof(float) : 0;
 }
 
-int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, hipStream_t st) {
-  hipLaunchKernelGGL(conv_wt_kernel, dim3(cdiv(cin, 32), cdiv(cout, 32), T), dim3(256), 0, st, w, wt, cout, T, cin);
+int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T, int cin, hipStream_t st) {
+  if (cin % 32 || cout % 32) {
+    lotus_set_error("lotus_conv_weight_transpose: cin and cout must be multiples of 32 (got %d, %d)", cin, cout);
+    return LOTUS_E_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
   LOTUS_LAUNCH_CHECK("lotus_conv_weight_transpose");
   return LOTUS_OK;
 }
 
 // returns 1 if the pair-compacted path handled the call, 0 if the shape is not eligible.
-// mode 0 needs the transposed weights w_t [cin][T][cout]; mode 1 uses w [cout][T][cin] directly.
+// Both modes read the packed weights w_t of lotus_conv_weight_transpose (fwd half / dgrad half).
 int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
                          float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
                          size_t workspace_bytes, hipStream_t st, int* rc) {
   const int KD = mode == 0 ? cin : cout, ND = mode == 0 ? cout : cin;
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
-  if (mode == 0 && !w_t) return 0;
+  if (!w_t || ((uintptr_t)w_t) % 16) return 0;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16) return 0;
   const int nz = tap_splits(n, ND);
   if (nz > 1 && (!workspace || workspace_bytes < (size_t)nz * n * ND * sizeof(float))) return 0;
   ConvP2 p;
   p.x = x; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
   p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
-  if (mode == 0) { p.w = w_t; p.wld = (long)T * cout; p.tapw = cout; }
-  else           { p.w = w;   p.wld = (long)T * cin;  p.tapw = cin; }
+  p.w = w_t + (mode == 0 ? 0 : (long)cout * T * cin);
   p.tpz = cdiv(T, nz);
   {
     static int dbg = -1;

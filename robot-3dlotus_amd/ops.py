@@ -202,10 +202,11 @@ def ln_bwd(dy, x, mean, rstd, g, add=None):
 
 
 def conv_weight_t(w):
-    """[cout, k,k,k, cin] -> [cin, T, cout] copy (coalesced weight fragments for the forward conv)."""
+    """[cout, k,k,k, cin] -> packed MFMA weight fragments for the forward and the input-gradient convolution
+    (2 * w.numel() floats; layout in csrc/conv_pairs.hip)."""
     cout, cin = w.shape[0], w.shape[-1]
     T = w.numel() // (cout * cin)
-    wt = torch.empty(cin, T, cout, dtype=torch.float32, device=w.device)
+    wt = torch.empty(2 * w.numel(), dtype=torch.float32, device=w.device)
     call("lotus_conv_weight_transpose", w, wt, cout, T, cin)
     return wt
 
@@ -224,12 +225,12 @@ def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None):
     return y
 
 
-def conv_dgrad(dy, w, nbr, rowidx, add=None):
+def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None):
     n, cout = dy.shape
     cin, T = w.shape[-1], nbr.shape[0]
     dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
     ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
-    call("lotus_subm_conv", 1, dy, w, None, None, add, dx, nbr, rowidx, n, T, cin, cout, ws,
+    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, ws,
          ws.numel() if ws is not None else 0)
     return dx
 
@@ -336,16 +337,17 @@ class CpeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl):
         same = xs is x
-        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=conv_weight_t(cw))
+        wt = conv_weight_t(cw)
+        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt)
         l, _ = linear_fwd(c, lw, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
-        ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd)
+        ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd, wt)
         ctx.lvl, ctx.same = lvl, same
         return y
 
     @_joined
     def backward(ctx, dy):
-        xs, cw, lw, g, c, l, mean, rstd = ctx.saved_tensors
+        xs, cw, lw, g, c, l, mean, rstd, wt = ctx.saved_tensors
         lvl = ctx.lvl
         dy = dy.contiguous()
         dl, dg, db = ln_bwd(dy, l, mean, rstd, g)
@@ -353,9 +355,9 @@ class CpeFn(torch.autograd.Function):
         dc = linear_dgrad(dl, lw)
         dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
         if ctx.same:  # d x = dy (residual) + conv dgrad
-            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy)
+            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt)
             return dx, None, dcw, dcb, dlw, dlb, dg, db, None
-        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0])
+        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt)
         return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None
 
 

@@ -149,9 +149,10 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
     yref = om.subm_conv(xd, nbr_ref, wd, bd)
     y = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0])
     _close(y, yref, 3e-6, "conv fwd")
+    wt = ops.conv_weight_t(w.cuda()) if k == 3 else None
     if k == 3:
-        y2 = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0], w_t=ops.conv_weight_t(w.cuda()))
-        _close(y2, yref, 3e-6, "conv fwd (pair-compacted, transposed weights)")
+        y2 = ops.conv_fwd(x.cuda(), w.cuda(), b.cuda(), nbr, got[0].order[0], w_t=wt)
+        _close(y2, yref, 3e-6, "conv fwd (pair-compacted, packed weights)")
     yref.backward(dy.double())
     if cin == cout:
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, got[0].order[0])
@@ -162,6 +163,9 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
     if cin != cout and k == 3:
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, None)
         _close(dx, xd.grad, 3e-6, "conv dgrad (cin != cout, natural row order)")
+    if k == 3:
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, got[0].order[0], w_t=wt)
+        _close(dx, xd.grad, 3e-6, "conv dgrad (pair-compacted, packed weights)")
 
 
 # ------------------------------------------------------------------------------------ attention

@@ -20,7 +20,7 @@ for i, (s, C) in enumerate(chans):
     pairs = int((L.nbr27 >= 0).sum())
     fl = 2.0 * pairs * C * C
     for kind, fn in (("fwd", lambda: ops.conv_fwd(x, w, b, L.nbr27, L.order[0], w_t=wt)),
-                     ("dgrad", lambda: ops.conv_dgrad(x, w, L.nbr27, L.order[0])),
+                     ("dgrad", lambda: ops.conv_dgrad(x, w, L.nbr27, L.order[0], w_t=wt)),
                      ("wgrad", lambda: ops.conv_wgrad(x, x, w.shape, L.nbr27))):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
