@@ -216,8 +216,14 @@ def main():
                     for r in sorted(rep, reverse=True):
                         f.write("%.3f %s %d %d %d %d %.4f %.1f\n" % r)
             ach = flop / (gms * 1e-3) / 1e12
+            traffic = None  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/pmc_summary.py)
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")))
+                traffic = pmc["kernels"]["gemm_kernel"]["hbm_bytes_per_launch"]
+            except (OSError, KeyError, ValueError):
+                pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": "gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
                                "launches_per_step": nl, "ms_per_step": round(gms, 3),
                                "gflop_per_step": round(flop / 1e9, 1)}
