@@ -71,7 +71,7 @@ def gemm_roofline(ops, calls, dev, reps=5, report=None):
     return tot_flop, tot_ms, n_launch
 
 
-def cpu_baseline_measure(cfg_name="v1", clouds=2, npoints=4096, iters=2, threads=None):
+def cpu_baseline_measure(cfg_name="v1", clouds=8, npoints=4096, iters=3, threads=None):
     """The oracle (CPU PyTorch restatement of the reference path) timed on the host cores:
     forward + loss + backward of `clouds` clouds, median of `iters` after one warm-up."""
     import golden_util as gu
@@ -113,7 +113,7 @@ def cpu_baseline(timeout_s=150):
         return {"value": None, "unit": "keystep-samples/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-200:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "keystep-samples/s", "cores": 0, "kind": "port",
-                "sample": f"oracle did not finish 3 x (2 clouds x 4096 pts) within {timeout_s} s on this host"}
+                "sample": f"oracle did not finish 4 x (8 clouds x 4096 pts) within {timeout_s} s on this host"}
 
 
 def main():
