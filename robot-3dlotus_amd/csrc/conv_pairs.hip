@@ -47,8 +47,11 @@ struct PairsCfg {
   // two blocks per CU with the odd stride)
   static constexpr bool AVEC = NCS == 4;
   static constexpr int XLD = AVEC ? KC + 4 : KC + 1;
+  // output tile row stride: +4 floats so that the 16-byte fold accesses of lanes on consecutive rows land on
+  // distinct 16-byte LDS slots
+  static constexpr int OLD = NW + 4;
   static constexpr size_t bytes() {
-    return (size_t)(NRT * (BM + 1) * NW + NRT * HT * XLD) * 4 + (size_t)NRT * HT * 4 + (size_t)NRT * MAXT * BM * 2 +
+    return (size_t)(NRT * (BM + 1) * OLD + NRT * HT * XLD) * 4 + (size_t)NRT * HT * 4 + (size_t)NRT * MAXT * BM +
            (size_t)NRT * MAXT * BM + (size_t)(NRT * MAXT + NRT * 64 + 16 + NRT * BM) * 4;
   }
 };
@@ -57,17 +60,18 @@ template <int NCS>
 __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   using Cfg = PairsCfg<NCS>;
   constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT, XLD = Cfg::XLD;
+  constexpr int OLD = Cfg::OLD;
   constexpr int TG = BM / 32;   // max pair groups per tap
   constexpr int GT = 64 * NCS;  // threads of one row tile's team
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* out_s = smem;                                   // [NRT][BM+1][NW]  (row BM = dummy sink of padded pairs)
-  float* xs_s = out_s + NRT * (BM + 1) * NW;             // [NRT][HT][KC+1]
+  float* out_s = smem;                                   // [NRT][BM+1][OLD]  (row BM = dummy sink of padded pairs)
+  float* xs_s = out_s + NRT * (BM + 1) * OLD;            // [NRT][HT][XLD]
   int* hkey_s = (int*)(xs_s + NRT * HT * XLD);      // [NRT][HT] global row id or -1
   int* cnt_s = hkey_s + NRT * HT;                        // [NRT][MAXT]
   int* grp_s = cnt_s + NRT * MAXT;                       // [NRT][64] pair groups: tap | offset << 8 | pairs << 16
   int* misc_s = grp_s + NRT * 64;                        // [16]: groups per rt (0..3), overflow (4), dummy row ids (8..15)
   int* prow_s = misc_s + 16;                             // [NRT][BM]
-  unsigned short* slot_s = (unsigned short*)(prow_s + NRT * BM);  // [NRT][MAXT][BM]
+  unsigned char* slot_s = (unsigned char*)(prow_s + NRT * BM);    // [NRT][MAXT][BM] image slot of every pair (HT <= 256)
   unsigned char* row_s = (unsigned char*)(slot_s + NRT * MAXT * BM);  // [NRT][MAXT][BM]
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   stamp();  // 0 start
   static_assert(HT * XLD >= MAXT * BM, "row image must be able to hold the temporary neighbour list");
   int* src_tmp = (int*)my_xs;  // [taps][BM] neighbour ids, aliased onto the row image (first phase only)
-  for (int i = tid; i < NRT * (BM + 1) * NW; i += 256) out_s[i] = 0.f;
+  for (int i = tid; i < NRT * (BM + 1) * OLD; i += 256) out_s[i] = 0.f;
   if (tid < 8) misc_s[8 + tid] = BM * 0x01010101;  // 32 row ids that all name the dummy sink row
   for (int r = gt; r < BM; r += GT) {
     const int m = m0 + r;
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         pos = pos + 1 == HT ? 0 : pos + 1;
         if (++probes >= HT) { misc_s[4] = 1; break; }
       }
-      slot_s[(rt * MAXT + t) * BM + k] = (unsigned short)pos;
+      slot_s[(rt * MAXT + t) * BM + k] = (unsigned char)pos;
     }
     __syncthreads();
     if (misc_s[4]) {  // block-uniform: retry with half the taps (a single tap always fits: <= BM rows)
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     };
     issue_fill(0);
     store_fill();
-    float* ob = out_s + rt * (BM + 1) * NW + cs * 32 + l31;
+    // fold base of this lane: its wave's 32-column slice, the 4-column run 4 * hh of every 8-column group
+    float* ob = out_s + rt * (BM + 1) * OLD + cs * 32 + 4 * hh;
     constexpr int KS = KC / 2;  // MFMAs (k-steps) per group and chunk
     // image offset of this lane's A fragment run for group word gw: pair (offset + min(lane, pairs - 1)), k half hh
     auto a_base = [&](int gw) {
@@ -286,33 +291,34 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         const bool next_in_chunk = g_cur + 1 < ngr;
         const int gwn2 = __builtin_amdgcn_readlane(vgrp, g_cur + 2 < ngr ? g_cur + 2 : (g_cur + 2 - ngr) % ngr);
         constexpr int Q1 = KS / 8, Q2 = KS / 4, Q3 = 5 * KS / 8;
+        // The product is computed TRANSPOSED (MFMA A operand = weight fragment, B operand = gathered rows):
+        // C[channel][pair], so a lane owns ONE pair = one output row and its 16 registers are four runs of
+        // four consecutive channels -> the fold is 4 x (ds_read_b128, 4 adds, ds_write_b128) through a single
+        // row offset instead of 16 x (ds_read_b32, add, ds_write_b32) through 16 unpacked offsets.
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac[r] = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < Q1; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        for (int s2 = 0; s2 < Q1; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        unsigned pk[4];
+        const int prid = prows[l31];  // output row of the pending group's pair l31 (dummy sink row for padding)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = *reinterpret_cast<const unsigned*>(prows + 8 * q + 4 * hh);
-#pragma unroll
-        for (int s2 = Q1; s2 < Q2; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        for (int s2 = Q1; s2 < Q2; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        int ro[16];
-        float ov[16];
+        float4* orow = reinterpret_cast<float4*>(ob + prid * OLD);
+        float4 ov[4];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ro[r] = (int)((pk[r >> 2] >> (8 * (r & 3))) & 255u) * NW;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ov[r] = ob[ro[r]];
+        for (int q = 0; q < 4; ++q) ov[q] = orow[2 * q];
         if (next_in_chunk) read_a(An, abase_n);
         const int ab2 = a_base(gwn2);
 #pragma unroll
-        for (int s2 = Q2; s2 < Q3; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        for (int s2 = Q2; s2 < Q3; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // (LDS float atomics — ds_add_f32 — were measured 5x slower than this read / add / write)
+        // (LDS float atomics — ds_add_f32 — were measured 5x slower than read / add / write)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[ro[r]] = ov[r] + ap[r];
+        for (int q = 0; q < 4; ++q)
+          orow[2 * q] = make_float4(ov[q].x + ap[4 * q], ov[q].y + ap[4 * q + 1], ov[q].z + ap[4 * q + 2], ov[q].w + ap[4 * q + 3]);
 #pragma unroll
-        for (int s2 = Q3; s2 < KS; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(A[s2], bc[s2], ac, 0, 0, 0);
+        for (int s2 = Q3; s2 < KS; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         abase_n = ab2;
         prows = row_s + (rt * MAXT + (gw & 255)) * BM + ((gw >> 8) & 255);
@@ -328,14 +334,16 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         if (i + 5 < nsteps) step(bst[2], bst[1], accs[1], accs[0], afr[1], afr[0]);
       }
       {  // fold of the last step (its accumulator set has the parity of nsteps - 1)
-        unsigned pk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = *reinterpret_cast<const unsigned*>(prows + 8 * q + 4 * hh);
+        float4* orow = reinterpret_cast<float4*>(ob + (int)prows[l31] * OLD);
         const bool odd = (nsteps - 1) & 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ro = (int)((pk[r >> 2] >> (8 * (r & 3))) & 255u) * NW;
-          ob[ro] += odd ? accs[1][r] : accs[0][r];
+        for (int q = 0; q < 4; ++q) {
+          float4 v = orow[2 * q];
+          v.x += odd ? accs[1][4 * q] : accs[0][4 * q];
+          v.y += odd ? accs[1][4 * q + 1] : accs[0][4 * q + 1];
+          v.z += odd ? accs[1][4 * q + 2] : accs[0][4 * q + 2];
+          v.w += odd ? accs[1][4 * q + 3] : accs[0][4 * q + 3];
+          orow[2 * q] = v;
         }
       }
     }
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     const int r = i / (NW / 4), c4 = i % (NW / 4);
     const int pr = prow_s[rt * BM + r];
     if (pr < 0) continue;
-    float4 v = *reinterpret_cast<const float4*>(out_s + (rt * (BM + 1) + r) * NW + c4 * 4);
+    float4 v = *reinterpret_cast<const float4*>(out_s + (rt * (BM + 1) + r) * OLD + c4 * 4);
     const int col = n0 + c4 * 4;
     const long o = (long)pr * p.ND + col;
     if (final_out) {
