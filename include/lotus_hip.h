@@ -95,7 +95,8 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
  * w is (cout, k, k, k, cin) row-major; rowidx (optional) = processing order of the rows.  w_t
  * (optional; 2 * cout*T*cin floats written by lotus_conv_weight_transpose: MFMA-fragment-packed copies of w
  * for both modes, cin and cout multiples of 32) and workspace (optional) enable the pair-compacted,
- * tap-split fast path for the 3^3 convolutions. */
+ * tap-split fast path for the 3^3 convolutions.  For thin inputs (mode 0, cin <= 8, e.g. the 5^3 stem) a workspace
+ * of >= T*cin*cout floats selects the active-pair VALU kernel. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
 int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream);
 int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,

@@ -297,16 +297,21 @@ size_t lotus_subm_conv_workspace(int n, int cin, int cout) {
 // Stem convolution (5^3 taps, cin = 6..8 -> cout = 64): 125 taps x 7 channels is far too thin for MFMA tiles
 // (the dense gather-GEMM above spends > 80 % of its MFMAs on absent neighbours), so this one is a VALU kernel over
 // the ACTIVE pairs only.  Block = 32 rows x 64 output channels; 8 lanes per row own 8 channels each.  Every row's
-// active (tap, neighbour) list is compacted in tap order by prefix sums over its 8 lanes (deterministic), the weights
-// of a chunk of taps sit transposed in LDS ([tap][ci][cout]: a lane's 8 channels are two ds_read_b128).
+// active (tap, neighbour) list is compacted in tap order by prefix sums over its 8 lanes (deterministic).
 #define STEM_ROWS 32
 #define STEM_TP 128  // taps are scanned as 8 lanes x 16
 
+// wt[t][ci][c] = w[c][t][ci]
+__global__ void conv_stem_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int T, int cin) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= cout * T * cin) return;
+  const int c = i % cout, rem = i / cout;  // rem = t * cin + ci
+  wt[i] = w[(long)c * T * cin + rem];
+}
+
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
-  extern __shared__ __attribute__((aligned(16))) float stem_s[];
-  float* wl = stem_s;                                            // [tch][cin][64]
-  int* list_nb = reinterpret_cast<int*>(wl + tch * p.cin * 64);  // [STEM_ROWS][STEM_TP]
-  unsigned char* list_t = reinterpret_cast<unsigned char*>(list_nb + STEM_ROWS * STEM_TP);  // [STEM_ROWS][STEM_TP]
+  __shared__ int list_nb[STEM_ROWS * STEM_TP];
+  __shared__ unsigned char list_t[STEM_ROWS * STEM_TP];
   __shared__ int cnt_s[STEM_ROWS];
   const int tid = threadIdx.x, r = tid >> 3, j = tid & 7;
   const int m = blockIdx.y * STEM_ROWS + r, cb = blockIdx.x;
@@ -342,28 +347,21 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
   for (int k = 0; k < 8; ++k) acc[k] = p.bias ? p.bias[cb * 64 + j * 8 + k] : 0.f;
   __syncthreads();
   const int len = cnt_s[r];
-  int cur = 0;
-  for (int t0 = 0; t0 < p.T; t0 += tch) {
-    const int tl = min(tch, p.T - t0), span = tl * p.cin;
-    if (t0) __syncthreads();  // everyone is done with the previous chunk of weights
-    for (int idx = tid; idx < 64 * span; idx += 256) {
-      const int c = idx / span, rem = idx - c * span;  // rem = (tap - t0) * cin + ci : contiguous in w
-      wl[rem * 64 + c] = p.w[((long)(cb * 64 + c) * p.T + t0) * p.cin + rem];
-    }
-    __syncthreads();
-    while (cur < len) {
-      const int t = list_t[r * STEM_TP + cur];
-      if (t >= t0 + tl) break;
-      const float* xr = p.x + (long)list_nb[r * STEM_TP + cur] * p.cin;
-      const float* wr = wl + (t - t0) * p.cin * 64 + j * 8;
-      for (int ci = 0; ci < p.cin; ++ci) {
-        const float xv = xr[ci];
-        const float4 w0 = *reinterpret_cast<const float4*>(wr + ci * 64);
-        const float4 w1 = *reinterpret_cast<const float4*>(wr + ci * 64 + 4);
-        acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
-        acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
-      }
-      ++cur;
+  // pair loop: the weights (pre-transposed [T][cin][cout], 224 KB for the stem) stay in L2 — a lane's 8 channels
+  // are two 16-byte loads, the 8 lanes of a row read 256 contiguous bytes — so the kernel needs no weight staging,
+  // no chunk barriers and only 20 KB of LDS: occupancy, not a software pipeline, hides the load latency.
+  // Lane j fetches input channel j of the neighbour row; the row's 8 lanes share it through 8-wide shuffles.
+  const float* wbase = p.w + cb * 64 + j * 8;
+  for (int cur = 0; cur < len; ++cur) {
+    const int t = list_t[r * STEM_TP + cur];
+    const float xl = j < p.cin ? p.x[(long)list_nb[r * STEM_TP + cur] * p.cin + j] : 0.f;
+    const float* wr = wbase + (long)t * p.cin * p.cout;
+    for (int ci = 0; ci < p.cin; ++ci) {
+      const float4 w0 = *reinterpret_cast<const float4*>(wr + ci * p.cout);
+      const float4 w1 = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
+      const float xv = __shfl(xl, ci, 8);
+      acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+      acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
     }
   }
   if (valid) {
@@ -406,13 +404,14 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
   p.ND = mode == 0 ? cout : cin;
   p.mirror = mode == 1;
   hipStream_t st = (hipStream_t)stream;
-  if (mode == 0 && cin <= 8 && cout % 64 == 0 && T <= STEM_TP && ((uintptr_t)y) % 16 == 0) {
-    // thin-input stem: VALU kernel over the active pairs (rows are independent, so the processing order is moot)
-    int tch = (48 * 1024) / (cin * 64 * (int)sizeof(float));
-    if (tch > T) tch = T;
-    const size_t dyn = (size_t)tch * cin * 64 * sizeof(float) + (size_t)STEM_ROWS * STEM_TP * 5;
-    (void)hipFuncSetAttribute((const void*)conv_smallcin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(cout / 64, cdiv(n, STEM_ROWS)), dim3(256), dyn, st, p, tch);
+  if (mode == 0 && cin <= 8 && cout % 64 == 0 && T <= STEM_TP && ((uintptr_t)y) % 16 == 0 && workspace &&
+      ((uintptr_t)workspace) % 16 == 0 && workspace_bytes >= (size_t)T * cin * cout * sizeof(float)) {
+    // thin-input stem: VALU kernel over the active pairs (rows are independent, so the processing order is moot);
+    // the workspace receives the weights transposed to [T][cin][cout]
+    hipLaunchKernelGGL(conv_stem_wt_kernel, dim3(cdiv((long)cout * T * cin, 256)), dim3(256), 0, st, w, (float*)workspace, cout, T,
+                       cin);
+    p.w = (const float*)workspace;
+    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(cout / 64, cdiv(n, STEM_ROWS)), dim3(256), 0, st, p, 0);
     LOTUS_LAUNCH_CHECK("lotus_subm_conv(stem)");
     return LOTUS_OK;
   }

@@ -220,7 +220,10 @@ def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None):
     n, cin = x.shape
     cout, T = w.shape[0], nbr.shape[0]
     y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
-    ws = _conv_ws(n, cin, cout, x.device) if T == 27 else None
+    if T == 27:
+        ws = _conv_ws(n, cin, cout, x.device)
+    else:  # thin-input stem kernel: room for the transposed weights
+        ws = WS.get(4 * T * cin * cout, x.device, slot=2) if cin <= 8 else None
     call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, ws, ws.numel() if ws is not None else 0)
     return y
 
