@@ -196,6 +196,20 @@ static int ln_geometry(int C, int* LPR, int* NV) {
   return 0;
 }
 
+// backward geometry: as few lanes per row as 4 float4 per lane allow — every lane then has 8 independent 16-byte
+// loads (x, dy) in flight per row instead of 2, which is what the HBM latency needs at 8-16 waves per CU
+static int ln_geometry_bwd(int C, int* LPR, int* NV) {
+  if (C % 4) return -1;
+  const int c4 = C / 4;
+  int lpr = 64;
+  while (lpr > 4 && c4 <= (lpr / 2) * 4) lpr /= 2;
+  const int nv = (c4 + lpr - 1) / lpr;
+  if (nv > 4) return -1;
+  *LPR = lpr;
+  *NV = nv;
+  return 0;
+}
+
 // --------------------------------------------------------------------------------- BatchNorm
 // Column statistics in double: per-block partial (sum, sumsq) -> fixed-order reduction.
 struct BnStatP {
@@ -403,7 +417,7 @@ int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, co
 
 #define LN_BWD_MAX_GRID 1024
 static int ln_bwd_grid(int M, int rpb) {
-  int grid = cdiv(M > 0 ? M : 1, rpb * 4);  // >= 4 row groups per block, <= 4 blocks per CU
+  int grid = cdiv(M > 0 ? M : 1, rpb * 2);  // >= 2 row groups per block, <= 4 blocks per CU
   return grid > LN_BWD_MAX_GRID ? LN_BWD_MAX_GRID : grid;
 }
 size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)LN_BWD_MAX_GRID * 2 * C * sizeof(float); }
@@ -418,7 +432,7 @@ int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
   p.dy = dy; p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.add = add; p.dx = dx;
   p.part = (float*)workspace; p.M = M; p.C = C;
   LOTUS_CHECK_ARG(dy && x && mean && rstd && gamma && dx && M >= 0, "lotus_layernorm_bwd: bad arguments");
-  LOTUS_CHECK_ARG(ln_geometry(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_bwd: unsupported C=%d", C);
+  LOTUS_CHECK_ARG(ln_geometry_bwd(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_bwd: unsupported C=%d", C);
   const int rpb = 256 / p.LPR;
   const int grid = ln_bwd_grid(M, rpb);
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(float),
@@ -438,7 +452,7 @@ int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamm
                                void* stream) {
   int lpr, nv;
   LOTUS_CHECK_ARG(workspace && dgamma && dbeta && M >= 0, "lotus_layernorm_bwd_params: bad arguments");
-  LOTUS_CHECK_ARG(ln_geometry(C, &lpr, &nv) == 0, "lotus_layernorm_bwd_params: unsupported C=%d", C);
+  LOTUS_CHECK_ARG(ln_geometry_bwd(C, &lpr, &nv) == 0, "lotus_layernorm_bwd_params: unsupported C=%d", C);
   const int grid = ln_bwd_grid(M, 256 / lpr);
   hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, dgamma, dbeta, grid, C, accumulate);
