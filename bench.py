@@ -119,8 +119,8 @@ def cpu_baseline(timeout_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="key-step clouds per GPU")
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
