@@ -224,7 +224,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       gload(k0 + BK);  // past-the-end prefetch is clamped / zeroed and never consumed
-      gemm_slab<BM, BN, BK, A_KC, B_KC, SUM_A>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      // only the first column block reports the column sums of A (bias gradient): the others skip the VALU adds
+      if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      else gemm_slab<BM, BN, BK, A_KC, B_KC, false>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       cur ^= 1;
       lstore(As + cur * AF, Bs + cur * BF);
       __syncthreads();
