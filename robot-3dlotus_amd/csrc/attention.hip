@@ -48,19 +48,14 @@ struct AttnP {
   long long* clk;  // optional phase timestamps of block (0,0) (profiling aid, LOTUS_ATTN_CLK)
 };
 
-// keep/scale factor of probability (tile, head, row, col); 1 when dropout is off
-__device__ __forceinline__ float pmask(const AttnP& p, int tile, int h, int row, int col) {
-  if (!p.drop_thresh) return 1.f;
-  const unsigned long long idx = ((((unsigned long long)tile * p.H + h) * AT + row) * AT) + col;
-  return dropout_scale(p.drop_seed, idx, p.drop_thresh, p.drop_inv_keep);
-}
-
-// lotus_hash32(seed, idx) >= thresh with the index split as (hi, lo): the hi / seed terms are hoisted by the callers
-// (c2 = hi * 0x7FEB352D + seed_hi, s0 = seed_lo), only the low word changes inside a tile
+// Attention-probability dropout: keep iff mix(seed, idx) >= thresh, idx = ((tile * H + h) * 128 + q) * 128 + key.  The
+// index is split as (hi, lo): the hi / seed terms are hoisted by the callers (c2 = hi * 0x7FEB352D + seed_hi,
+// s0 = seed_lo) and only the low word changes inside a tile.  One multiply-xorshift round after the affine step
+// (8 VALU ops; the P-phase of these kernels is VALU-issue bound, the full murmur finaliser costs 11).
 __device__ __forceinline__ bool keep_lo(unsigned lo, unsigned s0, unsigned c2, unsigned thresh) {
   unsigned x = lo * 0x9E3779B1u + s0;
   x ^= c2;
-  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
   return x >= thresh;
 }
 
@@ -217,8 +212,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   sum += __shfl_xor(sum, 32, 64);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
   if (p.drop_thresh) {
-    // same counter hash as pmask(): idx = row_base + key with row_base a multiple of 128, so only the low
-    // word changes with the key and the high-word / seed terms are per-lane constants
+    // idx = row_base + key with row_base a multiple of 128: only the low word changes with the key and the
+    // high-word / seed terms are per-lane constants (keep_lo)
     const unsigned long long rb = (((unsigned long long)blockIdx.x * p.H + h) * AT + qi) * AT;
     const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
     const unsigned s0 = (unsigned)p.drop_seed;
@@ -226,12 +221,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        unsigned x = (lo0 + (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh)) * 0x9E3779B1u + s0;
-        x ^= c2;
-        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
-        acc[t][r] *= x >= p.drop_thresh ? keep : 0.f;
-      }
+      for (int r = 0; r < 16; ++r)
+        acc[t][r] *= keep_lo(lo0 + (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh), s0, c2, p.drop_thresh) ? keep : 0.f;
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -407,14 +398,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
           sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow_p[2 * s2], kb[s2], sa, 0, 0, 0);
           dpa = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow_p[2 * s2], vb[s2], dpa, 0, 0, 0);
         }
+        float lse4[16], d4[16];  // per-query scalars of this lane's 16 rows: four aligned runs of four queries
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 a = *reinterpret_cast<const float4*>(s.lse + qt * 32 + 8 * q4 + 4 * hh);
+          const float4 b = *reinterpret_cast<const float4*>(s.Dv + qt * 32 + 8 * q4 + 4 * hh);
+          lse4[4 * q4] = a.x; lse4[4 * q4 + 1] = a.y; lse4[4 * q4 + 2] = a.z; lse4[4 * q4 + 3] = a.w;
+          d4[4 * q4] = b.x; d4[4 * q4 + 1] = b.y; d4[4 * q4 + 2] = b.z; d4[4 * q4 + 3] = b.w;
+        }
+        const bool kok = kj < k_len;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const bool ok = qq < q_len && kj < k_len;
-          const float pv = ok ? __expf((sa[r] + c_a) * p.scale - s.lse[qq]) : 0.f;
+          const bool ok = qq < q_len && kok;
+          const float pv = ok ? __expf((sa[r] + c_a) * p.scale - lse4[r]) : 0.f;
           const bool keep = !p.drop_thresh || keep_lo(lo_a + qq * AT, s0, c2, p.drop_thresh);
           sa[r] = keep ? pv * p.drop_inv_keep : 0.f;                                                   // dropout(P)
-          dpa[r] = p.scale * pv * ((keep ? dpa[r] * p.drop_inv_keep : 0.f) - s.Dv[qq]);                // dS
+          dpa[r] = p.scale * pv * ((keep ? dpa[r] * p.drop_inv_keep : 0.f) - d4[r]);                   // dS
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         }
       }
     }
+    stamp();  // 3: orientation A done (wave 0)
     // ---- orientation B: lane <-> query qi of this wave's 32 queries, registers <-> keys of tile t
     //        S^T[k][qi], dP^T[k][qi]  ->  dQn^T[:, qi] += Kn^T dS^T
     f32x16 acc_dq = zero16();
