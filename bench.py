@@ -144,16 +144,15 @@ def main():
     torch.manual_seed(0)
     model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
     reducer = None
-    if world > 1:  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
+    if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1":  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=64.0)
         parallel.enable_sync_batchnorm()
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
 
     params = [p for p in model.parameters() if p.requires_grad]
-    if reducer is None:
-        # gradients are dropped (set to None) before every step and nothing reads them during backward:
-        # the weight-gradient stream only has to be joined once, at the end of the backward pass
-        ops.set_wgrad_join("end")
+    # gradients are dropped (set to None) before every step and nothing reads them during backward except the
+    # reducer's bucket flush (which joins the weight-gradient stream itself): one join per backward pass
+    ops.set_wgrad_join("end")
 
     def step():
         if reducer is not None:

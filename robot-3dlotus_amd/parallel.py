@@ -35,7 +35,13 @@ def init_distributed(backend=None):
 
 
 class GradReducer:
-    """Flat-buffer bucketed gradient averaging with backward overlap."""
+    """Flat-buffer bucketed gradient averaging with backward overlap.
+
+    Parameter gradients arrive as whatever tensors backward produced (`.grad` is None on entry, so autograd adopts
+    them without an accumulation kernel per parameter).  When the last gradient of a bucket has arrived, ONE fused
+    multi-tensor copy packs the bucket into its slice of the flat fp32 buffer, `.grad` of those parameters is
+    re-pointed at the slice views, and the slice is all-reduced asynchronously (RCCL) while backward continues.
+    Buckets follow reverse registration order ~ gradient completion order."""
 
     def __init__(self, module, bucket_mb=64.0, group=None, broadcast=True):
         self.group = group
@@ -46,46 +52,63 @@ class GradReducer:
                 dist.broadcast(t.data, 0, group=group)
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        # reverse registration order ~ gradient completion order
         order = list(reversed(self.params))
         cap = int(bucket_mb * (1 << 20) / 4)
-        self.buckets, cur, cur_n, offset = [], [], 0, 0
+        self.buckets, self._bparams, self._bviews = [], [], []
         self._slot = {}
+        cur_p, cur_v, cur_n, offset, start = [], [], 0, 0, 0
         for p in order:
-            p.grad = self.flat[offset:offset + p.numel()].view_as(p)
             self._slot[p] = len(self.buckets)
-            cur.append((offset, p.numel()))
+            cur_p.append(p)
+            cur_v.append(self.flat[offset:offset + p.numel()].view_as(p))
             cur_n += p.numel()
             offset += p.numel()
             if cur_n >= cap:
-                self.buckets.append((cur[0][0], offset))
-                cur, cur_n = [], 0
-        if cur:
-            self.buckets.append((cur[0][0], offset))
+                self.buckets.append((start, offset))
+                self._bparams.append(cur_p)
+                self._bviews.append(cur_v)
+                cur_p, cur_v, cur_n, start = [], [], 0, offset
+        if cur_p:
+            self.buckets.append((start, offset))
+            self._bparams.append(cur_p)
+            self._bviews.append(cur_v)
         self._pending = [0] * len(self.buckets)
-        self._count = [0] * len(self.buckets)
-        for p in order:
-            self._count[self._slot[p]] += 1
+        self._count = [len(ps) for ps in self._bparams]
         self._handles = []
-        if self.world > 1:
-            for p in order:
-                p.register_post_accumulate_grad_hook(self._hook)
+        self._avg = self.world > 1 and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
+        for p in order:
+            p.grad = None
+            p.register_post_accumulate_grad_hook(self._hook)
 
     def _hook(self, p):
         b = self._slot[p]
         self._pending[b] += 1
         if self._pending[b] == self._count[b]:
+            self._flush(b)
+
+    def _flush(self, b):
+        ops.sync_side_stream()  # the bucket's weight gradients may still be running on the side stream
+        ps, views = self._bparams[b], self._bviews[b]
+        torch._foreach_copy_(views, [p.grad for p in ps])
+        for p, v in zip(ps, views):
+            p.grad = v
+        if self.world > 1:
             lo, hi = self.buckets[b]
             buf = self.flat[lo:hi]
-            buf.mul_(1.0 / self.world)
-            self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self._avg:
+                self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+            else:
+                buf.mul_(1.0 / self.world)
+                self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def zero_grad(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None
         self._pending = [0] * len(self.buckets)
 
     def finish(self):
-        """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser)."""
+        """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser).  Afterwards
+        every `.grad` is a view into the flat, rank-averaged buffer."""
         for h in self._handles:
             h.wait()
         self._handles = []
