@@ -441,6 +441,64 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
   return LOTUS_OK;
 }
 
+// Weight gradient of the thin-input stem (cin <= 8): dw[c][t][ci] += sum over the active pairs of tap t of
+// dy[row][c] * x[nbr][ci].  Block = (64 output channels, tap t, row range z); the pairs of a 256-row window are
+// compacted in row order (wave ballots), their input rows staged in LDS; wave g takes pairs g, g+4, ... and the four
+// waves are summed in fixed order -> deterministic.  Same partial-slab layout as conv_wgrad_kernel.
+__global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
+  __shared__ int prow_s[256];
+  __shared__ int pnb_s[256];
+  __shared__ __attribute__((aligned(16))) float xs[256][8];
+  __shared__ float red[4][64][8];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, c = tid & 63, g = tid >> 6, lane = tid & 63;
+  const int cb = blockIdx.x, t = blockIdx.y, z = blockIdx.z;
+  const int rbeg = z * p.chunk, rend = min(p.n, rbeg + p.chunk);
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int r0 = rbeg; r0 < rend; r0 += 256) {
+    const int row = r0 + tid;
+    const int nb = row < rend ? p.nbr[(long)t * p.n + row] : -1;
+    const unsigned long long m = __ballot(nb >= 0);
+    if (lane == 0) wcnt[g] = __popcll(m);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < g) base += wcnt[w];
+      total += wcnt[w];
+    }
+    if (nb >= 0) {
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      prow_s[pos] = row;
+      pnb_s[pos] = nb;
+    }
+    __syncthreads();
+    for (int i = tid; i < total * 8; i += 256) {
+      const int pi = i >> 3, ci = i & 7;
+      xs[pi][ci] = ci < p.cin ? p.x[(long)pnb_s[pi] * p.cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pi = g; pi < total; pi += 4) {
+      const float dyv = p.dy[(long)prow_s[pi] * p.cout + cb * 64 + c];
+      const float4 xa = *reinterpret_cast<const float4*>(&xs[pi][0]);
+      const float4 xb = *reinterpret_cast<const float4*>(&xs[pi][4]);
+      acc[0] = fmaf(dyv, xa.x, acc[0]); acc[1] = fmaf(dyv, xa.y, acc[1]); acc[2] = fmaf(dyv, xa.z, acc[2]); acc[3] = fmaf(dyv, xa.w, acc[3]);
+      acc[4] = fmaf(dyv, xb.x, acc[4]); acc[5] = fmaf(dyv, xb.y, acc[5]); acc[6] = fmaf(dyv, xb.z, acc[6]); acc[7] = fmaf(dyv, xb.w, acc[7]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[g][c][k] = acc[k];
+  __syncthreads();
+  if (g == 0) {
+    float* out = p.part + (long)z * p.part_stride + ((long)(cb * 64 + c) * p.T + t) * p.cin;
+    for (int k = 0; k < p.cin; ++k) out[k] = ((red[0][c][k] + red[1][c][k]) + red[2][c][k]) + red[3][c][k];
+  }
+}
+
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout) {
   const int nsplit = cdiv(n > 0 ? n : 1, WG_MAX_PAIRS);
   return (size_t)nsplit * ((size_t)cout * T * cin + cout) * sizeof(float);
@@ -467,8 +525,12 @@ int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db,
     p.part = (float*)workspace; p.part_stride = (long)slab;
     p.bias_part = db ? p.part + wsz : nullptr;
   }
-  dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
-  hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+  if (cin <= 8 && cout % 64 == 0 && !db) {  // thin-input stem: VALU kernel over the active pairs
+    hipLaunchKernelGGL(conv_smallcin_wgrad_kernel, dim3(cout / 64, T, nsplit), dim3(256), 0, st, p);
+  } else {
+    dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+  }
   LOTUS_LAUNCH_CHECK("lotus_subm_conv_wgrad");
   if (direct) return LOTUS_OK;
   if (db && db == dw + wsz) return lotus_reduce_parts(p.part, dw, (long)slab, (long)slab, nsplit, accumulate, st);

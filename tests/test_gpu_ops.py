@@ -160,6 +160,8 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
     dw, db = ops.conv_wgrad(dy.cuda(), x.cuda(), w.shape, nbr)
     _close(dw, wd.grad, 5e-6, "conv wgrad")
     _close(db, bd.grad, 5e-6, "conv bgrad")
+    dw2, _ = ops.conv_wgrad(dy.cuda(), x.cuda(), w.shape, nbr, need_bias=False)  # (thin inputs: active-pair VALU kernel)
+    _close(dw2, wd.grad, 5e-6, "conv wgrad (no bias)")
     if cin != cout and k == 3:
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, None)
         _close(dx, xd.grad, 3e-6, "conv dgrad (cin != cout, natural row order)")
