@@ -216,6 +216,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   };
 
+  // Unguarded prefetch of a slab that lies fully inside [kbeg, kend): per-thread base pointers (rows / columns clamped
+  // once) plus the slab offset — one 64-bit add per 16-byte load, no k clamp, no zero select.  Issued at the top of the
+  // iteration and pinned there (sched_barrier), so the loads fly under the whole slab of MFMAs instead of being
+  // sunk next to their consumers.
+  const float* pa[A4];
+  const float* pb[B4];
+  if (FAST) {
+#pragma unroll
+    for (int t = 0; t < A4; ++t) {
+      const int f = tid + t * 256;
+      if (A_KC) pa[t] = p.A + (long)min(m0 + f / (BK / 4), p.M - 1) * p.lda + (f % (BK / 4)) * 4;
+      else pa[t] = p.A + (long)(f / (BM / 4)) * p.lda + min(m0 + (f % (BM / 4)) * 4, p.M - 4);
+    }
+#pragma unroll
+    for (int t = 0; t < B4; ++t) {
+      const int f = tid + t * 256;
+      if (B_KC) pb[t] = p.B + (long)min(n0 + f / (BK / 4), p.N - 1) * p.ldb + (f % (BK / 4)) * 4;
+      else pb[t] = p.B + (long)(f / (BN / 4)) * p.ldb + min(n0 + (f % (BN / 4)) * 4, p.N - 4);
+    }
+  }
+  auto gload_full = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < A4; ++t) ra[t] = *reinterpret_cast<const float4*>(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
+#pragma unroll
+    for (int t = 0; t < B4; ++t) rb[t] = *reinterpret_cast<const float4*>(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
+  };
+
   // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs
   if (kbeg < kend) {
     gload(kbeg);
@@ -223,10 +250,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      gload(k0 + BK);  // past-the-end prefetch is clamped / zeroed and never consumed
+      if (FAST && k0 + 2 * BK <= kend) gload_full(k0 + BK);
+      else gload(k0 + BK);  // tail / past-the-end prefetch: clamped, zeroed, never consumed past kend
+      __builtin_amdgcn_sched_barrier(0);
       // only the first column block reports the column sums of A (bias gradient): the others skip the VALU adds
       if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       else gemm_slab<BM, BN, BK, A_KC, B_KC, false>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
       lstore(As + cur * AF, Bs + cur * BF);
       __syncthreads();
