@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--npoints", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="also run lr schedule + clip_grad_norm_(10) + fused AdamW inside every step (SURVEY 8f rank 1); "
+                         "the headline metric of BASELINE.json is forward + backward only, so this is off by default")
     ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -150,6 +153,14 @@ def main():
     batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
 
     params = [p for p in model.parameters() if p.requires_grad]
+    opt = None
+    if args.with_optimizer:
+        from types import SimpleNamespace
+        from robot_3dlotus_amd import optim as loptim
+        topts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.05, optim="adamw", betas=[0.9, 0.98], lr_sched="cosine",
+                                warmup_steps=5000, num_train_steps=150000, grad_norm=10.0)  # simple_policy_ptv3.yaml TRAIN
+        opt, init_lrs = loptim.build_optimizer(model, topts)
+        gstep = [0]
     # gradients are dropped (set to None) before every step and nothing reads them during backward except the
     # reducer's bucket flush (which joins the weight-gradient stream itself): one join per backward pass
     ops.set_wgrad_join("end")
@@ -165,6 +176,11 @@ def main():
         losses["total"].backward()
         if reducer is not None:
             reducer.finish()
+        if opt is not None:
+            loptim.set_lr(opt, init_lrs, gstep[0], topts)
+            opt.clip_grad_norm_(topts.grad_norm)
+            opt.step()
+            gstep[0] += 1
         return losses
 
     # the step runs on a high-priority stream: the weight-gradient and front-end side streams then only fill
@@ -206,6 +222,8 @@ def main():
                        "model_gflop_per_sample": GFLOP_PER_SAMPLE,
                        "model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 2)},
         }
+        if opt is not None:
+            out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
         if not args.no_roofline:
             calls = []
             ops.CALL_LOG = calls

@@ -193,6 +193,17 @@ int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long 
 int lotus_debug_conv_clock(long long* host64);
 int lotus_debug_attn_clock(long long* host64);
 
+/* ---- optimiser step: genrobo3d/train/optim/adamw.py:53-112 (HF AdamW: eps outside the bias
+ * correction, decoupled decay after the update) and torch.nn.utils.clip_grad_norm_ (train_simple_policy.py:237-241) as
+ * two multi-tensor launches.  All tables are device memory built by the caller: pointer arrays [T] (a null gradient
+ * skips the tensor), numel [T], chunks [nchunks][2] = (tensor, chunk index) with lotus_mt_chunk() elements per chunk. */
+int lotus_mt_chunk(void);
+int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, int nchunks, double* partial, float* norm_out,
+                    float max_norm, void* stream);
+int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const long* numel,
+                     const float* step_size, const float* decay, const int* chunks, int nchunks, float beta1, float beta2,
+                     float eps, const float* clip_coef, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
