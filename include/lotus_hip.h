@@ -193,6 +193,16 @@ int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long 
 int lotus_debug_conv_clock(long long* host64);
 int lotus_debug_attn_clock(long long* host64);
 
+/* ---- soft position targets / arg-max position decode: get_disc_gt_pos_prob and
+ * get_best_pos_from_disc_pos(best='max'), genrobo3d/utils/action_position_utils.py:7-46, :48-64.  pc = point rows whose
+ * first three columns are xyz (row stride ld); kind 0 'plain' / 1 'dist'; tgt has the layout lotus_loss_fwd consumes. */
+size_t lotus_pos_workspace(int B);
+int lotus_pos_targets(const float* pc, long ld, const int* off, const int* batch, const float* gt, int ga,
+                      const unsigned char* robot, int B, int n, int nb, double bin_size, int kind, float* tgt, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
+                         double* best_pos, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- optimiser step: genrobo3d/train/optim/adamw.py:53-112 (HF AdamW: eps outside the bias
  * correction, decoupled decay after the update) and torch.nn.utils.clip_grad_norm_ (train_simple_policy.py:237-241) as
  * two multi-tensor launches.  All tables are device memory built by the caller: pointer arrays [T] (a null gradient

@@ -281,6 +281,148 @@ __global__ void dropout_mask_kernel(const float* __restrict__ x, float* __restri
     y[i] = x[i] * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Soft position targets and arg-max position decoding on the device (SURVEY.md 8f rank 2;
+// genrobo3d/utils/action_position_utils.py:7-46 and :48-64 best='max').  Candidate coordinate of (point n, axis c,
+// bin j): xyz[n][c] + (j - pos_bins) * pos_bin_size, evaluated in double exactly like the reference's numpy code.
+#define PT_SPLITS 32
+
+// candidate coordinate shift[j] + x with numpy's two roundings (no fma contraction)
+__device__ __forceinline__ double cand_coord(int jrel, double bin, double x) {
+#pragma clang fp contract(off)
+  const double sft = (double)jrel * bin;
+  return sft + x;
+}
+
+__device__ __forceinline__ double pt_weight(double dist, int kind) {  // kind 0 'plain', 1 'dist'
+  if (kind == 0) return dist < 0.01 ? 1.0 : 0.0;
+  return dist > 0.01 ? 0.0 : 1.0 / fmax(dist, 1e-4);
+}
+
+// first-index arg-min / arg-max pairs
+__device__ __forceinline__ void pick_min(double& v, long& i, double v2, long i2) {
+  if (v2 < v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+__device__ __forceinline__ void pick_max(float& v, long& i, float v2, long i2) {
+  if (v2 > v || (v2 == v && i2 < i)) { v = v2; i = i2; }
+}
+
+// slice s of (cloud b, axis c): (sum of weights, nearest candidate distance, its index n * nb + j)
+__global__ __launch_bounds__(256) void pos_tgt_part_kernel(const float* __restrict__ pc, long ld, const int* __restrict__ off,
+                                                           const float* __restrict__ gt, int ga,
+                                                           const unsigned char* __restrict__ robot, int nb, double bin,
+                                                           int kind, double* __restrict__ part) {
+  __shared__ double rs[4], rv[4];
+  __shared__ long ri[4];
+  const int s = blockIdx.x, bc = blockIdx.y, b = bc / 3, c = bc % 3;
+  const int n0 = off[b], nn = off[b + 1] - n0;
+  const int p0 = (int)((long)nn * s / PT_SPLITS), p1 = (int)((long)nn * (s + 1) / PT_SPLITS);
+  const double g = (double)gt[(long)b * ga + c];
+  const int j0 = threadIdx.x & 31, grp = threadIdx.x >> 5, pb = nb / 2;
+  double sum = 0.0, best = INFINITY;
+  long bi = 0x7fffffffffffffffL;
+  for (int p = p0 + grp; p < p1; p += 8) {
+    const double x = (double)pc[(long)(n0 + p) * ld + c];
+    const bool rob = robot && robot[n0 + p];
+    for (int j = j0; j < nb; j += 32) {
+      const double dist = fabs(g - cand_coord(j - pb, bin, x));
+      if (!rob) sum += pt_weight(dist, kind);
+      pick_min(best, bi, dist, (long)p * nb + j);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sum += __shfl_xor(sum, o, 64);
+    const double v2 = __shfl_xor(best, o, 64);
+    const long i2 = __shfl_xor(bi, o, 64);
+    pick_min(best, bi, v2, i2);
+  }
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = sum; rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    for (int w = 1; w < 4; ++w) pick_min(rv[0], ri[0], rv[w], ri[w]);
+    double* o = part + ((long)bc * PT_SPLITS + s) * 3;
+    o[0] = t; o[1] = rv[0]; o[2] = (double)ri[0];
+  }
+}
+
+// stats[bc] = (total weight, index of the nearest candidate)   (slices in fixed order)
+__global__ __launch_bounds__(64) void pos_tgt_merge_kernel(const double* __restrict__ part, double* __restrict__ stats) {
+  const int bc = blockIdx.x;
+  if (threadIdx.x) return;
+  double sum = 0.0, best = INFINITY;
+  long bi = 0x7fffffffffffffffL;
+  for (int s = 0; s < PT_SPLITS; ++s) {
+    const double* o = part + ((long)bc * PT_SPLITS + s) * 3;
+    sum += o[0];
+    pick_min(best, bi, o[1], (long)o[2]);
+  }
+  stats[bc * 2] = sum;
+  stats[bc * 2 + 1] = (double)bi;
+}
+
+// tgt: per cloud [3][nn * nb] normalised weights (or the one-hot nearest candidate when an axis has no weight)
+__global__ void pos_tgt_write_kernel(const float* __restrict__ pc, long ld, const int* __restrict__ off,
+                                     const int* __restrict__ batch, const float* __restrict__ gt, int ga,
+                                     const unsigned char* __restrict__ robot, int n, int nb, double bin, int kind,
+                                     const double* __restrict__ stats, float* __restrict__ tgt) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)n * 3 * nb) return;
+  const int j = (int)(gid % nb), c = (int)((gid / nb) % 3), p = (int)(gid / (3L * nb));
+  const int b = batch[p], n0 = off[b], nn = off[b + 1] - n0, pl = p - n0;
+  const double dist = fabs((double)gt[(long)b * ga + c] - cand_coord(j - nb / 2, bin, (double)pc[(long)p * ld + c]));
+  const double sum = stats[(b * 3 + c) * 2];
+  double w;
+  if (sum == 0.0) w = ((long)pl * nb + j == (long)stats[(b * 3 + c) * 2 + 1]) ? 1.0 : 0.0;
+  else w = (robot && robot[p]) ? 0.0 : pt_weight(dist, kind);
+  const float out = kind == 0 ? (float)w / (float)(sum == 0.0 ? 1.0 : sum) : (float)(w / (sum == 0.0 ? 1.0 : sum));
+  tgt[(long)3 * nb * n0 + (long)c * nn * nb + (long)pl * nb + j] = out;
+}
+
+// slice s of (cloud b, axis c): first arg-max of the position logits xt[n][c][j]
+__global__ __launch_bounds__(256) void pos_argmax_part_kernel(const float* __restrict__ xt, const int* __restrict__ off, int nb,
+                                                              double* __restrict__ part) {
+  __shared__ float rv[4];
+  __shared__ long ri[4];
+  const int s = blockIdx.x, bc = blockIdx.y, b = bc / 3, c = bc % 3;
+  const int n0 = off[b], nn = off[b + 1] - n0;
+  const int p0 = (int)((long)nn * s / PT_SPLITS), p1 = (int)((long)nn * (s + 1) / PT_SPLITS);
+  const int j0 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float best = -INFINITY;
+  long bi = 0x7fffffffffffffffL;
+  for (int p = p0 + grp; p < p1; p += 8)
+    for (int j = j0; j < nb; j += 32) pick_max(best, bi, xt[(long)(n0 + p) * (3 * nb) + c * nb + j], (long)p * nb + j);
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(best, o, 64);
+    const long i2 = __shfl_xor(bi, o, 64);
+    pick_max(best, bi, v2, i2);
+  }
+  if ((threadIdx.x & 63) == 0) { rv[threadIdx.x >> 6] = best; ri[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) pick_max(rv[0], ri[0], rv[w], ri[w]);
+    double* o = part + ((long)bc * PT_SPLITS + s) * 3;
+    o[0] = (double)rv[0]; o[1] = (double)ri[0];
+  }
+}
+
+__global__ __launch_bounds__(64) void pos_argmax_merge_kernel(const double* __restrict__ part, const float* __restrict__ pc,
+                                                              long ld, const int* __restrict__ off, int nb, double bin,
+                                                              double* __restrict__ best_pos) {
+  const int bc = blockIdx.x, b = bc / 3, c = bc % 3;
+  if (threadIdx.x) return;
+  float best = -INFINITY;
+  long bi = 0x7fffffffffffffffL;
+  for (int s = 0; s < PT_SPLITS; ++s) {
+    const double* o = part + ((long)bc * PT_SPLITS + s) * 3;
+    pick_max(best, bi, (float)o[0], (long)o[1]);
+  }
+  if (off[b + 1] == off[b]) { best_pos[bc] = 0.0; return; }
+  const long p = bi / nb;
+  const int j = (int)(bi % nb);
+  best_pos[bc] = cand_coord(j - nb / 2, bin, (double)pc[(long)(off[b] + p) * ld + c]);
+}
+
 extern "C" {
 
 int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,
@@ -384,6 +526,41 @@ int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long 
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
                      1.f / (1.f - p));
   LOTUS_LAUNCH_CHECK("lotus_dropout");
+  return LOTUS_OK;
+}
+
+size_t lotus_pos_workspace(int B) { return (size_t)B * 3 * (PT_SPLITS * 3 + 2) * sizeof(double); }
+
+// tgt (per cloud [3][nn * nb], the layout lotus_loss_fwd consumes) from the point coordinates (first 3 columns of pc)
+// and the ground-truth positions gt[b][0..2].  kind 0 'plain', 1 'dist'; robot (optional) = 1 for points to exclude.
+int lotus_pos_targets(const float* pc, long ld, const int* off, const int* batch, const float* gt, int ga,
+                      const unsigned char* robot, int B, int n, int nb, double bin_size, int kind, float* tgt, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  LOTUS_CHECK_ARG(pc && off && batch && gt && tgt && B > 0 && nb > 0 && nb % 2 == 0 && (kind == 0 || kind == 1),
+                  "lotus_pos_targets: bad arguments");
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_pos_workspace(B), "lotus_pos_targets: workspace too small");
+  if (n == 0) return LOTUS_OK;
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  double* stats = part + (size_t)B * 3 * PT_SPLITS * 3;
+  hipLaunchKernelGGL(pos_tgt_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, pc, ld, off, gt, ga, robot, nb, bin_size, kind, part);
+  hipLaunchKernelGGL(pos_tgt_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, stats);
+  hipLaunchKernelGGL(pos_tgt_write_kernel, dim3(cdiv((long)n * 3 * nb, 256)), dim3(256), 0, st, pc, ld, off, batch, gt, ga, robot, n,
+                     nb, bin_size, kind, (const double*)stats, tgt);
+  LOTUS_LAUNCH_CHECK("lotus_pos_targets");
+  return LOTUS_OK;
+}
+
+// best_pos[b][c] (double) = coordinate of the first arg-max of the position logits xt [n][3 * nb] of cloud b, axis c
+int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
+                         double* best_pos, void* workspace, size_t workspace_bytes, void* stream) {
+  LOTUS_CHECK_ARG(xt && pc && off && best_pos && B > 0 && nb > 0 && nb % 2 == 0, "lotus_pos_decode_max: bad arguments");
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_pos_workspace(B), "lotus_pos_decode_max: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace;
+  hipLaunchKernelGGL(pos_argmax_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, xt, off, nb, part);
+  hipLaunchKernelGGL(pos_argmax_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, pc, ld, off, nb, bin_size, best_pos);
+  LOTUS_LAUNCH_CHECK("lotus_pos_decode_max");
   return LOTUS_OK;
 }
 

@@ -260,6 +260,26 @@ def dropout(x, p, seed):
     return y
 
 
+def pos_targets(pc_fts, off, batch_idx, gt, nb, bin_size, kind="plain", robot_mask=None):
+    """Soft position targets on the device (get_disc_gt_pos_prob, utils/action_position_utils.py:7-46), in the
+    concatenated per-cloud [3][n_b * nb] layout the loss consumes.  pc_fts: f32 [N, >=3]; gt: f32 [B, >=3]."""
+    N, B = pc_fts.shape[0], gt.shape[0]
+    tgt = torch.empty(N * 3 * nb, dtype=torch.float32, device=pc_fts.device)
+    ws = _ws(query("lotus_pos_workspace", B), pc_fts.device)
+    rm = None if robot_mask is None else robot_mask.to(torch.uint8).contiguous()
+    call("lotus_pos_targets", pc_fts, pc_fts.stride(0), off, batch_idx, gt, gt.stride(0), rm, B, N, nb, float(bin_size),
+         {"plain": 0, "dist": 1}[kind], tgt, ws, ws.numel())
+    return tgt
+
+
+def pos_decode_max(xt, pc_fts, off, B, nb, bin_size):
+    """get_best_pos_from_disc_pos(best='max') (utils/action_position_utils.py:48-64) for every cloud: f64 [B, 3]."""
+    out = torch.empty(B, 3, dtype=torch.float64, device=xt.device)
+    ws = _ws(query("lotus_pos_workspace", B), xt.device)
+    call("lotus_pos_decode_max", xt, pc_fts, pc_fts.stride(0), off, B, nb, float(bin_size), out, ws, ws.numel())
+    return out
+
+
 def add(a, b):
     y = torch.empty_like(a)
     call("lotus_add", a, b, y, a.numel())

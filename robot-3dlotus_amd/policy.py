@@ -120,9 +120,19 @@ class SimplePolicyPTV3CA(BaseModel):
         tgt = None
         with_loss = bool(compute_loss)
         if with_loss:
-            dp = batch["disc_pos_probs"]
-            tgt = dp if isinstance(dp, torch.Tensor) else torch.cat([t.reshape(-1) for t in dp]).to(dev)
-            tgt = tgt.float().contiguous()
+            dp = batch.get("disc_pos_probs")
+            if dp is None:
+                # no host-made soft labels in the batch: build them on the device from the ground-truth positions
+                # (get_disc_gt_pos_prob, utils/action_position_utils.py:7-46; the dataset would otherwise ship
+                # 3 * n * 2 * pos_bins floats per cloud over PCIe).  Options of the reference dataset
+                # (simple_policy_dataset.py:41-42): batch["pos_heatmap_type"] 'plain' | 'dist', and
+                # batch["robot_point_mask"] (bool [N]) for pos_heatmap_no_robot.
+                pc = batch["pc_fts"] if batch["pc_fts"].stride(1) == 1 else batch["pc_fts"].contiguous()
+                tgt = ops.pos_targets(pc, lvl.off, lvl.batch, gt, 2 * head.pos_bins, act.pos_bin_size,
+                                      batch.get("pos_heatmap_type", "plain"), batch.get("robot_point_mask"))
+            else:
+                tgt = dp if isinstance(dp, torch.Tensor) else torch.cat([t.reshape(-1) for t in dp]).to(dev)
+                tgt = tgt.float().contiguous()
         self._step += 1
         hm, am = head.heatmap_mlp, head.action_mlp
         p = head.dropout if self.training else 0.0
@@ -146,7 +156,8 @@ class SimplePolicyPTV3CA(BaseModel):
             # skipped unless decode_actions=True is passed.  See INTEGRATION.md.
             return None, {"pos": losses[0], "rot": losses[1], "open": losses[2], "total": losses[3]}
         if decode:
-            pos = self._decode_pos(xt, last.coord, lvl, nb, act)
+            pc = batch["pc_fts"] if batch["pc_fts"].stride(1) == 1 else batch["pc_fts"].contiguous()
+            pos = ops.pos_decode_max(xt, pc, lvl.off, B, nb, act.pos_bin_size)  # f64 [B, 3], one launch pair
         else:
             pos = gt[..., :3]
         # euler_disc decode, simple_policy_ptv3.py:292-296 (float64 on purpose)
@@ -157,19 +168,6 @@ class SimplePolicyPTV3CA(BaseModel):
         if compute_loss:
             return final, {"pos": losses[0], "rot": losses[1], "open": losses[2], "total": losses[3]}
         return final
-
-    @torch.no_grad()
-    def _decode_pos(self, xt, coord, lvl, nb, act):
-        """get_best_pos_from_disc_pos(best='max'), utils/action_position_utils.py:48-64: per cloud and
-        axis, arg-max over (point, bin) -> coordinate + bin shift."""
-        shift = (torch.arange(-nb // 2, nb // 2, device=xt.device) * act.pos_bin_size).float()
-        out = []
-        for b, (a, e) in enumerate(zip(lvl.off_host[:-1], lvl.off_host[1:])):
-            lg = xt[a:e].view(-1, 3, nb).permute(1, 0, 2).reshape(3, -1)
-            idx = lg.argmax(-1)
-            pt, bn = idx // nb, idx % nb
-            out.append(coord[a:e][pt, torch.arange(3, device=xt.device)] + shift[bn])
-        return torch.stack(out, 0)
 
 
 MODEL_FACTORY = {"SimplePolicyPTV3CA": SimplePolicyPTV3CA}
