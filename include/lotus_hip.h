@@ -183,6 +183,12 @@ int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const flo
 int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
                    const float* dae_saved, const float* gl, float pos_w, float rot_w, int B, int n, int nb, int nrot,
                    float* dxt, float* dae_out, void* stream);
+/* heatmap cross entropy alone, for the trajectory head (one call per trajectory step; per-cloud step masks enter as
+ * the upstream gradients g[B*3]), genrobo3d/models/motion_planner_ptv3.py:327-336.  pos_stats as for lotus_loss_fwd;
+ * pos_stats[(b*3+c)*4] = CE of cloud b, axis c. */
+int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream);
+int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                     const float* g, int B, int n, int nb, float* dxt, void* stream);
 /* elementwise plumbing */
 int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */

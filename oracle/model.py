@@ -161,12 +161,20 @@ class Oracle:
         """SimplePolicyPTV3AdaNorm.forward + SimplePolicyPTV3CA.prepare_ptv3_batch,
         simple_policy_ptv3.py:225-306, :403-431.  batch uses the reference schema
         (pc_fts, npoints_in_batch, txt_embeds, txt_lens, gt_actions, disc_pos_probs)."""
-        p3, act = self.cfg["ptv3"], self.cfg["action"]
-        sd = self.sd
         pc = batch["pc_fts"].float()
         counts = list(batch["npoints_in_batch"])
+        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")  # simple_policy_ptv3.py:414
+        x, out = self.backbone(pc, pc[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        return self.head(x, counts, batch, out, compute_loss)
+
+    def backbone(self, feat, xyz, counts, ctx, ctx_counts, perms):
+        """PointTransformerV3CA.forward, PointTransformerV3/model_ca.py:314-347: embedding, encoder, decoder.
+        Returns (last decoder features, dict(levels, feats))."""
+        p3, act = self.cfg["ptv3"], self.cfg["action"]
+        sd = self.sd
+        pc = feat
         n_lv = len(p3["enc_channels"])
-        levels = fe.build_all_levels(pc[:, :3].detach().numpy(), counts, n_lv,
+        levels = fe.build_all_levels(xyz.detach().numpy(), counts, n_lv,
                                      patch_size=p3["enc_patch_size"][0], perms=perms,
                                      grid_size=np.float32(act["voxel_size"]))
         for lv in levels:
@@ -174,8 +182,6 @@ class Oracle:
                 lv[k + "_t"] = _t(lv[k])
             lv["pad_t"], lv["unpad_t"] = _t(lv["pad"]), _t(lv["unpad"])
             lv["nbr27_t"] = _t(lv["nbr27"])
-        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")  # simple_policy_ptv3.py:414
-        ctx_counts = list(batch["txt_lens"])
         out = {"levels": levels}
 
         # Embedding, PointTransformerV3/model.py:844-861
@@ -205,8 +211,11 @@ class Oracle:
             x = self.ca_block(x, lvl, ctx, ctx_counts, name + ".ca_block0", p3["dec_num_head"][s])
             feats.append(x)
         out["feats"] = feats
+        return x, out
 
-        # ActionHead.forward (heatmap_disc / max / euler_disc), simple_policy_ptv3.py:113-157
+    def head(self, x, counts, batch, out, compute_loss):
+        """ActionHead.forward (heatmap_disc / max / euler_disc), simple_policy_ptv3.py:113-157, and
+        compute_loss, :308-373."""
         h = F.leaky_relu(self.lin(x, "act_proj_head.heatmap_mlp.0"), 0.02)
         xt = self.lin(h, "act_proj_head.heatmap_mlp.3")  # (N, 3*2*pos_bins)
         nb = xt.shape[1] // 3
@@ -228,4 +237,47 @@ class Oracle:
             lc = self.cfg["loss"]
             out["losses"] = dict(pos=pos, rot=rot, open=opn,
                                  total=lc["pos_weight"] * pos + lc["rot_weight"] * rot + opn)
+        return out
+
+    # -- 3D-LOTUS++ motion planner (BASELINE configs[3]) -----------------------------------------
+    def forward_mp(self, batch, perms, compute_loss=True):
+        """MotionPlannerPTV3CA: prepare_ptv3_batch motion_planner_ptv3.py:433-463, forward :222-305, trajectory
+        ActionHead.forward :77-148 (heatmap_disc / max / euler_disc), compute_loss :307-397.  batch: pc_fts [N,4],
+        pc_labels, txt_embeds, txt_lens, npoints_in_batch, gt_trajs [B,T,7], gt_trajs_stop, traj_masks,
+        gt_trajs_disc_pos_probs (list of [T,3,n*nb])."""
+        sd, act = self.sd, self.cfg["action"]
+        pc = batch["pc_fts"].float()
+        counts = list(batch["npoints_in_batch"])
+        feat = torch.cat([pc, sd["pc_label_embedding.weight"][batch["pc_labels"].long()]], -1)   # :441-442
+        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")                                      # :447
+        x, out = self.backbone(feat, pc[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        T, B = act["max_traj_len"], len(counts)
+        te = sd["act_proj_head.traj_embedding.weight"]
+        pe = torch.cat([x.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(x.shape[0], -1, -1)], -1)  # :90-97
+        xt = self.lin(F.leaky_relu(self.lin(pe, "act_proj_head.heatmap_mlp.0"), 0.02), "act_proj_head.heatmap_mlp.3")
+        nb = xt.shape[-1] // 3
+        xt = xt.view(-1, T, 3, nb).permute(1, 2, 0, 3)                       # 'n t (c b) -> t c n b', :113-114
+        pcs = torch.stack([t_.max(0)[0] for t_ in torch.split(pe, counts)], 0)                   # :116-120
+        ae = self.lin(F.leaky_relu(self.lin(pcs, "act_proj_head.action_mlp.0"), 0.02), "act_proj_head.action_mlp.3")
+        ebins = 360 // 5
+        xr = ae[..., : ebins * 3].reshape(B, T, ebins, 3)                    # :139-142
+        xo, xs = ae[..., -2], ae[..., -1]                                     # :145-146
+        out.update(xt=xt, xr=xr, xo=xo, xstop=xs)
+        if compute_loss:
+            gt, m = batch["gt_trajs"].float(), batch["traj_masks"].float()
+            pos = 0
+            for i, lg in enumerate(torch.split(xt, counts, dim=2)):          # :324-336
+                ce = F.cross_entropy(lg.reshape(T * 3, -1), batch["gt_trajs_disc_pos_probs"][i].float().reshape(T * 3, -1),
+                                     reduction="none")
+                mk = m[i].unsqueeze(1).expand(-1, 3).reshape(-1)
+                pos = pos + (ce * mk).sum() / mk.sum()
+            pos = pos / B
+            rl = F.cross_entropy(xr.permute(0, 1, 3, 2).reshape(-1, ebins), gt[..., 3:-1].long().reshape(-1),
+                                 reduction="none").view(B, T, 3)             # :365-372
+            rot = (rl * m.unsqueeze(-1)).sum() / m.sum() / 3
+            opn = (F.binary_cross_entropy_with_logits(xo, gt[..., -1], reduction="none") * m).sum() / m.sum()
+            stp = (F.binary_cross_entropy_with_logits(xs, batch["gt_trajs_stop"].float(), reduction="none") * m).sum() / m.sum()
+            lc = self.cfg["loss"]
+            out["losses"] = dict(pos=pos, rot=rot, open=opn, stop=stp,
+                                 total=lc["pos_weight"] * pos + lc["rot_weight"] * rot + opn + stp)
         return out

@@ -118,7 +118,37 @@ def load_model_config(yaml_path=None, overrides=()):
     return to_cfg(merge_overrides(model, list(overrides)))
 
 
+# genrobo3d/configs/rlbench/motion_planner_ptv3.yaml:103-164 differs from the simple-policy YAML in these MODEL keys
+_YAML_MP_DELTA = dict(model_class="MotionPlannerPTV3AdaNorm",
+                      action_config=dict(pc_label_channels=64, traj_embed_size=64, max_traj_len=5,
+                                         rot_pred_type="euler_disc"))
+
+# job_scripts/train_3dlotusplus_motion_planner.sh:71-98 (MODEL.* overrides; pos_bin_size=15, max_traj_len=5)
+MP_OVERRIDES = [
+    "ptv3_config.drop_path", "0.0", "ptv3_config.attn_drop", "0.1", "ptv3_config.proj_drop", "0.1",
+    "action_config.dropout", "0.2", "action_config.voxel_size", "0.01", "action_config.reduce", "max",
+    "action_config.dim_actions", "7", "action_config.rot_pred_type", "euler_disc",
+    "action_config.pos_pred_type", "heatmap_disc", "action_config.pos_heatmap_temp", "0.1",
+    "ptv3_config.in_channels", "4", "ptv3_config.pdnorm_only_decoder", "False", "ptv3_config.qk_norm", "True",
+    "ptv3_config.scaled_cosine_attn", "False", "ptv3_config.enable_flash", "True",
+    "action_config.max_steps", "30", "ptv3_config.enc_depths", "[1, 1, 1, 1, 1]",
+    "ptv3_config.dec_depths", "[1, 1, 1, 1]", "ptv3_config.enc_channels", "[64, 128, 256, 512, 768]",
+    "ptv3_config.dec_channels", "[128, 128, 256, 512]", "loss_config.pos_weight", "1",
+    "loss_config.rot_weight", "1", "action_config.max_traj_len", "5", "action_config.pos_bins", "15",
+    "action_config.txt_reduce", "attn", "action_config.use_ee_pose", "False",
+    "model_class", "MotionPlannerPTV3CA", "ptv3_config.pdnorm_bn", "False",
+    "ptv3_config.pdnorm_ln", "False", "ptv3_config.pdnorm_adaptive", "False",
+]
+MP_TINY_OVERRIDES = MP_OVERRIDES + TINY_OVERRIDES[len(V1_OVERRIDES):]
+
+
 def preset(name="v1"):
+    """'v1' / 'tiny': 3D-LOTUS policy; 'mp' / 'mp_tiny': 3D-LOTUS++ motion planner (BASELINE configs[3])."""
+    if name in ("mp", "mp_tiny"):
+        model = copy.deepcopy(_YAML_MODEL)
+        model["model_class"] = _YAML_MP_DELTA["model_class"]
+        model["action_config"].update(_YAML_MP_DELTA["action_config"])
+        return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES}[name]))
     return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES}[name])
 
 

@@ -259,6 +259,23 @@ __global__ void pos_ce_bwd_kernel(const float* __restrict__ xt, const float* __r
   dxt[gid] = coef * (expf(xt[gid] - s[1]) * s[2] - t);
 }
 
+// per-(cloud, axis) upstream gradients g[B*3] (trajectory heads weight each cloud by its step mask,
+// motion_planner_ptv3.py:327-336): dxt = g[b*3+c] * (softmax * tsum - t)
+__global__ void pos_ce_bwd_w_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+                                    const int* __restrict__ off, const int* __restrict__ batch,
+                                    const float* __restrict__ stats, const float* __restrict__ g, int n, int nb,
+                                    float* __restrict__ dxt) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)n * 3 * nb;
+  if (gid >= total) return;
+  const int p = (int)(gid / (3 * nb)), rem = (int)(gid % (3 * nb)), c = rem / nb, bin = rem % nb;
+  const int b = batch[p];
+  const int n0 = off[b], nn = off[b + 1] - n0;
+  const float t = tgt[(long)3 * nb * n0 + (long)c * nn * nb + (long)(p - n0) * nb + bin];
+  const float* s = stats + (long)(b * 3 + c) * 4;
+  dxt[gid] = g[b * 3 + c] * (expf(xt[gid] - s[1]) * s[2] - t);
+}
+
 // dae_out = dae_saved * (upstream weight of its column): rot columns g[1] + rot_w * g[3], open column g[2] + g[3]
 __global__ void ae_grad_kernel(const float* __restrict__ x, const float* __restrict__ gl, float rot_w, int W, long n,
                                float* __restrict__ y) {
@@ -505,6 +522,27 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
   hipLaunchKernelGGL(ae_grad_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, st, dae_saved, gl, rot_w, W,
                      (long)B * W, dae_out);
   LOTUS_LAUNCH_CHECK("lotus_loss_bwd");
+  return LOTUS_OK;
+}
+
+// Heatmap cross entropy alone (trajectory heads call it once per step): pos_stats[(b*3+c)*4] = CE of cloud b, axis c
+int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream) {
+  LOTUS_CHECK_ARG(xt && tgt && off && pos_stats && B > 0 && nb > 0, "lotus_pos_ce_fwd: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  float* part = pos_stats + (size_t)B * 3 * 4;
+  hipLaunchKernelGGL(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
+  hipLaunchKernelGGL(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
+  LOTUS_LAUNCH_CHECK("lotus_pos_ce_fwd");
+  return LOTUS_OK;
+}
+int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                     const float* g, int B, int n, int nb, float* dxt, void* stream) {
+  LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && g && dxt && B > 0, "lotus_pos_ce_bwd: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  const long total = (long)n * 3 * nb;
+  hipLaunchKernelGGL(pos_ce_bwd_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xt, tgt, off, batch,
+                     pos_stats, g, n, nb, dxt);
+  LOTUS_LAUNCH_CHECK("lotus_pos_ce_bwd");
   return LOTUS_OK;
 }
 

@@ -650,3 +650,49 @@ class HeadLossFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         call("lotus_cloud_max_bwd", dpc, arg, lvl.batch, N, C, dxh, dx)
         return (dx, dhw0, dhb0, dhw3, dhb3, daw0, dab0, daw3, dab3) + (None,) * 8
+
+
+class PosCEFn(torch.autograd.Function):
+    """Soft-target heatmap cross entropy per (cloud, axis): F.cross_entropy(rearrange(pred, 'c n b -> c (n b)'),
+    probs, reduction='none') of motion_planner_ptv3.py:329-334 for one trajectory step.  Returns [B, 3]."""
+
+    @staticmethod
+    def forward(ctx, xt, tgt, lvl):
+        B = len(lvl.counts)
+        nb = xt.shape[1] // 3
+        stats = torch.empty(query("lotus_loss_stats_floats", B), dtype=torch.float32, device=xt.device)
+        call("lotus_pos_ce_fwd", xt, tgt, lvl.off, B, nb, stats)
+        ctx.save_for_backward(xt, tgt, stats)
+        ctx.lvl = lvl
+        return stats[:B * 12].view(B, 3, 4)[:, :, 0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        xt, tgt, stats = ctx.saved_tensors
+        lvl = ctx.lvl
+        dxt = torch.empty_like(xt)
+        call("lotus_pos_ce_bwd", xt, tgt, lvl.off, lvl.batch, stats, g.contiguous().float(), len(lvl.counts), xt.shape[0],
+             xt.shape[1] // 3, dxt)
+        return dxt, None, None
+
+
+class CloudMaxFn(torch.autograd.Function):
+    """torch.stack([torch.max(x, 0)[0] for x in torch.split(feat, npoints_in_batch)]),
+    motion_planner_ptv3.py:117-119 / simple_policy_ptv3.py:117-119."""
+
+    @staticmethod
+    def forward(ctx, x, lvl):
+        B, C = len(lvl.counts), x.shape[1]
+        y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
+        call("lotus_cloud_max_fwd", x, lvl.off, B, C, y, arg)
+        ctx.save_for_backward(arg)
+        ctx.lvl, ctx.n = lvl, x.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        dx = torch.empty(ctx.n, dy.shape[1], dtype=torch.float32, device=dy.device)
+        call("lotus_cloud_max_bwd", dy.contiguous(), arg, ctx.lvl.batch, ctx.n, dy.shape[1], None, dx)
+        return dx, None

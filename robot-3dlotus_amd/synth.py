@@ -80,3 +80,45 @@ def synth_batch(batch_size=16, npoints=4096, ragged=False, seed=0, pos_bins=15, 
         "ee_poses": torch.zeros(batch_size, 8),
         "step_ids": torch.zeros(batch_size, dtype=torch.long),
     }
+
+
+def synth_batch_mp(batch_size=8, npoints=4096, ragged=False, seed=0, pos_bins=15, txt_dim=512, max_traj_len=5):
+    """Motion-planner batch (schema of genrobo3d/train/datasets/motion_planner_dataset.py:360-415, use_color False):
+    pc_fts f32[N,4] (xyz, height), pc_labels i64[N] in 0..3, gt_trajs f32[B,T,7] (xyz, 3 euler bins, open; short
+    trajectories repeat their last action), gt_trajs_stop f32[B,T], traj_lens list, traj_masks bool[B,T],
+    gt_trajs_disc_pos_probs list of f32[T,3,n*2*pos_bins], plus the text fields of synth_batch."""
+    rng = np.random.default_rng(seed)
+    T = max_traj_len
+    pcs, labels, txt, probs, trajs, stops, lens = [], [], [], [], [], [], []
+    for b in range(batch_size):
+        n = int(rng.integers(npoints // 2, npoints + 1)) if ragged else npoints
+        pc = synth_cloud(rng, n)
+        pcs.append(np.concatenate([pc[:, :3], pc[:, 6:7]], 1))
+        labels.append(rng.integers(0, 4, size=n).astype(np.int64))
+        L = int(rng.integers(6, 20))
+        txt.append(rng.standard_normal((L, txt_dim)).astype(np.float32))
+        z = rng.standard_normal((T, 3, n * 2 * pos_bins)).astype(np.float32)
+        z = np.exp(z - z.max(2, keepdims=True))
+        probs.append((z / z.sum(2, keepdims=True)).astype(np.float32))
+        tl = int(rng.integers(1, T + 1))
+        tr = np.concatenate([rng.normal(0, 0.1, size=(tl, 3)), rng.integers(0, 72, size=(tl, 3)).astype(np.float64),
+                             rng.integers(0, 2, size=(tl, 1)).astype(np.float64)], 1)
+        tr = np.concatenate([tr, np.repeat(tr[-1:], T - tl, 0)], 0).astype(np.float32)
+        st = np.zeros(T, np.float32)
+        st[tl - 1:] = 1.0
+        trajs.append(tr); stops.append(st); lens.append(tl)
+    npts = [len(p) for p in pcs]
+    masks = np.arange(T)[None, :] < np.array(lens)[:, None]
+    return {
+        "pc_fts": torch.from_numpy(np.concatenate(pcs, 0)),
+        "pc_labels": torch.from_numpy(np.concatenate(labels, 0)),
+        "npoints_in_batch": npts,
+        "offset": torch.from_numpy(np.cumsum(npts)).long(),
+        "txt_embeds": torch.from_numpy(np.concatenate(txt, 0)),
+        "txt_lens": [len(t) for t in txt],
+        "gt_trajs": torch.from_numpy(np.stack(trajs, 0)),
+        "gt_trajs_stop": torch.from_numpy(np.stack(stops, 0)),
+        "traj_lens": lens,
+        "traj_masks": torch.from_numpy(masks),
+        "gt_trajs_disc_pos_probs": [torch.from_numpy(p) for p in probs],
+    }

@@ -301,3 +301,45 @@ def reference_forward(ref, batch, full=True):
                              temp=1, gt_pos=batch["gt_actions"][..., :3], dec_layers_embed=None)
     return ref.compute_loss(pred, batch["gt_actions"], disc_pos_probs=batch.get("disc_pos_probs"),
                             npoints_in_batch=batch["npoints_in_batch"])
+
+
+# ----------------------------------------------------------------------------- 3D-LOTUS++ motion planner
+def reference_mp_config(variant="mp"):
+    """Reference YAML (motion_planner_ptv3.yaml) + the MODEL overrides of
+    job_scripts/train_3dlotusplus_motion_planner.sh:71-98 (pos_bin_size=15, max_traj_len=5); 'mp_tiny' adds the
+    two-stage geometry of BASELINE configs[0]."""
+    import yaml
+
+    with open(f"{REFERENCE_ROOT}/genrobo3d/configs/rlbench/motion_planner_ptv3.yaml") as f:
+        cfg = yaml.safe_load(f)["MODEL"]
+    p, a = cfg["ptv3_config"], cfg["action_config"]
+    cfg["model_class"] = "MotionPlannerPTV3CA"
+    p.update(drop_path=0.0, attn_drop=0.1, proj_drop=0.1, in_channels=4, pdnorm_only_decoder=False,
+             qk_norm=True, scaled_cosine_attn=False, enable_flash=True,
+             enc_depths=[1, 1, 1, 1, 1], dec_depths=[1, 1, 1, 1],
+             enc_channels=[64, 128, 256, 512, 768], dec_channels=[128, 128, 256, 512],
+             pdnorm_bn=False, pdnorm_ln=False, pdnorm_adaptive=False)
+    a.update(dropout=0.2, voxel_size=0.01, reduce="max", dim_actions=7, rot_pred_type="euler_disc",
+             pos_pred_type="heatmap_disc", pos_heatmap_temp=0.1, max_steps=30, max_traj_len=5, pos_bins=15,
+             txt_reduce="attn", use_ee_pose=False)
+    cfg["loss_config"].update(pos_weight=1, rot_weight=1)
+    if variant == "mp_tiny":
+        p.update(enc_depths=[1, 1], enc_channels=[64, 64], enc_num_head=[2, 2], enc_patch_size=[128, 128],
+                 stride=[2], dec_depths=[1], dec_channels=[64], dec_num_head=[2], dec_patch_size=[128])
+    return to_cfg(cfg)
+
+
+def build_reference_mp(variant="mp"):
+    install_shims()
+    if "einops" not in sys.modules:
+        import einops  # noqa: F401  (installed in this image)
+    from genrobo3d.models.motion_planner_ptv3 import MotionPlannerPTV3CA
+
+    cfg = reference_mp_config(variant)
+    return MotionPlannerPTV3CA(cfg), cfg
+
+
+def reference_forward_mp(ref, batch):
+    """MotionPlannerPTV3AdaNorm.forward itself (motion_planner_ptv3.py:222-305), training-step call."""
+    acts, losses = ref(batch, compute_loss=True, compute_final_action=False)
+    return losses

@@ -32,6 +32,7 @@ def state_template(cfg):
     """name -> zero tensor with the reference's state_dict layout, derived
     from the configuration alone (no reference import)."""
     p3, act = cfg["ptv3_config"], cfg["action_config"]
+    mp = "pc_label_channels" in act and str(cfg.get("model_class", "")).startswith("MotionPlanner")
     t = {}
 
     def lin(n, o, i):
@@ -58,7 +59,8 @@ def state_template(cfg):
     ec, eh = p3["enc_channels"], p3["enc_num_head"]
     dc, dh = list(p3["dec_channels"]) + [ec[-1]], p3["dec_num_head"]
     ctx = 256
-    t["ptv3_model.embedding.stem.conv.weight"] = torch.zeros(ec[0], 5, 5, 5, p3["in_channels"])
+    t["ptv3_model.embedding.stem.conv.weight"] = torch.zeros(
+        ec[0], 5, 5, 5, p3["in_channels"] + (act["pc_label_channels"] if mp else 0))
     norm("ptv3_model.embedding.stem.norm", ec[0], True)
     for s in range(len(ec)):
         n = f"ptv3_model.enc.enc{s}"
@@ -72,6 +74,32 @@ def state_template(cfg):
         block(n + ".block0", dc[s], dh[s]); ca(n + ".ca_block0", dc[s], dh[s], ctx)
     lin("txt_fc", act["context_channels"], act["txt_ft_size"])
     hs = dc[0]
+    if mp:  # motion_planner_ptv3.py:165-185, :41-73
+        t["pc_label_embedding.weight"] = torch.zeros(4, act["pc_label_channels"])
+        lin("txt_attn_fc", 1, act["txt_ft_size"])
+        t["act_proj_head.traj_embedding.weight"] = torch.zeros(act["max_traj_len"], act["traj_embed_size"])
+        hi = hs + act["traj_embed_size"]
+        lin("act_proj_head.heatmap_mlp.0", hs, hi); lin("act_proj_head.heatmap_mlp.3", 3 * act["pos_bins"] * 2, hs)
+        lin("act_proj_head.action_mlp.0", hs, hi); lin("act_proj_head.action_mlp.3", 72 * 3 + 2, hs)
+        return t
     lin("act_proj_head.heatmap_mlp.0", hs, hs); lin("act_proj_head.heatmap_mlp.3", 3 * act["pos_bins"] * 2, hs)
     lin("act_proj_head.action_mlp.0", hs, hs); lin("act_proj_head.action_mlp.3", 72 * 3 + 1, hs)
     return t
+
+
+MP_CASES = ["mp_tiny_scaled_train", "mp_init_train", "mp_scaled_eval"]
+
+
+def load_case_mp(name):
+    """Motion-planner fixture (tests/golden/make_golden_mp.py): (fixture, cfg, batch, state_dict)."""
+    fx = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+    cfg = lcfg.preset(str(fx["meta_variant"]))
+    batch = synth.synth_batch_mp(int(fx["meta_B"]), int(fx["meta_n"]), ragged=bool(fx["meta_ragged"]),
+                                 seed=int(fx["meta_dseed"]))
+    assert batch["npoints_in_batch"] == fx["npoints_in_batch"].tolist()
+    ck = batch["pc_fts"].double().sum().item() + batch["pc_labels"].double().sum().item()
+    assert abs(ck - float(fx["input_checksum"])) < 1e-9
+    sd = seeded_state_dict(state_template(cfg), int(fx["meta_wseed"]), str(fx["meta_wvar"]))
+    ck = sum(v.double().sum().item() for v in sd.values())
+    assert abs(ck - float(fx["weight_checksum"])) < 1e-6 * max(1.0, abs(ck)), "weight rebuild mismatch"
+    return fx, cfg, batch, sd

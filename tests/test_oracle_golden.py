@@ -66,3 +66,35 @@ def test_padding_tables_known_answer():
     assert pad.tolist() == [0, 1, 2, 3, 4, 5, 2, 3, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 15, 16]
     assert cu.tolist() == [0, 4, 8, 11, 15, 19, 23]
     assert unpad.tolist() == [0, 1, 2, 3, 4, 5, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20]
+
+
+@pytest.mark.parametrize("case", gu.MP_CASES)
+def test_oracle_mp_matches_reference_fixture(case):
+    """Motion-planner restatement (Oracle.forward_mp) against the fixtures of the imported MotionPlannerPTV3CA."""
+    fx, cfg, batch, sd = gu.load_case_mp(case)
+    train = bool(fx["meta_train"])
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    orc = Oracle(sdg, lcfg.plain(cfg), training=train)
+    out = orc.forward_mp(batch, list(fx["perms"]))
+    for k in ("xt", "xr", "xo", "xstop"):
+        ref = fx[k]
+        tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(out[k].detach().numpy(), ref, atol=tol, rtol=0, err_msg=f"{case} {k}")
+    assert set(out["losses"]) == {"pos", "rot", "open", "stop", "total"}
+    for k, v in out["losses"].items():
+        assert abs(v.item() - float(fx["loss_" + k])) < 2e-5 * max(1.0, abs(float(fx["loss_" + k])))
+    out["losses"]["total"].backward()
+    gmax = max(float(fx[k]) for k in fx if k.startswith("gnorm/"))
+    for name in fx["nograd"].tolist():            # txt_attn_fc is built but unused by the CA variant
+        assert sdg[name].grad is None
+    for k in fx:
+        if k.startswith("gnorm/"):
+            name = k[6:]
+            g = sdg[name].grad
+            ref = float(fx[k])
+            assert abs(g.double().norm().item() - ref) <= 1e-4 * ref + 1e-6 * gmax, name
+            np.testing.assert_allclose(g.flatten()[:48].numpy(), fx["ghead/" + name],
+                                       atol=1e-4 * float(np.abs(fx["ghead/" + name]).max()) + 1e-7 * gmax, rtol=0)
+    if train:
+        for k, v in orc.new_running.items():
+            np.testing.assert_allclose(v.numpy(), fx["buf/" + k], atol=2e-3, rtol=2e-3)
