@@ -512,7 +512,9 @@ class StemFn(torch.autograd.Function):
         lvl, training = ctx.meta
         dc, dg, db = bn_bwd(dy.contiguous(), c, mean, invstd, g, b, training, ACT_GELU)
         dcw, _ = conv_wgrad(dc, x, cw.shape, lvl.nbr125, need_bias=False)
-        return None, dcw, dg, db, None, None, None, None
+        # the policy feeds raw point features (no gradient); the motion planner concatenates a learned label embedding
+        dx = conv_dgrad(dc, cw, lvl.nbr125, lvl.order[0]) if ctx.needs_input_grad[0] else None
+        return dx, dcw, dg, db, None, None, None, None
 
 
 class PoolFn(torch.autograd.Function):
@@ -590,9 +592,9 @@ class LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dw, db = linear_wgrad(dy, x)
+        dw, db = linear_wgrad(dy, x, need_bias=ctx.needs_input_grad[2])
         dx = linear_dgrad(dy, w) if ctx.needs_input_grad[0] else None
-        return dx, dw, db
+        return dx, dw, (db if ctx.needs_input_grad[2] else None)
 
 
 class HeadLossFn(torch.autograd.Function):

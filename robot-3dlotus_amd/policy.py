@@ -170,4 +170,20 @@ class SimplePolicyPTV3CA(BaseModel):
         return final
 
 
-MODEL_FACTORY = {"SimplePolicyPTV3CA": SimplePolicyPTV3CA}
+
+
+def _factory():
+    from .motion_planner import MotionPlannerPTV3CA
+    return {"SimplePolicyPTV3CA": SimplePolicyPTV3CA, "MotionPlannerPTV3CA": MotionPlannerPTV3CA}
+
+
+class _Factory(dict):
+    """name -> class table of genrobo3d/train/train_simple_policy.py:46-50 / train_motion_planner.py (lazy: the
+    motion planner imports this module)."""
+
+    def __missing__(self, k):
+        self.update(_factory())
+        return dict.__getitem__(self, k)
+
+
+MODEL_FACTORY = _Factory({"SimplePolicyPTV3CA": SimplePolicyPTV3CA})

@@ -1,0 +1,130 @@
+"""GPU parity of the motion-planner drop-in (BASELINE configs[3], 3D-LOTUS++) against the fixtures captured from the
+imported MotionPlannerPTV3CA and against the oracle run live.  Same tolerance rule as test_gpu_model.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+
+LOGIT_TOL = 1e-4
+
+
+def _build(cfg, sd, train):
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd.policy import MODEL_FACTORY
+
+    m = MODEL_FACTORY["MotionPlannerPTV3CA"](cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    m.train(train)
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0      # fixtures are dropout-free
+    m.act_proj_head.dropout = 0.0
+    return m
+
+
+def _dev_batch(batch):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else
+                ([t.cuda() for t in v] if k == "gt_trajs_disc_pos_probs" else v)) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("case", gu.MP_CASES)
+def test_mp_golden_fixture_parity(case):
+    fx, cfg, batch, sd = gu.load_case_mp(case)
+    train = bool(fx["meta_train"])
+    m = _build(cfg, sd, train)
+    m.ptv3_model.order_perms = [p.tolist() for p in fx["perms"]]
+    _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False, decode_actions=True)
+    _, xr, xo, xs = m.last_pred
+    for name, got in (("xt", m.pred_pos()), ("xr", xr), ("xo", xo), ("xstop", xs)):
+        ref = fx[name]
+        tol = LOGIT_TOL * max(1.0, float(np.abs(ref).max()))
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        assert err <= tol, f"{case} {name}: max |diff| {err:.3e} > {tol:.3e}"
+    assert set(losses) == {"pos", "rot", "open", "stop", "total"}
+    for k in losses:
+        ref = float(fx["loss_" + k])
+        assert abs(losses[k].item() - ref) <= 1e-4 * max(1.0, abs(ref)), (k, losses[k].item(), ref)
+    losses["total"].backward()
+    gmax = max(float(fx[k]) for k in fx if k.startswith("gnorm/"))
+    nograd = set(fx["nograd"].tolist())
+    worst = (0.0, None)
+    for name, p in m.named_parameters():
+        if name in nograd:                       # txt_attn_fc: the reference leaves it without gradient too
+            assert p.grad is None, name
+            continue
+        assert p.grad is not None, f"no gradient for {name}"
+        ref = float(fx["gnorm/" + name])
+        got = p.grad.double().norm().item()
+        worst = max(worst, (abs(got - ref) / (ref + 1e-3 * gmax), name))
+        head = fx["ghead/" + name]
+        np.testing.assert_allclose(p.grad.flatten()[:48].cpu().numpy(), head,
+                                   atol=2e-3 * float(np.abs(head).max()) + 2e-5 * gmax, rtol=0, err_msg=name)
+    assert worst[0] < 2e-3, f"gradient norm mismatch {worst}"
+    if train:
+        sdn = m.state_dict()
+        for k in fx:
+            if k.startswith("buf/"):
+                np.testing.assert_allclose(sdn[k[4:]].cpu().numpy(), fx[k], atol=2e-3, rtol=2e-3, err_msg=k)
+
+
+def test_mp_live_oracle_parity_decode_and_determinism():
+    """Fresh seeded inputs: HIP motion planner vs the oracle on the host (logits, losses), the decoded trajectory
+    against the oracle's get_best_pos_from_disc_pos restatement, and a bit-identical repeat."""
+    from oracle.labels import best_pos_max
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("mp_tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 41, "scaled")
+    batch = synth.synth_batch_mp(3, 640, ragged=True, seed=77)
+    perms = [[2, 0, 3, 1], [1, 3, 0, 2]]
+    with torch.no_grad():
+        ref = Oracle(sd, lcfg.plain(cfg), training=False).forward_mp(batch, perms)
+    m = _build(cfg, sd, False)
+    m.ptv3_model.order_perms = perms
+    with torch.no_grad():
+        final, losses = m(_dev_batch(batch), compute_loss=True)
+    for name, got in (("xt", m.pred_pos()), ("xr", m.last_pred[1]), ("xo", m.last_pred[2]), ("xstop", m.last_pred[3])):
+        r = ref[name].numpy()
+        assert float(np.abs(got.cpu().numpy() - r).max()) <= LOGIT_TOL * max(1.0, float(np.abs(r).max())), name
+    for k, v in ref["losses"].items():
+        assert abs(losses[k].item() - v.item()) <= 1e-4 * max(1.0, abs(v.item())), k
+    B, T = 3, cfg.action_config.max_traj_len
+    assert final.shape == (B, T, 3 + 4 + 2)
+    # decode: arg-max bin per axis of the HIP logits, through the oracle's restatement (float64 -> .float())
+    xt = m.pred_pos().cpu()
+    counts = batch["npoints_in_batch"]
+    pcs = torch.split(batch["pc_fts"], counts)
+    for b, lg in enumerate(torch.split(xt, counts, dim=2)):
+        for t in range(T):
+            prob = torch.softmax(lg[t].reshape(3, -1), -1).numpy()
+            want = best_pos_max(prob, pcs[b][:, :3].numpy(), cfg.action_config.pos_bin_size, cfg.action_config.pos_bins)
+            np.testing.assert_array_equal(final[b, t, :3].cpu().numpy(), want.astype(np.float32))
+    with torch.no_grad():
+        final2, losses2 = m(_dev_batch(batch), compute_loss=True)
+    assert torch.equal(final, final2) and all(torch.equal(losses[k], losses2[k]) for k in losses)
+
+
+def test_mp_train_step_is_deterministic():
+    """Two identical training steps from the same state give bit-identical gradients (no atomics on the gradient path:
+    the label-embedding gradient is a GEMM reduction)."""
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("mp_tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 43, "scaled")
+    batch = _dev_batch(synth.synth_batch_mp(2, 512, ragged=True, seed=78))
+    grads = []
+    for _ in range(2):
+        m = _build(cfg, sd, True)
+        m.ptv3_model.order_perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
+        _, losses = m(dict(batch), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        torch.cuda.synchronize()
+        grads.append({n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
