@@ -35,6 +35,8 @@ def dev_batch(batch, dev):
             out[k] = v.to(dev)
         elif k == "disc_pos_probs":
             out[k] = torch.cat([t.reshape(-1) for t in v]).to(dev)  # packed once, stays in HBM
+        elif k == "gt_trajs_disc_pos_probs":
+            out[k] = torch.cat([t.reshape(t.shape[0], -1) for t in v], 1).to(dev)  # [T, sum 3*n*nb]
         else:
             out[k] = v
     return out
@@ -128,6 +130,9 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run lr schedule + clip_grad_norm_(10) + fused AdamW inside every step (SURVEY 8f rank 1); "
                          "the headline metric of BASELINE.json is forward + backward only, so this is off by default")
+    ap.add_argument("--workload", choices=["policy", "mp"], default="policy",
+                    help="policy = 3D-LOTUS v1 (BASELINE configs[1], the headline metric); mp = the 3D-LOTUS++ motion "
+                         "planner (configs[3]) — a side measurement, same step structure")
     ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -145,12 +150,17 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
-    model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
+    mp = args.workload == "mp"
+    if mp:
+        from robot_3dlotus_amd.motion_planner import MotionPlannerPTV3CA
+        model = MotionPlannerPTV3CA(lcfg.preset("mp")).to(dev).train()
+    else:
+        model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
     reducer = None
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1":  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=64.0)
         parallel.enable_sync_batchnorm()
-    batch = dev_batch(synth.synth_batch(args.batch, args.npoints, seed=rank), dev)
+    batch = dev_batch((synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank), dev)
 
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
@@ -172,7 +182,8 @@ def main():
             for p in params:  # model.zero_grad(set_to_none=True) without the module-tree walk (2 ms of host time)
                 p.grad = None
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
-        model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
+        if not mp:
+            model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
         losses["total"].backward()
         if reducer is not None:
             reducer.finish()
@@ -222,6 +233,11 @@ def main():
                        "model_gflop_per_sample": GFLOP_PER_SAMPLE,
                        "model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 2)},
         }
+        if mp:
+            out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS++ motion planner"
+            out["config"]["workload"] = (f"3D-LOTUS++ motion planner (68.68M params, 5-step trajectory head), {args.batch} "
+                                         f"clouds x {args.npoints} pts per GPU, fwd+loss+bwd, train mode, fp32 exact")
+            out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
         if opt is not None:
             out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
         if not args.no_roofline:

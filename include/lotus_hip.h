@@ -33,6 +33,14 @@ extern "C" {
 const char* lotus_last_error(void);
 int lotus_abi_version(void);
 
+/* ---- stream link: order `to_stream` after everything enqueued on `from_stream` so far (event record + stream
+ * wait from a caller-owned ring of timing-less events; no host synchronisation).  The Python host uses it to fork the
+ * weight-gradient stream from / join it to the stream autograd runs on — what `side.wait_stream(main)` does in
+ * torch, at ~2 us instead of ~15 us per fork.  create returns an opaque handle (0 on failure). */
+unsigned long long lotus_streamlink_create(int nevents);
+int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_stream);
+int lotus_streamlink_destroy(unsigned long long link);
+
 /* ---- front end (integer, bit-exact) ------------------------------------------------------- */
 /* Point.serialization grid step, PointTransformerV3/model.py:96-98: grid = int32(trunc((coord -
  * coord.min(0)) / grid_size)) with an IEEE fp32 divide; gmax = max grid coordinate.  coord rows have

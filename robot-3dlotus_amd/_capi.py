@@ -96,20 +96,74 @@ def stream_ptr():
     """hipStream_t of torch's current stream (the raw-handle query is ~20x cheaper than building a
     torch.cuda.Stream object, and this runs once per kernel launch)."""
     if _raw_stream is not None:
-        return _raw_stream(_cur_dev())
+        return _raw_stream(_get_dev() if _get_dev is not None else _cur_dev())
     return torch.cuda.current_stream().cuda_stream
+
+
+def _load_fastcall():
+    """csrc/_lotus_fastcall.so: generated METH_FASTCALL trampolines to the same entry points (csrc/gen_fastcall.py).
+    ~1 us per call instead of ~10 us through ctypes; optional — ctypes is the fallback binding."""
+    path = os.path.join(_HERE, "csrc", "_lotus_fastcall.so")
+    if os.environ.get("LOTUS_NO_FASTCALL") == "1" or not os.path.exists(path):
+        return None
+    lib()  # liblotus_hip.so first (the module links it by $ORIGIN rpath)
+    import importlib.machinery
+    import importlib.util
+    loader = importlib.machinery.ExtensionFileLoader("_lotus_fastcall", path)
+    spec = importlib.util.spec_from_loader("_lotus_fastcall", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    missing = [n for n in lib().protos if not hasattr(mod, n)]
+    if missing:  # header changed after the module was built
+        raise LotusError(f"_lotus_fastcall.so is stale (missing {missing[:3]}...): rerun robot-3dlotus_amd/csrc/build.py")
+    return mod
+
+
+_FAST = None
+_FAST_TRIED = False
+_get_dev = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def fastcall():
+    global _FAST, _FAST_TRIED
+    if not _FAST_TRIED:
+        _FAST = _load_fastcall()
+        _FAST_TRIED = True
+    return _FAST
+
+
+# When non-zero, every call() enqueues on this hipStream_t instead of torch's current stream (ops._OnSide: the
+# weight-gradient stream).  Cheaper than switching torch's current stream, which nothing inside those blocks needs.
+STREAM_OVERRIDE = 0
 
 
 def call(name, *args):
     """Call an int-returning entry point; tensors -> device pointers; appends the current stream."""
+    F = _FAST if _FAST_TRIED else fastcall()
+    if F is not None:
+        rc = getattr(F, name)(*args, STREAM_OVERRIDE or _raw_stream(_get_dev()))
+        if rc != 0:
+            raise LotusError(f"{name} failed ({rc}): {F.lotus_last_error()}")
+        return
     L = _LIB or lib()
-    rc = L.fn[name](*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], stream_ptr())
+    rc = L.fn[name](*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args], STREAM_OVERRIDE or stream_ptr())
     if rc != 0:
         raise LotusError(f"{name} failed ({rc}): {L.last_error()}")
 
 
+def call_raw(name, *args):
+    """Entry points without a trailing stream parameter (stream link)."""
+    F = _FAST if _FAST_TRIED else fastcall()
+    rc = getattr(F, name)(*args) if F is not None else lib().fn[name](*args)
+    if rc != 0:
+        raise LotusError(f"{name} failed ({rc}): {lib().last_error()}")
+
+
 def query(name, *args):
     """Call a size_t-returning *_workspace() function."""
+    F = _FAST if _FAST_TRIED else fastcall()
+    if F is not None:
+        return getattr(F, name)(*args)
     return lib().fn[name](*args)
 
 

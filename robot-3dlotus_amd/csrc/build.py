@@ -50,7 +50,28 @@ def build(force=False):
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
+    build_fastcall()
     return LIB
+
+
+def build_fastcall():
+    """CPython trampolines (generated from include/lotus_hip.h) -> csrc/_lotus_fastcall.so, linked against the C-ABI
+    library next to it.  Host-side only: plain gcc."""
+    import sysconfig
+
+    sys.path.insert(0, HERE)
+    import gen_fastcall
+
+    src, _ = gen_fastcall.generate()
+    out = os.path.join(HERE, "_lotus_fastcall.so")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "lotus_hip.h")
+    if _stale(out, [src, hdr, LIB]):
+        cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], src, "-o", out,
+               "-L" + HERE, "-llotus_hip", "-Wl,-rpath,$ORIGIN"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("fastcall module failed to build:\n" + r.stderr)
+    return out
 
 
 if __name__ == "__main__":

@@ -580,7 +580,10 @@ static int wgrad_splits(int M, int N, int K) {
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
   if (tiles >= 128 && M < 1024) return 1;  // deep levels: the second (reduce) launch costs more than it hides
   // both operands are streamed exactly once: keep ~4 blocks per CU in flight (Little's law), >= 128 rows each
-  while (nz < 256 && tiles * nz < 1024 && M / (nz * 2) >= 128) nz *= 2;
+  static int target = 0, minrows = 0;
+  if (!target) { target = tune_env("LOTUS_WGRAD_BLOCKS"); if (target <= 0) target = 1024; }
+  if (!minrows) { minrows = tune_env("LOTUS_WGRAD_MINROWS"); if (minrows <= 0) minrows = 128; }
+  while (nz < 256 && tiles * nz < target && M / (nz * 2) >= minrows) nz *= 2;
   return nz;
 }
 

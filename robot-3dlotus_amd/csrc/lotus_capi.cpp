@@ -1,6 +1,9 @@
 // lotus-hip: C-ABI plumbing shared by every op family (error string, version).
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -14,4 +17,55 @@ void lotus_set_error(const char* fmt, ...) {
 extern "C" {
 const char* lotus_last_error(void) { return g_err; }
 int lotus_abi_version(void) { return 1; }
+
+// Stream link: a caller-owned ring of timing-less events used to order one stream after another without a host
+// round trip ("to" waits for everything enqueued on "from" so far).  Re-recording a ring event later is safe:
+// hipStreamWaitEvent captures the event's state at the time of the call.
+struct StreamLink {
+  int n, next;
+  hipEvent_t ev[1];
+};
+unsigned long long lotus_streamlink_create(int nevents) {
+  if (nevents < 1 || nevents > 4096) {
+    lotus_set_error("lotus_streamlink_create: nevents out of range");
+    return 0;
+  }
+  StreamLink* l = (StreamLink*)malloc(sizeof(StreamLink) + sizeof(hipEvent_t) * (nevents - 1));
+  if (!l) return 0;
+  l->n = nevents;
+  l->next = 0;
+  for (int i = 0; i < nevents; ++i) {
+    hipError_t e = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming);
+    if (e != hipSuccess) {
+      lotus_set_error("lotus_streamlink_create: %s", hipGetErrorString(e));
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(l->ev[j]);
+      free(l);
+      return 0;
+    }
+  }
+  return (unsigned long long)(uintptr_t)l;
+}
+int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_stream) {
+  StreamLink* l = (StreamLink*)(uintptr_t)link;
+  if (!l) {
+    lotus_set_error("lotus_streamlink_wait: null link");
+    return -1;
+  }
+  hipEvent_t ev = l->ev[l->next];
+  l->next = (l->next + 1) % l->n;
+  hipError_t e = hipEventRecord(ev, (hipStream_t)from_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)to_stream, ev, 0);
+  if (e != hipSuccess) {
+    lotus_set_error("lotus_streamlink_wait: %s", hipGetErrorString(e));
+    return -2; /* LOTUS_E_LAUNCH */
+  }
+  return 0;
+}
+int lotus_streamlink_destroy(unsigned long long link) {
+  StreamLink* l = (StreamLink*)(uintptr_t)link;
+  if (!l) return 0;
+  for (int i = 0; i < l->n; ++i) (void)hipEventDestroy(l->ev[i]);
+  free(l);
+  return 0;
+}
 }

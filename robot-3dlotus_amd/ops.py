@@ -15,6 +15,7 @@ import os
 
 import torch
 
+from . import _capi
 from ._capi import call, query, WS
 
 ACT_NONE, ACT_GELU, ACT_LEAKY = 0, 1, 2
@@ -60,43 +61,64 @@ def enable_side_stream(on=True):
 _IN_NODE = 0  # > 0 while a `_joined` backward is running: only then is the join guaranteed
 
 
+_SIDE_PTR = 0   # hipStream_t of SIDE
+_LINK = 0       # lotus_streamlink handle (event ring) used for every fork / join
+
+
 def _side():
-    global SIDE
+    global SIDE, _SIDE_PTR, _LINK
     if not _SIDE_ON or _IN_NODE == 0:
         return None
     if SIDE is None:
         SIDE = torch.cuda.Stream()
+        _SIDE_PTR = SIDE.cuda_stream
+        if not _LINK:
+            _LINK = query("lotus_streamlink_create", 256)
+            if not _LINK:
+                raise _capi.LotusError("lotus_streamlink_create failed: " + _capi.lib().last_error())
     return SIDE
 
 
 def sync_side_stream():
+    """The current stream waits for everything enqueued on the weight-gradient stream."""
     if SIDE is not None:
-        torch.cuda.current_stream().wait_stream(SIDE)
+        _capi.call_raw("lotus_streamlink_wait", _LINK, _SIDE_PTR, _capi.stream_ptr())
+
+
+def _side_ws(nbytes, dev):
+    """Workspace of the side-stream producers; (re)allocated under the side stream so the caching allocator orders
+    its reuse after the side stream's work."""
+    b = WS.buf.get((dev, 3))
+    if b is None or b.numel() < nbytes:
+        with torch.cuda.stream(SIDE):
+            b = WS.get(nbytes, dev, slot=3)
+    return b
 
 
 class _OnSide:
     """Run a weight-gradient producer on the side stream after the main stream's pending work.  Outputs are
     allocated by the caller on the main stream (they stay alive until after the join); `reads` are the tensors
-    the side-stream kernels consume."""
+    the side-stream kernels consume.  Inside the block every ops.call() enqueues on the side stream
+    (_capi.STREAM_OVERRIDE); torch's current stream is left alone — nothing in these blocks launches ATen kernels —
+    and the fork is one event record + stream wait through the C-ABI stream link."""
 
     def __init__(self, *reads):
         self.reads = reads
 
     def __enter__(self):
-        self.side = _side()
-        if self.side is None:
+        side = self.side = _side()
+        if side is None:
             return self
-        self.side.wait_stream(torch.cuda.current_stream())
+        _capi.call_raw("lotus_streamlink_wait", _LINK, _capi.stream_ptr(), _SIDE_PTR)
         if _JOIN == "end":  # no join at the end of the node: the allocator must know about the second reader
             for t in self.reads:
-                t.record_stream(self.side)
-        self.ctx = torch.cuda.stream(self.side)
-        self.ctx.__enter__()
+                t.record_stream(side)
+        _capi.STREAM_OVERRIDE = _SIDE_PTR
         return self
 
     def __exit__(self, *a):
         if self.side is not None:
-            self.ctx.__exit__(*a)
+            _capi.STREAM_OVERRIDE = 0
 
 
 def _end_of_backward():
@@ -167,7 +189,7 @@ def linear_wgrad(dy, x, need_bias=True):
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
     with _OnSide(dy, x):
-        ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
+        ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
     return dw, db
 
@@ -247,7 +269,7 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
     with _OnSide(dy, x, nbr):
-        ws = WS.get(nbytes, dy.device, slot=3 if _side() is not None else 0)
+        ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
     return dw, db
 
