@@ -56,47 +56,58 @@ def enable_side_stream(on=True):
     if not on:
         sync_side_stream()
         SIDE = None
+        _SIDES.clear()
 
 
 _IN_NODE = 0  # > 0 while a `_joined` backward is running: only then is the join guaranteed
 
 
-_SIDE_PTR = 0   # hipStream_t of SIDE
+_NSIDE = max(1, int(os.environ.get("LOTUS_SIDE_STREAMS", "1")))
+_SIDES = []     # [(torch.cuda.Stream, hipStream_t)]: weight-gradient producers go round-robin over these
+_RR = 0         # next side stream
+_CUR = 0        # side stream of the _OnSide block being executed
 _LINK = 0       # lotus_streamlink handle (event ring) used for every fork / join
 
 
 def _side():
-    global SIDE, _SIDE_PTR, _LINK
+    global SIDE, _LINK
     if not _SIDE_ON or _IN_NODE == 0:
         return None
     if SIDE is None:
-        SIDE = torch.cuda.Stream()
-        _SIDE_PTR = SIDE.cuda_stream
+        # measured: more than one side stream (766 vs 796 samples/s) and CU-masked side streams (<= 796) only add
+        # contention with the critical path; LOTUS_SIDE_STREAMS stays as a tuning knob
+        for _ in range(_NSIDE):
+            st = torch.cuda.Stream()
+            _SIDES.append((st, st.cuda_stream))
         if not _LINK:
             _LINK = query("lotus_streamlink_create", 256)
             if not _LINK:
                 raise _capi.LotusError("lotus_streamlink_create failed: " + _capi.lib().last_error())
+        SIDE = _SIDES[0][0]
     return SIDE
 
 
 def sync_side_stream():
-    """The current stream waits for everything enqueued on the weight-gradient stream."""
+    """The current stream waits for everything enqueued on the weight-gradient stream(s)."""
     if SIDE is not None:
-        _capi.call_raw("lotus_streamlink_wait", _LINK, _SIDE_PTR, _capi.stream_ptr())
+        cur = _capi.stream_ptr()
+        for _, ptr in _SIDES:
+            _capi.call_raw("lotus_streamlink_wait", _LINK, ptr, cur)
 
 
 def _side_ws(nbytes, dev):
-    """Workspace of the side-stream producers; (re)allocated under the side stream so the caching allocator orders
-    its reuse after the side stream's work."""
-    b = WS.buf.get((dev, 3))
+    """Workspace of the side-stream producer being enqueued (one per side stream); (re)allocated under that stream
+    so the caching allocator orders its reuse after the stream's work."""
+    slot = 16 + _CUR
+    b = WS.buf.get((dev, slot))
     if b is None or b.numel() < nbytes:
-        with torch.cuda.stream(SIDE):
-            b = WS.get(nbytes, dev, slot=3)
+        with torch.cuda.stream(_SIDES[_CUR][0]):
+            b = WS.get(nbytes, dev, slot=slot)
     return b
 
 
 class _OnSide:
-    """Run a weight-gradient producer on the side stream after the main stream's pending work.  Outputs are
+    """Run a weight-gradient producer on a side stream after the main stream's pending work.  Outputs are
     allocated by the caller on the main stream (they stay alive until after the join); `reads` are the tensors
     the side-stream kernels consume.  Inside the block every ops.call() enqueues on the side stream
     (_capi.STREAM_OVERRIDE); torch's current stream is left alone — nothing in these blocks launches ATen kernels —
@@ -106,18 +117,22 @@ class _OnSide:
         self.reads = reads
 
     def __enter__(self):
-        side = self.side = _side()
-        if side is None:
+        global _RR, _CUR
+        self.on = _side() is not None
+        if not self.on:
             return self
-        _capi.call_raw("lotus_streamlink_wait", _LINK, _capi.stream_ptr(), _SIDE_PTR)
+        _CUR = _RR
+        _RR = (_RR + 1) % _NSIDE
+        side, ptr = _SIDES[_CUR]
+        _capi.call_raw("lotus_streamlink_wait", _LINK, _capi.stream_ptr(), ptr)
         if _JOIN == "end":  # no join at the end of the node: the allocator must know about the second reader
             for t in self.reads:
                 t.record_stream(side)
-        _capi.STREAM_OVERRIDE = _SIDE_PTR
+        _capi.STREAM_OVERRIDE = ptr
         return self
 
     def __exit__(self, *a):
-        if self.side is not None:
+        if self.on:
             _capi.STREAM_OVERRIDE = 0
 
 
