@@ -133,6 +133,9 @@ def main():
     ap.add_argument("--workload", choices=["policy", "mp"], default="policy",
                     help="policy = 3D-LOTUS v1 (BASELINE configs[1], the headline metric); mp = the 3D-LOTUS++ motion "
                          "planner (configs[3]) — a side measurement, same step structure")
+    ap.add_argument("--gemm-precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                    help="operand precision of the dense fwd/dgrad products: fp32 = exact fp32 MFMA (default, the parity mode "
+                         "the headline is quoted in); bf16x3 / bf16 are the opt-in faster modes (DESIGN.md 4)")
     ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -174,6 +177,7 @@ def main():
     # gradients are dropped (set to None) before every step and nothing reads them during backward except the
     # reducer's bucket flush (which joins the weight-gradient stream itself): one join per backward pass
     ops.set_wgrad_join("end")
+    ops.set_gemm_precision(args.gemm_precision)
 
     def step():
         if reducer is not None:
@@ -238,6 +242,9 @@ def main():
             out["config"]["workload"] = (f"3D-LOTUS++ motion planner (68.68M params, 5-step trajectory head), {args.batch} "
                                          f"clouds x {args.npoints} pts per GPU, fwd+loss+bwd, train mode, fp32 exact")
             out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
+        if args.gemm_precision != "fp32":
+            out["config"]["workload"] += f"; dense fwd/dgrad products in {args.gemm_precision} (opt-in, NOT the headline mode)"
+            out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM operands"
         if opt is not None:
             out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
         if not args.no_roofline:

@@ -41,6 +41,12 @@ unsigned long long lotus_streamlink_create(int nevents);
 int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_stream);
 int lotus_streamlink_destroy(unsigned long long link);
 
+/* ---- operand precision of the dense forward / input-gradient products (process-wide knob, also LOTUS_GEMM_PREC):
+ * 0 = fp32 MFMA, exact products (default; the 1e-4 logit parity mode); 1 = bf16 operands, fp32 accumulate (the bf16
+ * compute mode of BASELINE configs[4]); 3 = bf16x3 split products (a = hi + lo; hi*hi + hi*lo + lo*hi). */
+int lotus_set_gemm_precision(int precision);
+int lotus_get_gemm_precision(void);
+
 /* ---- front end (integer, bit-exact) ------------------------------------------------------- */
 /* Point.serialization grid step, PointTransformerV3/model.py:96-98: grid = int32(trunc((coord -
  * coord.min(0)) / grid_size)) with an IEEE fp32 divide; gmax = max grid coordinate.  coord rows have

@@ -94,17 +94,81 @@ __device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const fl
   }
 }
 
+// ---- bf16 operand path (PREC 1: plain bf16 operands, fp32 accumulate — the bf16 compute mode of BASELINE configs[4];
+// PREC 3: "bf16x3" split, a = hi + lo with hi = bf16(a), lo = bf16(a - hi), products hi*hi + hi*lo + lo*hi accumulated
+// in fp32: ~2^-17 relative error per product at 3/16 of the fp32-MFMA issue time).  v_mfma_f32_32x32x16_bf16: lane
+// l holds 8 consecutive k (k = 8 * (l >> 5) + 0..7) of row / column l & 31; C/D layout as the fp32 32x32 form.
+// LDS images are k-contiguous bf16 rows for BOTH global layouts: [R][BK] bf16, row stride BK * 2 + 16 bytes (the 16
+// lanes of a ds_read_b128 group land on distinct 16-byte slots), PREC 3 keeps a second plane with the lo parts.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+
+template <int R, int BK, int PREC>
+struct BTile {
+  static constexpr int kLdW = BK / 2 + 4;   // row stride in 32-bit words
+  static constexpr int kPlaneW = R * kLdW;  // words per plane
+  static constexpr int kWords = (PREC == 3 ? 2 : 1) * kPlaneW;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// (hi, lo) words of the value pair (a, b); lo = bf16(x - float(hi))
+__device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
+template <int BM, int BN, int BK, int PREC>
+__device__ __forceinline__ void gemm_slab_bf16(const unsigned* __restrict__ Aw, const unsigned* __restrict__ Bw, int wr0,
+                                               int wc0, f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using TA = BTile<BM, BK, PREC>;
+  using TB = BTile<BN, BK, PREC>;
+  const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const unsigned* q = Aw + (wr0 + tm * 32 + l31) * TA::kLdW + ks * 8 + h * 4;
+      ah[tm] = *reinterpret_cast<const uint4*>(q);
+      if (PREC == 3) al[tm] = *reinterpret_cast<const uint4*>(q + TA::kPlaneW);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const unsigned* q = Bw + (wc0 + tn * 32 + l31) * TB::kLdW + ks * 8 + h * 4;
+      bh[tn] = *reinterpret_cast<const uint4*>(q);
+      if (PREC == 3) bl[tn] = *reinterpret_cast<const uint4*>(q + TB::kPlaneW);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (PREC == 3) {  // small terms first
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tm]), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn], 0, 0, 0);
+        }
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
+      }
+  }
+}
+
 // value-wise select (a pointer select between the loaded vector and a zero constant goes through scratch)
 __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, int PREC = 0>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
-  constexpr int AF = GTile<BM, A_KC, BK>::kFloats, BF = GTile<BN, B_KC, BK>::kFloats;
+  static_assert(PREC == 0 || (!SUM_A && BK % 16 == 0 && (A_KC || A4 % 2 == 0) && (B_KC || B4 % 2 == 0)),
+                "bf16 path: no bias-gradient sums; operands contiguous along their non-reduction index are staged as k pairs");
+  constexpr int AF = PREC ? BTile<BM, BK, PREC>::kWords : GTile<BM, A_KC, BK>::kFloats;
+  constexpr int BF = PREC ? BTile<BN, BK, PREC>::kWords : GTile<BN, B_KC, BK>::kFloats;
   constexpr int WN = BN / 2, SLD = WN + 4;  // epilogue staging: per wave [32][WN + 4]
   constexpr int LDSF = (2 * AF + 2 * BF) > (4 * 32 * SLD) ? (2 * AF + 2 * BF) : (4 * 32 * SLD);
   __shared__ __attribute__((aligned(16))) float smem[LDSF];
@@ -155,7 +219,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
         }
       } else {
-        const int kr = f / (BM / 4), iq = f % (BM / 4);
+        const int f2 = PREC ? tid + (t >> 1) * 256 : f;  // bf16 path: registers 2p, 2p+1 hold k, k+1 of one row quad
+        const int kr = PREC ? (f2 / (BM / 4)) * 2 + (t & 1) : f / (BM / 4), iq = f2 % (BM / 4);
         if (FAST) {
           const int k = k0 + kr;
           const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
@@ -178,7 +243,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
         }
       } else {
-        const int kr = f / (BN / 4), jq = f % (BN / 4);
+        const int f2 = PREC ? tid + (t >> 1) * 256 : f;
+        const int kr = PREC ? (f2 / (BN / 4)) * 2 + (t & 1) : f / (BN / 4), jq = f2 % (BN / 4);
         if (FAST) {
           const int k = k0 + kr;
           const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
@@ -190,6 +256,61 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   };
   auto lstore = [&](float* Ad, float* Bd) {
+    if (PREC) {  // convert (and split) while staging: bf16 rows, k-contiguous for both layouts
+      unsigned* Aw = reinterpret_cast<unsigned*>(Ad);
+      unsigned* Bw = reinterpret_cast<unsigned*>(Bd);
+      using TA = BTile<BM, BK, PREC ? PREC : 1>;
+      using TB = BTile<BN, BK, PREC ? PREC : 1>;
+      if (A_KC) {
+#pragma unroll
+        for (int t = 0; t < A4; ++t) {
+          const int f = tid + t * 256, row = f / (BK / 4), kq = f % (BK / 4);
+          unsigned h0, l0, h1, l1;
+          split_bf16(ra[t].x, ra[t].y, h0, l0);
+          split_bf16(ra[t].z, ra[t].w, h1, l1);
+          *reinterpret_cast<uint2*>(&Aw[row * TA::kLdW + kq * 2]) = make_uint2(h0, h1);
+          if (PREC == 3) *reinterpret_cast<uint2*>(&Aw[TA::kPlaneW + row * TA::kLdW + kq * 2]) = make_uint2(l0, l1);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t + 1 < A4; t += 2) {
+          const int f2 = tid + (t >> 1) * 256, kr2 = f2 / (BM / 4), iq = f2 % (BM / 4);
+          const float va[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w}, vb[4] = {ra[t + 1].x, ra[t + 1].y, ra[t + 1].z, ra[t + 1].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned hw, lw;
+            split_bf16(va[e], vb[e], hw, lw);
+            Aw[(iq * 4 + e) * TA::kLdW + kr2] = hw;
+            if (PREC == 3) Aw[TA::kPlaneW + (iq * 4 + e) * TA::kLdW + kr2] = lw;
+          }
+        }
+      }
+      if (B_KC) {
+#pragma unroll
+        for (int t = 0; t < B4; ++t) {
+          const int f = tid + t * 256, row = f / (BK / 4), kq = f % (BK / 4);
+          unsigned h0, l0, h1, l1;
+          split_bf16(rb[t].x, rb[t].y, h0, l0);
+          split_bf16(rb[t].z, rb[t].w, h1, l1);
+          *reinterpret_cast<uint2*>(&Bw[row * TB::kLdW + kq * 2]) = make_uint2(h0, h1);
+          if (PREC == 3) *reinterpret_cast<uint2*>(&Bw[TB::kPlaneW + row * TB::kLdW + kq * 2]) = make_uint2(l0, l1);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t + 1 < B4; t += 2) {
+          const int f2 = tid + (t >> 1) * 256, kr2 = f2 / (BN / 4), jq = f2 % (BN / 4);
+          const float va[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w}, vb[4] = {rb[t + 1].x, rb[t + 1].y, rb[t + 1].z, rb[t + 1].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            unsigned hw, lw;
+            split_bf16(va[e], vb[e], hw, lw);
+            Bw[(jq * 4 + e) * TB::kLdW + kr2] = hw;
+            if (PREC == 3) Bw[TB::kPlaneW + (jq * 4 + e) * TB::kLdW + kr2] = lw;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
@@ -227,12 +348,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
       if (A_KC) pa[t] = p.A + (long)min(m0 + f / (BK / 4), p.M - 1) * p.lda + (f % (BK / 4)) * 4;
+      else if (PREC) pa[t] = p.A + (long)(((tid + (t >> 1) * 256) / (BM / 4)) * 2 + (t & 1)) * p.lda + min(m0 + ((tid + (t >> 1) * 256) % (BM / 4)) * 4, p.M - 4);
       else pa[t] = p.A + (long)(f / (BM / 4)) * p.lda + min(m0 + (f % (BM / 4)) * 4, p.M - 4);
     }
 #pragma unroll
     for (int t = 0; t < B4; ++t) {
       const int f = tid + t * 256;
       if (B_KC) pb[t] = p.B + (long)min(n0 + f / (BK / 4), p.N - 1) * p.ldb + (f % (BK / 4)) * 4;
+      else if (PREC) pb[t] = p.B + (long)(((tid + (t >> 1) * 256) / (BN / 4)) * 2 + (t & 1)) * p.ldb + min(n0 + ((tid + (t >> 1) * 256) % (BN / 4)) * 4, p.N - 4);
       else pb[t] = p.B + (long)(f / (BN / 4)) * p.ldb + min(n0 + (f % (BN / 4)) * 4, p.N - 4);
     }
   }
@@ -254,7 +377,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       else gload(k0 + BK);  // tail / past-the-end prefetch: clamped, zeroed, never consumed past kend
       __builtin_amdgcn_sched_barrier(0);
       // only the first column block reports the column sums of A (bias gradient): the others skip the VALU adds
-      if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      if (PREC) gemm_slab_bf16<BM, BN, BK, PREC ? PREC : 1>(reinterpret_cast<const unsigned*>(As + cur * AF), reinterpret_cast<const unsigned*>(Bs + cur * BF), wr0, wc0, acc);
+      else if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       else gemm_slab<BM, BN, BK, A_KC, B_KC, false>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
       __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
@@ -397,6 +521,7 @@ static int tune_env(const char* name) {
   const char* e = getenv(name);
   return e ? atoi(e) : 0;
 }
+static int g_prec = -1;  // LOTUS_GEMM_PREC / lotus_set_gemm_precision: 0 fp32 MFMA (exact, default), 1 bf16, 3 bf16x3 split
 static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 3: 64x64), LOTUS_GEMM_NZ, LOTUS_GEMM_BK
 #define GEMM_KALIGN 64  // split-K ranges are multiples of the largest slab depth
 
@@ -409,6 +534,22 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
   if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
   int tile = g_force_tile;
+  if (g_prec < 0) { g_prec = tune_env("LOTUS_GEMM_PREC"); if (g_prec != 1 && g_prec != 3) g_prec = 0; }
+  if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
+    // bf16 / bf16x3 operand path (forward and input-gradient products).  Weight gradients with a bias keep the fp32
+    // path: routing them here was measured at +0.3 % (bf16x3) / +3 % (bf16) of a step and costs gradient accuracy.
+    const bool big = tile == 1 || (tile == 0 && !small_n && blocks128 * nz >= 512);
+    dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
+    if (g_prec == 1) {
+      if (big) hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 1>), g128, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 1>), g64, block, 0, st, p);
+    } else {
+      if (big) hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 3>), g128, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 3>), g64, block, 0, st, p);
+    }
+    LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
+    return LOTUS_OK;
+  }
   // measured (tools/gemm_sweep.py): 128x128 tiles only pay with >= 4 blocks per CU; otherwise 64x64 tiles
   // (more blocks in flight) win, including the N <= 64 layers and every split-K weight gradient
   if (tile == 0) tile = (!small_n && !SUM_A && blocks128 * nz >= 1024) ? 1 : 3;
@@ -585,6 +726,18 @@ static int wgrad_splits(int M, int N, int K) {
   if (!minrows) { minrows = tune_env("LOTUS_WGRAD_MINROWS"); if (minrows <= 0) minrows = 128; }
   while (nz < 256 && tiles * nz < target && M / (nz * 2) >= minrows) nz *= 2;
   return nz;
+}
+
+// Process-wide operand precision of the forward / input-gradient GEMMs: 0 = fp32 MFMA (exact products, default),
+// 1 = bf16 operands (BASELINE configs[4] compute mode), 3 = bf16x3 split (fp32-class accuracy, ~2^-17 per product).
+int lotus_set_gemm_precision(int precision) {
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_set_gemm_precision: 0, 1 or 3");
+  g_prec = precision;
+  return LOTUS_OK;
+}
+int lotus_get_gemm_precision(void) {
+  if (g_prec < 0) { g_prec = tune_env("LOTUS_GEMM_PREC"); if (g_prec != 1 && g_prec != 3) g_prec = 0; }
+  return g_prec;
 }
 
 size_t lotus_linear_wgrad_workspace(int M, int N, int K) {

@@ -43,6 +43,22 @@ _JOIN = "node"
 _END_CB_PENDING = False
 
 
+_PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+
+
+def set_gemm_precision(mode):
+    """Operand precision of the dense forward / input-gradient products (process-wide): 'fp32' = fp32 MFMA, exact
+    products (default, the 1e-4 logit parity mode); 'bf16x3' = split-bf16 products hi*hi + hi*lo + lo*hi with fp32
+    accumulation (~2^-17 per product; measured max |dlogit| 1.4e-5, +7 % step throughput); 'bf16' = bf16 operands
+    (the bf16 compute mode of BASELINE configs[4], GEMMs only so far; +11 %).  Weight gradients stay fp32."""
+    _capi.call_raw("lotus_set_gemm_precision", _PRECISIONS[mode])
+
+
+def get_gemm_precision():
+    v = query("lotus_get_gemm_precision")
+    return {v_: k for k, v_ in _PRECISIONS.items()}[v]
+
+
 def set_wgrad_join(mode):
     global _JOIN
     assert mode in ("node", "end")

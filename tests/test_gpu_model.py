@@ -96,6 +96,37 @@ def test_live_oracle_parity_and_determinism():
     assert torch.equal(m2.last_pred[0], xt), "forward must be bit-reproducible"
 
 
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
+def test_gemm_precision_modes_against_golden(mode, tol):
+    """Opt-in operand precisions of the dense fwd/dgrad products (ops.set_gemm_precision).  'bf16x3' must still meet
+    the north-star bar (fp32 logits within 1e-4 of the fp32-ideal reference); 'bf16' is the bf16 compute mode of
+    BASELINE configs[4] (GEMMs only so far) and is held to a bf16-sized bound.  The default mode is restored."""
+    from robot_3dlotus_amd import config as lcfg, ops
+
+    fx, cfg, batch, sd = gu.load_case("v1_scaled_train", gu.state_template(lcfg.preset("v1")))
+    assert ops.get_gemm_precision() == "fp32"
+    ops.set_gemm_precision(mode)
+    try:
+        m = _build(cfg, sd, True)
+        m.ptv3_model.order_perms = [p.tolist() for p in fx["perms"]]
+        _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        xt, xr, xo = m.last_pred
+    finally:
+        ops.set_gemm_precision("fp32")
+    errs = {}
+    for name, got in (("xt", xt), ("xr", xr), ("xo", xo)):
+        ref = fx[name]
+        errs[name] = float(np.abs(got.detach().cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+        assert errs[name] <= tol, (mode, name, errs[name])
+    assert abs(losses["total"].item() - float(fx["loss_total"])) <= 10 * tol * abs(float(fx["loss_total"]))
+    gmax = max(float(fx[k]) for k in fx if k.startswith("gnorm/"))
+    worst = max(abs(p.grad.double().norm().item() - float(fx["gnorm/" + n])) / (float(fx["gnorm/" + n]) + 1e-3 * gmax)
+                for n, p in m.named_parameters())
+    assert worst < (2e-2 if mode == "bf16x3" else 0.5), (mode, worst)
+    print(f"{mode}: logit errors {errs}, worst gradient-norm deviation {worst:.2e}")
+
+
 def test_full_size_train_step_properties():
     """BASELINE configs[1] size (16 x 4096, v1): forward+backward runs, everything finite, every
     parameter receives a gradient, eval-mode API returns f64[B, 8] like the reference."""

@@ -61,6 +61,37 @@ def test_linear_dgrad_wgrad(M, N, K):
     assert torch.equal(dw, dw2), "wgrad must be deterministic"
 
 
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 64), (23894, 128, 512), (1000, 64, 192), (441, 3072, 768), (6077, 256, 1024)])
+def test_linear_bf16_operand_paths(prec, M, N, K):
+    """LOTUS_GEMM_PREC 1 (bf16 operands: products of bf16-rounded inputs are exact in fp32, so the result must match
+    the fp64 product of the ROUNDED operands to fp32-accumulation accuracy) and 3 (bf16x3 split: within 2^-16 of the
+    exact fp32-operand product, relative to sum |a||b|)."""
+    from robot_3dlotus_amd import _capi
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K + prec)
+    x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g)
+    _capi.call_raw("lotus_set_gemm_precision", prec)
+    try:
+        y, _ = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+        dx = ops.linear_dgrad(dy.cuda(), w.cuda())
+    finally:
+        _capi.call_raw("lotus_set_gemm_precision", 0)
+    if prec == 1:
+        xr, wr, dyr = (t.bfloat16().double() for t in (x, w, dy))
+        tol_k, tol_n = 4e-7 * K ** 0.5 + 1e-6, 4e-7 * N ** 0.5 + 1e-6
+    else:
+        xr, wr, dyr = x.double(), w.double(), dy.double()
+        tol_k = tol_n = 2.0 ** -16
+    ref_y, ref_dx = xr @ wr.t() + b.double(), dyr @ wr
+    sy = (x.abs().double() @ w.abs().double().t()).clamp_min(1.0)     # sum |a||b| scale of every output
+    sx = (dy.abs().double() @ w.abs().double()).clamp_min(1.0)
+    ey = ((y.cpu().double() - ref_y).abs() / sy).max().item()
+    ex = ((dx.cpu().double() - ref_dx).abs() / sx).max().item()
+    assert ey <= tol_k and ex <= tol_n, (prec, ey, ex)
+
+
 def test_linear_dropout_statistics_and_replay():
     ops = _ops()
     x = torch.ones(4096, 64).cuda()
