@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--gemm-precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="operand precision of the dense fwd/dgrad products: fp32 = exact fp32 MFMA (default, the parity mode "
                          "the headline is quoted in); bf16x3 / bf16 are the opt-in faster modes (DESIGN.md 4)")
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the bf16x3 / bf16 side measurement")
     ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -223,6 +224,29 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(losses["total"]).item()
 
+    # side measurement (after the timed region of the headline): the same step with the opt-in operand precisions of the
+    # dense and sparse-convolution products; reported next to the headline, never as `value`
+    other = {}
+    if args.gemm_precision == "fp32" and not mp and not args.no_other_modes:
+        for mode in ("bf16x3", "bf16"):
+            ops.set_gemm_precision(mode)
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            d2 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([d2], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                d2 = float(t.item())
+            other[mode] = round(args.batch * world * 20 / d2, 2)
+        ops.set_gemm_precision("fp32")
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -242,9 +266,13 @@ def main():
             out["config"]["workload"] = (f"3D-LOTUS++ motion planner (68.68M params, 5-step trajectory head), {args.batch} "
                                          f"clouds x {args.npoints} pts per GPU, fwd+loss+bwd, train mode, fp32 exact")
             out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
+        if other:
+            out["opt_in_modes"] = {"unit": "keystep-samples/s", **other,
+                                   "note": "same step with ops.set_gemm_precision(mode): dense fwd/dgrad + sparse-conv products as "
+                                           "bf16x3 split (max logit error 2e-5, inside the 1e-4 bar) / plain bf16; not the headline"}
         if args.gemm_precision != "fp32":
             out["config"]["workload"] += f"; dense fwd/dgrad products in {args.gemm_precision} (opt-in, NOT the headline mode)"
-            out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM operands"
+            out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM + conv operands"
         if opt is not None:
             out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
         if not args.no_roofline:

@@ -13,6 +13,7 @@
 // k = h*KC/2 + s, so every lane reads a contiguous run).
 #include "mma.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct ConvP2 {
   const float* x;    // [n][KD]
@@ -56,7 +57,22 @@ struct PairsCfg {
   }
 };
 
-template <int NCS>
+// bf16 helpers (PREC 1: bf16 operands; PREC 3: bf16x3 split, see gemm.hip)
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 cbf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 cbf16x2;
+__device__ __forceinline__ unsigned cpack_bf16(float a, float b) {
+  const cbf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void csplit_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = cpack_bf16(a, b);
+  lo = cpack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
+// PREC != 0: the row image keeps, per row and chunk, KC/2 words of bf16 hi pairs followed by KC/2 words of lo pairs
+// (same XLD as the fp32 image), the packed weights hold 8 words per (tap, 16-k block, k half, column): 4 hi + 4 lo;
+// a step issues KC/16 x (1 | 3) v_mfma_f32_32x32x16_bf16 instead of KC/2 fp32 MFMAs.
+template <int NCS, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   using Cfg = PairsCfg<NCS>;
   constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT, XLD = Cfg::XLD;
@@ -131,20 +147,33 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   stamp();  // 2 after compaction
 
   const int nkc = p.KD / KC;
-  float bst[3][KC / 2];
+  // operand fragment registers: fp32 keeps one float per k; the bf16 paths keep whole 4-word MFMA operands (hi, lo per
+  // 16-k block) so that no operand has to be re-assembled from scattered registers
+  using Frag = typename std::conditional<PREC != 0, float4, float>::type;
+  constexpr int NF = PREC ? KC / 8 : KC / 2;
+  Frag bst[3][NF];
   static_assert(2 * MAXT <= 64, "the group list must fit the lanes of one VGPR");
 
-  auto load_b = [&](float (&dst)[KC / 2], int t, int kc) {  // weight fragment of (tap, chunk): this lane's KC/2 consecutive k
+  auto load_b = [&](Frag (&dst)[NF], int t, int kc) {  // weight fragment of (tap, chunk): this lane's KC/2 consecutive k
     // k-quads (4 consecutive k) are the 16-byte unit: quad (kc * KC + hh * KC/2) / 4 + q of column j sits at float4
     // index quad * ND + j, so a wave instruction reads two contiguous 512-byte runs; 32-bit index from the uniform
     // base -> scalar-base global loads with one VALU op of address math each
     const int tw = p.mirror ? (p.T - 1 - t) : t;
     const float4* wp4 = reinterpret_cast<const float4*>(p.w);
-    const unsigned base = (unsigned)((tw * (p.KD / 4) + (kc * KC + hh * (KC / 2)) / 4) * p.ND + n0 + cs * 32 + l31);
+    if constexpr (PREC != 0) {  // per 16-k block: [hi x4 | lo x4] words of (k half hh, column j) -> float4 index 2 * (...)
 #pragma unroll
-    for (int q = 0; q < KC / 8; ++q) {
-      const float4 v = wp4[base + (unsigned)(q * p.ND)];
-      dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      for (int q2 = 0; q2 < KC / 16; ++q2) {
+        const unsigned base = (unsigned)((((tw * (p.KD / 16) + kc * (KC / 16) + q2) * 2 + hh) * p.ND + n0 + cs * 32 + l31) * 2);
+        dst[2 * q2] = wp4[base];
+        if (PREC == 3) dst[2 * q2 + 1] = wp4[base + 1];
+      }
+    } else {
+      const unsigned base = (unsigned)((tw * (p.KD / 4) + (kc * KC + hh * (KC / 2)) / 4) * p.ND + n0 + cs * 32 + l31);
+#pragma unroll
+      for (int q = 0; q < KC / 8; ++q) {
+        const float4 v = wp4[base + (unsigned)(q * p.ND)];
+        dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+      }
     }
   };
 
@@ -213,7 +242,14 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       for (int j = 0; j < FILL; ++j) {
         const int i = gt + j * GT;
         float* o = my_xs + (i / (KC / 4)) * XLD + (i % (KC / 4)) * 4;
-        if (Cfg::AVEC) {
+        if (PREC) {  // words 2q, 2q+1 of the hi run (and of the lo run KC/2 words further) of this row
+          unsigned* ow = reinterpret_cast<unsigned*>(my_xs) + (i / (KC / 4)) * XLD + (i % (KC / 4)) * 2;
+          unsigned h0, l0, h1, l1;
+          csplit_bf16(vv[j].x, vv[j].y, h0, l0);
+          csplit_bf16(vv[j].z, vv[j].w, h1, l1);
+          ow[0] = h0; ow[1] = h1;
+          if (PREC == 3) { ow[KC / 2] = l0; ow[KC / 2 + 1] = l1; }
+        } else if (Cfg::AVEC) {
           *reinterpret_cast<float4*>(o) = vv[j];
         } else {
           o[0] = vv[j].x; o[1] = vv[j].y; o[2] = vv[j].z; o[3] = vv[j].w;
@@ -228,10 +264,22 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     // image offset of this lane's A fragment run for group word gw: pair (offset + min(lane, pairs - 1)), k half hh
     auto a_base = [&](int gw) {
       const int t = gw & 255, off = (gw >> 8) & 255, cn = gw >> 16;
-      return (int)slot_s[(rt * MAXT + t) * BM + off + min(l31, cn - 1)] * XLD + hh * KS;
+      return (int)slot_s[(rt * MAXT + t) * BM + off + min(l31, cn - 1)] * XLD + (PREC ? hh * 4 : hh * KS);
     };
-    auto read_a = [&](float (&dst)[KS], int ab) {  // this lane's run of KS consecutive k of one image row
-      if (Cfg::AVEC) {
+    auto read_a = [&](Frag (&dst)[NF], int ab) {  // this lane's run of KS consecutive k of one image row
+      if constexpr (PREC != 0) {  // per 16-k block q2: 4 hi words at 8 * q2 + 4 * hh, the lo words KC/2 further
+#pragma unroll
+        for (int q2 = 0; q2 < KC / 16; ++q2) {
+          if (Cfg::AVEC) {
+            dst[2 * q2] = *reinterpret_cast<const float4*>(my_xs + ab + q2 * 8);
+            if (PREC == 3) dst[2 * q2 + 1] = *reinterpret_cast<const float4*>(my_xs + ab + KC / 2 + q2 * 8);
+          } else {
+            const float* r = my_xs + ab + q2 * 8;
+            dst[2 * q2] = make_float4(r[0], r[1], r[2], r[3]);
+            if (PREC == 3) dst[2 * q2 + 1] = make_float4(r[KC / 2], r[KC / 2 + 1], r[KC / 2 + 2], r[KC / 2 + 3]);
+          }
+        }
+      } else if constexpr (Cfg::AVEC) {
 #pragma unroll
         for (int s4 = 0; s4 < KS / 4; ++s4) {
           const float4 v4 = *reinterpret_cast<const float4*>(my_xs + ab + s4 * 4);
@@ -263,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       }
     } else {
       f32x16 accs[2];
-      float afr[2][KS];
+      Frag afr[2][NF];
       const unsigned char* prows = (const unsigned char*)(misc_s + 8);  // pending fold: none yet -> dummy sink
       int g_cur = 0, kc_cur = 0;  // position of the running step
       int g_b = 0, kc_b = 0;      // position of the weight prefetch (two steps ahead)
@@ -277,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       if (nkc > 1) issue_fill(1);  // after the first weight loads: vmcnt retires in order
       read_a(afr[0], a_base(__builtin_amdgcn_readlane(vgrp, 0)));
       int abase_n = a_base(__builtin_amdgcn_readlane(vgrp, min(1, ngr - 1)));
-      auto step = [&](const float (&bc)[KS], float (&bl)[KS], f32x16& ac, const f32x16& ap, float (&A)[KS], float (&An)[KS]) {
+      auto step = [&](const Frag (&bc)[NF], Frag (&bl)[NF], f32x16& ac, const f32x16& ap, Frag (&A)[NF], Frag (&An)[NF]) {
         if (g_cur == 0 && kc_cur > 0) {  // chunk boundary (block-uniform count: nkc - 1 per wave)
           __syncthreads();               // every wave is done with the old image
           store_fill();
@@ -290,7 +338,19 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         load_b(bl, gwb & 255, min(kc_b, nkc - 1));
         const bool next_in_chunk = g_cur + 1 < ngr;
         const int gwn2 = __builtin_amdgcn_readlane(vgrp, g_cur + 2 < ngr ? g_cur + 2 : (g_cur + 2 - ngr) % ngr);
-        constexpr int Q1 = KS / 8, Q2 = KS / 4, Q3 = 5 * KS / 8;
+        // MFMA list of the step.  fp32: KS k-steps of 32x32x2.  bf16: per 16-k block (lo*hi, hi*lo,) hi*hi of
+        // 32x32x16 (small terms first).  mm(i) issues entry i; the list is cut in four runs around the fold.
+        constexpr int NM = PREC ? (KC / 16) * (PREC == 3 ? 3 : 1) : KS;
+        constexpr int Q1 = PREC ? NM / 4 : KS / 8, Q2 = PREC ? NM / 2 : KS / 4, Q3 = PREC ? (3 * NM + 3) / 4 : 5 * KS / 8;
+        auto mm = [&](int i) {
+          if constexpr (PREC == 0) {
+            ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[i], A[i], ac, 0, 0, 0);
+          } else {
+            const int q2 = PREC == 3 ? i / 3 : i, term = PREC == 3 ? i % 3 : 2;  // 0: w_lo x_hi, 1: w_hi x_lo, 2: w_hi x_hi
+            ac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, bc[2 * q2 + (term == 0 ? 1 : 0)]),
+                                                         __builtin_bit_cast(cbf16x8, A[2 * q2 + (term == 1 ? 1 : 0)]), ac, 0, 0, 0);
+          }
+        };
         // The product is computed TRANSPOSED (MFMA A operand = weight fragment, B operand = gathered rows):
         // C[channel][pair], so a lane owns ONE pair = one output row and its 16 registers are four runs of
         // four consecutive channels -> the fold is 4 x (ds_read_b128, 4 adds, ds_write_b128) through a single
@@ -298,11 +358,11 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ac[r] = 0.f;
 #pragma unroll
-        for (int s2 = 0; s2 < Q1; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
+        for (int s2 = 0; s2 < Q1; ++s2) mm(s2);
         __builtin_amdgcn_sched_barrier(0);
         const int prid = prows[l31];  // output row of the pending group's pair l31 (dummy sink row for padding)
 #pragma unroll
-        for (int s2 = Q1; s2 < Q2; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
+        for (int s2 = Q1; s2 < Q2; ++s2) mm(s2);
         __builtin_amdgcn_sched_barrier(0);
         float4* orow = reinterpret_cast<float4*>(ob + prid * OLD);
         float4 ov[4];
@@ -311,14 +371,14 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         if (next_in_chunk) read_a(An, abase_n);
         const int ab2 = a_base(gwn2);
 #pragma unroll
-        for (int s2 = Q2; s2 < Q3; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
+        for (int s2 = Q2; s2 < Q3; ++s2) mm(s2);
         __builtin_amdgcn_sched_barrier(0);
         // (LDS float atomics — ds_add_f32 — were measured 5x slower than read / add / write)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           orow[2 * q] = make_float4(ov[q].x + ap[4 * q], ov[q].y + ap[4 * q + 1], ov[q].z + ap[4 * q + 2], ov[q].w + ap[4 * q + 3]);
 #pragma unroll
-        for (int s2 = Q3; s2 < KS; ++s2) ac = __builtin_amdgcn_mfma_f32_32x32x2f32(bc[s2], A[s2], ac, 0, 0, 0);
+        for (int s2 = Q3; s2 < NM; ++s2) mm(s2);
         __builtin_amdgcn_sched_barrier(0);
         abase_n = ab2;
         prows = row_s + (rt * MAXT + (gw & 255)) * BM + ((gw >> 8) & 255);
@@ -426,6 +486,38 @@ __global__ __launch_bounds__(256) void conv_wpack_kernel(const float* __restrict
   }
 }
 
+// bf16 packing of the same weights (PREC 1 / 3): per direction, 8 words per (tap, 16-k block kb, k half h, column j)
+// at ((((t * (KD/16) + kb) * 2 + h) * ND + j) * 8: words 0..3 = bf16 hi pairs of k = kb*16 + h*8 + (0,1)(2,3)(4,5)(6,7),
+// words 4..7 = the lo pairs (w - float(hi)).  Same buffer size as the fp32 packing.
+__global__ __launch_bounds__(256) void conv_wpack_bf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wp, int cout,
+                                                              int T, int cin) {
+  const long half = (long)cout * T * cin;
+  const long per_dir = half / 8;  // (t, kb, h, j) tuples per direction
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * per_dir; i += (long)gridDim.x * blockDim.x) {
+    const int dir = i >= per_dir;
+    long r = i - dir * per_dir;
+    const int KD = dir == 0 ? cin : cout, ND = dir == 0 ? cout : cin;
+    const int j = (int)(r % ND); r /= ND;
+    const int h = (int)(r & 1); r >>= 1;
+    const int kb = (int)(r % (KD / 16));
+    const int t = (int)(r / (KD / 16));
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kb * 16 + h * 8 + e;
+      v[e] = dir == 0 ? w[((long)j * T + t) * cin + k] : w[((long)k * T + t) * cin + j];
+    }
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) csplit_bf16(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
+    uint4* o = reinterpret_cast<uint4*>(wp + dir * half + (i - dir * per_dir) * 8);
+    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    o[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
+}
+
+extern "C" int lotus_get_gemm_precision(void);
+
 static long long* g_conv_clk = nullptr;
 extern "C" int lotus_debug_conv_clock(long long* host64) {
   if (!g_conv_clk) return -1;
@@ -440,17 +532,25 @@ static int tap_splits(int n, int ND) {
   return nz;
 }
 
-template <int NCS>
-static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
+template <int NCS, int PREC>
+static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
   using Cfg = PairsCfg<NCS>;
   static int pad = -1;
   if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
   const size_t sm = Cfg::bytes() + (size_t)pad;
-  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
-  hipLaunchKernelGGL((conv_pairs_kernel<NCS>), grid, dim3(256), sm, st, p);
+  hipLaunchKernelGGL((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
+}
+// the packed weights and the kernel must agree on the operand precision: both follow lotus_get_gemm_precision()
+template <int NCS>
+static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
+  const int prec = lotus_get_gemm_precision();
+  if (prec == 3) return launch_pairs_p<NCS, 3>(p, nz, st);
+  if (prec == 1) return launch_pairs_p<NCS, 1>(p, nz, st);
+  return launch_pairs_p<NCS, 0>(p, nz, st);
 }
 
 size_t lotus_conv_pairs_workspace(int n, int ND) {
@@ -463,7 +563,13 @@ int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T,
     lotus_set_error("lotus_conv_weight_transpose: cin and cout must be multiples of 32 (got %d, %d)", cin, cout);
     return LOTUS_E_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
+  if (lotus_get_gemm_precision() != 0) {
+    const long tuples = 2L * cout * T * cin / 8;
+    const int g = (int)((tuples + 255) / 256);
+    hipLaunchKernelGGL(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin);
+  } else {
+    hipLaunchKernelGGL(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
+  }
   LOTUS_LAUNCH_CHECK("lotus_conv_weight_transpose");
   return LOTUS_OK;
 }

@@ -201,6 +201,41 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
         _close(dx, xd.grad, 3e-6, "conv dgrad (pair-compacted, packed weights)")
 
 
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 256), (64, 128)])
+def test_subm_conv_bf16_operand_paths(prec, cin, cout):
+    """Pair-compacted 3^3 convolution (fwd + dgrad) with bf16 (1) / bf16x3 (3) operands: against the fp64 convolution of
+    the bf16-ROUNDED operands (products of two bf16 are exact in fp32) resp. of the exact operands within 2^-16."""
+    from robot_3dlotus_amd import _capi
+    ops = _ops()
+    batch, ref, got = _cloud_levels(3, 1500, seed=cin + 3)
+    n = got[0].n
+    g = torch.Generator().manual_seed(cin * cout + prec)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cout, 3, 3, 3, cin, generator=g) / (cin * 9) ** 0.5
+    dy = torch.randn(n, cout, generator=g)
+    nbr_ref = torch.from_numpy(ref[0]["nbr27"]).long()
+    _capi.call_raw("lotus_set_gemm_precision", prec)
+    try:
+        wt = ops.conv_weight_t(w.cuda())
+        y = ops.conv_fwd(x.cuda(), w.cuda(), None, got[0].nbr27, got[0].order[0], w_t=wt)
+        dx = ops.conv_dgrad(dy.cuda(), w.cuda(), got[0].nbr27, got[0].order[0], w_t=wt)
+    finally:
+        _capi.call_raw("lotus_set_gemm_precision", 0)
+    rnd = (lambda t: t.bfloat16().double()) if prec == 1 else (lambda t: t.double())
+    xd, wd = rnd(x).requires_grad_(True), rnd(w)
+    yref = om.subm_conv(xd, nbr_ref, wd, None)
+    (dxref,) = torch.autograd.grad(yref, xd, rnd(dy))
+    sy = om.subm_conv(x.abs().double(), nbr_ref, w.abs().double(), None).clamp_min(1.0)
+    tol = 2e-6 if prec == 1 else 2.0 ** -16
+    ey = ((y.cpu().double() - yref.detach()).abs() / sy).max().item()
+    assert ey <= tol, (prec, "fwd", ey)
+    xa = x.abs().double().requires_grad_(True)
+    (sx,) = torch.autograd.grad(om.subm_conv(xa, nbr_ref, w.abs().double(), None), xa, dy.abs().double())
+    ex = ((dx.cpu().double() - dxref).abs() / sx.clamp_min(1.0)).max().item()
+    assert ex <= tol, (prec, "dgrad", ex)
+
+
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("C,H", [(64, 2), (128, 4), (768, 32)])
 def test_patch_attention_fwd_bwd(C, H):
