@@ -179,8 +179,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by linear id, each XCD has its own L2.  Give every
   // XCD a contiguous run of the row-major tile list so that the column blocks sharing an A row tile (and the
   // neighbouring row tiles sharing B) hit the same L2 instead of fetching the operand once per XCD.
-  int bx = blockIdx.x, by = blockIdx.y;
-  {
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+    // split-K (weight gradients): the output tiles of ONE split read the same rows of both operands, so they must
+    // share an L2.  Hardware id = (z * gy + y) * gx + x goes to XCD id % 8: give XCD c the splits z = c (mod 8) and walk
+    // the tiles of a split on consecutive ids of that XCD.
+    const int tiles = gridDim.x * gridDim.y;
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;           // slot-th block of this XCD
+    bz = xcd + 8 * (slot / tiles);
+    const int t = slot - (slot / tiles) * tiles;
+    by = t / (int)gridDim.x;
+    bx = t - by * (int)gridDim.x;
+  } else {
     const int nbx = gridDim.x, total = nbx * gridDim.y;
     const int lin = by * nbx + bx, xcd = lin & 7, slot = lin >> 3;
     const int q = total >> 3, r = total & 7;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     bx = t - by * nbx;
   }
   const int m0 = by * BM, n0 = bx * BN;
-  const int kbeg = blockIdx.z * p.klen;
+  const int kbeg = bz * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
 
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
 
   // ---- epilogue
-  float* __restrict__ C = p.C + (long)blockIdx.z * p.part_stride;
+  float* __restrict__ C = p.C + (long)bz * p.part_stride;
   if (FAST) {
     // Stage each wave's 32 x WN sub-tile through LDS and leave as float4 rows: 16 B per lane loads of
     // residual / pre-activation and 16 B stores (4 B-per-lane stores ran at ~1 TB/s, 4x below HBM).
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       for (int tm = 0; tm < TM; ++tm) {
         float s = asum[tm] + __shfl_xor(asum[tm], 32, 64);
         const int i = m0 + wr0 + tm * 32 + (tid & 31);
-        if ((tid & 32) == 0 && i < p.M) p.bias_part[(long)blockIdx.z * p.bias_stride + i] = s;
+        if ((tid & 32) == 0 && i < p.M) p.bias_part[(long)bz * p.bias_stride + i] = s;
       }
     }
   }
