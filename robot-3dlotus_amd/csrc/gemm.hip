@@ -120,6 +120,13 @@ __device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsig
   lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
 }
 
+// w[e] <- w[(e + rot) & 3] with value selects (a dynamically indexed register array would go through scratch)
+__device__ __forceinline__ void rot4(unsigned (&w)[4], int rot) {
+  const bool r1 = rot & 1, r2 = rot & 2;
+  const unsigned a0 = r1 ? w[1] : w[0], a1 = r1 ? w[2] : w[1], a2 = r1 ? w[3] : w[2], a3 = r1 ? w[0] : w[3];
+  w[0] = r2 ? a2 : a0; w[1] = r2 ? a3 : a1; w[2] = r2 ? a0 : a2; w[3] = r2 ? a1 : a3;
+}
+
 template <int BM, int BN, int BK, int PREC>
 __device__ __forceinline__ void gemm_slab_bf16(const unsigned* __restrict__ Aw, const unsigned* __restrict__ Bw, int wr0,
                                                int wc0, f32x16 (&acc)[BM / 64][BN / 64]) {
@@ -287,12 +294,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int t = 0; t + 1 < A4; t += 2) {
           const int f2 = tid + (t >> 1) * 256, kr2 = f2 / (BM / 4), iq = f2 % (BM / 4);
           const float va[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w}, vb[4] = {ra[t + 1].x, ra[t + 1].y, ra[t + 1].z, ra[t + 1].w};
+          unsigned hw[4], lw[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_bf16(va[e], vb[e], hw[e], lw[e]);
+          // the four rows of a quad are written in a per-lane rotated order so that the 64 lanes of one store
+          // instruction hit 64 (BM = 64) / 32 (BM = 128) distinct banks instead of 16 / 8
+          const int rot = (iq >> 2) & 3;
+          rot4(hw, rot);
+          if (PREC == 3) rot4(lw, rot);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            unsigned hw, lw;
-            split_bf16(va[e], vb[e], hw, lw);
-            Aw[(iq * 4 + e) * TA::kLdW + kr2] = hw;
-            if (PREC == 3) Aw[TA::kPlaneW + (iq * 4 + e) * TA::kLdW + kr2] = lw;
+            const int row = iq * 4 + ((e + rot) & 3);
+            Aw[row * TA::kLdW + kr2] = hw[e];
+            if (PREC == 3) Aw[TA::kPlaneW + row * TA::kLdW + kr2] = lw[e];
           }
         }
       }
@@ -311,12 +325,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         for (int t = 0; t + 1 < B4; t += 2) {
           const int f2 = tid + (t >> 1) * 256, kr2 = f2 / (BN / 4), jq = f2 % (BN / 4);
           const float va[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w}, vb[4] = {rb[t + 1].x, rb[t + 1].y, rb[t + 1].z, rb[t + 1].w};
+          unsigned hw[4], lw[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_bf16(va[e], vb[e], hw[e], lw[e]);
+          const int rot = (jq >> 2) & 3;
+          rot4(hw, rot);
+          if (PREC == 3) rot4(lw, rot);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            unsigned hw, lw;
-            split_bf16(va[e], vb[e], hw, lw);
-            Bw[(jq * 4 + e) * TB::kLdW + kr2] = hw;
-            if (PREC == 3) Bw[TB::kPlaneW + (jq * 4 + e) * TB::kLdW + kr2] = lw;
+            const int row = jq * 4 + ((e + rot) & 3);
+            Bw[row * TB::kLdW + kr2] = hw[e];
+            if (PREC == 3) Bw[TB::kPlaneW + row * TB::kLdW + kr2] = lw[e];
           }
         }
       }
