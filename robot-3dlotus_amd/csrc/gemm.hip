@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
-  static_assert(PREC == 0 || (!SUM_A && BK % 16 == 0 && (A_KC || A4 % 2 == 0) && (B_KC || B4 % 2 == 0)),
-                "bf16 path: no bias-gradient sums; operands contiguous along their non-reduction index are staged as k pairs");
+  static_assert(PREC == 0 || ((!SUM_A || !A_KC) && BK % 16 == 0 && (A_KC || A4 % 2 == 0) && (B_KC || B4 % 2 == 0)),
+                "bf16 path: operands contiguous along their non-reduction index are staged as k pairs; the bias-gradient "
+                "sums are taken from the fp32 staging registers of such an A operand");
   constexpr int AF = PREC ? BTile<BM, BK, PREC>::kWords : GTile<BM, A_KC, BK>::kFloats;
   constexpr int BF = PREC ? BTile<BN, BK, PREC>::kWords : GTile<BN, B_KC, BK>::kFloats;
   constexpr int WN = BN / 2, SLD = WN + 4;  // epilogue staging: per wave [32][WN + 4]
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // bf16 path, SUM_A: this thread's partial row sums of A (exact fp32 inputs)
   float4 ra[A4], rb[B4];
   auto gload = [&](int k0) {
 #pragma unroll
@@ -297,6 +299,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           unsigned hw[4], lw[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) split_bf16(va[e], vb[e], hw[e], lw[e]);
+          if (SUM_A && bx == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bsum[e] += va[e] + vb[e];
+          }
           // the four rows of a quad are written in a per-lane rotated order so that the 64 lanes of one store
           // instruction hit 64 (BM = 64) / 32 (BM = 128) distinct banks instead of 16 / 8
           const int rot = (iq >> 2) & 3;
@@ -495,7 +501,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         }
       }
   }
-  if (SUM_A) {
+  if (SUM_A && PREC) {
+    // every staged slab was summed exactly once (slabs past the split range are zero): reduce the partial row sums
+    // of the 256 / (BM / 4) threads that staged the same row quad, in a fixed order
+    __syncthreads();
+    if (p.bias_part && bx == 0) {
+      float4* red = reinterpret_cast<float4*>(smem);
+      red[tid] = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+      __syncthreads();
+      if (tid < BM) {
+        constexpr int G = 256 / (BM / 4);
+        float sacc = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float4 v = red[g * (BM / 4) + (tid >> 2)];
+          sacc += (tid & 3) == 0 ? v.x : (tid & 3) == 1 ? v.y : (tid & 3) == 2 ? v.z : v.w;
+        }
+        if (m0 + tid < p.M) p.bias_part[(long)bz * p.bias_stride + m0 + tid] = sacc;
+      }
+    }
+  } else if (SUM_A) {
     if (p.bias_part && bx == 0 && (wave & 1) == 0) {
 #pragma unroll
       for (int tm = 0; tm < TM; ++tm) {
@@ -565,9 +590,18 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
   int tile = g_force_tile;
   if (g_prec < 0) { g_prec = tune_env("LOTUS_GEMM_PREC"); if (g_prec != 1 && g_prec != 3) g_prec = 0; }
+  if (g_prec && SUM_A && FAST && !A_KC && !B_KC) {
+    // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
+    dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
+    if constexpr (SUM_A && !A_KC && !B_KC && FAST) {
+      if (g_prec == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 32, false, false, true, true, 1>), g64, block, 0, st, p);
+      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, false, false, true, true, 3>), g64, block, 0, st, p);
+    }
+    LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
+    return LOTUS_OK;
+  }
   if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
-    // bf16 / bf16x3 operand path (forward and input-gradient products).  Weight gradients with a bias keep the fp32
-    // path: routing them here was measured at +0.3 % (bf16x3) / +3 % (bf16) of a step and costs gradient accuracy.
+    // bf16 / bf16x3 operand path (forward and input-gradient products)
     const bool big = tile == 1 || (tile == 0 && !small_n && blocks128 * nz >= 512);
     dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if (g_prec == 1) {

@@ -76,8 +76,11 @@ def test_linear_bf16_operand_paths(prec, M, N, K):
     try:
         y, _ = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
         dx = ops.linear_dgrad(dy.cuda(), w.cuda())
+        dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
+        dw2, db2 = ops.linear_wgrad(dy.cuda(), x.cuda())
     finally:
         _capi.call_raw("lotus_set_gemm_precision", 0)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient must stay deterministic"
     if prec == 1:
         xr, wr, dyr = (t.bfloat16().double() for t in (x, w, dy))
         tol_k, tol_n = 4e-7 * K ** 0.5 + 1e-6, 4e-7 * N ** 0.5 + 1e-6
@@ -90,6 +93,12 @@ def test_linear_bf16_operand_paths(prec, M, N, K):
     ey = ((y.cpu().double() - ref_y).abs() / sy).max().item()
     ex = ((dx.cpu().double() - ref_dx).abs() / sx).max().item()
     assert ey <= tol_k and ex <= tol_n, (prec, ey, ex)
+    # weight gradient: split-K partials of bf16(-split) products; the bias gradient is summed from the exact fp32 inputs
+    tol_m = (4e-7 * M ** 0.5 + 1e-6) if prec == 1 else 2.0 ** -16
+    sw = (dy.abs().double().t() @ x.abs().double()).clamp_min(1.0)
+    ew = ((dw.cpu().double() - dyr.t() @ xr).abs() / sw).max().item()
+    eb = ((db.cpu().double() - dy.double().sum(0)).abs() / dy.abs().double().sum(0).clamp_min(1.0)).max().item()
+    assert ew <= tol_m and eb <= 4e-7 * M ** 0.5 + 1e-6, (prec, ew, eb)
 
 
 def test_linear_dropout_statistics_and_replay():
