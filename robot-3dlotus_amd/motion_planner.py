@@ -7,9 +7,10 @@ per-sample trajectory length.  Module surface kept: `cls(config.MODEL)`, `forwar
 **kwargs)` -> `final_pred_actions [B, T, 3+4+2]` or `(final_pred_actions, losses)`, kwarg `compute_final_action`,
 the reference's state_dict keys (incl. the unused `txt_attn_fc` the CA variant builds for txt_reduce == 'attn').
 
-What runs where: every matrix product, the sparse convolutions, attention, norms, the per-cloud max and the
-heatmap cross entropy are lotus-hip kernels (ops.*Fn); the [B, T]-sized rotation / openness / stop losses and the
-trajectory-embedding bias (5 x 64 floats) are a few ATen launches on tensors of a few hundred floats.
+What runs where: every matrix product over points, the sparse convolutions, attention, norms, the per-cloud max and the
+heatmap cross entropy are lotus-hip kernels (ops.*Fn); the [B, T]-sized rotation / openness / stop losses, the
+trajectory-embedding bias (5 x 64 floats) and the effective stem weight (see prepare_ptv3_batch) are a few ATen
+launches on small tensors.
 """
 import numpy as np
 import torch
@@ -67,14 +68,18 @@ class MotionPlannerPTV3CA(BaseModel):
     def prepare_ptv3_batch(self, batch):
         """motion_planner_ptv3.py:433-463: feat = [pc_fts | label embedding], context = txt_fc(txt_embeds)."""
         labels = batch["pc_labels"].long()
-        # embedding lookup as a 4-column one-hot product: the weight gradient is a fixed-order GEMM reduction
-        # instead of index_add atomics, so the step stays run-to-run deterministic
-        onehot = F.one_hot(labels, 4).float()
-        emb = ops.LinearFn.apply(onehot, self.pc_label_embedding.weight.t().contiguous(), None)
-        feat = torch.cat([batch["pc_fts"].float(), emb], -1)
+        # The 64 embedding channels take only 4 distinct values per point, and the stem convolution is linear:
+        #   conv(W, [pc | E[label]]) == conv([W_pc | W_emb E^T], [pc | onehot(label)])
+        # so the 68-channel 5^3 convolution (81 % of whose gathered rows are absent neighbours) becomes the 8-channel
+        # stem the policy already has a kernel for, with an effective weight that autograd differentiates back into
+        # the stem weight and the embedding table (two products of a few hundred kFLOP); no input gradient is needed.
+        W, E = self.ptv3_model.embedding.stem.conv.weight, self.pc_label_embedding.weight
+        c_pc = batch["pc_fts"].shape[1]
+        w_eff = torch.cat([W[..., :c_pc], torch.matmul(W[..., c_pc:], E.t())], -1)                  # [64,5,5,5,c_pc+4]
+        feat = torch.cat([batch["pc_fts"].float(), F.one_hot(labels, 4).float()], -1)
         ctx = ops.LinearFn.apply(batch["txt_embeds"].contiguous(), self.txt_fc.weight, self.txt_fc.bias)
         return {"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
-                "feat": feat, "context": ctx, "counts": list(batch["npoints_in_batch"]),
+                "feat": feat, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
                 "context_counts": list(batch["txt_lens"])}
 
     def forward(self, batch, compute_loss=False, **kwargs):

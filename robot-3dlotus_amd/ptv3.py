@@ -262,7 +262,9 @@ class PointTransformerV3CA(nn.Module):
 
         st = self.embedding.stem
         _tick(st.norm, training)
-        x = ops.StemFn.apply(feat, st.conv.weight, st.norm.weight, st.norm.bias, st.norm.running_mean,
+        # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input
+        # features are a linear code of something smaller, e.g. the motion planner's label embedding
+        x = ops.StemFn.apply(feat, data_dict.get("stem_weight", st.conv.weight), st.norm.weight, st.norm.bias, st.norm.running_mean,
                              st.norm.running_var, levels[0], training)
         skips = []
         for s in range(self.num_stages):
