@@ -10,7 +10,6 @@ sized neighbour / patch / tile tables are built.
 import numpy as np
 import torch
 
-from . import _capi
 from ._capi import call, query, WS
 
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
