@@ -247,6 +247,14 @@ def main():
             other[mode] = round(args.batch * world * 20 / d2, 2)
         ops.set_gemm_precision("fp32")
 
+    # one more step on EVERY rank (it contains collectives when N > 1) with the dense launches logged; rank 0 replays them
+    calls = []
+    if not args.no_roofline:
+        ops.CALL_LOG = calls
+        step()
+        ops.CALL_LOG = None
+        torch.cuda.synchronize()
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = args.batch * world * args.steps / dt
@@ -276,11 +284,6 @@ def main():
         if opt is not None:
             out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
         if not args.no_roofline:
-            calls = []
-            ops.CALL_LOG = calls
-            step()
-            ops.CALL_LOG = None
-            torch.cuda.synchronize()
             rep = [] if args.gemm_report else None
             flop, gms, nl = gemm_roofline(ops, calls, dev, report=rep)
             if rep is not None:
