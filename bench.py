@@ -303,7 +303,7 @@ def main():
                                "kernel": "gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
                                "launches_per_step": nl, "ms_per_step": round(gms, 3),
                                "gflop_per_step": round(flop / 1e9, 1)}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only (the other ranks would idle in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
