@@ -162,7 +162,7 @@ def main():
         model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
     reducer = None
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1":  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
-        reducer = parallel.GradReducer(model, bucket_mb=64.0)
+        reducer = parallel.GradReducer(model, bucket_mb=32.0)
         parallel.enable_sync_batchnorm()
     batch = dev_batch((synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank), dev)
 

@@ -104,10 +104,11 @@ def _side():
     return SIDE
 
 
-def sync_side_stream():
-    """The current stream waits for everything enqueued on the weight-gradient stream(s)."""
+def sync_side_stream(target=None):
+    """The current stream (or the stream with raw handle `target`) waits for everything enqueued on the
+    weight-gradient stream(s)."""
     if SIDE is not None:
-        cur = _capi.stream_ptr()
+        cur = _capi.stream_ptr() if target is None else target
         for _, ptr in _SIDES:
             _capi.call_raw("lotus_streamlink_wait", _LINK, ptr, cur)
 
