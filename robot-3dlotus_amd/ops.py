@@ -347,17 +347,17 @@ class BnState:
     reduce = None
 
 
-def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS):
+def _bn_stats(x, sums):
     M, C = x.shape
-    dev = x.device
-    mean = torch.empty(C, dtype=torch.float32, device=dev)
-    invstd = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
+    call("lotus_batchnorm_stats", x, sums, M, C, ws, ws.numel())
+
+
+def _bn_finish(x, sums, g, b, rmean, rvar, training, act, momentum, eps):
+    M, C = x.shape
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
     if training:
-        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-        ws = _ws(query("lotus_batchnorm_workspace", M, C), dev)
-        call("lotus_batchnorm_stats", x, sums, M, C, ws, ws.numel())
-        if BnState.reduce is not None:
-            BnState.reduce(sums)
         call("lotus_batchnorm_finalize", sums, mean, invstd, rmean, rvar, C, float(eps), float(momentum))
     else:
         call("lotus_batchnorm_eval_stats", rmean, rvar, mean, invstd, C, float(eps))
@@ -366,26 +366,77 @@ def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS
     return y, mean, invstd
 
 
-def bn_bwd(dy, x, mean, invstd, g, b, training, act):
+def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS):
+    sums = None
+    if training:
+        sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
+        _bn_stats(x, sums)
+        if BnState.reduce is not None:
+            BnState.reduce(sums)
+    return _bn_finish(x, sums, g, b, rmean, rvar, training, act, momentum, eps)
+
+
+def bn_fwd_pair(xa, pa, xb, pb, training, act, momentum=BN_MOMENTUM, eps=BN_EPS):
+    """Two independent BatchNorms (the two branches of SerializedUnpooling) with ONE statistics message when
+    SyncBatchNorm is on: the all-reduces are latency-bound, 26 -> 18 per step.  pa / pb = (g, b, rmean, rvar)."""
+    if not training or BnState.reduce is None:
+        return bn_fwd(xa, *pa, training, act, momentum, eps), bn_fwd(xb, *pb, training, act, momentum, eps)
+    na, nb_ = 2 * xa.shape[1] + 1, 2 * xb.shape[1] + 1
+    sums = torch.empty(na + nb_, dtype=torch.float64, device=xa.device)
+    _bn_stats(xa, sums[:na])
+    _bn_stats(xb, sums[na:])
+    BnState.reduce(sums)
+    return (_bn_finish(xa, sums[:na], *pa, training, act, momentum, eps),
+            _bn_finish(xb, sums[na:], *pb, training, act, momentum, eps))
+
+
+def _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums):
     M, C = x.shape
-    dev = x.device
-    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
-    ws = _ws(query("lotus_batchnorm_workspace", M, C), dev)
+    ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
     call("lotus_batchnorm_bwd_stats", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel())
+
+
+def _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced):
     # dgamma / dbeta are the LOCAL sums (gradient averaging across ranks is the reducer's job);
     # dx uses the statistics of the whole (all-rank) batch
+    M, C = x.shape
     dx = torch.empty_like(x)
-    if training and BnState.reduce is not None:
-        dg = sums[C:2 * C].float()
-        db = sums[:C].float()
-        BnState.reduce(sums)
+    if reduced is not None:  # (dg, db) were taken from the local sums before the all-reduce
+        dg, db = reduced
         call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, None, None, M, C, act, 1, 0)
     else:  # local statistics: the apply kernel writes the parameter gradients itself
-        dg = torch.empty(C, dtype=torch.float32, device=dev)
-        db = torch.empty(C, dtype=torch.float32, device=dev)
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
         call("lotus_batchnorm_bwd_apply", dy, x, mean, invstd, g, b, sums, dx, dg, db, M, C, act,
              1 if training else 0, 0)
     return dx, dg, db
+
+
+def bn_bwd(dy, x, mean, invstd, g, b, training, act):
+    C = x.shape[1]
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+    _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums)
+    reduced = None
+    if training and BnState.reduce is not None:
+        reduced = (sums[C:2 * C].float(), sums[:C].float())
+        BnState.reduce(sums)
+    return _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced)
+
+
+def bn_bwd_pair(a, bb, training, act):
+    """Backward of bn_fwd_pair: a / bb = (dy, x, mean, invstd, g, b); one statistics message for both."""
+    if not training or BnState.reduce is None:
+        return bn_bwd(*a, training, act), bn_bwd(*bb, training, act)
+    Ca, Cb = a[1].shape[1], bb[1].shape[1]
+    na = 2 * Ca + 1
+    sums = torch.empty(na + 2 * Cb + 1, dtype=torch.float64, device=a[1].device)
+    sa, sb = sums[:na], sums[na:]
+    _bn_bwd_stats(*a, act, sa)
+    _bn_bwd_stats(*bb, act, sb)
+    ra = (sa[Ca:2 * Ca].float(), sa[:Ca].float())
+    rb = (sb[Cb:2 * Cb].float(), sb[:Cb].float())
+    BnState.reduce(sums)
+    return _bn_bwd_apply(*a, training, act, sa, ra), _bn_bwd_apply(*bb, training, act, sb, rb)
 
 
 def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d,
@@ -607,9 +658,8 @@ class UnpoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xc, xp, wu, bu, gu, betau, rmu, rvu, ws_, bs, gs, betas, rms, rvs, child, training):
         lu, _ = linear_fwd(xc, wu, bu)
-        up, mu, iu = bn_fwd(lu, gu, betau, rmu, rvu, training, ACT_GELU)
         ls, _ = linear_fwd(xp, ws_, bs)
-        skip, ms, is_ = bn_fwd(ls, gs, betas, rms, rvs, training, ACT_GELU)
+        (up, mu, iu), (skip, ms, is_) = bn_fwd_pair(lu, (gu, betau, rmu, rvu), ls, (gs, betas, rms, rvs), training, ACT_GELU)
         x = torch.empty_like(skip)
         call("lotus_unpool_fwd", skip, up, child.cluster, skip.shape[0], skip.shape[1], x)
         ctx.save_for_backward(xc, xp, wu, gu, betau, ws_, gs, betas, lu, ls, mu, iu, ms, is_)
@@ -624,11 +674,11 @@ class UnpoolFn(torch.autograd.Function):
         dx = dx.contiguous()
         dup = torch.empty(child.n, C, dtype=torch.float32, device=dx.device)
         call("lotus_unpool_bwd", dx, child.members, child.seg_start, child.n, C, dup)
-        dlu, dgu, dbetau = bn_bwd(dup, lu, mu, iu, gu, betau, training, ACT_GELU)
+        dsk = add(dx, dskip.contiguous()) if dskip is not None else dx
+        (dlu, dgu, dbetau), (dls, dgs, dbetas) = bn_bwd_pair((dup, lu, mu, iu, gu, betau), (dsk, ls, ms, is_, gs, betas),
+                                                            training, ACT_GELU)
         dwu, dbu = linear_wgrad(dlu, xc)
         dxc = linear_dgrad(dlu, wu)
-        dsk = add(dx, dskip.contiguous()) if dskip is not None else dx
-        dls, dgs, dbetas = bn_bwd(dsk, ls, ms, is_, gs, betas, training, ACT_GELU)
         dws, dbs = linear_wgrad(dls, xp)
         dxp = linear_dgrad(dls, ws_)
         return dxc, dxp, dwu, dbu, dgu, dbetau, None, None, dws, dbs, dgs, dbetas, None, None, None, None
