@@ -276,8 +276,8 @@ def main():
             out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
         if other:
             out["opt_in_modes"] = {"unit": "keystep-samples/s", **other,
-                                   "note": "same step with ops.set_gemm_precision(mode): dense fwd/dgrad + sparse-conv products as "
-                                           "bf16x3 split (max logit error 2e-5, inside the 1e-4 bar) / plain bf16; not the headline"}
+                                   "note": "same step with ops.set_gemm_precision(mode): dense + sparse-conv + attention products as "
+                                           "bf16x3 split (max logit error 2.2e-5, inside the 1e-4 bar) / plain bf16; not the headline"}
         if args.gemm_precision != "fp32":
             out["config"]["workload"] += f"; dense fwd/dgrad products in {args.gemm_precision} (opt-in, NOT the headline mode)"
             out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM + conv operands"

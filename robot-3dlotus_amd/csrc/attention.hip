@@ -152,6 +152,40 @@ __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
 //   * the probabilities are ALREADY the B fragments of O^T = V^T P^T (k = key: lane-half hh of step (t, r)
 //     supplies exactly the key it holds in register r; the A fragment V[key][dcol] comes from the LDS image);
 // the 128 x 128 score image never exists in LDS (3 row images = 51 KB -> three blocks per CU).
+// ---- bf16 operand paths (PREC 1: bf16; PREC 3: bf16x3 split, see gemm.hip).  v_mfma_f32_32x32x16_bf16: a lane holds 8
+// k-values (k = 8 * (lane >> 5) + 0..7) of its row / column; the C layout equals the fp32 32x32 form, so the softmax and
+// the transposed-accumulator trick are unchanged.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 abf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 abf16x2;
+__device__ __forceinline__ unsigned apack_bf16(float a, float b) {
+  const abf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+template <int PREC>
+__device__ __forceinline__ void split8(const float (&v)[8], uint4& hi, uint4& lo) {
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h[q] = apack_bf16(v[2 * q], v[2 * q + 1]);
+    if (PREC == 3)
+      l[q] = apack_bf16(v[2 * q] - __builtin_bit_cast(float, h[q] << 16), v[2 * q + 1] - __builtin_bit_cast(float, h[q] & 0xffff0000u));
+    else
+      l[q] = 0u;
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+// acc += A * B with A = (ah, al), B = (bh, bl): lo*hi + hi*lo + hi*hi (PREC 3) or hi*hi (PREC 1)
+template <int PREC>
+__device__ __forceinline__ f32x16 mfma_split(const uint4& ah, const uint4& al, const uint4& bh, const uint4& bl, f32x16 acc) {
+  if (PREC == 3) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, al), __builtin_bit_cast(abf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ah), __builtin_bit_cast(abf16x8, bl), acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(abf16x8, ah), __builtin_bit_cast(abf16x8, bh), acc, 0, 0, 0);
+}
+
+template <int PREC>
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnSmem s = carve(smem, false);
@@ -182,11 +216,38 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   f32x16 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = zero16();
-  for (int kk = 0; kk < d; kk += 2) {
-    const float bq = s.Q[qi * ALD + kk + hh];
+  if constexpr (PREC != 0) {
+    // S^T = K Q^T: lane = (key row | query column) l31, k-half hh holds d-columns 16 * q2 + 8 * hh + 0..7 (image columns
+    // >= d are zero).  The query fragments are hoisted over the key tiles.
+    uint4 qh[2], ql[2];
+#pragma unroll
+    for (int q2 = 0; q2 < 2; ++q2) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = s.Q[qi * ALD + q2 * 16 + hh * 8 + e];
+      split8<PREC>(v, qh[q2], ql[q2]);
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[(t * 32 + l31) * ALD + kk + hh], bq, acc[t], 0, 0, 0);
+      if (t < ktiles) {
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          if (q2 * 16 >= d) continue;
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = s.K[(t * 32 + l31) * ALD + q2 * 16 + hh * 8 + e];
+          uint4 kh, kl;
+          split8<PREC>(v, kh, kl);
+          acc[t] = mfma_split<PREC>(kh, kl, qh[q2], ql[q2], acc[t]);
+        }
+      }
+  } else {
+    for (int kk = 0; kk < d; kk += 2) {
+      const float bq = s.Q[qi * ALD + kk + hh];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[(t * 32 + l31) * ALD + kk + hh], bq, acc[t], 0, 0, 0);
+    }
   }
   // softmax over this query's keys: registers of both lane halves
   float m = -INFINITY;
@@ -235,10 +296,28 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     if (t < ktiles) {
+      if constexpr (PREC != 0) {
+        // registers 8g .. 8g+7 of the probability tile are this lane's k-slots of MFMA g: keys 16g + (j & 3) + 8 (j >> 2)
+        // + 4 hh — the V operand gathers exactly those rows
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        o = __builtin_amdgcn_mfma_f32_32x32x2f32(s.V[key * ALD + l31], acc[t][r], o, 0, 0, 0);
+        for (int g = 0; g < 2; ++g) {
+          float pv[8], vv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pv[j] = acc[t][8 * g + j];
+            vv[j] = s.V[(t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * hh) * ALD + l31];
+          }
+          uint4 ph, pl, vh, vl;
+          split8<PREC>(pv, ph, pl);
+          split8<PREC>(vv, vh, vl);
+          o = mfma_split<PREC>(vh, vl, ph, pl, o);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          o = __builtin_amdgcn_mfma_f32_32x32x2f32(s.V[key * ALD + l31], acc[t][r], o, 0, 0, 0);
+        }
       }
     }
   if (qi < q_len && s.qown[qi]) {
@@ -289,6 +368,7 @@ __device__ __forceinline__ void ln_rows_bwd(float* g, const float* xh, const flo
   for (int j = 0; j < d; ++j) gr[j] = rs * (gr[j] * gam[j] - s1 - xr[j] * s2);
 }
 
+template <int PREC>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   AttnSmem s = carve(smem, true);
@@ -374,13 +454,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       // q_norm's affine is folded into the hoisted key fragment: (xq g + b) . kn = xq . (g kn) + b . kn, so the
       // A operand is the raw normalised row and the bias term is one per-key constant
       float kb[16], vb[16], c_a = 0.f;
+      uint4 kbh[2], kbl[2], vbh[2], vbl[2];  // bf16 paths: the same fragments as whole MFMA operands (k = 16 q2 + 8 hh + j)
+      if constexpr (PREC != 0) {
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) {
-        const int k = 2 * s2 + hh;
-        const float kn = s.K[kj * ALD + k] * s.gk[k] + s.bk[k];
-        c_a += s.bq[k] * kn;
-        kb[s2] = kn * s.gq[k];
-        vb[s2] = s.V[kj * ALD + k];
+        for (int q2 = 0; q2 < 2; ++q2) {
+          float k8[8], v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = 16 * q2 + 8 * hh + j;
+            const float kn = s.K[kj * ALD + k] * s.gk[k] + s.bk[k];
+            c_a += s.bq[k] * kn;
+            k8[j] = kn * s.gq[k];
+            v8[j] = s.V[kj * ALD + k];
+          }
+          split8<PREC>(k8, kbh[q2], kbl[q2]);
+          split8<PREC>(v8, vbh[q2], vbl[q2]);
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const int k = 2 * s2 + hh;
+          const float kn = s.K[kj * ALD + k] * s.gk[k] + s.bk[k];
+          c_a += s.bq[k] * kn;
+          kb[s2] = kn * s.gq[k];
+          vb[s2] = s.V[kj * ALD + k];
+        }
       }
       c_a += __shfl_xor(c_a, 32, 64);
       // dropout index ((tile * H + h) * 128 + q) * 128 + key: the tile/head part is a multiple of 2^14, so the
@@ -393,10 +491,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         f32x16 sa = zero16(), dpa = zero16();
         const float* qrow_p = s.Q + (qt * 32 + l31) * ALD + hh;
         const float* dorow_p = s.dO + (qt * 32 + l31) * ALD + hh;
+        if constexpr (PREC != 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow_p[2 * s2], kb[s2], sa, 0, 0, 0);
-          dpa = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow_p[2 * s2], vb[s2], dpa, 0, 0, 0);
+          for (int q2 = 0; q2 < 2; ++q2) {
+            if (q2 * 16 >= d) continue;
+            float q8[8], d8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              q8[j] = s.Q[(qt * 32 + l31) * ALD + 16 * q2 + 8 * hh + j];
+              d8[j] = s.dO[(qt * 32 + l31) * ALD + 16 * q2 + 8 * hh + j];
+            }
+            uint4 ah, al, bh, bl;
+            split8<PREC>(q8, ah, al);
+            split8<PREC>(d8, bh, bl);
+            sa = mfma_split<PREC>(ah, al, kbh[q2], kbl[q2], sa);
+            dpa = mfma_split<PREC>(bh, bl, vbh[q2], vbl[q2], dpa);
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) {
+            sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow_p[2 * s2], kb[s2], sa, 0, 0, 0);
+            dpa = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow_p[2 * s2], vb[s2], dpa, 0, 0, 0);
+          }
         }
         float lse4[16], d4[16];  // per-query scalars of this lane's 16 rows: four aligned runs of four queries
 #pragma unroll
@@ -416,11 +532,34 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
           sa[r] = keep ? pv * p.drop_inv_keep : 0.f;                                                   // dropout(P)
           dpa[r] = p.scale * pv * ((keep ? dpa[r] * p.drop_inv_keep : 0.f) - d4[r]);                   // dS
         }
+        if constexpr (PREC != 0) {
+          // registers 8g .. 8g+7 are this lane's k-slots of MFMA g: queries 16g + (j & 3) + 8 (j >> 2) + 4 hh
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.dO[qq * ALD + l31], sa[r], acc_dv, 0, 0, 0);
-          acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Q[qq * ALD + l31] * gq_l + bq_l, dpa[r], acc_dk, 0, 0, 0);
+          for (int g = 0; g < 2; ++g) {
+            float p8[8], s8[8], o8[8], q8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int qq = qt * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+              p8[j] = sa[8 * g + j];
+              s8[j] = dpa[8 * g + j];
+              o8[j] = s.dO[qq * ALD + l31];
+              q8[j] = s.Q[qq * ALD + l31] * gq_l + bq_l;
+            }
+            uint4 ph, pl, sh, sl, oh, ol, qh, ql;
+            split8<PREC>(p8, ph, pl);
+            split8<PREC>(s8, sh, sl);
+            split8<PREC>(o8, oh, ol);
+            split8<PREC>(q8, qh, ql);
+            acc_dv = mfma_split<PREC>(oh, ol, ph, pl, acc_dv);
+            acc_dk = mfma_split<PREC>(qh, ql, sh, sl, acc_dk);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.dO[qq * ALD + l31], sa[r], acc_dv, 0, 0, 0);
+            acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Q[qq * ALD + l31] * gq_l + bq_l, dpa[r], acc_dk, 0, 0, 0);
+          }
         }
       }
     }
@@ -431,13 +570,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
     if (r0 < q_len) {
       const int qi = r0 + l31;
       float qb[16], dob[16], c_b = 0.f;  // k_norm's affine folded into the hoisted query fragment (as above)
+      uint4 qbh[2], qbl[2], dobh[2], dobl[2];
+      if constexpr (PREC != 0) {
 #pragma unroll
-      for (int s2 = 0; s2 < 16; ++s2) {
-        const int k = 2 * s2 + hh;
-        const float qn = s.Q[qi * ALD + k] * s.gq[k] + s.bq[k];
-        c_b += s.bk[k] * qn;
-        qb[s2] = qn * s.gk[k];
-        dob[s2] = s.dO[qi * ALD + k];
+        for (int q2 = 0; q2 < 2; ++q2) {
+          float q8[8], d8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int k = 16 * q2 + 8 * hh + j;
+            const float qn = s.Q[qi * ALD + k] * s.gq[k] + s.bq[k];
+            c_b += s.bk[k] * qn;
+            q8[j] = qn * s.gk[k];
+            d8[j] = s.dO[qi * ALD + k];
+          }
+          split8<PREC>(q8, qbh[q2], qbl[q2]);
+          split8<PREC>(d8, dobh[q2], dobl[q2]);
+        }
+      } else {
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          const int k = 2 * s2 + hh;
+          const float qn = s.Q[qi * ALD + k] * s.gq[k] + s.bq[k];
+          c_b += s.bk[k] * qn;
+          qb[s2] = qn * s.gk[k];
+          dob[s2] = s.dO[qi * ALD + k];
+        }
       }
       c_b += __shfl_xor(c_b, 32, 64);
       const float lse_q = s.lse[qi], d_q = s.Dv[qi];
@@ -448,10 +605,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         f32x16 sb = zero16(), dpb = zero16();
         const float* krow_p = s.K + (t * 32 + l31) * ALD + hh;
         const float* vrow_p = s.V + (t * 32 + l31) * ALD + hh;
+        if constexpr (PREC != 0) {
 #pragma unroll
-        for (int s2 = 0; s2 < 16; ++s2) {
-          sb = __builtin_amdgcn_mfma_f32_32x32x2f32(krow_p[2 * s2], qb[s2], sb, 0, 0, 0);
-          dpb = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow_p[2 * s2], dob[s2], dpb, 0, 0, 0);
+          for (int q2 = 0; q2 < 2; ++q2) {
+            if (q2 * 16 >= d) continue;
+            float k8[8], v8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              k8[j] = s.K[(t * 32 + l31) * ALD + 16 * q2 + 8 * hh + j];
+              v8[j] = s.V[(t * 32 + l31) * ALD + 16 * q2 + 8 * hh + j];
+            }
+            uint4 ah, al, bh, bl;
+            split8<PREC>(k8, ah, al);
+            split8<PREC>(v8, bh, bl);
+            sb = mfma_split<PREC>(ah, al, qbh[q2], qbl[q2], sb);
+            dpb = mfma_split<PREC>(bh, bl, dobh[q2], dobl[q2], dpb);
+          }
+        } else {
+#pragma unroll
+          for (int s2 = 0; s2 < 16; ++s2) {
+            sb = __builtin_amdgcn_mfma_f32_32x32x2f32(krow_p[2 * s2], qb[s2], sb, 0, 0, 0);
+            dpb = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow_p[2 * s2], dob[s2], dpb, 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -461,10 +636,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
           const bool keep = !p.drop_thresh || keep_lo(lo_b + key, s0, c2, p.drop_thresh);
           sb[r] = p.scale * pv * ((keep ? dpb[r] * p.drop_inv_keep : 0.f) - d_q);                      // dS^T
         }
+        if constexpr (PREC != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          acc_dq = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[key * ALD + l31] * gk_l + bk_l, sb[r], acc_dq, 0, 0, 0);
+          for (int g = 0; g < 2; ++g) {
+            float s8[8], k8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int key = t * 32 + 16 * g + (j & 3) + 8 * (j >> 2) + 4 * hh;
+              s8[j] = sb[8 * g + j];
+              k8[j] = s.K[key * ALD + l31] * gk_l + bk_l;
+            }
+            uint4 sh, sl, kh, kl;
+            split8<PREC>(s8, sh, sl);
+            split8<PREC>(k8, kh, kl);
+            acc_dq = mfma_split<PREC>(kh, kl, sh, sl, acc_dq);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            acc_dq = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[key * ALD + l31] * gk_l + bk_l, sb[r], acc_dq, 0, 0, 0);
+          }
         }
       }
     }
@@ -630,6 +822,8 @@ extern "C" int lotus_debug_attn_clock(long long* host64) {
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
 
+extern "C" int lotus_get_gemm_precision(void);
+
 extern "C" {
 
 // Forward.  tiles: int32 [ntiles][4] (device).  Rows: q row r lives at q + r*q_ld + q_off + h*d;
@@ -649,8 +843,17 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
   const size_t sm = attn_smem_bytes(false);
-  (void)hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+  const int prec = lotus_get_gemm_precision();
+  if (prec == 3) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+  } else if (prec == 1) {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+  }
   LOTUS_LAUNCH_CHECK("lotus_attention_fwd");
   return LOTUS_OK;
 }
@@ -698,8 +901,17 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   }
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = attn_smem_bytes(true);
-  (void)hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblocks, H), dim3(256), sm, st, p);
+  const int prec = lotus_get_gemm_precision();
+  if (prec == 3) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
+  } else if (prec == 1) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nblocks, H), dim3(256), sm, st, p);
+  } else {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(nblocks, H), dim3(256), sm, st, p);
+  }
   if (p.dkv_extra) {
     const int w4 = 2 * H * d / 4;
     hipLaunchKernelGGL(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,

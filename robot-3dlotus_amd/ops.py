@@ -50,8 +50,9 @@ def set_gemm_precision(mode):
     """Operand precision of the dense and sparse-convolution forward / input-gradient products (process-wide; set it
     before a forward pass — the packed conv weights of a step follow the mode they were packed in): 'fp32' = fp32 MFMA,
     exact products (default, the 1e-4 logit parity mode); 'bf16x3' = split-bf16 products hi*hi + hi*lo + lo*hi with
-    fp32 accumulation (~2^-17 per product; measured max logit error 2e-5, +20 % step throughput); 'bf16' = bf16
-    operands (the bf16 compute mode of BASELINE configs[4]; attention and the conv weight gradient still fp32; +29 %)."""
+    fp32 accumulation (~2^-17 per product; measured max logit error 2.2e-5, +23-27 % step throughput); 'bf16' = bf16
+    operands (the bf16 compute mode of BASELINE configs[4]; the conv weight gradient is still fp32; +20-35 %).
+    Covers the dense, sparse-convolution and attention products."""
     _capi.call_raw("lotus_set_gemm_precision", _PRECISIONS[mode])
 
 

@@ -281,6 +281,47 @@ def test_patch_attention_fwd_bwd(C, H):
         _close(a, b.grad, 5e-5, name)
 
 
+@pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 4e-2)])
+@pytest.mark.parametrize("C,H", [(64, 2), (128, 4), (768, 32)])
+def test_patch_attention_bf16_operand_paths(prec, tol, C, H):
+    """Tile attention forward and backward with bf16x3 (3) / bf16 (1) operands against the fp64 reference (head dims 32 and 24)."""
+    from robot_3dlotus_amd import _capi
+    ops = _ops()
+    batch, ref, got = _cloud_levels(3, 300, seed=C)
+    lv, r = got[0], ref[0]
+    n, d = lv.n, C // H
+    g = torch.Generator().manual_seed(C + prec)
+    qkv = torch.randn(n, 3 * C, generator=g) * 1.5
+    qn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    kn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
+    lvl = dict(order_t=torch.from_numpy(r["order"]), inverse_t=torch.from_numpy(r["inverse"]),
+               pad_t=torch.from_numpy(r["pad"]), unpad_t=torch.from_numpy(r["unpad"]), cu_seqlens=r["cu_seqlens"])
+    oref = om.patch_attention(qkv.double(), lvl, 0, H, *(t.double() for t in (*qn, *kn)), 128)
+    qc = qkv.cuda()
+    qnc, knc = tuple(t.cuda() for t in qn), tuple(t.cuda() for t in kn)
+    att = torch.empty(n, C, device="cuda")
+    lse = torch.empty(lv.npad, H, device="cuda")
+    dout = torch.randn(n, C, generator=g)
+    qd = qkv.double().requires_grad_(True)
+    pr = [t.double().requires_grad_(True) for t in (*qn, *kn)]
+    om.patch_attention(qd, lvl, 0, H, pr[0], pr[1], pr[2], pr[3], 128).backward(dout.double())
+    dqkv = torch.empty(n, 3 * C, device="cuda")
+    extra = torch.empty(max(lv.n_extra, 1), 2 * C, device="cuda")
+    _capi.call_raw("lotus_set_gemm_precision", prec)
+    try:
+        ops.attention_fwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.n_self_tiles,
+                          qnc, knc, att, lse, H, d)
+        gr = ops.attention_bwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.self_blocks,
+                               lv.n_self_tiles, qnc, knc, att, dout.cuda(), lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0,
+                               H, d, 0.0, 0, lv.kext, lv.ext_pos, lv.n_extra, extra)
+    finally:
+        _capi.call_raw("lotus_set_gemm_precision", 0)
+    _close(att, oref, tol, f"attn fwd prec {prec}")
+    _close(dqkv, qd.grad, 4 * tol, f"attn dqkv prec {prec}")
+    for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
+        _close(a, b.grad, 10 * tol, f"{name} prec {prec}")
+
+
 @pytest.mark.parametrize("C,H", [(64, 2), (768, 32)])
 def test_cross_attention_fwd_bwd(C, H):
     ops = _ops()
