@@ -21,6 +21,31 @@ from ._capi import call, query, WS
 ACT_NONE, ACT_GELU, ACT_LEAKY = 0, 1, 2
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01
 CALL_LOG = None  # bench.py sets this to a list to record the (kind, M, N, K) of every dense launch
+EVENT_LOG = None  # ... and this to a list to get (kind, M, N, K, start event, end event) of every dense launch, recorded on
+                  # the stream the launch went to (the timed quantities of bench.py's in-step roofline figure)
+
+
+class _Timed:
+    """Bracket a dense launch with HIP events on the stream it is enqueued on (diagnostic; only when EVENT_LOG is set)."""
+
+    def __init__(self, key):
+        self.key = key
+
+    def __enter__(self):
+        if EVENT_LOG is None:
+            return self
+        # inside a weight-gradient block the launches go to the side stream although torch's current stream is unchanged
+        self.st = _SIDES[_CUR][0] if _capi.STREAM_OVERRIDE else torch.cuda.current_stream()
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record(self.st)
+        return self
+
+    def __exit__(self, *a):
+        if EVENT_LOG is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(self.st)
+            EVENT_LOG.append(self.key + (self.e0, e1))
+
 
 # Weight gradients are off the critical path of backward (nothing downstream consumes them before the
 # optimiser / gradient all-reduce) and their kernels are latency-bound streams over dy and x, while the
@@ -197,7 +222,8 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
         CALL_LOG.append(("fwd", M, N, K))
     nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
     ws = _ws(nb, x.device) if nb else None
-    call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed), ws, nb)
+    with _Timed(("fwd", M, N, K)):
+        call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed), ws, nb)
     return y, pre
 
 
@@ -209,7 +235,8 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
         CALL_LOG.append(("dgrad", M, N, K))
     nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
     ws = _ws(nb, dy.device) if nb else None
-    call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed), ws, nb)
+    with _Timed(("dgrad", M, N, K)):
+        call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed), ws, nb)
     return dx
 
 
@@ -224,7 +251,8 @@ def linear_wgrad(dy, x, need_bias=True):
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
     with _OnSide(dy, x):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
-        call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
+        with _Timed(("wgrad", M, N, K)):
+            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
     return dw, db
 
 
