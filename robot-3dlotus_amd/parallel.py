@@ -151,12 +151,24 @@ class GradReducer:
         self._keep = []
 
 
+_BN_GROUP = None
+
+
 def enable_sync_batchnorm(group=None):
     """SyncBatchNorm semantics: batch statistics over the points of ALL ranks.  One fused message
-    per BN layer and direction: (sum, sumsq | sum dz, sum dz*xhat) + count, in fp64."""
+    per BN layer and direction: (sum, sumsq | sum dz, sum dz*xhat) + count, in fp64.
+
+    The statistics travel on their OWN communicator (collective call: every rank must enter): the messages are on the
+    critical path of forward and backward, and on the communicator of the gradient buckets they would queue behind a
+    32+ MB all-reduce that is itself waiting for lagging weight gradients."""
+    global _BN_GROUP
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         ops.BnState.reduce = None
         return
+    if group is None:
+        if _BN_GROUP is None:
+            _BN_GROUP = dist.new_group(backend=dist.get_backend())
+        group = _BN_GROUP
 
     def reduce(sums):
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # in place, no host sync
