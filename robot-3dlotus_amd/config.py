@@ -142,14 +142,19 @@ MP_OVERRIDES = [
 MP_TINY_OVERRIDES = MP_OVERRIDES + TINY_OVERRIDES[len(V1_OVERRIDES):]
 
 
+# job_scripts/train_3dlotus_policy_peract.sh:55-75: the v1 model; `txt_reduce attn` is set but SimplePolicyPTV3CA ignores it
+PERACT_OVERRIDES = V1_OVERRIDES + ["action_config.txt_reduce", "attn"]
+
+
 def preset(name="v1"):
-    """'v1' / 'tiny': 3D-LOTUS policy; 'mp' / 'mp_tiny': 3D-LOTUS++ motion planner (BASELINE configs[3])."""
+    """'v1' / 'tiny': 3D-LOTUS policy; 'peract': the RLBench-18task (PerAct) variant of BASELINE configs[4] (same network;
+    its bf16 compute mode is ops.set_gemm_precision("bf16")); 'mp' / 'mp_tiny': 3D-LOTUS++ motion planner (configs[3])."""
     if name in ("mp", "mp_tiny"):
         model = copy.deepcopy(_YAML_MODEL)
         model["model_class"] = _YAML_MP_DELTA["model_class"]
         model["action_config"].update(_YAML_MP_DELTA["action_config"])
         return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES}[name]))
-    return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES}[name])
+    return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES, "peract": PERACT_OVERRIDES}[name])
 
 
 def plain(cfg):

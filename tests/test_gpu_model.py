@@ -127,6 +127,36 @@ def test_gemm_precision_modes_against_golden(mode, tol):
     print(f"{mode}: logit errors {errs}, worst gradient-norm deviation {worst:.2e}")
 
 
+def test_peract_config_bf16_mode_dense_clouds():
+    """BASELINE configs[4] as a parity case: PerAct preset (the v1 network), dense 4096-point clouds, bf16 operand mode
+    of the dense / sparse-convolution / attention products, against the fp32 oracle at a bf16-sized bound; the exact
+    mode on the same inputs stays inside the 1e-4 bar."""
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("peract")
+    sd = seeded_state_dict(gu.state_template(cfg), 91, "scaled")
+    batch = synth.synth_batch(2, 4096, ragged=False, seed=321)
+    assert batch["npoints_in_batch"] == [4096, 4096]
+    perms = [[3, 1, 0, 2], [0, 2, 1, 3], [1, 0, 3, 2], [2, 3, 1, 0], [0, 1, 2, 3]]
+    with torch.no_grad():
+        ref = Oracle({k: v.clone() for k, v in sd.items()}, lcfg.plain(cfg), training=False).forward(batch, perms)["xt"].numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    errs = {}
+    for mode in ("fp32", "bf16"):
+        ops.set_gemm_precision(mode)
+        try:
+            m = _build(cfg, sd, False)
+            m.ptv3_model.order_perms = perms
+            with torch.no_grad():
+                m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+            errs[mode] = float(np.abs(m.last_pred[0].cpu().numpy() - ref).max()) / scale
+        finally:
+            ops.set_gemm_precision("fp32")
+    assert errs["fp32"] <= LOGIT_TOL and errs["bf16"] <= 3e-2, errs
+
+
 def test_full_size_train_step_properties():
     """BASELINE configs[1] size (16 x 4096, v1): forward+backward runs, everything finite, every
     parameter receives a gradient, eval-mode API returns f64[B, 8] like the reference."""
