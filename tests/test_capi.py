@@ -29,6 +29,21 @@ def test_library_exports_every_declared_symbol(built):
     assert L.last_error() == ""
 
 
+def test_trampoline_module_covers_the_header(built):
+    """csrc/_lotus_fastcall.so (generated from the header) exposes one METH_FASTCALL function per prototype, argument
+    conversion included: pointers accept int | None | objects with data_ptr(), wrong arity raises TypeError."""
+    F = _capi.fastcall()
+    assert F is not None
+    protos = _capi.parse_header()
+    assert all(callable(getattr(F, n, None)) for n in protos), [n for n in protos if not hasattr(F, n)]
+    assert F.lotus_abi_version() == 1 and F.lotus_last_error() == ""
+    assert F.lotus_linear_wgrad_workspace(65536, 256, 64) == _capi.lib().fn["lotus_linear_wgrad_workspace"](65536, 256, 64)
+    with pytest.raises(TypeError):
+        F.lotus_add(None, None)
+    t = torch.zeros(8)
+    assert F.lotus_add(t, t, None, 8, 0) < 0 and "lotus_add" in F.lotus_last_error()      # argument check, no launch
+
+
 def test_header_cites_reference_for_every_entry():
     src = open(_capi.HEADER_PATH).read()
     assert "model.py" in src and "model_ca.py" in src and "simple_policy_ptv3.py" in src
