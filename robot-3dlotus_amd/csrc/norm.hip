@@ -101,15 +101,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
     const int row = row0 + rslot;
     const bool valid = row < p.M;
     const float mean = valid ? p.mean[row] : 0.f, rstd = valid ? p.rstd[row] : 0.f;
-    float4 xh[4], g[4];
+    float4 xh[4], g[4], av[4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int q = l + j * p.LPR;
-      xh[j] = g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      xh[j] = g[j] = av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid && j < p.NV && q < c4) {
         const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
         const float4 dv = reinterpret_cast<const float4*>(p.dy + (long)row * p.C)[q];
+        if (p.add) av[j] = reinterpret_cast<const float4*>(p.add + (long)row * p.C)[q];  // in flight with x / dy
         const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
         xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         pg[j].x += dv.x * xh[j].x; pg[j].y += dv.y * xh[j].y; pg[j].z += dv.z * xh[j].z; pg[j].w += dv.w * xh[j].w;
@@ -130,10 +131,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
         o.y = rstd * (g[j].y - s1 - xh[j].y * s2);
         o.z = rstd * (g[j].z - s1 - xh[j].z * s2);
         o.w = rstd * (g[j].w - s1 - xh[j].w * s2);
-        if (p.add) {
-          const float4 a = reinterpret_cast<const float4*>(p.add + (long)row * p.C)[q];
-          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
-        }
+        o.x += av[j].x; o.y += av[j].y; o.z += av[j].z; o.w += av[j].w;
         reinterpret_cast<float4*>(p.dx + (long)row * p.C)[q] = o;
       }
     }
