@@ -239,7 +239,50 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
         gm = reinterpret_cast<const float4*>(p.gamma)[q];
         bt = reinterpret_cast<const float4*>(p.beta)[q];
       }
-      for (int row = blockIdx.x * rslots + rslot; row < p.M; row += gridDim.x * rslots) {
+      const int stride = gridDim.x * rslots;
+      int row = blockIdx.x * rslots + rslot;
+      if (!p.dy) {
+        // forward statistics: four independent row loads in flight per thread (one load per iteration left the
+        // kernel latency-bound at 0.24 TB/s); the accumulation order per thread is unchanged
+        for (; row + 3 * stride < p.M; row += 4 * stride) {
+          float4 xv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xv[u] = reinterpret_cast<const float4*>(p.x + (long)(row + u * stride) * p.C)[q];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s0[e] += xs[e];
+              s1[e] += (double)xs[e] * xs[e];
+            }
+          }
+        }
+      }
+      if (p.dy) {  // backward statistics: two rows (four loads) in flight per thread
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+        const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+        for (; row + stride < p.M; row += 2 * stride) {
+          float4 xv[2], dv[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            xv[u] = reinterpret_cast<const float4*>(p.x + (long)(row + u * stride) * p.C)[q];
+            dv[u] = reinterpret_cast<const float4*>(p.dy + (long)(row + u * stride) * p.C)[q];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w}, ds[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xh = (xs[e] - m4[e]) * i4[e];
+              const float dz = ds[e] * act_grad_f(xh * g4[e] + b4[e], p.act);
+              s0[e] += dz;
+              s1[e] += (double)dz * xh;
+            }
+          }
+        }
+      }
+      for (; row < p.M; row += stride) {
         const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         if (!p.dy) {
