@@ -384,37 +384,53 @@ struct BnApplyP {
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
   const int c4 = p.C / 4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.total4; i += (long)gridDim.x * 256) {
-    const int q = (int)(i % c4);
-    const float4 xv = reinterpret_cast<const float4*>(p.x)[i];
+  // The launch makes gridDim.x * 256 a multiple of c4, so a thread keeps ONE column quad for its whole grid-stride
+  // walk: the per-column constants (incl. the two fp64 divisions of the backward) are loaded / computed once, and the
+  // walk keeps two row loads in flight.
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
+  if (i0 < p.total4) {
+    const int q = (int)(i0 % c4);
     const float4 mu = reinterpret_cast<const float4*>(p.mean)[q];
     const float4 is = reinterpret_cast<const float4*>(p.invstd)[q];
     const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
     const float4 bt = reinterpret_cast<const float4*>(p.beta)[q];
-    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, m4[4] = {mu.x, mu.y, mu.z, mu.w};
-    const float i4[4] = {is.x, is.y, is.z, is.w}, g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
-    float o[4];
-    if (!p.dy) {
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+    const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
+    float mdz[4] = {0.f, 0.f, 0.f, 0.f}, mdx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.dy && p.sums) {
+      const double count = p.sums[2 * p.C];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = act_f((xs[e] - m4[e]) * i4[e] * g4[e] + b4[e], p.act);
-    } else {
-      const float4 dv = reinterpret_cast<const float4*>(p.dy)[i];
-      const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
+      for (int e = 0; e < 4; ++e) {
+        mdz[e] = (float)(p.sums[q * 4 + e] / count);
+        mdx[e] = (float)(p.sums[p.C + q * 4 + e] / count);
+      }
+    }
+    auto one = [&](const float4 xv, const float4 dv) {
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+      float o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float xh = (xs[e] - m4[e]) * i4[e];
-        const float dz = ds[e] * act_grad_f(xh * g4[e] + b4[e], p.act);
-        if (p.sums) {
-          const double count = p.sums[2 * p.C];
-          const float mdz = (float)(p.sums[q * 4 + e] / count);
-          const float mdx = (float)(p.sums[p.C + q * 4 + e] / count);
-          o[e] = g4[e] * i4[e] * (dz - mdz - xh * mdx);
+        if (!p.dy) {
+          o[e] = act_f(xh * g4[e] + b4[e], p.act);
         } else {
-          o[e] = g4[e] * i4[e] * dz;
+          const float dz = ds[e] * act_grad_f(xh * g4[e] + b4[e], p.act);
+          o[e] = p.sums ? g4[e] * i4[e] * (dz - mdz[e] - xh * mdx[e]) : g4[e] * i4[e] * dz;
         }
       }
+      return make_float4(o[0], o[1], o[2], o[3]);
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    long i = i0;
+    for (; i + step < p.total4; i += 2 * step) {
+      const float4 xa = reinterpret_cast<const float4*>(p.x)[i], xb = reinterpret_cast<const float4*>(p.x)[i + step];
+      const float4 da = p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4;
+      const float4 db = p.dy ? reinterpret_cast<const float4*>(p.dy)[i + step] : z4;
+      reinterpret_cast<float4*>(p.y)[i] = one(xa, da);
+      reinterpret_cast<float4*>(p.y)[i + step] = one(xb, db);
     }
-    reinterpret_cast<float4*>(p.y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (i < p.total4)
+      reinterpret_cast<float4*>(p.y)[i] = one(reinterpret_cast<const float4*>(p.x)[i], p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4);
   }
   if (p.dy && p.dgamma && blockIdx.x == 0) {
     for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -423,6 +439,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
       p.dbeta[c] = p.accumulate ? p.dbeta[c] + db : db;
     }
   }
+}
+
+// grid of bn_apply_kernel: ~2 float4 per thread, at most 4096 blocks, and gridDim.x * 256 a multiple of C / 4 (a thread
+// then stays on one column quad)
+static int bn_apply_grid(long total4, int C) {
+  const int c4 = C / 4;
+  int a = 256, b = c4;
+  while (b) { const int t = a % b; a = b; b = t; }   // a = gcd(256, c4)
+  const int unit = c4 / a;                             // blocks per column period
+  long g = (total4 + 511) / 512;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  g = (g + unit - 1) / unit * unit;
+  return (int)g;
 }
 
 static int bn_grid(int M, int C) {
@@ -547,8 +577,7 @@ int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd
   memset(&p, 0, sizeof(p));
   p.x = x; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.y = y;
   p.total4 = (long)M * C / 4; p.C = C; p.act = act;
-  int grid = cdiv(p.total4, 256 * 4);
-  if (grid > 2048) grid = 2048;
+  const int grid = bn_apply_grid(p.total4, C);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_apply");
   return LOTUS_OK;
@@ -584,8 +613,7 @@ int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean
   p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.sums = sums; p.y = dx; p.dgamma = dgamma; p.dbeta = dbeta;
   p.total4 = (long)M * C / 4; p.C = C; p.act = act; p.accumulate = accumulate;
-  int grid = cdiv(p.total4 > 0 ? p.total4 : 1, 256 * 4);
-  if (grid > 2048) grid = 2048;
+  const int grid = bn_apply_grid(p.total4, C);
   hipStream_t st = (hipStream_t)stream;
   if (!train) {
     // eval: dx = gamma * invstd * dz ; dgamma/dbeta still come from sums
