@@ -86,6 +86,7 @@ class GradReducer:
             self._bparams.append(cur_p)
             self._bviews.append(cur_v)
         self._pending = [0] * len(self.buckets)
+        self._flushed = [False] * len(self.buckets)
         self._count = [len(ps) for ps in self._bparams]
 
     def _hook(self, p):
@@ -96,8 +97,12 @@ class GradReducer:
         if self._pending[b] == self._count[b]:
             self._flush(b)
 
-    def _flush(self, b):
+    def _flush(self, b, partial=False):
         ps, views = self._bparams[b], self._bviews[b]
+        if partial:  # finish(): parameters of this bucket that received no gradient in this pass are skipped
+            keep = [i for i, p in enumerate(ps) if p.grad is not None]
+            ps, views = [ps[i] for i in keep], [views[i] for i in keep]
+        self._flushed[b] = True
         grads = [p.grad for p in ps]
         lo, hi = self.buckets[b]
         buf = self.flat[lo:hi]
@@ -133,16 +138,21 @@ class GradReducer:
         for p in self.params:
             p.grad = None
         self._pending = [0] * len(self.buckets)
+        self._flushed = [False] * len(self.buckets)
         if self._learning and self._arrival:
             # first backward seen: re-lay the flat buffer in arrival order (every rank observes the same order: it is
-            # a property of the autograd graph); parameters that got no gradient keep their relative order at the end
-            seen = set(self._arrival)
-            self._layout(self._arrival + [p for p in reversed(self.params) if p not in seen])
+            # a property of the autograd graph).  Parameters that received no gradient (modules a model builds but
+            # never uses, e.g. the motion planner's txt_attn_fc) are left out: their .grad stays None, as under the
+            # reference's DistributedDataParallel(find_unused_parameters=True)
+            self._layout(self._arrival)
             self._arrival, self._learning = [], False
 
     def finish(self):
         """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser).  Afterwards
         every `.grad` is a view into the flat, rank-averaged buffer."""
+        for b in range(len(self.buckets)):  # buckets some of whose parameters got no gradient in this pass
+            if not self._flushed[b] and self._pending[b] > 0:
+                self._flush(b, partial=True)
         for h in self._handles:
             h.wait()
         self._handles = []

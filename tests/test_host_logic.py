@@ -100,6 +100,37 @@ def _reducer_worker(rank, world, port, q):
     # the bucket order was re-learnt from the first backward: gradients of the LAST layer arrive first
     ok = ok and (not red._learning) and red._bparams[0][0] in set(net[3].parameters())
     ok = ok and sorted(id(p) for ps in red._bparams for p in ps) == sorted(id(p) for p in net.parameters())
+    # a module with a parameter that never receives a gradient (DDP's find_unused_parameters case): the used
+    # parameters are still averaged — in the learning pass (partial flush at finish()) and afterwards
+    class Net2(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.unused, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 1), torch.nn.Linear(4, 2)
+
+        def forward(self, x):
+            return self.b(torch.relu(self.a(x)))
+
+    torch.manual_seed(0)
+    n2 = Net2()
+    red2 = parallel.GradReducer(n2, bucket_mb=10.0)   # one bucket holding used and unused parameters
+    for step in range(2):
+        red2.zero_grad()
+        g = torch.Generator().manual_seed(500 + rank + 7 * step)
+        n2(torch.randn(3, 4, generator=g)).square().sum().backward()
+        red2.finish()
+        loc = torch.cat([p.grad.flatten() for p in (n2.a.weight, n2.a.bias, n2.b.weight, n2.b.bias)])
+        gathered = [torch.zeros_like(loc) for _ in range(world)]
+        dist.all_gather(gathered, loc)
+        ok = ok and all(torch.allclose(gathered[0], t_, atol=1e-7) for t_ in gathered) and n2.unused.weight.grad is None
+    torch.manual_seed(0)
+    ref2, acc2 = Net2(), None
+    for rr in range(world):
+        ref2.zero_grad()
+        g = torch.Generator().manual_seed(500 + rr + 7)
+        ref2(torch.randn(3, 4, generator=g)).square().sum().backward()
+        v = torch.cat([p.grad.flatten() for p in (ref2.a.weight, ref2.a.bias, ref2.b.weight, ref2.b.bias)])
+        acc2 = v if acc2 is None else acc2 + v
+    ok = ok and torch.allclose(loc, acc2 / world, atol=1e-6)
     # SyncBN statistics hook: (sum, sumsq, count) vector is summed in place
     parallel.enable_sync_batchnorm()
     from robot_3dlotus_amd import ops
