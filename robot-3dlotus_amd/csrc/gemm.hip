@@ -602,7 +602,7 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   }
   if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
     // bf16 / bf16x3 operand path (forward and input-gradient products)
-    const bool big = tile == 1 || (tile == 0 && !small_n && blocks128 * nz >= 512);
+    const bool big = tile == 1;  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
     dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if (g_prec == 1) {
       if (big) hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 1>), g128, block, 0, st, p);
@@ -614,9 +614,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
     return LOTUS_OK;
   }
-  // measured (tools/gemm_sweep.py): 128x128 tiles only pay with >= 4 blocks per CU; otherwise 64x64 tiles
-  // (more blocks in flight) win, including the N <= 64 layers and every split-K weight gradient
-  if (tile == 0) tile = (!small_n && !SUM_A && blocks128 * nz >= 1024) ? 1 : 3;
+  // In isolation 128x128 tiles win once there are >= 4 blocks per CU, but inside the training step — with the
+  // weight-gradient stream sharing the CUs — 64x64 tiles are better or equal at every batch size measured
+  // (16 clouds: 820 vs 806 samples/s; 32: 945 vs 920; 64: 1051 vs 1032; 128: equal), so 128x128 is opt-in only
+  if (tile == 0) tile = 3;
+  (void)blocks128; (void)small_n;
   if (tile == 1) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
     hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
