@@ -17,6 +17,20 @@ pytestmark = pytest.mark.gpu
 
 
 def _worker(rank, world, port, q):
+    try:
+        import faulthandler
+        os.makedirs("gpurun_out", exist_ok=True)
+        _fh = open(f"gpurun_out/parallel_worker_{rank}.trace", "w")
+        faulthandler.dump_traceback_later(120, file=_fh, exit=False)   # where is a stuck worker? (diagnostic)
+        _worker_body(rank, world, port, q)
+        faulthandler.cancel_dump_traceback_later()
+    except BaseException as e:  # report instead of leaving the parent to time out
+        import traceback
+        q.put((rank, {"error": f"{type(e).__name__}: {e}\n{traceback.format_exc()}"}))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK="0", LOTUS_DIST_BACKEND="gloo")
     import sys
@@ -89,17 +103,37 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_on_device():
+def _run_two_ranks(port):
+    import queue
+
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 1000)
     ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in ps:
         p.start()
-    out = dict(q.get(timeout=300) for _ in ps)
+    try:
+        out = dict(q.get(timeout=180) for _ in ps)
+    except queue.Empty:
+        out = None
     for p in ps:
-        p.join(timeout=60)
+        p.join(timeout=5 if out is None else 60)
+        if p.is_alive():
+            p.kill()
+    return out
+
+
+def test_two_rank_data_parallel_on_device():
+    # a stuck rendezvous / transport (seen once in ~25 runs on a shared box, never reproduced) gets ONE retry on a fresh
+    # port; wrong numbers never do
+    out = _run_two_ranks(29600 + (os.getpid() % 1000))
+    if out is None:
+        out = _run_two_ranks(31600 + (os.getpid() % 1000))
+    if out is None:
+        traces = "".join(open(f).read() for f in ("gpurun_out/parallel_worker_0.trace", "gpurun_out/parallel_worker_1.trace")
+                         if os.path.exists(f))
+        pytest.fail("two-rank workers did not finish within the time limit (twice)\n" + traces[-4000:])
     for r, res in out.items():
+        assert "error" not in res, res["error"]
         assert res["finite"]
         assert res["replicated_rel_err"] < 1e-5, res
         assert res["replicated_rv_err"] < 1e-6, res
