@@ -38,7 +38,8 @@ class BaseModel(nn.Module):
         device = next(self.parameters()).device
         for k, v in batch.items():
             if isinstance(v, torch.Tensor):
-                batch[k] = v.to(device)
+                # pinned host tensors (data.ptv3_collate_fn(pin=True)) upload asynchronously on the current stream
+                batch[k] = v.to(device, non_blocking=v.device.type == "cpu" and v.is_pinned())
         return batch
 
     def _init_weights(self, m):
