@@ -1,6 +1,11 @@
 """bench.py — keystep-samples/sec (train fwd+bwd) of the 3D-LOTUS v1 policy on N MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process is
+one rank; started bare, `--gpus N` re-executes itself through `python -m torch.distributed.run --nproc-per-node N`
+on 127.0.0.1 and rank 0 prints the JSON line.  Ranks talk over RCCL (backend "nccl"); when fewer than N devices are
+visible the ranks share devices and fall back to gloo (a functional check only: `rccl_ranks` in the JSON says which).
 
 One "step" = forward + loss + backward (+ gradient all-reduce when N > 1) of the v1 model over one
 synthetic GemBench-shape batch of 16 key-step clouds x 4096 points per GPU (BASELINE.json
@@ -118,6 +123,23 @@ def cpu_baseline(timeout_s=150):
                 "sample": f"oracle did not finish 4 x (8 clouds x 4096 pts) within {timeout_s} s on this host"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script through torch.distributed.run
+    (env:// rendezvous on 127.0.0.1, the semantics of genrobo3d/train/utils/distributed.py:67-81) and pass the
+    JSON line of rank 0 through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,8 +171,15 @@ def main():
     from robot_3dlotus_amd import config as lcfg, ops, parallel, synth
     from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.gpus > 1 and torch.cuda.device_count() < args.gpus and "LOTUS_DIST_BACKEND" not in os.environ:
+        os.environ["LOTUS_DIST_BACKEND"] = "gloo"  # ranks share a device: RCCL needs one device per rank
     rank, local, world = parallel.init_distributed()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, "
+                         f"or start bench.py bare and let it spawn its ranks)")
+    rccl_ranks = world if (world > 1 and dist.get_backend() == "nccl") else 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -193,10 +222,10 @@ def main():
         if reducer is not None:
             reducer.finish()
         if opt is not None:
+            gstep[0] += 1
             loptim.set_lr(opt, init_lrs, gstep[0], topts)
             opt.clip_grad_norm_(topts.grad_norm)
             opt.step()
-            gstep[0] += 1
         return losses
 
     # the step runs on a high-priority stream: the weight-gradient and front-end side streams then only fill
@@ -268,10 +297,11 @@ def main():
             "metric": "keystep-samples/sec (train fwd+bwd) 3D-LOTUS GemBench", "value": round(value, 2),
             "unit": "keystep-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": f"3D-LOTUS v1 (68.18M params), {args.batch} key-step clouds x {args.npoints} pts "
                                    f"per GPU, fwd+loss+bwd, train mode (dropout on), fp32 exact (MFMA f32)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
+                       "dist_backend": dist.get_backend() if world > 1 else None,
                        "model_gflop_per_sample": GFLOP_PER_SAMPLE,
                        "model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 2)},
         }

@@ -69,6 +69,25 @@ _END_CB_PENDING = False
 
 
 _PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 3}
+_M64 = (1 << 64) - 1
+
+
+def mix_seed(seed, k=0):
+    """splitmix64 finaliser of (seed, k): a well-mixed 64-bit sub-seed.  The device mask hash adds the low word of the
+    seed to index * odd constant and XORs the high word in before its own finaliser (csrc/common.h lotus_hash32), so seeds
+    that differ by small integers would give index-shifted copies of one stream; every dropout site therefore gets
+    its seed through this function (layer, use site, step and rank all enter as `k` of a nested call)."""
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(k) + 1)) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def dist_rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank()
+    return int(os.environ.get("RANK", "0"))
 
 
 def set_gemm_precision(mode):
@@ -526,7 +545,7 @@ class FfnFn(torch.autograd.Function):
     def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed):
         n, mean, rstd = ln_fwd(x, g, b)
         a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
-        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=seed + 1)
+        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
         ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         ctx.drop = (drop_p, seed)
         return y
@@ -536,7 +555,7 @@ class FfnFn(torch.autograd.Function):
         x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
         p, seed = ctx.drop
         dy = dy.contiguous()
-        dz2 = dropout(dy, p, seed + 1)
+        dz2 = dropout(dy, p, mix_seed(seed, 1))
         dw2, db2 = linear_wgrad(dz2, a)
         dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
         dw1, db1 = linear_wgrad(dh, n)
@@ -557,7 +576,7 @@ class SelfAttnFn(torch.autograd.Function):
         att = torch.empty(N, C, dtype=torch.float32, device=x.device)
         lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
         attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
-                      lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, seed + 1)
+                      lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, mix_seed(seed, 1))
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
@@ -578,7 +597,7 @@ class SelfAttnFn(torch.autograd.Function):
         extra = torch.empty(max(lvl.n_extra, 1), 2 * C, dtype=torch.float32, device=x.device)
         gq, bq, gk, bk = attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner,
                                        lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, (qnw, qnb), (knw, knb), att,
-                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, attn_p, seed + 1,
+                                       datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, attn_p, mix_seed(seed, 1),
                                        lvl.kext, lvl.ext_pos, lvl.n_extra, extra)
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
         dn = linear_dgrad(dqkv, wqkv)
@@ -599,7 +618,7 @@ class CrossAttnFn(torch.autograd.Function):
         att = torch.empty(N, C, dtype=torch.float32, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
-                      att, lse, H, d, attn_p, seed + 1)
+                      att, lse, H, d, attn_p, mix_seed(seed, 1))
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
@@ -620,7 +639,7 @@ class CrossAttnFn(torch.autograd.Function):
         dkv_part = torch.empty(G, L, 2 * C, dtype=torch.float32, device=dev)
         gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
                                          lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
-                                         2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, seed + 1)
+                                         2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1))
         dkv = dkv_part[0] if G == 1 else dkv_part.sum(0)
         dwkv, dbkv = linear_wgrad(dkv, context)
         dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
@@ -745,7 +764,7 @@ class HeadLossFn(torch.autograd.Function):
         pc = torch.empty(B, C, dtype=torch.float32, device=dev)
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
         call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg)
-        a, apre = linear_fwd(pc, aw0, ab0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=seed + 1)
+        a, apre = linear_fwd(pc, aw0, ab0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=mix_seed(seed, 1))
         ae, _ = linear_fwd(a, aw3, ab3)
         losses = torch.zeros(4, dtype=torch.float32, device=dev)
         nb = xt.shape[1] // 3
@@ -775,7 +794,7 @@ class HeadLossFn(torch.autograd.Function):
              dxt, dae_o)
         # action branch (B rows)
         daw3, dab3 = linear_wgrad(dae_o, a)
-        dapre = linear_dgrad(dae_o, aw3, pre=apre, act=ACT_LEAKY, drop_p=p, seed=seed + 1)
+        dapre = linear_dgrad(dae_o, aw3, pre=apre, act=ACT_LEAKY, drop_p=p, seed=mix_seed(seed, 1))
         daw0, dab0 = linear_wgrad(dapre, pc)
         dpc = linear_dgrad(dapre, aw0)
         # heatmap branch (N rows)

@@ -53,14 +53,12 @@ def set_lr(optimizer, init_lrs, global_step, opts):
 
 class AdamW(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
-        if lr < 0.0:
-            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
-        if not 0.0 <= betas[0] < 1.0:
-            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
-        if not 0.0 <= betas[1] < 1.0:
-            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
-        if not 0.0 <= eps:
-            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        # same admissible ranges as the reference class (adamw.py:40-47)
+        b1, b2 = (float(b) for b in betas)
+        for name, value, ok in (("learning rate", lr, lr >= 0.0), ("beta1", b1, 0.0 <= b1 < 1.0),
+                                ("beta2", b2, 0.0 <= b2 < 1.0), ("epsilon", eps, eps >= 0.0)):
+            if not ok:
+                raise ValueError(f"AdamW: {name} = {value} is outside its admissible range")
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, correct_bias=correct_bias)
         super().__init__(params, defaults)
         self._tables = None
@@ -167,23 +165,24 @@ class AdamW(torch.optim.Optimizer):
 
 
 def build_optimizer(model, opts):
-    """misc.py:13-55 for `optim: 'adamw'`: two groups per parameter family, selected by substring match on the name."""
-    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
-    rgb, other = {}, {}
-    for n, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        (rgb if "rgb_encoder" in n else other)[n] = p
-    groups, init_lrs = [], []
-    for ptype, pdict in (("rgb", rgb), ("others", other)):
-        if not pdict:
-            continue
-        init_lr = opts.learning_rate * (getattr(opts, "rgb_encoder_lr_multi", 1) if ptype == "rgb" else 1)
-        groups.extend([
-            {"params": [p for n, p in pdict.items() if not any(nd in n for nd in no_decay)], "weight_decay": opts.weight_decay,
-             "lr": init_lr},
-            {"params": [p for n, p in pdict.items() if any(nd in n for nd in no_decay)], "weight_decay": 0.0, "lr": init_lr}])
-        init_lrs.extend([init_lr] * 2)
+    """Parameter groups of misc.py:13-55 for `optim: 'adamw'`: per family (`rgb_encoder` parameters with their learning-rate
+    multiplier, everything else) one group with weight decay and one without.  A parameter is exempt from decay when its
+    NAME contains 'bias', 'LayerNorm.bias' or 'LayerNorm.weight' — in this model that is every `*.bias` and nothing
+    else, because the norm layers are called norm1.0 / cpe.2.  -> (optimizer, init_lrs)"""
     if getattr(opts, "optim", "adamw") != "adamw":
         raise NotImplementedError("only the optimiser the published configs select ('adamw') is built")
+    exempt_tags = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+    families = {"rgb": [], "others": []}
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            families["rgb" if "rgb_encoder" in name else "others"].append((name, p))
+    groups, init_lrs = [], []
+    for fam, members in families.items():
+        if not members:
+            continue
+        lr = opts.learning_rate * (getattr(opts, "rgb_encoder_lr_multi", 1) if fam == "rgb" else 1)
+        exempt = [any(tag in name for tag in exempt_tags) for name, _ in members]
+        for want_exempt, wd in ((False, opts.weight_decay), (True, 0.0)):
+            groups.append({"params": [p for (_, p), e in zip(members, exempt) if e == want_exempt], "weight_decay": wd, "lr": lr})
+            init_lrs.append(lr)
     return AdamW(groups, lr=opts.learning_rate, betas=opts.betas), init_lrs

@@ -3,13 +3,14 @@
 The path shards by independent units (key-step clouds): each rank runs the whole model on its own
 clouds; the only exchanges are (1) the gradient all-reduce and (2) the BatchNorm statistics, as
 in the reference (DDP + SyncBatchNorm, genrobo3d/train/utils/distributed.py:196-205,
-train_simple_policy.py:116-117).  Design for xGMI (point-to-point links, no switch): gradients live
-in ONE flat fp32 buffer (parameters' .grad are views), cut into a few large buckets in reverse
-registration order (~ the order autograd finishes them: head -> decoder -> encoder -> stem); a
+train_simple_policy.py:116-117).  Design for xGMI (point-to-point links, no switch): gradients are
+packed into ONE flat fp32 buffer, cut into a few large buckets that follow the order in which
+backward finishes the gradients (learnt in the first pass, agreed across ranks by a broadcast); a
 bucket's all-reduce is launched asynchronously from the post-accumulate hook of its last gradient,
 so RCCL overlaps with the remaining backward.  Large buckets keep the collectives bandwidth-bound
 over all 7 links instead of latency-bound.
 """
+import contextlib
 import os
 
 import torch
@@ -43,9 +44,17 @@ class GradReducer:
     re-pointed at the slice views, and the slice is all-reduced asynchronously (RCCL) while backward continues.
 
     Bucket order = gradient ARRIVAL order.  It is learnt during the first backward pass (which starts from reverse
-    registration order) and the flat buffer is re-laid-out once: with the static order the text projection `txt_fc`
-    — whose gradient is complete only at the very end of backward because every cross-attention block feeds it —
-    sat in the first bucket and held 76 MB (28 % of all gradients) back until after backward."""
+    registration order), rank 0's order is broadcast, and the flat buffer is re-laid-out once: with the static order the
+    text projection `txt_fc` — whose gradient is complete only at the very end of backward because every
+    cross-attention block feeds it — sat in the first bucket and held 76 MB (28 % of all gradients) back until after
+    backward.  Parameters that got no gradient in the learning pass form a trailing "cold" bucket.
+
+    Protocol per optimisation step:  zero_grad();  [with no_sync(): backward of micro-batches 1..k-1];  backward of the
+    last micro-batch;  finish().  Every bucket is all-reduced exactly once per step on every rank — from its hook when
+    all its gradients arrived, else in finish() with the slots of gradient-less parameters zeroed — so ranks whose
+    parameter usage differs stay in lock-step (what DistributedDataParallel(find_unused_parameters=True) achieves with
+    its usage bitmap; the difference: a parameter no rank used ends with a zero gradient instead of None when
+    world > 1).  A backward that would add onto already averaged gradients raises instead of silently diverging."""
 
     def __init__(self, module, bucket_mb=32.0, group=None, broadcast=True):
         self.group = group
@@ -57,55 +66,99 @@ class GradReducer:
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self._cap = int(bucket_mb * (1 << 20) / 4)
-        self._layout(list(reversed(self.params)))
+        self._layout(list(reversed(self.params)), [])
         self._handles = []
         self._avg = self.world > 1 and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
-        self._arrival, self._learning = [], True
+        self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
+        self._sync = True
         for p in self.params:
             p.grad = None
             p.register_post_accumulate_grad_hook(self._hook)
 
-    def _layout(self, order):
-        """Contiguous buckets of >= cap elements over `order`; every parameter gets a view into the flat buffer."""
+    def _layout(self, order, cold):
+        """Contiguous buckets of >= cap elements over `order`, then one bucket with the `cold` parameters; every
+        parameter gets a view into the flat buffer."""
         self.buckets, self._bparams, self._bviews, self._slot = [], [], [], {}
-        cur_p, cur_v, cur_n, offset, start = [], [], 0, 0, 0
-        for p in order:
-            self._slot[p] = len(self.buckets)
-            cur_p.append(p)
-            cur_v.append(self.flat[offset:offset + p.numel()].view_as(p))
-            cur_n += p.numel()
-            offset += p.numel()
-            if cur_n >= self._cap:
-                self.buckets.append((start, offset))
-                self._bparams.append(cur_p)
-                self._bviews.append(cur_v)
-                cur_p, cur_v, cur_n, start = [], [], 0, offset
-        if cur_p:
-            self.buckets.append((start, offset))
-            self._bparams.append(cur_p)
-            self._bviews.append(cur_v)
+        state = dict(p=[], v=[], n=0, offset=0, start=0)
+
+        def close():
+            if state["p"]:
+                self.buckets.append((state["start"], state["offset"]))
+                self._bparams.append(state["p"])
+                self._bviews.append(state["v"])
+                state.update(p=[], v=[], n=0, start=state["offset"])
+
+        for group_, cap in ((order, self._cap), (cold, None)):
+            for p in group_:
+                self._slot[p] = len(self.buckets)
+                state["p"].append(p)
+                state["v"].append(self.flat[state["offset"]:state["offset"] + p.numel()].view_as(p))
+                state["n"] += p.numel()
+                state["offset"] += p.numel()
+                if cap is not None and state["n"] >= cap:
+                    close()
+            close()
+        self._count = [len(ps) for ps in self._bparams]
+        self._rearm()
+
+    def _rearm(self):
         self._pending = [0] * len(self.buckets)
         self._flushed = [False] * len(self.buckets)
-        self._count = [len(ps) for ps in self._bparams]
+        self._ready = [False] * len(self.buckets)
+        self._next = 0
 
     def _hook(self, p):
-        if self._learning:
-            self._arrival.append(p)
+        if not self._sync:
+            return  # no_sync(): gradients accumulate locally in whatever tensors autograd holds
         b = self._slot[p]
+        if self._flushed[b]:
+            raise RuntimeError(
+                "GradReducer: a gradient arrived for a bucket that was already averaged in this step — call "
+                "reducer.zero_grad() before every optimisation step and wrap all but the last micro-batch of a "
+                "gradient-accumulation step in `with reducer.no_sync():`")
+        if self._learning and p not in self._seen:
+            self._seen.add(p)
+            self._arrival.append(p)
         self._pending[b] += 1
         if self._pending[b] == self._count[b]:
-            self._flush(b)
+            # collectives are matched across ranks by issue order: buckets go out strictly in layout order (which IS the
+            # arrival order, so nothing waits unless a rank's usage pattern differs from the learnt one)
+            self._ready[b] = True
+            while self._next < len(self.buckets) and self._ready[self._next]:
+                self._flush(self._next)
+                self._next += 1
 
-    def _flush(self, b, partial=False):
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (gradient_accumulation_steps > 1 in the reference trainer): inside this context
+        backward only accumulates local gradients; the next backward outside of it packs the accumulated sums and
+        all-reduces them once.  Accumulating onto a parameter's gradient is a read of a tensor the weight-gradient
+        stream may still be writing, so the per-node join is required (ops.set_wgrad_join("node"), the default)."""
+        if ops._JOIN != "node":
+            raise RuntimeError("gradient accumulation needs ops.set_wgrad_join('node')")
+        self._sync = False
+        try:
+            yield
+        finally:
+            self._sync = True
+
+    def _flush(self, b):
         ps, views = self._bparams[b], self._bviews[b]
-        if partial:  # finish(): parameters of this bucket that received no gradient in this pass are skipped
-            keep = [i for i, p in enumerate(ps) if p.grad is not None]
-            ps, views = [ps[i] for i in keep], [views[i] for i in keep]
         self._flushed[b] = True
-        grads = [p.grad for p in ps]
+        have = [i for i, p in enumerate(ps) if p.grad is not None]
         lo, hi = self.buckets[b]
         buf = self.flat[lo:hi]
+        grads = [ps[i].grad for i in have]
+        dst = [views[i] for i in have]
+
+        def pack():
+            if len(have) < len(ps):  # finish(): gradient-less parameters contribute zeros to the average
+                buf.zero_()
+            if grads:
+                torch._foreach_copy_(dst, grads)
+            self._reduce(buf)
+
         if buf.is_cuda:
             # pack + all-reduce on a communication stream that waits for the producers (the stream backward runs on and
             # the weight-gradient stream): the critical stream itself never waits for the lagging weight gradients
@@ -115,16 +168,15 @@ class GradReducer:
             comm.wait_stream(torch.cuda.current_stream())
             ops.sync_side_stream(target=comm.cuda_stream)
             with torch.cuda.stream(comm):
-                torch._foreach_copy_(views, grads)
-                self._reduce(buf)
+                pack()
             # the adopted gradient tensors were allocated on the backward stream and are read on `comm`: keep them
             # alive until finish() has made the backward stream wait for `comm` (cheaper than 421 record_stream calls)
             self._keep.extend(grads)
         else:
-            torch._foreach_copy_(views, grads)
-            self._reduce(buf)
-        for p, v in zip(ps, views):
-            p.grad = v
+            pack()
+        for i, (p, v) in enumerate(zip(ps, views)):
+            if self.world > 1 or p.grad is not None:  # world == 1: an unused parameter keeps .grad None
+                p.grad = v
 
     def _reduce(self, buf):
         if self.world > 1:
@@ -137,22 +189,29 @@ class GradReducer:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
-        self._pending = [0] * len(self.buckets)
-        self._flushed = [False] * len(self.buckets)
         if self._learning and self._arrival:
-            # first backward seen: re-lay the flat buffer in arrival order (every rank observes the same order: it is
-            # a property of the autograd graph).  Parameters that received no gradient (modules a model builds but
-            # never uses, e.g. the motion planner's txt_attn_fc) are left out: their .grad stays None, as under the
-            # reference's DistributedDataParallel(find_unused_parameters=True)
-            self._layout(self._arrival)
-            self._arrival, self._learning = [], False
+            # first backward seen: re-lay the flat buffer in arrival order.  The order is a property of the autograd
+            # graph, but ranks whose first batches exercised different modules would disagree: rank 0 decides.
+            index = {p: i for i, p in enumerate(self.params)}
+            order = [index[p] for p in self._arrival]
+            if self.world > 1:
+                t = torch.full((len(self.params),), -1, dtype=torch.int64, device=self.flat.device)
+                t[:len(order)] = torch.tensor(order, dtype=torch.int64)
+                dist.broadcast(t, 0, group=self.group)
+                order = [i for i in t.tolist() if i >= 0]
+            hot = [self.params[i] for i in order]
+            hot_set = set(hot)
+            self._layout(hot, [p for p in self.params if p not in hot_set])
+            self._arrival, self._seen, self._learning = [], set(), False
+        self._rearm()
 
     def finish(self):
         """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser).  Afterwards
-        every `.grad` is a view into the flat, rank-averaged buffer."""
-        for b in range(len(self.buckets)):  # buckets some of whose parameters got no gradient in this pass
-            if not self._flushed[b] and self._pending[b] > 0:
-                self._flush(b, partial=True)
+        `.grad` of every parameter is a view into the flat, rank-averaged buffer."""
+        for b in range(self._next, len(self.buckets)):  # buckets some (or all) of whose parameters got no gradient
+            if not self._flushed[b] and (self.world > 1 or self._pending[b] > 0):
+                self._flush(b)
+        self._next = len(self.buckets)
         for h in self._handles:
             h.wait()
         self._handles = []

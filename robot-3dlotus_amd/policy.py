@@ -85,7 +85,6 @@ class SimplePolicyPTV3CA(BaseModel):
                                         config.ptv3_config.dec_channels[0], act.dim_actions, dropout=act.dropout,
                                         voxel_size=act.voxel_size, pos_bins=act.pos_bins)
         self.apply(self._init_weights)
-        self._step = 0
 
     # -- reference API ---------------------------------------------------------------------
     def prepare_ptv3_batch(self, batch):
@@ -134,7 +133,6 @@ class SimplePolicyPTV3CA(BaseModel):
             else:
                 tgt = dp if isinstance(dp, torch.Tensor) else torch.cat([t.reshape(-1) for t in dp]).to(dev)
                 tgt = tgt.float().contiguous()
-        self._step += 1
         hm, am = head.heatmap_mlp, head.action_mlp
         p = head.dropout if self.training else 0.0
         lc = self.config.loss_config
@@ -142,7 +140,7 @@ class SimplePolicyPTV3CA(BaseModel):
         losses, xt, ae = ops.HeadLossFn.apply(
             last.feat, hm[0].weight, hm[0].bias, hm[3].weight, hm[3].bias, am[0].weight, am[0].bias, am[3].weight,
             am[3].bias, lvl, tgt if with_loss else dummy, gt if gt is not None else dummy.view(1, 1),
-            float(lc.pos_weight), float(lc.rot_weight), p, (self._step << 24) + 7, with_loss)
+            float(lc.pos_weight), float(lc.rot_weight), p, ops.mix_seed(self.ptv3_model.last_seed, 1000), with_loss)
         nb = 2 * head.pos_bins
         pred_pos = xt.view(-1, 3, nb).permute(1, 0, 2)          # (3, N, 2*pos_bins) like the reference
         pred_rot = ae[:, :head.euler_bins * 3].view(B, head.euler_bins, 3)

@@ -82,7 +82,7 @@ class Block(nn.Module):
                                  drop_p, seed, attn_p)
         m, n2 = self.mlp[0], self.norm2[0]
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
-                               seed + 2)
+                               ops.mix_seed(seed, 2))
 
 
 class CABlock(nn.Module):
@@ -103,7 +103,7 @@ class CABlock(nn.Module):
                                   a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p)
         m, n2 = self.mlp[0], self.norm2[0]
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
-                               seed + 2)
+                               ops.mix_seed(seed, 2))
 
 
 class _Down(nn.Module):
@@ -140,10 +140,6 @@ class _Embedding(nn.Module):
 class PointDict(dict):
     """EasyDict stand-in for the reference's `_pack_point_dict` (model.py:1065-1070)."""
     __getattr__ = dict.__getitem__
-
-
-def _tick(bn, training):
-    """num_batches_tracked bookkeeping is batched: one fused launch per forward (see forward())."""
 
 
 class PointTransformerV3CA(nn.Module):
@@ -194,10 +190,47 @@ class PointTransformerV3CA(nn.Module):
             dec.add_module("block0", Block(dc[s], dec_num_head[s], mlp_ratio))
             dec.add_module("ca_block0", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
             self.dec.add_module(f"dec{s}", dec)
-        self._step = 0
+        self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
+        self._seed_base = None
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
         self._pending, self._fe_stream = None, None  # prefetch() state
         self._nbt = None
+        self._sync_bn_checked = False
+        self.register_load_state_dict_post_hook(lambda m, _keys: setattr(m, "_step", None))
+
+    def _apply(self, fn, *a, **kw):  # .to() / .cuda() replace the buffers: drop the cached handles
+        self._nbt = None
+        return super()._apply(fn, *a, **kw)
+
+    def _bn_counters(self):
+        """num_batches_tracked of every norm layer — BatchNorm1d, or SyncBatchNorm after convert_sync_batchnorm (not a
+        BatchNorm1d subclass)."""
+        if self._nbt is None:
+            self._nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        return self._nbt
+
+    def _seeds(self):
+        """Base seed of this forward's dropout masks.  Independent per rank (data-parallel ranks must not draw the
+        same masks: the reference's ATen / flash-attn Philox streams are seeded per rank, train_simple_policy.py:64-67)
+        and per optimisation step; the step is the stem BatchNorm's num_batches_tracked — a state_dict entry — so a
+        resumed run continues the mask stream instead of replaying it from step 1."""
+        if self._seed_base is None:
+            self._seed_base = ops.mix_seed(torch.initial_seed(), ops.dist_rank())
+        if self._step is None:
+            self._step = int(self.embedding.stem.norm.num_batches_tracked.item())  # one host sync, first forward only
+        self._step += 1
+        return ops.mix_seed(self._seed_base, self._step)
+
+    def _check_sync_bn(self):
+        """`nn.SyncBatchNorm.convert_sync_batchnorm(model)` (train_simple_policy.py:116-117) swaps the BatchNorm1d
+        containers for SyncBatchNorm: honour it — batch statistics over the points of ALL ranks — instead of
+        silently normalising per rank.  (Collective: every rank enters its first forward.)"""
+        self._sync_bn_checked = True
+        import torch.distributed as dist
+        if (ops.BnState.reduce is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules())):
+            from . import parallel
+            parallel.enable_sync_batchnorm()
 
     def _pack(self, feat, lvl):
         return PointDict(feat=feat, coord=lvl.coord, offset=lvl.off[1:].long(), level=lvl)
@@ -251,17 +284,19 @@ class PointTransformerV3CA(nn.Module):
             perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
             levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
         training = self.training
-        if training:  # BatchNorm1d.num_batches_tracked += 1 for every norm layer, one fused launch
-            if self._nbt is None:
-                self._nbt = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm1d)]
-            torch._foreach_add_(self._nbt, 1)
+        if not self._sync_bn_checked:
+            self._check_sync_bn()
         p = self.proj_drop if training else 0.0
         pa = self.attn_drop if training else 0.0
-        self._step += 1
-        seed = (self._step << 24)
+        base = self._seeds() if training else 0
+        self.last_seed = base  # the policy head derives its dropout seeds from the same (rank, step) stream
+        if training:  # num_batches_tracked += 1 for every norm layer (BatchNorm1d or SyncBatchNorm), one fused launch
+            nbt = self._bn_counters()
+            if nbt:
+                torch._foreach_add_(nbt, 1)
+        site = 0
 
         st = self.embedding.stem
-        _tick(st.norm, training)
         # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input
         # features are a linear code of something smaller, e.g. the motion planner's label embedding
         x = ops.StemFn.apply(feat, data_dict.get("stem_weight", st.conv.weight), st.norm.weight, st.norm.bias, st.norm.running_mean,
@@ -269,26 +304,25 @@ class PointTransformerV3CA(nn.Module):
         skips = []
         for s in range(self.num_stages):
             enc, lvl = self.enc[s], levels[s]
-            seed += 64
+            site += 1
+            seed = ops.mix_seed(base, site)
             if s > 0:
                 d, bn = enc.down, enc.down.norm[0]
-                _tick(bn, training)
                 x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      lvl, training)
             x = enc.block0.run(x, x, lvl, p, seed, pa)
-            x = enc.ca_block0.run(x, context, lvl, p, seed + 8, pa)
+            x = enc.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa)
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
             dec, lvl, child = self.dec[i], levels[s], levels[s + 1]
-            seed += 64
+            site += 1
+            seed = ops.mix_seed(base, site)
             u, us = dec.up.proj, dec.up.proj_skip
-            _tick(u[1], training)
-            _tick(us[1], training)
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
                                          us[1].running_mean, us[1].running_var, child, training)
             x = dec.block0.run(x, skip, lvl, p, seed, pa)
-            x = dec.ca_block0.run(x, context, lvl, p, seed + 8, pa)
+            x = dec.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa)
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]

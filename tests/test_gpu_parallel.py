@@ -139,3 +139,24 @@ def test_two_rank_data_parallel_on_device():
         assert res["replicated_rv_err"] < 1e-6, res
         assert res["cross_rank_diff"] == 0.0, res
         assert res["cross_rank_rv_diff"] == 0.0, res
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` started bare must spawn two ranks (torch.distributed.run on 127.0.0.1), run the
+    data-parallel step (GradReducer + SyncBN statistics; gloo here because both ranks share the one device of this
+    box) and print ONE JSON line from rank 0 (it used to assert on WORLD_SIZE)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--batch", "4", "--npoints", "1024", "--no-roofline", "--no-other-modes", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
+    assert out["rccl_ranks"] in (0, 2) and out["value"] > 0

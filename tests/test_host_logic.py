@@ -121,7 +121,9 @@ def _reducer_worker(rank, world, port, q):
         loc = torch.cat([p.grad.flatten() for p in (n2.a.weight, n2.a.bias, n2.b.weight, n2.b.bias)])
         gathered = [torch.zeros_like(loc) for _ in range(world)]
         dist.all_gather(gathered, loc)
-        ok = ok and all(torch.allclose(gathered[0], t_, atol=1e-7) for t_ in gathered) and n2.unused.weight.grad is None
+        ok = ok and all(torch.allclose(gathered[0], t_, atol=1e-7) for t_ in gathered)
+        # nobody used it: world > 1 leaves a zero gradient (every bucket is reduced on every rank, see GradReducer)
+        ok = ok and n2.unused.weight.grad is not None and float(n2.unused.weight.grad.abs().max()) == 0.0
     torch.manual_seed(0)
     ref2, acc2 = Net2(), None
     for rr in range(world):
@@ -131,13 +133,78 @@ def _reducer_worker(rank, world, port, q):
         v = torch.cat([p.grad.flatten() for p in (ref2.a.weight, ref2.a.bias, ref2.b.weight, ref2.b.bias)])
         acc2 = v if acc2 is None else acc2 + v
     ok = ok and torch.allclose(loc, acc2 / world, atol=1e-6)
+    checks = {"average_unused": bool(ok)}
+    # gradient accumulation: two micro-batches per step, the first under no_sync(); the result is the
+    # rank-average of the per-rank SUM over micro-batches, step after step
+    torch.manual_seed(0)
+    n3 = Net2()
+    red3 = parallel.GradReducer(n3, bucket_mb=0.00005)
+    used = (n3.a.weight, n3.a.bias, n3.b.weight, n3.b.bias)
+    okacc = True
+    for step in range(3):
+        red3.zero_grad()
+        xs = [torch.randn(3, 4, generator=torch.Generator().manual_seed(900 + rank + 7 * step + 31 * mb)) for mb in range(2)]
+        with red3.no_sync():
+            n3(xs[0]).square().sum().backward()
+        n3(xs[1]).square().sum().backward()
+        red3.finish()
+        got = torch.cat([p.grad.flatten() for p in used]).clone()
+        accr = None
+        for rr in range(world):
+            for mb in range(2):
+                ref2.zero_grad()
+                x = torch.randn(3, 4, generator=torch.Generator().manual_seed(900 + rr + 7 * step + 31 * mb))
+                ref2(x).square().sum().backward()
+                v = torch.cat([p.grad.flatten() for p in (ref2.a.weight, ref2.a.bias, ref2.b.weight, ref2.b.bias)])
+                accr = v if accr is None else accr + v
+        okacc = okacc and torch.allclose(got, accr / world, atol=1e-6)
+    checks["accumulation"] = bool(okacc)
+    # ... and a second backward without zero_grad() / no_sync() must raise instead of adding onto averaged gradients
+    try:
+        n3(xs[0]).square().sum().backward()
+        checks["misuse_raises"] = False
+    except RuntimeError as e:
+        checks["misuse_raises"] = "no_sync" in str(e)
+    red3.zero_grad()
+
+    # a conditionally used module: unused in the learning pass, later used on ONE rank only -> no KeyError,
+    # every rank ends with the same averaged gradient for it
+    class Net3(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.opt, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+
+        def forward(self, x, use):
+            h = torch.relu(self.a(x))
+            if use:
+                h = h + self.opt(h)
+            return self.b(h)
+
+    torch.manual_seed(0)
+    n4 = Net3()
+    red4 = parallel.GradReducer(n4, bucket_mb=0.00005)
+    okc = True
+    for step, use in enumerate([False, rank == 0, True]):
+        red4.zero_grad()
+        x = torch.randn(3, 4, generator=torch.Generator().manual_seed(40 + rank + step))
+        n4(x, use).square().sum().backward()
+        red4.finish()
+        loc = torch.cat([p.grad.flatten() for p in n4.parameters()])
+        gathered = [torch.zeros_like(loc) for _ in range(world)]
+        dist.all_gather(gathered, loc)
+        okc = okc and all(torch.equal(gathered[0], t_) for t_ in gathered)
+        if step == 1:
+            okc = okc and float(n4.opt.weight.grad.abs().max()) > 0.0  # rank 0's contribution / world
+    checks["conditional_usage"] = bool(okc)
+    ok = all(checks.values())
     # SyncBN statistics hook: (sum, sumsq, count) vector is summed in place
     parallel.enable_sync_batchnorm()
     from robot_3dlotus_amd import ops
     s = torch.tensor([1.0 + rank, 2.0, 10.0], dtype=torch.float64)
     ops.BnState.reduce(s)
     ok = ok and s.tolist() == [3.0, 4.0, 20.0]
-    q.put((rank, bool(ok)))
+    checks["syncbn_hook"] = s.tolist() == [3.0, 4.0, 20.0]
+    q.put((rank, bool(ok) and checks["syncbn_hook"], checks))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -166,4 +233,31 @@ def test_grad_reducer_world2_gloo():
     if res is None:  # stuck rendezvous (port in use on a shared box): one retry elsewhere
         res = _run_reducer_workers(33500 + (os.getpid() % 2000))
     assert res is not None, "gloo workers did not finish"
-    assert all(ok for _, ok in res), res
+    assert all(r[1] for r in res), res
+
+
+def test_survives_convert_sync_batchnorm():
+    """train_simple_policy.py:116-117 converts the model when world_size > 1: the BatchNorm containers become
+    SyncBatchNorm (not a BatchNorm1d subclass); parameter names, the state_dict and the counter bookkeeping must not
+    notice."""
+    from robot_3dlotus_amd import config as lcfg
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+
+    m = SimplePolicyPTV3CA(lcfg.preset("tiny"))
+    keys = list(m.state_dict().keys())
+    n_bn = len(m.ptv3_model._bn_counters())
+    assert n_bn == sum(k.endswith("num_batches_tracked") for k in keys) > 0
+    m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(SimplePolicyPTV3CA(lcfg.preset("tiny")))
+    assert list(m2.state_dict().keys()) == keys
+    assert any(isinstance(x, torch.nn.SyncBatchNorm) for x in m2.modules())
+    assert len(m2.ptv3_model._bn_counters()) == n_bn
+
+
+def test_dropout_seed_streams():
+    """Seeds of different ranks / steps / sites are unrelated 64-bit values (no small additive offsets)."""
+    from robot_3dlotus_amd import ops
+
+    seeds = {ops.mix_seed(ops.mix_seed(ops.mix_seed(1234, r), step), site) for r in range(4) for step in range(50) for site in range(12)}
+    assert len(seeds) == 4 * 50 * 12
+    lows = sorted(s & 0xFFFFFFFF for s in seeds)
+    assert min(b - a for a, b in zip(lows, lows[1:])) > 0 and len({s >> 32 for s in seeds}) == len(seeds)

@@ -73,7 +73,7 @@ def main():
         losses["total"].backward()
         if reducer is not None:
             reducer.finish()
-        loptim.set_lr(opt, init_lrs, step, topts)
+        loptim.set_lr(opt, init_lrs, step + 1, topts)  # global_step is incremented before scheduling (train_simple_policy.py:225-229)
         gn = opt.clip_grad_norm_(topts.grad_norm)
         opt.step()
         if rank == 0 and (step % 10 == 0 or step == args.steps - 1):
