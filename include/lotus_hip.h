@@ -41,11 +41,11 @@ unsigned long long lotus_streamlink_create(int nevents);
 int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_stream);
 int lotus_streamlink_destroy(unsigned long long link);
 
-/* ---- operand precision of the dense forward / input-gradient products (process-wide knob, also LOTUS_GEMM_PREC):
- * 0 = fp32 MFMA, exact products (default; the 1e-4 logit parity mode); 1 = bf16 operands, fp32 accumulate (the bf16
- * compute mode of BASELINE configs[4]); 3 = bf16x3 split products (a = hi + lo; hi*hi + hi*lo + lo*hi). */
-int lotus_set_gemm_precision(int precision);
-int lotus_get_gemm_precision(void);
+/* ---- operand precision: a PER-CALL argument (`precision`) of the dense, sparse-convolution and attention entry points
+ * (no process-wide state: two models with different precisions can share a process).  0 = fp32 MFMA, exact products
+ * (the 1e-4 logit parity mode); 1 = bf16 operands, fp32 accumulate (the bf16 compute mode of BASELINE configs[4]);
+ * 3 = bf16x3 split products (a = hi + lo; hi*hi + hi*lo + lo*hi).  Packed convolution weights must be used with the
+ * precision they were packed for. */
 
 /* ---- front end (integer, bit-exact) ------------------------------------------------------- */
 /* Point.serialization grid step, PointTransformerV3/model.py:96-98: grid = int32(trunc((coord -
@@ -67,11 +67,13 @@ int lotus_fe_sort(const long long* code, long slot_stride, const int* n_ptr, int
                   long long* skeys, int* order, int* inverse, void* workspace, size_t workspace_bytes, void* stream);
 /* Index part of SerializedPooling.forward, model.py:726-772 (torch.unique + sort + head gather):
  * cluster[n], CSR seg_start[n_child+1] into order0, n_child (device int), child code (rows
- * permuted by perm4, host int[4]), child grid/batch and per-cloud child counts. */
+ * permuted by perm4, host int[4]), child grid/batch and per-cloud child counts.  n_dup (optional device int,
+ * zeroed by the caller) receives the number of parent points that share their voxel with a lower-indexed point
+ * (SURVEY.md Trap 5: augmented real batches have 1-7 % of them at level 0). */
 int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* order0, const int* pgrid,
                   const int* pbatch, const int* n_ptr, int n_max, const int* perm4, int nbatch, int* cluster,
                   int* seg_start, int* n_child, long long* ccode, int* cgrid, int* cbatch, int* ccounts,
-                  void* stream);
+                  int* n_dup, void* stream);
 /* torch_scatter.segment_csr(coord, reduce="mean"), model.py:763-765 */
 int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_start, int n_child, float* ccoord,
                         void* stream);
@@ -94,15 +96,15 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
 size_t lotus_linear_workspace(int M, int N, int K); /* optional split-K scratch for fwd / dgrad */
 int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                      float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
-                     void* workspace, size_t workspace_bytes, void* stream);
+                     int precision, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = (dy w) * act'(pre) * dropmask + add : chain rule through the producer of this layer's input */
 int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
-                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* workspace,
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
                        size_t workspace_bytes, void* stream);
 size_t lotus_linear_wgrad_workspace(int M, int N, int K);
 /* dw (+)= dy^T x, db (+)= colsum(dy); deterministic split-K */
 int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
-                       int accumulate, void* workspace, size_t workspace_bytes, void* stream);
+                       int accumulate, int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- submanifold sparse convolution (spconv.SubMConv3d, model.py:615-622, :844-853) -------- */
 /* mode 0 fwd: y[n][cout] = sum_t W[:,t,:] x[nbr[t][.]] + bias (+ add); mode 1 dgrad: x = dy, y = dx.
@@ -112,10 +114,18 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
  * tap-split fast path for the 3^3 convolutions.  For thin inputs (mode 0, cin <= 8, e.g. the 5^3 stem) a workspace
  * of >= T*cin*cout floats selects the active-pair VALU kernel. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
-int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream);
+int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, int precision, void* stream);
 int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
-                    size_t workspace_bytes, void* stream);
+                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
+                    void* workspace, size_t workspace_bytes, void* stream);
+/* Duplicate voxels (several points in one cell; the neighbour tables name the lowest index, `rep[p]` = centre tap
+ * row nbr[T/2][p]): the true input gradient of mode 0 is dx[q] = [rep[q] == q] * sum_t W_t^T sum_{p in voxel(q) - d_t} dy[p].
+ * lotus_conv_dup_fold writes dyr[r] = sum of dy over the points of r's voxel for representatives r (0 elsewhere), walking
+ * the points in sorted (code, index) order `order0` (code0 = curve code per point; fixed order -> deterministic); mode 1
+ * on dyr then yields the gradient for representatives, and lotus_conv_dup_mask resets the other rows to `add` (or 0). */
+int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* order0, int n, int C, float* dyr,
+                        void* stream);
+int lotus_conv_dup_mask(float* dx, const float* add, const int* rep, int n, int C, void* stream);
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout);
 int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
                           int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
@@ -161,7 +171,7 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
-                        unsigned long long drop_seed, void* stream);
+                        unsigned long long drop_seed, int precision, void* stream);
 size_t lotus_attention_bwd_workspace(int nblocks, int H);
 /* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.  kext / ext_pos /
  * dkv_extra (optional, from lotus_fe_patch): k/v gradients of the borrowed tail-patch copies go to a side
@@ -173,7 +183,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        int precision, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- pooling, head, losses ---------------------------------------------------------------- */
 /* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */
@@ -207,11 +217,6 @@ int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const in
 int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */
 int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
-
-/* ---- profiling aids (diagnostic only): phase timestamps (100 MHz wall clock) of block 0 of the last
- * pair-conv / attention-backward launch when LOTUS_CONV_CLK / LOTUS_ATTN_CLK is set; host64 = int64[64] (host) */
-int lotus_debug_conv_clock(long long* host64);
-int lotus_debug_attn_clock(long long* host64);
 
 /* ---- soft position targets / arg-max position decode: get_disc_gt_pos_prob and
  * get_best_pos_from_disc_pos(best='max'), genrobo3d/utils/action_position_utils.py:7-46, :48-64.  pc = point rows whose

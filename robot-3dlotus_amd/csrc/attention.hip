@@ -44,8 +44,6 @@ struct AttnP {
   unsigned long long drop_seed;
   unsigned drop_thresh;
   float drop_inv_keep;
-  int dbg;         // ablation switches (LOTUS_ATTN_DBG): 1 plain P epilogue, 2 no S MFMAs, 4 no affine on operands
-  long long* clk;  // optional phase timestamps of block (0,0) (profiling aid, LOTUS_ATTN_CLK)
 };
 
 // Attention-probability dropout: keep iff mix(seed, idx) >= thresh, idx = ((tile * H + h) * 128 + q) * 128 + key.  The
@@ -381,12 +379,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   const int k_start = bd[4], k_len = bd[5];
   const int r0 = wave * 32;
   const int ktiles = (k_len + 31) / 32;
-  int clk_i = 0;
-  auto stamp = [&]() {
-    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && clk_i < 40) p.clk[clk_i] = wall_clock64();
-    ++clk_i;
-  };
-  stamp();
 
   if (tid < AT) {
     s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
@@ -400,7 +392,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   __syncthreads();
   if (tid >= AT) ln_rows<false>(s.K, s.krstd, tid - AT, k_len, d, p.eps, nullptr, nullptr);
   __syncthreads();
-  stamp();  // 1: K/V loaded + K LN
 
   f32x16 acc_dv = zero16(), acc_dk = zero16();
   const float gk_l = s.gk[l31], bk_l = s.bk[l31], gq_l = s.gq[l31], bq_l = s.bq[l31];
@@ -437,7 +428,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
     __syncthreads();
     if (tid < AT) ln_rows<false>(s.Q, s.qrstd, tid, q_len, d, p.eps, nullptr, nullptr);
     __syncthreads();
-    stamp();  // 2: Q/dO/O loaded, D, Q LN
 
     // No score image: P and dS are recomputed in registers in the two accumulator orientations that the
     // three output products need (each lane owns ONE key, resp. ONE query; its registers run over the other
@@ -563,7 +553,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         }
       }
     }
-    stamp();  // 3: orientation A done (wave 0)
     // ---- orientation B: lane <-> query qi of this wave's 32 queries, registers <-> keys of tile t
     //        S^T[k][qi], dP^T[k][qi]  ->  dQn^T[:, qi] += Kn^T dS^T
     f32x16 acc_dq = zero16();
@@ -661,7 +650,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       }
     }
     __syncthreads();  // dO image is free now: reuse it for dQn
-    stamp();  // 6: dK, dQ
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // accumulator is dQn^T: col = query (lane), row = head column
       const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -692,7 +680,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
     __syncthreads();
     store_rows(s.dO, p.dq, p.dq_ld, p.dq_off + h * d, s.qrow, s.qown, q_len, d, 0);  // one owner per row
     __syncthreads();
-    stamp();  // 7: q-norm grads, LN bwd, dq stored
   }
 
   // ---- K / V gradients of this block
@@ -759,8 +746,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
              p.dkv_extra, p.dkv_extra_ld, p.dv_off - p.dk_off + h * d);
   if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
-  stamp();  // 8: k side done
-  if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.clk[63] = clk_i;
 }
 
 // out[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
@@ -813,16 +798,7 @@ __global__ void attn_extra_fixup_kernel(const float* __restrict__ extra, long ex
   *o = v;
 }
 
-static long long* g_attn_clk = nullptr;
-extern "C" int lotus_debug_attn_clock(long long* host64) {
-  if (!g_attn_clk) return -1;
-  (void)hipDeviceSynchronize();
-  return (int)hipMemcpy(host64, g_attn_clk, 64 * sizeof(long long), hipMemcpyDeviceToHost);
-}
-
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
-
-extern "C" int lotus_get_gemm_precision(void);
 
 extern "C" {
 
@@ -832,7 +808,7 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
-                        unsigned long long drop_seed, void* stream) {
+                        unsigned long long drop_seed, int precision, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && out && check_geom(H, d) == 0, "lotus_attention_fwd: bad arguments (H=%d d=%d)", H, d);
   if (ntiles == 0) return LOTUS_OK;
   AttnP p;
@@ -843,7 +819,7 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
   const size_t sm = attn_smem_bytes(false);
-  const int prec = lotus_get_gemm_precision();
+  const int prec = precision;
   if (prec == 3) {
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
@@ -870,7 +846,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        int precision, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
                   "lotus_attention_bwd: bad arguments");
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_attention_bwd_workspace(nblocks, H),
@@ -890,18 +866,9 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                   "lotus_attention_bwd: borrowed-row buffer needs dkv_extra, ext_pos and adjacent k|v column blocks");
   p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
-  {
-    static long long* clk = nullptr;
-    if (getenv("LOTUS_ATTN_CLK") && !clk) (void)hipMalloc(&clk, 64 * sizeof(long long));
-    p.clk = clk;
-    g_attn_clk = clk;
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("LOTUS_ATTN_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-  }
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = attn_smem_bytes(true);
-  const int prec = lotus_get_gemm_precision();
+  const int prec = precision;
   if (prec == 3) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
     hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);

@@ -16,9 +16,9 @@
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);
 int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
                          float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
-                         size_t workspace_bytes, hipStream_t st, int* rc);
+                         size_t workspace_bytes, int prec, hipStream_t st, int* rc);
 size_t lotus_conv_pairs_workspace(int n, int ND);
-int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, hipStream_t st);
+int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, int prec, hipStream_t st);
 
 struct ConvP {
   const float* x;   // [n][KD] gathered operand (features, or dy for dgrad)
@@ -378,22 +378,24 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
 
 // w_t [2][cout*T*cin]: MFMA-fragment-packed copies of w for the forward and the input-gradient direction
 // (layout: conv_pairs.hip); cin and cout must be multiples of 32
-int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, void* stream) {
+int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, int precision, void* stream) {
   LOTUS_CHECK_ARG(w && w_t && cout > 0 && T > 0 && cin > 0, "lotus_conv_weight_transpose: bad arguments");
-  return lotus_conv_weight_transpose_impl(w, w_t, cout, T, cin, (hipStream_t)stream);
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_conv_weight_transpose: precision must be 0, 1 or 3");
+  return lotus_conv_weight_transpose_impl(w, w_t, cout, T, cin, precision, (hipStream_t)stream);
 }
 
 // mode 0: fwd  (x [n][cin]  -> y [n][cout]);  mode 1: dgrad (x = dy [n][cout] -> y = dx [n][cin]).
 // w_t (optional) and workspace (optional) enable the pair-compacted tap-split fast path in both modes.
 int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
-                    size_t workspace_bytes, void* stream) {
+                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
+                    void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_subm_conv: precision must be 0, 1 or 3");
   if (n == 0) return LOTUS_OK;
   {
     int rc = 0;  // pair-compacted fast path (conv_pairs.hip) for the 3^3 CPE convolutions
     if (lotus_conv_pairs_try(mode, x, w, w_t, bias, add, y, nbr, rowidx, n, T, cin, cout, workspace, workspace_bytes,
-                             (hipStream_t)stream, &rc))
+                             precision, (hipStream_t)stream, &rc))
       return rc;
   }
   ConvP p;
@@ -497,6 +499,53 @@ __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
     float* out = p.part + (long)z * p.part_stride + ((long)(cb * 64 + c) * p.T + t) * p.cin;
     for (int k = 0; k < p.cin; ++k) out[k] = ((red[0][c][k] + red[1][c][k]) + red[2][c][k]) + red[3][c][k];
   }
+}
+
+// ---- duplicate voxels: see include/lotus_hip.h.  One thread per (sorted position, float4 column).
+__global__ void conv_dup_fold_kernel(const float* __restrict__ dy, const long long* __restrict__ code0,
+                                     const int* __restrict__ order0, int n, int c4n, float* __restrict__ dyr) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(id / c4n), c4 = (int)(id % c4n);
+  if (i >= n) return;
+  const int row = order0[i];
+  const long long key = code0[row];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i == 0 || code0[order0[i - 1]] != key) {  // representative: lowest index of its voxel (stable sort)
+    acc = reinterpret_cast<const float4*>(dy)[(long)row * c4n + c4];
+    for (int j = i + 1; j < n; ++j) {
+      const int rj = order0[j];
+      if (code0[rj] != key) break;
+      const float4 v = reinterpret_cast<const float4*>(dy)[(long)rj * c4n + c4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  reinterpret_cast<float4*>(dyr)[(long)row * c4n + c4] = acc;
+}
+__global__ void conv_dup_mask_kernel(float* __restrict__ dx, const float* __restrict__ add, const int* __restrict__ rep,
+                                     int n, int c4n) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)(id / c4n), c4 = (int)(id % c4n);
+  if (i >= n || rep[i] == i) return;
+  reinterpret_cast<float4*>(dx)[id] = add ? reinterpret_cast<const float4*>(add)[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* order0, int n, int C, float* dyr,
+                        void* stream) {
+  LOTUS_CHECK_ARG(dy && code0 && order0 && dyr && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_fold: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  const long total = (long)n * (C / 4);
+  hipLaunchKernelGGL(conv_dup_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, code0, order0, n,
+                     C / 4, dyr);
+  LOTUS_LAUNCH_CHECK("lotus_conv_dup_fold");
+  return LOTUS_OK;
+}
+int lotus_conv_dup_mask(float* dx, const float* add, const int* rep, int n, int C, void* stream) {
+  LOTUS_CHECK_ARG(dx && rep && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_mask: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  const long total = (long)n * (C / 4);
+  hipLaunchKernelGGL(conv_dup_mask_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, add, rep, n, C / 4);
+  LOTUS_LAUNCH_CHECK("lotus_conv_dup_mask");
+  return LOTUS_OK;
 }
 
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout) {

@@ -26,8 +26,6 @@ struct ConvP2 {
   int n, T, KD, ND, mirror;
   int tpz;           // taps per blockIdx.z
   long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
-  long long* clk;    // optional phase timestamps of block (0,0,0) (profiling aid)
-  int dbg;           // ablation switches for profiling (LOTUS_CONV_DBG): 1 no fold, 2 no B reload, 4 no image fill, 8 no MFMA
 };
 
 // Kernel structure (v2, "resident rows"): the distinct neighbour rows touched by a 128-row tile
@@ -99,12 +97,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   float* my_xs = xs_s + rt * HT * XLD;
   int* my_hkey = hkey_s + rt * HT;
 
-  int clk_i = 0;
-  auto stamp = [&]() {
-    if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0 && clk_i < 64) p.clk[clk_i] = wall_clock64();
-    ++clk_i;
-  };
-  stamp();  // 0 start
   static_assert(HT * XLD >= MAXT * BM, "row image must be able to hold the temporary neighbour list");
   int* src_tmp = (int*)my_xs;  // [taps][BM] neighbour ids, aliased onto the row image (first phase only)
   for (int i = tid; i < NRT * (BM + 1) * OLD; i += 256) out_s[i] = 0.f;
@@ -125,7 +117,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     }
   }
   __syncthreads();
-  stamp();  // 1 after neighbour loads
   for (int t = z_beg + cs; t < z_end; t += NCS) {
     int base = 0;
     for (int r0 = 0; r0 < BM; r0 += 64) {
@@ -144,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     if (base + lane < ((base + 31) & ~31)) row_s[(rt * MAXT + t) * BM + base + lane] = (unsigned char)BM;
   }
   __syncthreads();
-  stamp();  // 2 after compaction
 
   const int nkc = p.KD / KC;
   // operand fragment registers: fp32 keeps one float per k; the bf16 paths keep whole 4-word MFMA operands (hi, lo per
@@ -219,7 +209,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     __syncthreads();
     const int ngr = __builtin_amdgcn_readfirstlane(misc_s[rt]);
     const int vgrp = grp_s[rt * 64 + min(lane, max(ngr - 1, 0))];  // lane j: j-th group (read as a scalar with v_readlane)
-    stamp();  // 3 after hashing + work list
 
     // Resident image: chunk kc + 1 is fetched into registers while the groups of chunk kc run (one HBM/L2 read
     // per row and chunk, its latency under the MFMAs) and written to LDS between the two barriers ending the chunk.
@@ -234,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       for (int j = 0; j < FILL; ++j) {
         const int q = (gt + j * GT) % (KC / 4);
         vv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gs[j] >= 0 && !(p.dbg & 4)) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
+        if (gs[j] >= 0) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
       }
     };
     auto store_fill = [&]() {
@@ -300,7 +289,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     // Group words live in the lanes of one VGPR and are read as scalars with v_readlane.
     const int nsteps = nkc * ngr;
     __syncthreads();
-    stamp();  // 4 image of chunk 0 visible
     if (ngr == 0) {  // nothing to multiply in this phase: keep the block's barrier sequence
       if (nkc > 1) issue_fill(1);
       for (int kc = 1; kc < nkc; ++kc) {
@@ -407,7 +395,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         }
       }
     }
-    stamp();  // 5 after the pipeline (wave 0)
     __syncthreads();
     t0 = t1;
   }
@@ -434,8 +421,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     }
     *reinterpret_cast<float4*>(yo + o) = v;
   }
-  stamp();  // last: after epilogue
-  if (p.clk && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) p.clk[63] = clk_i;
 }
 
 // y = sum_z part[z] + bias + add   (fixed order -> deterministic)
@@ -516,15 +501,6 @@ __global__ __launch_bounds__(256) void conv_wpack_bf16_kernel(const float* __res
   }
 }
 
-extern "C" int lotus_get_gemm_precision(void);
-
-static long long* g_conv_clk = nullptr;
-extern "C" int lotus_debug_conv_clock(long long* host64) {
-  if (!g_conv_clk) return -1;
-  (void)hipDeviceSynchronize();
-  return (int)hipMemcpy(host64, g_conv_clk, 64 * sizeof(long long), hipMemcpyDeviceToHost);
-}
-
 static int tap_splits(int n, int ND) {
   const long base = (long)cdiv(n, 64 * (ND <= 64 ? 2 : 1)) * (ND <= 64 ? 1 : ND / 128);
   int nz = 1;
@@ -544,10 +520,10 @@ static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
-// the packed weights and the kernel must agree on the operand precision: both follow lotus_get_gemm_precision()
+// the packed weights and the kernel must agree on the operand precision (the caller passes the same `precision` to
+// lotus_conv_weight_transpose and lotus_subm_conv)
 template <int NCS>
-static int launch_pairs(ConvP2& p, int nz, hipStream_t st) {
-  const int prec = lotus_get_gemm_precision();
+static int launch_pairs(ConvP2& p, int nz, int prec, hipStream_t st) {
   if (prec == 3) return launch_pairs_p<NCS, 3>(p, nz, st);
   if (prec == 1) return launch_pairs_p<NCS, 1>(p, nz, st);
   return launch_pairs_p<NCS, 0>(p, nz, st);
@@ -558,12 +534,12 @@ size_t lotus_conv_pairs_workspace(int n, int ND) {
   return nz > 1 ? (size_t)nz * n * ND * sizeof(float) : 0;
 }
 
-int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T, int cin, hipStream_t st) {
+int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T, int cin, int prec, hipStream_t st) {
   if (cin % 32 || cout % 32) {
     lotus_set_error("lotus_conv_weight_transpose: cin and cout must be multiples of 32 (got %d, %d)", cin, cout);
     return LOTUS_E_UNSUPPORTED;
   }
-  if (lotus_get_gemm_precision() != 0) {
+  if (prec != 0) {
     const long tuples = 2L * cout * T * cin / 8;
     const int g = (int)((tuples + 255) / 256);
     hipLaunchKernelGGL(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin);
@@ -578,7 +554,7 @@ int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T,
 // Both modes read the packed weights w_t of lotus_conv_weight_transpose (fwd half / dgrad half).
 int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
                          float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
-                         size_t workspace_bytes, hipStream_t st, int* rc) {
+                         size_t workspace_bytes, int prec, hipStream_t st, int* rc) {
   const int KD = mode == 0 ? cin : cout, ND = mode == 0 ? cout : cin;
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
   if (!w_t || ((uintptr_t)w_t) % 16) return 0;
@@ -590,18 +566,9 @@ int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* 
   p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
   p.w = w_t + (mode == 0 ? 0 : (long)cout * T * cin);
   p.tpz = cdiv(T, nz);
-  {
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("LOTUS_CONV_DBG"); dbg = e ? atoi(e) : 0; }
-    p.dbg = dbg;
-    static long long* clk = nullptr;
-    if (getenv("LOTUS_CONV_CLK") && !clk) (void)hipMalloc(&clk, 64 * sizeof(long long));
-    p.clk = clk;
-    g_conv_clk = clk;
-  }
   p.y = nz > 1 ? (float*)workspace : y;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
-  *rc = ND == 64 ? launch_pairs<2>(p, nz, st) : launch_pairs<4>(p, nz, st);
+  *rc = ND == 64 ? launch_pairs<2>(p, nz, prec, st) : launch_pairs<4>(p, nz, prec, st);
   if (*rc == 0 && nz > 1) {
     const long total4 = (long)n * ND / 4;
     int g = cdiv(total4, 256);

@@ -253,20 +253,26 @@ __global__ void fe_inverse_kernel(const int* __restrict__ order, int* __restrict
 // parent = rank of (code[0] >> 3) among the distinct values; children are therefore stored in
 // ascending parent-cell order, exactly like torch.unique(sorted=True).
 // cluster heads (first element of every run of equal parent keys) counted per 1024-element block
+// n_dup (optional): += number of points that share their voxel with a lower-indexed point (equal full keys)
 __global__ __launch_bounds__(1024) void fe_pool_count_kernel(const long long* __restrict__ skey,
-                                                             const int* __restrict__ n_ptr, int* __restrict__ blk) {
-  __shared__ int wsum[16];
+                                                             const int* __restrict__ n_ptr, int* __restrict__ blk,
+                                                             int* __restrict__ n_dup) {
+  __shared__ int wsum[16], dsum[16];
   const int n = *n_ptr;
   const int i = blockIdx.x * 1024 + threadIdx.x;
-  int head = 0;
-  if (i < n) head = (i == 0) || ((skey[i] >> 3) != (skey[i - 1] >> 3));
-  const int c = __popcll(__ballot(head));
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  int head = 0, dup = 0;
+  if (i < n) {
+    head = (i == 0) || ((skey[i] >> 3) != (skey[i - 1] >> 3));
+    dup = (i > 0) && (skey[i] == skey[i - 1]);
+  }
+  const int c = __popcll(__ballot(head)), d = __popcll(__ballot(dup));
+  if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = c; dsum[threadIdx.x >> 6] = d; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int t = 0;
-    for (int w = 0; w < 16; ++w) t += wsum[w];
+    int t = 0, td = 0;
+    for (int w = 0; w < 16; ++w) { t += wsum[w]; td += dsum[w]; }
     blk[blockIdx.x] = t;
+    if (n_dup && td) atomicAdd(n_dup, td);
   }
 }
 
@@ -505,7 +511,7 @@ int lotus_fe_sort(const long long* code, long slot_stride, const int* n_ptr, int
 int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* order0, const int* pgrid,
                   const int* pbatch, const int* n_ptr, int n_max, const int* perm4, int nbatch, int* cluster,
                   int* seg_start, int* n_child, long long* ccode, int* cgrid, int* cbatch, int* ccounts,
-                  void* stream) {
+                  int* n_dup, void* stream) {
   LOTUS_CHECK_ARG(pcode && skey0 && order0 && pgrid && pbatch && n_ptr && perm4 && cluster && seg_start && n_child &&
                       ccode && cgrid && cbatch && ccounts,
                   "lotus_fe_pool: bad arguments");
@@ -515,7 +521,7 @@ int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* ord
   // cbatch doubles as the per-block head-count scratch until fe_pool_child_kernel overwrites it
   const int nblk = cdiv(n_max, 1024);
   LOTUS_CHECK_ARG(nblk <= n_max, "lotus_fe_pool: n_max too small");
-  hipLaunchKernelGGL(fe_pool_count_kernel, dim3(nblk), dim3(1024), 0, st, skey0, n_ptr, cbatch);
+  hipLaunchKernelGGL(fe_pool_count_kernel, dim3(nblk), dim3(1024), 0, st, skey0, n_ptr, cbatch, n_dup);
   hipLaunchKernelGGL(fe_pool_scan_kernel, dim3(nblk), dim3(1024), 0, st, skey0, order0, n_ptr, (const int*)cbatch, cluster,
                      seg_start, n_child);
   hipLaunchKernelGGL(fe_pool_child_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, pcode, (long)n_max, order0,

@@ -32,6 +32,7 @@ struct GemmP {
   unsigned long long drop_seed;
   unsigned drop_thresh;
   float drop_inv_keep;
+  int prec;  // operand precision of this call: 0 fp32 MFMA (exact), 1 bf16, 3 bf16x3 split
 };
 
 // FAST: operands are 16-byte aligned with ld % 4 == 0 and the contiguous extents are multiples of 4,
@@ -576,7 +577,6 @@ static int tune_env(const char* name) {
   const char* e = getenv(name);
   return e ? atoi(e) : 0;
 }
-static int g_prec = -1;  // LOTUS_GEMM_PREC / lotus_set_gemm_precision: 0 fp32 MFMA (exact, default), 1 bf16, 3 bf16x3 split
 static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 3: 64x64), LOTUS_GEMM_NZ, LOTUS_GEMM_BK
 #define GEMM_KALIGN 64  // split-K ranges are multiples of the largest slab depth
 
@@ -589,7 +589,7 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
   if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
   int tile = g_force_tile;
-  if (g_prec < 0) { g_prec = tune_env("LOTUS_GEMM_PREC"); if (g_prec != 1 && g_prec != 3) g_prec = 0; }
+  const int g_prec = p.prec;
   if (g_prec && SUM_A && FAST && !A_KC && !B_KC) {
     // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
     dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
@@ -746,8 +746,9 @@ size_t lotus_linear_workspace(int M, int N, int K) {
 
 int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                      float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
-                     void* workspace, size_t workspace_bytes, void* stream) {
+                     int precision, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_fwd: precision must be 0, 1 or 3");
   if (M == 0) return LOTUS_OK;
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -755,7 +756,7 @@ int lotus_linear_fwd(const float* x, const float* w, const float* bias, const fl
   p.lda = K; p.ldb = K; p.ldc = N;
   p.bias = bias; p.residual = residual; p.pre = pre; p.act = act;
   p.klen = cdiv(K, GEMM_KALIGN) * GEMM_KALIGN;
-  p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K);
+  p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K); p.prec = precision;
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, true>(p, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -764,9 +765,10 @@ int lotus_linear_fwd(const float* x, const float* w, const float* bias, const fl
 // `pre`/`act`/`drop_*` describe the layer that PRODUCED this layer's input (its pre-activation,
 // activation and output dropout), so the chain rule through it is fused into this epilogue.
 int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
-                       int N, int K, int act, float drop_p, unsigned long long drop_seed, void* workspace,
+                       int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
                        size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_dgrad: precision must be 0, 1 or 3");
   if (M == 0) return LOTUS_OK;
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -775,7 +777,7 @@ int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* 
   p.act = LOTUS_ACT_NONE;
   p.mulpre = pre; p.dact = act; p.residual = add;
   p.klen = cdiv(N, GEMM_KALIGN) * GEMM_KALIGN;
-  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K);
+  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K); p.prec = precision;
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, false>(p, workspace, workspace_bytes, (hipStream_t)stream);
 }
@@ -794,18 +796,6 @@ static int wgrad_splits(int M, int N, int K) {
   return nz;
 }
 
-// Process-wide operand precision of the forward / input-gradient GEMMs: 0 = fp32 MFMA (exact products, default),
-// 1 = bf16 operands (BASELINE configs[4] compute mode), 3 = bf16x3 split (fp32-class accuracy, ~2^-17 per product).
-int lotus_set_gemm_precision(int precision) {
-  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_set_gemm_precision: 0, 1 or 3");
-  g_prec = precision;
-  return LOTUS_OK;
-}
-int lotus_get_gemm_precision(void) {
-  if (g_prec < 0) { g_prec = tune_env("LOTUS_GEMM_PREC"); if (g_prec != 1 && g_prec != 3) g_prec = 0; }
-  return g_prec;
-}
-
 size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
   return (size_t)wgrad_splits(M, N, K) * ((size_t)N * K + N) * sizeof(float);
 }
@@ -814,8 +804,9 @@ size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
 // When db == dw + N*K (one contiguous [N*K + N] gradient buffer) the split-K partials of both are
 // summed by a single launch; with one split and accumulate == 0 the GEMM writes dw/db directly.
 int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
-                       int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+                       int accumulate, int precision, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_wgrad: precision must be 0, 1 or 3");
   hipStream_t st = (hipStream_t)stream;
   const int nz = wgrad_splits(M, N, K);
   const size_t slab = (size_t)N * K + N;
@@ -828,7 +819,7 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
   p.A = dy; p.B = x; p.M = N; p.N = K; p.K = M;
   p.lda = N; p.ldb = K; p.ldc = K;
   p.klen = cdiv(cdiv(M > 0 ? M : 1, nz), GEMM_KALIGN) * GEMM_KALIGN;
-  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K);
+  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K); p.prec = precision;
   set_drop(p, 0.f, 0);
   if (direct) {
     p.C = dw; p.bias_part = db;

@@ -20,7 +20,7 @@ class Level:
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
                  "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
-                 "coord", "parent")
+                 "coord", "parent", "n_dup")
 
 
 def draw_order_perms(n_levels, shuffle=True):
@@ -110,7 +110,7 @@ class FrontEnd:
                 cbatch = torch.empty(N, **i32)
                 perm = np.asarray(perms[s + 1], dtype=np.int32)
                 call("lotus_fe_pool", code, skeys, order, grid, batch, n_dev[s:s + 1], N, perm.ctypes.data, B, cluster,
-                     seg, n_dev[s + 1:s + 2], ccode, cgrid, cbatch, cnts[s + 1])
+                     seg, n_dev[s + 1:s + 2], ccode, cgrid, cbatch, cnts[s + 1], state[2:3] if s == 0 else None)
                 raw[-1].update(cluster=cluster, seg=seg)
                 grid, batch, code = cgrid, cbatch, ccode
         for r in raw:
@@ -208,6 +208,9 @@ class FrontEnd:
             n, r, pl = ns[s], raw[s], plans[s]
             lv = Level()
             lv.n, lv.counts, lv.depth = n, cnt_h[s].tolist(), depth0 - s
+            # points sharing their voxel with a lower-indexed point: only the input level can have them (pooled levels
+            # are one point per cell by construction); a single-level model has no pooling pass to count them
+            lv.n_dup = (int(meta_h[2]) if Lv > 1 else -1) if s == 0 else 0
             lv.off, lv.off_host = view(pl["off"]), pl["off_host"]
             lv.grid, lv.batch = r["grid"][:n], r["batch"][:n]
             lv.code, lv.order, lv.inverse = r["code"][:, :n], r["order"][:, :n], r["inverse"][:, :n]

@@ -82,7 +82,13 @@ class MotionPlannerPTV3CA(BaseModel):
                 "feat": feat, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
                 "context_counts": list(batch["txt_lens"])}
 
+    gemm_precision = None  # as SimplePolicyPTV3CA.gemm_precision
+
     def forward(self, batch, compute_loss=False, **kwargs):
+        with ops.precision(self.gemm_precision):
+            return self._forward(batch, compute_loss, **kwargs)
+
+    def _forward(self, batch, compute_loss=False, **kwargs):
         batch = self.prepare_batch(batch)
         dev = batch["pc_fts"].device
         if dev.type != "cuda":

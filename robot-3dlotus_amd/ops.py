@@ -90,19 +90,47 @@ def dist_rank():
     return int(os.environ.get("RANK", "0"))
 
 
+def _env_precision():
+    v = os.environ.get("LOTUS_GEMM_PREC", "0")
+    return int(v) if v in ("1", "3") else 0
+
+
+_PREC = _env_precision()  # precision code the next forward pass captures (see set_gemm_precision / precision())
+
+
 def set_gemm_precision(mode):
-    """Operand precision of the dense and sparse-convolution forward / input-gradient products (process-wide; set it
-    before a forward pass — the packed conv weights of a step follow the mode they were packed in): 'fp32' = fp32 MFMA,
-    exact products (default, the 1e-4 logit parity mode); 'bf16x3' = split-bf16 products hi*hi + hi*lo + lo*hi with
-    fp32 accumulation (~2^-17 per product; measured max logit error 2.2e-5, +23-27 % step throughput); 'bf16' = bf16
-    operands (the bf16 compute mode of BASELINE configs[4]; the conv weight gradient is still fp32; +20-35 %).
-    Covers the dense, sparse-convolution and attention products."""
-    _capi.call_raw("lotus_set_gemm_precision", _PRECISIONS[mode])
+    """Default operand precision of the dense, sparse-convolution and attention products for forward passes started
+    from now on: 'fp32' = fp32 MFMA, exact products (default, the 1e-4 logit parity mode); 'bf16x3' = split-bf16 products
+    hi*hi + hi*lo + lo*hi with fp32 accumulation (~2^-17 per product; measured max logit error 2.2e-5, +23-27 % step
+    throughput); 'bf16' = bf16 operands (the bf16 compute mode of BASELINE configs[4]; +20-35 %).
+
+    Host-side only: the precision is an argument of every C-ABI call (no state in the library).  Each autograd node
+    captures it in forward and replays it in backward, and a model with a `gemm_precision` attribute overrides this
+    default for its own forward passes (`with ops.precision(mode)`), so models of different precisions coexist."""
+    global _PREC
+    _PREC = _PRECISIONS[mode]
 
 
 def get_gemm_precision():
-    v = query("lotus_get_gemm_precision")
-    return {v_: k for k, v_ in _PRECISIONS.items()}[v]
+    return {v_: k for k, v_ in _PRECISIONS.items()}[_PREC]
+
+
+class precision:
+    """Context manager: operand precision of the forward passes started inside (None = leave the default)."""
+
+    def __init__(self, mode):
+        self.code = None if mode is None else _PRECISIONS[mode]
+
+    def __enter__(self):
+        global _PREC
+        self.prev = _PREC
+        if self.code is not None:
+            _PREC = self.code
+        return self
+
+    def __exit__(self, *a):
+        global _PREC
+        _PREC = self.prev
 
 
 def set_wgrad_join(mode):
@@ -205,18 +233,28 @@ def _end_of_backward():
     sync_side_stream()
 
 
+def _fwd(fn):
+    """forward() decorator: the node remembers the operand precision it was computed in."""
+    def wrapped(ctx, *args):
+        ctx.prec = _PREC
+        return fn(ctx, *args)
+    return staticmethod(wrapped)
+
+
 def _joined(fn):
     """backward() decorator: join the side stream before the gradients leave the node ("node"), or once at the
-    end of the backward pass ("end")."""
+    end of the backward pass ("end"); the node's products run in the precision its forward captured."""
     def wrapped(ctx, *grads):
-        global _IN_NODE, _END_CB_PENDING
+        global _IN_NODE, _END_CB_PENDING, _PREC
         _IN_NODE += 1
+        prev, _PREC = _PREC, getattr(ctx, "prec", _PREC)
         try:
             if _JOIN == "end" and _SIDE_ON and not _END_CB_PENDING:
                 _END_CB_PENDING = True
                 torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
             return fn(ctx, *grads)
         finally:
+            _PREC = prev
             _IN_NODE -= 1
             if _JOIN == "node":
                 sync_side_stream()
@@ -232,7 +270,7 @@ def _empty_like_rows(x, cols):
 
 
 # ------------------------------------------------------------------------------------ primitives
-def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0, seed=0):
+def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0, seed=0, prec=None):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
@@ -242,11 +280,12 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
     nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
     ws = _ws(nb, x.device) if nb else None
     with _Timed(("fwd", M, N, K)):
-        call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed), ws, nb)
+        call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed),
+             _PREC if prec is None else prec, ws, nb)
     return y, pre
 
 
-def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
+def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0, prec=None):
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
@@ -255,11 +294,12 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0):
     nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
     ws = _ws(nb, dy.device) if nb else None
     with _Timed(("dgrad", M, N, K)):
-        call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed), ws, nb)
+        call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed),
+             _PREC if prec is None else prec, ws, nb)
     return dx
 
 
-def linear_wgrad(dy, x, need_bias=True):
+def linear_wgrad(dy, x, need_bias=True, prec=None):
     M, N = dy.shape
     K = x.shape[1]
     buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
@@ -271,7 +311,7 @@ def linear_wgrad(dy, x, need_bias=True):
     with _OnSide(dy, x):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         with _Timed(("wgrad", M, N, K)):
-            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, ws, ws.numel())
+            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, _PREC if prec is None else prec, ws, ws.numel())
     return dw, db
 
 
@@ -304,13 +344,13 @@ def ln_bwd(dy, x, mean, rstd, g, add=None):
     return dx, dg, db
 
 
-def conv_weight_t(w):
+def conv_weight_t(w, prec=None):
     """[cout, k,k,k, cin] -> packed MFMA weight fragments for the forward and the input-gradient convolution
-    (2 * w.numel() floats; layout in csrc/conv_pairs.hip)."""
+    (2 * w.numel() floats; layout in csrc/conv_pairs.hip); use them with the precision they were packed for."""
     cout, cin = w.shape[0], w.shape[-1]
     T = w.numel() // (cout * cin)
     wt = torch.empty(2 * w.numel(), dtype=torch.float32, device=w.device)
-    call("lotus_conv_weight_transpose", w, wt, cout, T, cin)
+    call("lotus_conv_weight_transpose", w, wt, cout, T, cin, _PREC if prec is None else prec)
     return wt
 
 
@@ -319,7 +359,7 @@ def _conv_ws(n, cin, cout, dev):
     return WS.get(nbytes, dev, slot=2) if nbytes else None
 
 
-def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None):
+def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None):
     n, cin = x.shape
     cout, T = w.shape[0], nbr.shape[0]
     y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
@@ -327,17 +367,28 @@ def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None):
         ws = _conv_ws(n, cin, cout, x.device)
     else:  # thin-input stem kernel: room for the transposed weights
         ws = WS.get(4 * T * cin * cout, x.device, slot=2) if cin <= 8 else None
-    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, ws, ws.numel() if ws is not None else 0)
+    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, _PREC if prec is None else prec, ws,
+         ws.numel() if ws is not None else 0)
     return y
 
 
-def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None):
+def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
+    """Input gradient of conv_fwd.  The kernel walks the mirrored taps of the forward table, which is the transposed
+    pair list exactly when every voxel holds one point; `lvl.n_dup != 0` (augmented real clouds: 1-7 % of the points
+    share a cell, SURVEY.md Trap 5) adds the fold / mask passes of lotus_conv_dup_* that make it the true gradient."""
     n, cout = dy.shape
     cin, T = w.shape[-1], nbr.shape[0]
+    dups = lvl is not None and lvl.n_dup != 0
+    if dups:
+        dyr = torch.empty_like(dy)
+        call("lotus_conv_dup_fold", dy, lvl.code[0], lvl.order[0], n, cout, dyr)
+        dy = dyr
     dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
     ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
-    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, ws,
+    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _PREC if prec is None else prec, ws,
          ws.numel() if ws is not None else 0)
+    if dups:
+        call("lotus_conv_dup_mask", dx, add, nbr[T // 2], n, cin)
     return dx
 
 
@@ -488,21 +539,22 @@ def bn_bwd_pair(a, bb, training, act):
 
 
 def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d,
-                  drop_p=0.0, seed=0):
+                  drop_p=0.0, seed=0, prec=None):
     call("lotus_attention_fwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles,
-         qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6, float(drop_p), int(seed))
+         qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6, float(drop_p), int(seed),
+         _PREC if prec is None else prec)
 
 
 def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
                   dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d, drop_p=0.0, seed=0,
-                  kext=None, ext_pos=None, n_extra=0, dkv_extra=None):
+                  kext=None, ext_pos=None, n_extra=0, dkv_extra=None, prec=None):
     dev = q.device
     grads = [torch.empty(d, dtype=torch.float32, device=dev) for _ in range(4)]
     ws = _ws(query("lotus_attention_bwd_workspace", nblocks, H), dev)
     call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
          qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
          part_stride, atomic, kext, ext_pos, n_extra, dkv_extra, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
-         int(seed), ws, ws.numel())
+         int(seed), _PREC if prec is None else prec, ws, ws.numel())
     return grads
 
 
@@ -511,7 +563,7 @@ class CpeFn(torch.autograd.Function):
     """x1 = x + LN(Linear(SubMConv3d_3(xs))).  In the encoder xs is x; in the decoder xs is the
     stale proj_skip branch (SURVEY.md Trap 3), hence two tensor inputs."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl):
         same = xs is x
         wt = conv_weight_t(cw)
@@ -532,16 +584,16 @@ class CpeFn(torch.autograd.Function):
         dc = linear_dgrad(dl, lw)
         dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
         if ctx.same:  # d x = dy (residual) + conv dgrad
-            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt)
+            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt, lvl=lvl)
             return dx, None, dcw, dcb, dlw, dlb, dg, db, None
-        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt)
+        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt, lvl=lvl)
         return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None
 
 
 class FfnFn(torch.autograd.Function):
     """y = x + drop(fc2(drop(GELU(fc1(LN(x))))))   (MLP, model.py:577-583; pre-norm residual)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed):
         n, mean, rstd = ln_fwd(x, g, b)
         a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
@@ -567,7 +619,7 @@ class FfnFn(torch.autograd.Function):
 class SelfAttnFn(torch.autograd.Function):
     """y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (SerializedAttention flash path)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
         N, C = x.shape
         d = C // H
@@ -608,7 +660,7 @@ class SelfAttnFn(torch.autograd.Function):
 class CrossAttnFn(torch.autograd.Function):
     """y = x + drop(proj(CrossAttention(q(LN(x)), kv(context))))   (model_ca.py:46-101, :135-140)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
         N, C = x.shape
         d = C // H
@@ -652,7 +704,7 @@ class CrossAttnFn(torch.autograd.Function):
 class StemFn(torch.autograd.Function):
     """Embedding: GELU(BN(SubMConv3d_5(x)))   (model.py:844-861; conv has no bias)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, cw, g, b, rmean, rvar, lvl, training):
         c = conv_fwd(x, cw, None, lvl.nbr125, lvl.order[0])
         y, mean, invstd = bn_fwd(c, g, b, rmean, rvar, training, ACT_GELU)
@@ -667,14 +719,14 @@ class StemFn(torch.autograd.Function):
         dc, dg, db = bn_bwd(dy.contiguous(), c, mean, invstd, g, b, training, ACT_GELU)
         dcw, _ = conv_wgrad(dc, x, cw.shape, lvl.nbr125, need_bias=False)
         # the policy feeds raw point features (no gradient); the motion planner concatenates a learned label embedding
-        dx = conv_dgrad(dc, cw, lvl.nbr125, lvl.order[0]) if ctx.needs_input_grad[0] else None
+        dx = conv_dgrad(dc, cw, lvl.nbr125, lvl.order[0], lvl=lvl) if ctx.needs_input_grad[0] else None
         return dx, dcw, dg, db, None, None, None, None
 
 
 class PoolFn(torch.autograd.Function):
     """SerializedPooling: GELU(BN(segment_max(Linear(x))))   (model.py:760-790)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, bias, g, b, rmean, rvar, child, training):
         proj, _ = linear_fwd(x, w, bias)
         C = w.shape[0]
@@ -703,7 +755,7 @@ class UnpoolFn(torch.autograd.Function):
     """SerializedUnpooling: skip = GELU(BN(Linear_skip(parent))), up = GELU(BN(Linear(point)));
     returns (skip + up[cluster], skip)   (model.py:817-828).  `skip` alone feeds the decoder CPE conv."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, xc, xp, wu, bu, gu, betau, rmu, rvu, ws_, bs, gs, betas, rms, rvs, child, training):
         lu, _ = linear_fwd(xc, wu, bu)
         ls, _ = linear_fwd(xp, ws_, bs)
@@ -735,7 +787,7 @@ class UnpoolFn(torch.autograd.Function):
 class LinearFn(torch.autograd.Function):
     """Plain nn.Linear (txt_fc, simple_policy_ptv3.py:387,414)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, w, b):
         y, _ = linear_fwd(x, w, b)
         ctx.save_for_backward(x, w)
@@ -754,7 +806,7 @@ class HeadLossFn(torch.autograd.Function):
     """ActionHead (heatmap_disc / max / euler_disc) + compute_loss, simple_policy_ptv3.py:113-157,
     :308-373.  Returns (losses[4] = pos, rot, open, total; xt [N, 3*2*pos_bins]; ae [B, 217])."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, hw0, hb0, hw3, hb3, aw0, ab0, aw3, ab3, lvl, tgt, gt, pos_w, rot_w, drop_p, seed, with_loss):
         dev = x.device
         N, C = x.shape
@@ -811,7 +863,7 @@ class PosCEFn(torch.autograd.Function):
     """Soft-target heatmap cross entropy per (cloud, axis): F.cross_entropy(rearrange(pred, 'c n b -> c (n b)'),
     probs, reduction='none') of motion_planner_ptv3.py:329-334 for one trajectory step.  Returns [B, 3]."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, xt, tgt, lvl):
         B = len(lvl.counts)
         nb = xt.shape[1] // 3
@@ -835,7 +887,7 @@ class CloudMaxFn(torch.autograd.Function):
     """torch.stack([torch.max(x, 0)[0] for x in torch.split(feat, npoints_in_batch)]),
     motion_planner_ptv3.py:117-119 / simple_policy_ptv3.py:117-119."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, x, lvl):
         B, C = len(lvl.counts), x.shape[1]
         y = torch.empty(B, C, dtype=torch.float32, device=x.device)

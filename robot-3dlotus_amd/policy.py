@@ -106,7 +106,13 @@ class SimplePolicyPTV3CA(BaseModel):
                                   "offset": batch["offset"], "feat": batch["pc_fts"],
                                   "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
 
+    gemm_precision = None  # 'fp32' | 'bf16x3' | 'bf16': operand precision of THIS model's products (None = ops default)
+
     def forward(self, batch, compute_loss=False, **kwargs):
+        with ops.precision(self.gemm_precision):
+            return self._forward(batch, compute_loss, **kwargs)
+
+    def _forward(self, batch, compute_loss=False, **kwargs):
         batch = self.prepare_batch(batch)
         dev = batch["pc_fts"].device
         if dev.type != "cuda":

@@ -122,3 +122,23 @@ def synth_batch_mp(batch_size=8, npoints=4096, ragged=False, seed=0, pos_bins=15
         "traj_masks": torch.from_numpy(masks),
         "gt_trajs_disc_pos_probs": [torch.from_numpy(p) for p in probs],
     }
+
+
+def augment_clouds(batch, seed=0, max_rot_deg=45.0, noise=0.002):
+    """The geometry part of the training-time augmentation (rotation of every cloud about z by U(-max_rot, max_rot) and
+    U(0, noise) metres of per-coordinate jitter; simple_policy_dataset.py:158-181) applied to a synthetic batch in place.
+    After re-gridding from the batch-global minimum this puts 1-7 % of the points into a voxel that already holds another
+    point (SURVEY.md Trap 5) — the duplicate-voxel case real batches present to the sparse convolutions."""
+    rng = np.random.default_rng(seed)
+    pc = batch["pc_fts"].numpy().copy()
+    start = 0
+    for n in batch["npoints_in_batch"]:
+        a = np.deg2rad(rng.uniform(-1.0, 1.0) * max_rot_deg)
+        c, s = np.cos(a), np.sin(a)
+        xy = pc[start:start + n, :2].astype(np.float64)
+        pc[start:start + n, 0] = (c * xy[:, 0] - s * xy[:, 1]).astype(np.float32)
+        pc[start:start + n, 1] = (s * xy[:, 0] + c * xy[:, 1]).astype(np.float32)
+        pc[start:start + n, :3] += rng.uniform(0.0, noise, size=(n, 3)).astype(np.float32)
+        start += n
+    batch["pc_fts"] = torch.from_numpy(pc)
+    return batch

@@ -82,3 +82,53 @@ def test_product_does_not_import_the_oracle():
         if f.endswith(".py"):
             s = open(os.path.join(pkg, f)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", s, flags=re.M), f
+
+
+def test_abi_has_no_process_wide_precision_state(built):
+    """no global mutable state in the library — operand precision is an argument of every dense / conv /
+    attention entry point (it used to be lotus_set_gemm_precision + a static)."""
+    protos = _capi.parse_header()
+    assert "lotus_set_gemm_precision" not in protos and "lotus_get_gemm_precision" not in protos
+    for name in ("lotus_linear_fwd", "lotus_linear_dgrad", "lotus_linear_wgrad", "lotus_conv_weight_transpose",
+                 "lotus_subm_conv", "lotus_attention_fwd", "lotus_attention_bwd"):
+        assert "precision" in protos[name][2], name
+
+
+_CTYPES_SMOKE = r"""
+import os, sys
+sys.path[:0] = [{root!r}, os.path.join({root!r}, "tests")]
+import numpy as np, torch
+import golden_util as gu
+from oracle.model import Oracle
+import robot_3dlotus_amd
+from robot_3dlotus_amd import _capi, config as lcfg, synth
+from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+from weights_util import seeded_state_dict
+assert _capi.fastcall() is None, "LOTUS_NO_FASTCALL=1 must select the ctypes binding"
+cfg = lcfg.preset("tiny")
+sd = seeded_state_dict(gu.state_template(cfg), 5, "scaled")
+batch = synth.synth_batch(2, 512, ragged=True, seed=42)
+perms = [[2, 0, 1, 3], [1, 3, 0, 2]]
+ref = Oracle({{k: v.clone() for k, v in sd.items()}}, lcfg.plain(cfg), training=True).forward(batch, perms)
+m = SimplePolicyPTV3CA(cfg); m.load_state_dict(sd); m = m.cuda().train()
+m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0; m.act_proj_head.dropout = 0.0
+m.ptv3_model.order_perms = perms
+dev = {{k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v)) for k, v in batch.items()}}
+_, losses = m(dev, compute_loss=True, compute_final_action=False)
+losses["total"].backward(); torch.cuda.synchronize()
+err = float(np.abs(m.last_pred[0].detach().cpu().numpy() - ref["xt"].numpy()).max())
+assert err <= 1e-4 * max(1.0, float(np.abs(ref["xt"].numpy()).max())), err
+assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+print("ctypes-path ok", err)
+"""
+
+
+@pytest.mark.gpu
+def test_documented_ctypes_binding_runs_the_model_on_the_gpu(built):
+    """INTEGRATION.md documents ctypes as THE FFI; every other GPU test goes through the generated trampolines.  Run one
+    forward + backward of the policy with LOTUS_NO_FASTCALL=1 (pure ctypes) against the oracle."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CTYPES_SMOKE.format(root=root)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LOTUS_NO_FASTCALL="1"))
+    assert r.returncode == 0 and "ctypes-path ok" in r.stdout, r.stderr[-3000:]

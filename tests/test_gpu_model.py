@@ -96,6 +96,35 @@ def test_live_oracle_parity_and_determinism():
     assert torch.equal(m2.last_pred[0], xt), "forward must be bit-reproducible"
 
 
+def test_live_oracle_parity_with_duplicate_voxels_backward():
+    """Augmented clouds (z rotation + jitter -> 1-7 % of the points share a voxel, SURVEY.md Trap 5): logits, losses and
+    EVERY parameter gradient of the HIP model against the oracle under autograd."""
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 21, "scaled")
+    batch = synth.augment_clouds(synth.synth_batch(3, 700, ragged=True, seed=321), seed=5)
+    perms = [[1, 3, 0, 2], [2, 0, 3, 1]]
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(cfg), training=True).forward(batch, perms)
+    out["losses"]["total"].backward()
+    m = _build(cfg, sd, True)
+    m.ptv3_model.order_perms = perms
+    _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    assert m.ptv3_model.frontend is not None
+    ref = out["xt"].detach().numpy()
+    assert float(np.abs(m.last_pred[0].detach().cpu().numpy() - ref).max()) <= LOGIT_TOL * max(1.0, float(np.abs(ref).max()))
+    assert abs(losses["total"].item() - out["losses"]["total"].item()) < 1e-4 * max(1.0, abs(out["losses"]["total"].item()))
+    losses["total"].backward()
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    for name, p in m.named_parameters():
+        r = sdg[name].grad
+        err = float((p.grad.cpu() - r).norm())
+        assert err <= 2e-3 * (float(r.norm()) + 1e-3 * gmax), f"{name}: |dgrad| {err:.3e} vs |g| {float(r.norm()):.3e}"
+
+
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
 def test_gemm_precision_modes_against_golden(mode, tol):
     """Opt-in operand precisions of the dense fwd/dgrad products (ops.set_gemm_precision).  'bf16x3' must still meet
@@ -245,3 +274,37 @@ def test_deferred_wgrad_join_is_bit_identical():
     for ga, gb in zip(a, b):
         for u, v in zip(ga, gb):
             assert torch.equal(u, v)
+
+
+def test_models_of_different_precisions_coexist():
+    """Operand precision is per call (captured per autograd node): an fp32 model and a bf16 model interleaved in one
+    process — forward of one, forward of the other, then both backward passes — give bit-identically the results of
+    running each alone (the old process-wide knob made this impossible)."""
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 8, "scaled")
+    batch = synth.synth_batch(2, 600, ragged=True, seed=77)
+    perms = [[0, 2, 1, 3], [3, 1, 0, 2]]
+
+    def alone(mode):
+        m = _build(cfg, sd, True)
+        m.gemm_precision, m.ptv3_model.order_perms = mode, perms
+        _, l = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+        l["total"].backward()
+        return m.last_pred[0].detach().clone(), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+
+    xa, ga = alone("fp32")
+    xb, gb = alone("bf16")
+    assert not torch.equal(xa, xb)
+    ma, mb = _build(cfg, sd, True), _build(cfg, sd, True)
+    ma.gemm_precision, mb.gemm_precision = "fp32", "bf16"
+    ma.ptv3_model.order_perms = mb.ptv3_model.order_perms = perms
+    _, la = ma(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    _, lb = mb(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    lb["total"].backward()
+    la["total"].backward()
+    assert torch.equal(ma.last_pred[0], xa) and torch.equal(mb.last_pred[0], xb)
+    assert torch.equal(torch.cat([p.grad.flatten() for p in ma.parameters()]), ga)
+    assert torch.equal(torch.cat([p.grad.flatten() for p in mb.parameters()]), gb)

@@ -72,14 +72,14 @@ def test_linear_bf16_operand_paths(prec, M, N, K):
     g = torch.Generator().manual_seed(M + N + K + prec)
     x, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
     dy = torch.randn(M, N, generator=g)
-    _capi.call_raw("lotus_set_gemm_precision", prec)
+    ops.set_gemm_precision({1: "bf16", 3: "bf16x3"}[prec])
     try:
         y, _ = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
         dx = ops.linear_dgrad(dy.cuda(), w.cuda())
         dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
         dw2, db2 = ops.linear_wgrad(dy.cuda(), x.cuda())
     finally:
-        _capi.call_raw("lotus_set_gemm_precision", 0)
+        ops.set_gemm_precision("fp32")
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "weight gradient must stay deterministic"
     if prec == 1:
         xr, wr, dyr = (t.bfloat16().double() for t in (x, w, dy))
@@ -210,6 +210,80 @@ def test_subm_conv_fwd_dgrad_wgrad(cin, cout, k):
         _close(dx, xd.grad, 3e-6, "conv dgrad (pair-compacted, packed weights)")
 
 
+def _dup_cloud_levels(seed):
+    """Clouds after the training-time augmentation (z rotation + 0-2 mm jitter): several per cent of the points share
+    a voxel with another point (SURVEY.md Trap 5)."""
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.augment_clouds(synth.synth_batch(3, 1500, ragged=True, seed=seed), seed=seed + 1)
+    perms = [[0, 1, 2, 3]] * 2
+    ref = fe.build_all_levels(batch["pc_fts"][:, :3].numpy(), batch["npoints_in_batch"], 2, perms=perms)
+    got = FrontEnd(2).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], perms)
+    rep = ref[0]["nbr27"][:, 13]
+    n_dup = int((rep != np.arange(len(rep))).sum())
+    assert 0.01 * len(rep) < n_dup < 0.10 * len(rep), f"augmentation should duplicate 1-10 % of the voxels, got {n_dup}"
+    assert got[0].n_dup == n_dup and got[1].n_dup == 0
+    return batch, ref, got
+
+
+@pytest.mark.parametrize("cin,k", [(64, 3), (128, 3), (8, 5)])
+def test_subm_conv_dgrad_with_duplicate_voxels(cin, k):
+    """with several points per voxel the input gradient must be the gradient of the forward that was
+    computed (neighbour = lowest index of the cell), not the mirrored-tap shortcut: autograd through the oracle's
+    subm_conv on the same tables is the reference (PointTransformerV3/model.py:615-625; duplicates arise from
+    simple_policy_dataset.py:158-181)."""
+    ops = _ops()
+    batch, ref, got = _dup_cloud_levels(seed=40 + cin)
+    n, lvl = got[0].n, got[0]
+    g = torch.Generator().manual_seed(cin * k)
+    x = torch.randn(n, cin, generator=g)
+    w = torch.randn(cin, k, k, k, cin, generator=g) / (cin * 9) ** 0.5
+    dy = torch.randn(n, cin, generator=g)
+    addt = torch.randn(n, cin, generator=g)
+    nbr_ref = torch.from_numpy(ref[0]["nbr27" if k == 3 else "nbr125"]).long()
+    nbr = lvl.nbr27 if k == 3 else lvl.nbr125
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    om.subm_conv(xd, nbr_ref, wd, None).backward(dy.double())
+    wt = ops.conv_weight_t(w.cuda()) if k == 3 else None
+    dx = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, lvl.order[0], add=addt.cuda(), w_t=wt, lvl=lvl)
+    _close(dx, xd.grad + addt.double(), 3e-6, "conv dgrad with duplicate voxels")
+    naive = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, lvl.order[0], add=addt.cuda(), w_t=wt)  # mirrored taps only
+    assert float((naive.cpu().double() - xd.grad - addt.double()).abs().max()) > 1e-2, "the case must exercise the fix"
+    dw, _ = ops.conv_wgrad(dy.cuda(), x.cuda(), w.shape, nbr, need_bias=False)
+    _close(dw, wd.grad, 5e-6, "conv wgrad with duplicate voxels")
+    dx2 = ops.conv_dgrad(dy.cuda(), w.cuda(), nbr, lvl.order[0], add=addt.cuda(), w_t=wt, lvl=lvl)
+    assert torch.equal(dx, dx2), "deterministic"
+
+
+@pytest.mark.parametrize("C", [64, 128])
+def test_cpe_block_fwd_bwd_with_duplicate_voxels(C):
+    """x + LN(Linear(SubMConv3d(x))) — the Block.cpe sub-block — forward and backward on augmented clouds against the
+    oracle under autograd (fp64), every input and parameter gradient."""
+    ops = _ops()
+    batch, ref, got = _dup_cloud_levels(seed=90 + C)
+    n, lvl = got[0].n, got[0]
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(n, C, generator=g)
+    cw = torch.randn(C, 3, 3, 3, C, generator=g) / (C * 9) ** 0.5
+    cb, lw, lb = torch.randn(C, generator=g) * 0.1, torch.randn(C, C, generator=g) / C ** 0.5, torch.randn(C, generator=g) * 0.1
+    gam, bet = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    dy = torch.randn(n, C, generator=g)
+    dev = [t.cuda().requires_grad_(True) for t in (x, cw, cb, lw, lb, gam, bet)]
+    y = ops.CpeFn.apply(dev[0], dev[0], *dev[1:], lvl)
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    dbl = [t.double().requires_grad_(True) for t in (x, cw, cb, lw, lb, gam, bet)]
+    nbr_ref = torch.from_numpy(ref[0]["nbr27"]).long()
+    c = om.subm_conv(dbl[0], nbr_ref, dbl[1], dbl[2])
+    yref = dbl[0] + F.layer_norm(c @ dbl[3].t() + dbl[4], (C,), dbl[5], dbl[6], 1e-5)
+    yref.backward(dy.double())
+    _close(y, yref, 3e-6, "cpe fwd")
+    for name, a, b in zip(("dx", "dconv_w", "dconv_b", "dlin_w", "dlin_b", "dgamma", "dbeta"), dev, dbl):
+        _close(a.grad, b.grad, 3e-6 if name == "dx" else 2e-5, name)
+
+
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (256, 256), (64, 128)])
 def test_subm_conv_bf16_operand_paths(prec, cin, cout):
@@ -224,13 +298,13 @@ def test_subm_conv_bf16_operand_paths(prec, cin, cout):
     w = torch.randn(cout, 3, 3, 3, cin, generator=g) / (cin * 9) ** 0.5
     dy = torch.randn(n, cout, generator=g)
     nbr_ref = torch.from_numpy(ref[0]["nbr27"]).long()
-    _capi.call_raw("lotus_set_gemm_precision", prec)
+    ops.set_gemm_precision({1: "bf16", 3: "bf16x3"}[prec])
     try:
         wt = ops.conv_weight_t(w.cuda())
         y = ops.conv_fwd(x.cuda(), w.cuda(), None, got[0].nbr27, got[0].order[0], w_t=wt)
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), got[0].nbr27, got[0].order[0], w_t=wt)
     finally:
-        _capi.call_raw("lotus_set_gemm_precision", 0)
+        ops.set_gemm_precision("fp32")
     rnd = (lambda t: t.bfloat16().double()) if prec == 1 else (lambda t: t.double())
     xd, wd = rnd(x).requires_grad_(True), rnd(w)
     yref = om.subm_conv(xd, nbr_ref, wd, None)
@@ -307,7 +381,7 @@ def test_patch_attention_bf16_operand_paths(prec, tol, C, H):
     om.patch_attention(qd, lvl, 0, H, pr[0], pr[1], pr[2], pr[3], 128).backward(dout.double())
     dqkv = torch.empty(n, 3 * C, device="cuda")
     extra = torch.empty(max(lv.n_extra, 1), 2 * C, device="cuda")
-    _capi.call_raw("lotus_set_gemm_precision", prec)
+    ops.set_gemm_precision({1: "bf16", 3: "bf16x3"}[prec])
     try:
         ops.attention_fwd(qc, 3 * C, 0, qc, 3 * C, C, 2 * C, lv.gidx, lv.gidx, lv.owner, lv.self_tiles, lv.n_self_tiles,
                           qnc, knc, att, lse, H, d)
@@ -315,7 +389,7 @@ def test_patch_attention_bf16_operand_paths(prec, tol, C, H):
                                lv.n_self_tiles, qnc, knc, att, dout.cuda(), lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0,
                                H, d, 0.0, 0, lv.kext, lv.ext_pos, lv.n_extra, extra)
     finally:
-        _capi.call_raw("lotus_set_gemm_precision", 0)
+        ops.set_gemm_precision("fp32")
     _close(att, oref, tol, f"attn fwd prec {prec}")
     _close(dqkv, qd.grad, 4 * tol, f"attn dqkv prec {prec}")
     for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
