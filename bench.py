@@ -352,10 +352,21 @@ def main():
             rep = [] if args.gemm_report else None
             flop, gms, nl = gemm_roofline(ops, calls, dev, report=rep)
             if rep is not None:
+                instep = {}
+                for kind, M, N, K, e0, e1 in events:
+                    d = instep.setdefault((kind, M, N, K), [0.0, 0])
+                    d[0] += e0.elapsed_time(e1)
+                    d[1] += 1
                 with open(args.gemm_report, "w") as f:
-                    f.write("total_ms kind M N K count ms_each TFLOPs\n")
-                    for r in sorted(rep, reverse=True):
-                        f.write("%.3f %s %d %d %d %d %.4f %.1f\n" % r)
+                    f.write("in_step_total_ms kind M N K count ms_each_isolated TFLOPs_isolated ms_each_in_step TFLOPs_in_step hbm_bound_us mfma_bound_us\n")
+                    rows = []
+                    for tot, kind, M, N, K, cnt, ms, tf in rep:
+                        ins = instep.get((kind, M, N, K), [0.0, 1])
+                        ims = ins[0] / max(ins[1], 1)
+                        byt = 4.0 * (M * K + N * K + M * N)
+                        rows.append((ins[0], kind, M, N, K, cnt, ms, tf, ims, 2e-9 * M * N * K / max(ims, 1e-9), byt / 6.3e6, 2.0 * M * N * K / 157.3e6))
+                    for r in sorted(rows, reverse=True):
+                        f.write("%.3f %s %d %d %d %d %.4f %.1f %.4f %.1f %.1f %.1f\n" % r)
             ach_iso = flop / (gms * 1e-3) / 1e12
             in_ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in events)
             in_flop = sum(2.0 * M * N * K for _, M, N, K, _, _ in events)

@@ -94,17 +94,23 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
  * `pre` (optional) receives x w^T + bias.  Call sites: model.py:386-387,572-574,623,707,804-805;
  * model_ca.py:27-31; simple_policy_ptv3.py:40-68,387. */
 size_t lotus_linear_workspace(int M, int N, int K); /* optional split-K scratch for fwd / dgrad */
+/* `counters` (optional, all three entry points): lotus_splitk_counters_bytes() bytes of device memory that are ZERO when
+ * first passed and owned by one stream at a time.  With it a split-K product is ONE launch: every block stores its partial
+ * tile, the last block to arrive at a tile sums the partials in fixed order and applies the epilogue, and resets the
+ * tile's counter (so the buffer stays zero between calls).  Without it the reduction is a second launch. */
+size_t lotus_splitk_counters_bytes(void);
 int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
                      float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
-                     int precision, void* workspace, size_t workspace_bytes, void* stream);
+                     int precision, void* workspace, size_t workspace_bytes, void* counters, void* stream);
 /* dx = (dy w) * act'(pre) * dropmask + add : chain rule through the producer of this layer's input */
 int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
                        int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
-                       size_t workspace_bytes, void* stream);
+                       size_t workspace_bytes, void* counters, void* stream);
 size_t lotus_linear_wgrad_workspace(int M, int N, int K);
 /* dw (+)= dy^T x, db (+)= colsum(dy); deterministic split-K */
 int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
-                       int accumulate, int precision, void* workspace, size_t workspace_bytes, void* stream);
+                       int accumulate, int precision, void* workspace, size_t workspace_bytes, void* counters,
+                       void* stream);
 
 /* ---- submanifold sparse convolution (spconv.SubMConv3d, model.py:615-622, :844-853) -------- */
 /* mode 0 fwd: y[n][cout] = sum_t W[:,t,:] x[nbr[t][.]] + bias (+ add); mode 1 dgrad: x = dy, y = dx.
@@ -136,9 +142,12 @@ int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db,
 int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                         float* mean, float* rstd, int M, int C, float eps, void* stream);
 size_t lotus_layernorm_bwd_workspace(int M, int C);
+/* dz (optional, with drop_p > 0): second output dz = dx * mask(drop_seed), the nn.Dropout mask (same element index and
+ * hash as the forward epilogue) of the layer that produced this block's input — its backward then needs no mask pass. */
 int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
-                        void* workspace, size_t workspace_bytes, void* stream);
+                        float* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
+                        void* stream);
 /* second half of the above when it was called with dgamma == NULL: reduce the column partials left in workspace */
 int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamma, float* dbeta, int accumulate,
                                void* stream);

@@ -821,13 +821,13 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
   const size_t sm = attn_smem_bytes(false);
   const int prec = precision;
   if (prec == 3) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a1 = true; } }
     hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   } else if (prec == 1) {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a2 = false; if (!a2) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a2 = true; } }
     hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   } else {
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a3 = false; if (!a3) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a3 = true; } }
     hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_attention_fwd");
@@ -870,13 +870,13 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   const size_t sm = attn_smem_bytes(true);
   const int prec = precision;
   if (prec == 3) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a4 = true; } }
     hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else if (prec == 1) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a5 = false; if (!a5) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a5 = true; } }
     hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+    { static bool a6 = false; if (!a6) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a6 = true; } }
     hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(nblocks, H), dim3(256), sm, st, p);
   }
   if (p.dkv_extra) {

@@ -423,19 +423,19 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
   if (p.ND <= 64) {
     dim3 grid(cdiv(p.ND, 64), cdiv(n, 128));
     if (mode == 0) {
-      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a1 = true; } }
       hipLaunchKernelGGL((conv_kernel<128, 64, true>), grid, block, dyn, st, p);
     } else {
-      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      { static bool a2 = false; if (!a2) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a2 = true; } }
       hipLaunchKernelGGL((conv_kernel<128, 64, false>), grid, block, dyn, st, p);
     }
   } else {
     dim3 grid(cdiv(p.ND, 128), cdiv(n, 128));
     if (mode == 0) {
-      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      { static bool a3 = false; if (!a3) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a3 = true; } }
       hipLaunchKernelGGL((conv_kernel<128, 128, true>), grid, block, dyn, st, p);
     } else {
-      (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+      { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a4 = true; } }
       hipLaunchKernelGGL((conv_kernel<128, 128, false>), grid, block, dyn, st, p);
     }
   }

@@ -514,7 +514,8 @@ static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
   static int pad = -1;
   if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
   const size_t sm = Cfg::bytes() + (size_t)pad;
-  (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+  static bool attr_set = false;  // per instantiation; the attribute call costs host time on every launch otherwise
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
   hipLaunchKernelGGL((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");

@@ -87,6 +87,12 @@ struct LnBwdP {
   float* dx;
   float* part;  // [gridDim.x][2][C]  (dgamma, dbeta partials)
   int M, C, LPR, NV;
+  // optional second output: dz = dx * dropout mask of the layer that PRODUCED this block's input (its backward would
+  // otherwise start with a stand-alone mask kernel over dx)
+  float* dz;
+  unsigned long long drop_seed;
+  unsigned drop_thresh;
+  float drop_inv_keep;
 };
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
@@ -133,6 +139,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
         o.w = rstd * (g[j].w - s1 - xh[j].w * s2);
         o.x += av[j].x; o.y += av[j].y; o.z += av[j].z; o.w += av[j].w;
         reinterpret_cast<float4*>(p.dx + (long)row * p.C)[q] = o;
+        if (p.dz) {
+          const unsigned long long e = (unsigned long long)row * p.C + 4 * q;
+          float4 z;
+          z.x = o.x * dropout_scale(p.drop_seed, e, p.drop_thresh, p.drop_inv_keep);
+          z.y = o.y * dropout_scale(p.drop_seed, e + 1, p.drop_thresh, p.drop_inv_keep);
+          z.z = o.z * dropout_scale(p.drop_seed, e + 2, p.drop_thresh, p.drop_inv_keep);
+          z.w = o.w * dropout_scale(p.drop_seed, e + 3, p.drop_thresh, p.drop_inv_keep);
+          reinterpret_cast<float4*>(p.dz + (long)row * p.C)[q] = z;
+        }
       }
     }
   }
@@ -498,8 +513,15 @@ size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)LN_BWD_MAX_G
 // another stream: the parameter gradients are off the critical path of backward).
 int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
-                        void* workspace, size_t workspace_bytes, void* stream) {
+                        float* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
+                        void* stream) {
   LnBwdP p;
+  p.dz = (dz && drop_p > 0.f) ? dz : nullptr;
+  p.drop_seed = drop_seed;
+  p.drop_thresh = (unsigned)(drop_p * 4294967296.0);
+  if (p.dz && p.drop_thresh == 0) p.drop_thresh = 1;
+  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  LOTUS_CHECK_ARG(!dz || drop_p > 0.f, "lotus_layernorm_bwd: dz needs drop_p > 0");
   p.dy = dy; p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.add = add; p.dx = dx;
   p.part = (float*)workspace; p.M = M; p.C = C;
   LOTUS_CHECK_ARG(dy && x && mean && rstd && gamma && dx && M >= 0, "lotus_layernorm_bwd: bad arguments");

@@ -265,6 +265,19 @@ def _ws(nbytes, dev):
     return WS.get(nbytes, dev, slot=0)
 
 
+_COUNTERS = {}
+
+
+def _counters(dev):
+    """Zeroed arrival counters of the fused split-K products, one buffer per stream that launches them (the kernels
+    leave them zero)."""
+    key = (dev, _capi.STREAM_OVERRIDE or _capi.stream_ptr())
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
+    return c
+
+
 def _empty_like_rows(x, cols):
     return torch.empty(x.shape[0], cols, dtype=torch.float32, device=x.device)
 
@@ -281,7 +294,7 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
     ws = _ws(nb, x.device) if nb else None
     with _Timed(("fwd", M, N, K)):
         call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed),
-             _PREC if prec is None else prec, ws, nb)
+             _PREC if prec is None else prec, ws, nb, _counters(x.device) if nb else None)
     return y, pre
 
 
@@ -295,7 +308,7 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0, pr
     ws = _ws(nb, dy.device) if nb else None
     with _Timed(("dgrad", M, N, K)):
         call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed),
-             _PREC if prec is None else prec, ws, nb)
+             _PREC if prec is None else prec, ws, nb, _counters(dy.device) if nb else None)
     return dx
 
 
@@ -311,7 +324,8 @@ def linear_wgrad(dy, x, need_bias=True, prec=None):
     with _OnSide(dy, x):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         with _Timed(("wgrad", M, N, K)):
-            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, _PREC if prec is None else prec, ws, ws.numel())
+            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, _PREC if prec is None else prec, ws, ws.numel(),
+                 _counters(dy.device))
     return dw, db
 
 
@@ -324,21 +338,54 @@ def ln_fwd(x, g, b, res=None, eps=1e-5, save=True):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, g, add=None):
+class Handoff:
+    """Backward-pass hand-over between two consecutive sub-blocks of a stage.  Forward order: A -> B, where A ends
+    with proj / fc2 dropout (p, seed).  B's backward finishes with a LayerNorm backward that produces dx — exactly the
+    gradient A's backward receives, and the first thing A would do with it is dz = dropout_mask(p, seed) * dx in a kernel
+    of its own.  B's LayerNorm backward writes dz as a second output instead and parks it here; A picks it up if the
+    gradient it was handed is that very tensor (B was the only consumer of A's output)."""
+    __slots__ = ("drop", "ptr", "dz")
+
+    def __init__(self):
+        self.drop, self.ptr, self.dz = None, 0, None
+
+    def arm(self, p, seed):      # A.forward: this is the mask my backward will need
+        self.drop, self.ptr, self.dz = ((float(p), int(seed)) if p > 0.0 else None), 0, None
+
+    def take(self, dy):          # A.backward
+        dz, self.dz = self.dz, None
+        return dz if (dz is not None and self.ptr == dy.data_ptr() and dz.shape == dy.shape) else None
+
+
+def _masked(dy, p, seed, hand):
+    """dz = dropout mask * dy for a backward pass: from the hand-over if the producer of dy left it, else a launch."""
+    if hand is not None:
+        dz = hand.take(dy)
+        if dz is not None:
+            return dz
+    return dropout(dy, p, seed)
+
+
+def ln_bwd(dy, x, mean, rstd, g, add=None, hand=None):
     M, C = x.shape
     dx = torch.empty_like(x)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
+    dz, dp, dseed = None, 0.0, 0
+    if hand is not None and hand.drop is not None:
+        dp, dseed = hand.drop
+        dz = torch.empty_like(x)
+        hand.ptr, hand.dz = dx.data_ptr(), dz
     nbytes = query("lotus_layernorm_bwd_workspace", M, C)
     if _side() is None:
         ws = _ws(nbytes, x.device)
-        call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, dg, db, M, C, 0, ws, ws.numel())
+        call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, dg, db, M, C, 0, dz, dp, dseed, ws, ws.numel())
         return dx, dg, db
     # dx on the main stream; the parameter-gradient reduction of the column partials (own workspace slot, joined
     # at the end of the node like every other weight gradient) on the side stream
     # ("end" join: the partials must outlive an unknown amount of main-stream progress -> a fresh buffer)
     ws = WS.get(nbytes, x.device, slot=4) if _JOIN == "node" else torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, None, None, M, C, 0, ws, ws.numel())
+    call("lotus_layernorm_bwd", dy, x, mean, rstd, g, add, dx, None, None, M, C, 0, dz, dp, dseed, ws, ws.numel())
     with _OnSide(ws):
         call("lotus_layernorm_bwd_params", ws, M, C, dg, db, 0)
     return dx, dg, db
@@ -352,6 +399,23 @@ def conv_weight_t(w, prec=None):
     wt = torch.empty(2 * w.numel(), dtype=torch.float32, device=w.device)
     call("lotus_conv_weight_transpose", w, wt, cout, T, cin, _PREC if prec is None else prec)
     return wt
+
+
+def prepack_conv_weights(weights):
+    """Pack the 3^3 convolution weights of a whole forward pass up front, on the weight-gradient stream when it is
+    enabled: nine small launches leave the critical stream (they ran in front of every Block.cpe) and overlap the stem.
+    The caller orders its stream after them with sync_side_stream() before the first use."""
+    global _IN_NODE
+    outs = [torch.empty(2 * w.numel(), dtype=torch.float32, device=w.device) for w in weights]
+    _IN_NODE += 1  # (the side stream is otherwise reserved for backward nodes)
+    try:
+        with _OnSide(*weights):
+            for w, o in zip(weights, outs):
+                cout, cin = w.shape[0], w.shape[-1]
+                call("lotus_conv_weight_transpose", w, o, cout, w.numel() // (cout * cin), cin, _PREC)
+    finally:
+        _IN_NODE -= 1
+    return outs
 
 
 def _conv_ws(n, cin, cout, dev):
@@ -564,9 +628,10 @@ class CpeFn(torch.autograd.Function):
     stale proj_skip branch (SURVEY.md Trap 3), hence two tensor inputs."""
 
     @_fwd
-    def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl):
+    def forward(ctx, x, xs, cw, cb, lw, lb, g, b, lvl, wt=None):
         same = xs is x
-        wt = conv_weight_t(cw)
+        if wt is None:
+            wt = conv_weight_t(cw)
         c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt)
         l, _ = linear_fwd(c, lw, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
@@ -585,42 +650,46 @@ class CpeFn(torch.autograd.Function):
         dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
         if ctx.same:  # d x = dy (residual) + conv dgrad
             dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt, lvl=lvl)
-            return dx, None, dcw, dcb, dlw, dlb, dg, db, None
+            return dx, None, dcw, dcb, dlw, dlb, dg, db, None, None
         dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt, lvl=lvl)
-        return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None
+        return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None, None
 
 
 class FfnFn(torch.autograd.Function):
     """y = x + drop(fc2(drop(GELU(fc1(LN(x))))))   (MLP, model.py:577-583; pre-norm residual)."""
 
     @_fwd
-    def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed):
+    def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed, hand_in=None, hand_out=None):
         n, mean, rstd = ln_fwd(x, g, b)
         a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
         y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
         ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         ctx.drop = (drop_p, seed)
+        ctx.hands = (hand_in, hand_out)
+        if hand_in is not None:
+            hand_in.arm(drop_p, mix_seed(seed, 1))
         return y
 
     @_joined
     def backward(ctx, dy):
         x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
         p, seed = ctx.drop
+        hand_in, hand_out = ctx.hands
         dy = dy.contiguous()
-        dz2 = dropout(dy, p, mix_seed(seed, 1))
+        dz2 = _masked(dy, p, mix_seed(seed, 1), hand_in)
         dw2, db2 = linear_wgrad(dz2, a)
         dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
         dw1, db1 = linear_wgrad(dh, n)
         dn = linear_dgrad(dh, w1)
-        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dg, db, dw1, db1, dw2, db2, None, None
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
+        return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
 
 
 class SelfAttnFn(torch.autograd.Function):
     """y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (SerializedAttention flash path)."""
 
     @_fwd
-    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
+    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0, hand_in=None):
         N, C = x.shape
         d = C // H
         n, mean, rstd = ln_fwd(x, g, b)
@@ -632,6 +701,9 @@ class SelfAttnFn(torch.autograd.Function):
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
+        ctx.hand_in = hand_in
+        if hand_in is not None:
+            hand_in.arm(drop_p, seed)
         return y
 
     @_joined
@@ -640,7 +712,7 @@ class SelfAttnFn(torch.autograd.Function):
         lvl, H, d, p, seed, attn_p = ctx.meta
         N, C = x.shape
         dy = dy.contiguous()
-        dz = dropout(dy, p, seed)
+        dz = _masked(dy, p, seed, ctx.hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
         # every (point, q|k|v column) is written exactly once by its owner position; the k/v gradients of the
@@ -654,14 +726,15 @@ class SelfAttnFn(torch.autograd.Function):
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
         dn = linear_dgrad(dqkv, wqkv)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None
+        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):
     """y = x + drop(proj(CrossAttention(q(LN(x)), kv(context))))   (model_ca.py:46-101, :135-140)."""
 
     @_fwd
-    def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0):
+    def forward(ctx, x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0,
+                hand_in=None, hand_out=None):
         N, C = x.shape
         d = C // H
         n, mean, rstd = ln_fwd(x, g, b)
@@ -674,6 +747,9 @@ class CrossAttnFn(torch.autograd.Function):
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
+        ctx.hands = (hand_in, hand_out)
+        if hand_in is not None:
+            hand_in.arm(drop_p, seed)
         return y
 
     @_joined
@@ -682,8 +758,9 @@ class CrossAttnFn(torch.autograd.Function):
         lvl, H, d, p, seed, attn_p = ctx.meta
         N, C = x.shape
         dev = x.device
+        hand_in, hand_out = ctx.hands
         dy = dy.contiguous()
-        dz = dropout(dy, p, seed)
+        dz = _masked(dy, p, seed, hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
         dq = torch.empty(N, C, dtype=torch.float32, device=dev)
@@ -697,8 +774,8 @@ class CrossAttnFn(torch.autograd.Function):
         dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
         dwq, dbq = linear_wgrad(dq, n)
         dn = linear_dgrad(dq, wq)
-        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None, None
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
+        return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None, None, None, None
 
 
 class StemFn(torch.autograd.Function):

@@ -73,16 +73,20 @@ class Block(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, xs, lvl, drop_p, seed, attn_p=0.0):
+    def run(self, x, xs, lvl, drop_p, seed, attn_p=0.0, wt=None):
+        """-> (x, hand): `hand` lets the next sub-block's backward pre-mask the gradient this block's MLP needs
+        (ops.Handoff; the blocks of a stage form a chain with a single consumer each)."""
         c0, c1, c2 = self.cpe[0], self.cpe[1], self.cpe[2]
-        x = ops.CpeFn.apply(x, xs, c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias, lvl)
+        x = ops.CpeFn.apply(x, xs, c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias, lvl, wt)
         a, n1 = self.attn, self.norm1[0]
+        h_attn, h_mlp = ops.Handoff(), ops.Handoff()
         x = ops.SelfAttnFn.apply(x, n1.weight, n1.bias, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.q_norm.bias,
                                  a.k_norm.weight, a.k_norm.bias, a.proj.weight, a.proj.bias, lvl, self.num_heads,
-                                 drop_p, seed, attn_p)
+                                 drop_p, seed, attn_p, h_attn)
         m, n2 = self.mlp[0], self.norm2[0]
-        return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
-                               ops.mix_seed(seed, 2))
+        x = ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
+                            ops.mix_seed(seed, 2), h_mlp, h_attn)
+        return x, h_mlp
 
 
 class CABlock(nn.Module):
@@ -96,14 +100,16 @@ class CABlock(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, context, lvl, drop_p, seed, attn_p=0.0):
+    def run(self, x, context, lvl, drop_p, seed, attn_p=0.0, prev_hand=None):
         a, n1 = self.attn, self.norm1[0]
+        h_attn = ops.Handoff()
         x = ops.CrossAttnFn.apply(x, context, n1.weight, n1.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
                                   a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight,
-                                  a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p)
+                                  a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p, h_attn, prev_hand)
         m, n2 = self.mlp[0], self.norm2[0]
+        # the stage's last MLP: its output may feed several consumers (pooling + decoder skip), no hand-over to it
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
-                               ops.mix_seed(seed, 2))
+                               ops.mix_seed(seed, 2), None, h_attn)
 
 
 class _Down(nn.Module):
@@ -297,10 +303,13 @@ class PointTransformerV3CA(nn.Module):
         site = 0
 
         st = self.embedding.stem
+        blocks = [e.block0 for e in self.enc] + [d.block0 for d in self.dec]
+        packs = dict(zip(blocks, ops.prepack_conv_weights([b.cpe[0].weight for b in blocks])))
         # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input
         # features are a linear code of something smaller, e.g. the motion planner's label embedding
         x = ops.StemFn.apply(feat, data_dict.get("stem_weight", st.conv.weight), st.norm.weight, st.norm.bias, st.norm.running_mean,
                              st.norm.running_var, levels[0], training)
+        ops.sync_side_stream()  # the packed convolution weights (they overlapped the stem)
         skips = []
         for s in range(self.num_stages):
             enc, lvl = self.enc[s], levels[s]
@@ -310,8 +319,8 @@ class PointTransformerV3CA(nn.Module):
                 d, bn = enc.down, enc.down.norm[0]
                 x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      lvl, training)
-            x = enc.block0.run(x, x, lvl, p, seed, pa)
-            x = enc.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa)
+            x, hand = enc.block0.run(x, x, lvl, p, seed, pa, packs[enc.block0])
+            x = enc.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa, hand)
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
@@ -322,7 +331,7 @@ class PointTransformerV3CA(nn.Module):
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
                                          us[1].running_mean, us[1].running_var, child, training)
-            x = dec.block0.run(x, skip, lvl, p, seed, pa)
-            x = dec.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa)
+            x, hand = dec.block0.run(x, skip, lvl, p, seed, pa, packs[dec.block0])
+            x = dec.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa, hand)
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]
