@@ -181,9 +181,13 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run lr schedule + clip_grad_norm_(10) + fused AdamW inside every step (SURVEY 8f rank 1); "
                          "the headline metric of BASELINE.json is forward + backward only, so this is off by default")
-    ap.add_argument("--workload", choices=["policy", "mp"], default="policy",
+    ap.add_argument("--workload", choices=["policy", "mp", "peract"], default="policy",
                     help="policy = 3D-LOTUS v1 (BASELINE configs[1], the headline metric); mp = the 3D-LOTUS++ motion "
-                         "planner (configs[3]) — a side measurement, same step structure")
+                         "planner (configs[3]); peract = RLBench-18task config (configs[4]): the v1 network on dense 4096-point "
+                         "clouds augmented as the PerAct job script does (aug_max_rot 45 -> duplicate voxels), bf16 operands — "
+                         "side measurements, same step structure")
+    ap.add_argument("--no-fresh-batches", action="store_true",
+                    help="skip the end-to-end side measurement (a new pinned host batch per step: H2D + front-end in the timed region)")
     ap.add_argument("--gemm-precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="operand precision of the dense fwd/dgrad products: fp32 = exact fp32 MFMA (default, the parity mode "
                          "the headline is quoted in); bf16x3 / bf16 are the opt-in faster modes (DESIGN.md 4)")
@@ -213,6 +217,9 @@ def main():
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
     mp = args.workload == "mp"
+    peract = args.workload == "peract"
+    if peract and args.gemm_precision == "fp32":
+        args.gemm_precision = "bf16"  # train_3dlotus_policy_peract.sh: the bf16 compute mode of BASELINE configs[4]
     if mp:
         from robot_3dlotus_amd.motion_planner import MotionPlannerPTV3CA
         model = MotionPlannerPTV3CA(lcfg.preset("mp")).to(dev).train()
@@ -222,7 +229,10 @@ def main():
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1":  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
         parallel.enable_sync_batchnorm()
-    batch = dev_batch((synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank), dev)
+    host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank)
+    if peract:  # aug_max_rot 45 + jitter (job_scripts/train_3dlotus_policy_peract.sh:42): 1-7 % duplicate voxels
+        host_batch = synth.augment_clouds(host_batch, seed=rank, max_rot_deg=45.0)
+    batch = dev_batch(host_batch, dev)
 
     params = [p for p in model.parameters() if p.requires_grad]
     opt = None
@@ -305,6 +315,59 @@ def main():
             other[mode] = round(args.batch * world * 20 / d2, 2)
         ops.set_gemm_precision("fp32")
 
+    # end-to-end side measurement: a NEW host batch every step (pinned + packed by the collate function, as a DataLoader
+    # with pin_memory would hand it over), uploaded and serialised by prefetch() under the previous step's backward, so
+    # H2D and the integer front-end are inside the timed region (genrobo3d/models/base.py:29-34,
+    # train_simple_policy.py:202-216).  Host-side synthesis of the clouds is done before the clock starts (the
+    # reference's DataLoader workers do that in parallel).
+    fresh = None
+    if not args.no_fresh_batches and not mp and not peract and args.gemm_precision == "fp32":
+        from robot_3dlotus_amd import data as ldata
+        nfresh, nwarm = 10, 3
+
+        def host(i):
+            b = synth.synth_batch(args.batch, args.npoints, seed=7919 * (rank + 1) + i)
+            items = []
+            for k in range(len(b["npoints_in_batch"])):
+                lo = sum(b["npoints_in_batch"][:k]); hi = lo + b["npoints_in_batch"][k]
+                tl = sum(b["txt_lens"][:k]); th = tl + b["txt_lens"][k]
+                items.append({"pc_fts": [b["pc_fts"][lo:hi]], "txt_embeds": [b["txt_embeds"][tl:th]], "ee_poses": [b["ee_poses"][k]],
+                              "gt_actions": [b["gt_actions"][k]], "step_ids": [int(b["step_ids"][k])],
+                              "disc_pos_probs": [b["disc_pos_probs"][k]], "pc_centroids": [], "data_ids": [f"s{i}-{k}"]})
+            return ldata.ptv3_collate_fn(items, pack=True, pin=True)
+
+        hb = [host(i) for i in range(nfresh + nwarm)]
+        npts = sum(sum(b["npoints_in_batch"]) for b in hb[nwarm:])
+        torch.cuda.synchronize()
+        model.prefetch(hb[0])
+        for i in range(nfresh + nwarm):
+            if i == nwarm:
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t1 = time.perf_counter()
+            if reducer is not None:
+                reducer.zero_grad()
+            else:
+                for p_ in params:
+                    p_.grad = None
+            _, losses = model(hb[i], compute_loss=True, compute_final_action=False)
+            if i + 1 < nfresh + nwarm:
+                model.prefetch(hb[i + 1])
+            losses["total"].backward()
+            if reducer is not None:
+                reducer.finish()
+        torch.cuda.synchronize()
+        d3 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d3], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d3 = float(t.item())
+        fresh = {"value": round(args.batch * world * nfresh / d3, 2), "unit": "keystep-samples/s", "steps": nfresh,
+                 "points_per_s": round(npts * world / d3), "h2d_bytes_per_step": int(sum(v.numel() * v.element_size() for v in hb[-1].values() if isinstance(v, torch.Tensor))),
+                 "note": "a new pinned host batch every step (same cloud size as the headline, different clouds and level sizes each step): "
+                         "H2D upload + integer front-end prefetched under the previous backward, inside the timed region"}
+
     # one more step on EVERY rank (it contains collectives when N > 1) with the dense launches logged; rank 0 replays them
     calls, events = [], []
     if not args.no_roofline:
@@ -339,11 +402,19 @@ def main():
             out["config"]["workload"] = (f"3D-LOTUS++ motion planner (68.68M params, 5-step trajectory head), {args.batch} "
                                          f"clouds x {args.npoints} pts per GPU, fwd+loss+bwd, train mode, fp32 exact")
             out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
+        if fresh is not None:
+            out["fresh_batches"] = fresh
+        if peract:
+            out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"
+            out["config"]["workload"] = (f"3D-LOTUS v1 network, PerAct preset (BASELINE configs[4]), {args.batch} dense clouds x {args.npoints} pts "
+                                         f"per GPU after aug_max_rot 45 + jitter (duplicate voxels present), fwd+loss+bwd, train mode; "
+                                         f"products with {args.gemm_precision} operands and fp32 accumulate, activations / weights stored in fp32")
+            out["dtype"] = "bf16" if args.gemm_precision == "bf16" else args.gemm_precision
         if other:
             out["opt_in_modes"] = {"unit": "keystep-samples/s", **other,
                                    "note": "same step with ops.set_gemm_precision(mode): dense + sparse-conv + attention products as "
                                            "bf16x3 split (max logit error 2.2e-5, inside the 1e-4 bar) / plain bf16; not the headline"}
-        if args.gemm_precision != "fp32":
+        if args.gemm_precision != "fp32" and not peract:
             out["config"]["workload"] += f"; dense fwd/dgrad products in {args.gemm_precision} (opt-in, NOT the headline mode)"
             out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM + conv operands"
         if opt is not None:
@@ -371,6 +442,11 @@ def main():
             in_ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in events)
             in_flop = sum(2.0 * M * N * K for _, M, N, K, _, _ in events)
             ach = in_flop / (in_ms * 1e-3) / 1e12
+            # per-launch bound: a dense layer moves A + B + C once (4 bytes each, fp32 storage) and needs 2 M N K flops; it
+            # cannot be faster than max(flops / MFMA peak, bytes / achievable HBM rate) — the thin C = 64 / 128 layers of
+            # level 0 are HBM-bound, not MFMA-bound
+            roof_ms = sum(max(2.0 * M * N * K / (MFMA_F32_PEAK_TFLOPS * 1e12), 4.0 * (M * K + N * K + M * N) / 6.3e12)
+                          for _, M, N, K, _, _ in events) * 1e3
             traffic = None  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/pmc_summary.py)
             try:
                 pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")))
@@ -381,6 +457,9 @@ def main():
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                                "kernel": "gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
                                "launches_per_step": len(events), "ms_per_step": round(in_ms, 3),
+                               "per_launch_roof": {"ms_per_step": round(roof_ms, 3), "frac": round(roof_ms / max(in_ms, 1e-9), 4),
+                                                   "note": "sum over the launches of max(2MNK / 157.3 TFLOP/s, 4(MK + NK + MN) B / 6.3 TB/s) "
+                                                           "divided by the measured in-step time of the same launches"},
                                "avg_launch_us": round(1e3 * in_ms / max(len(events), 1), 2),
                                "gflop_per_step": round(in_flop / 1e9, 1),
                                "measured": "HIP events around every dense launch of one training step, on the stream it runs on "

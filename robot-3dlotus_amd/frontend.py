@@ -48,7 +48,7 @@ class FrontEnd:
         return self.finish(self.launch(pc_fts, counts, perms), ctx_counts, need_coord)
 
     @torch.no_grad()
-    def launch(self, pc_fts, counts, perms, stream=None):
+    def launch(self, pc_fts, counts, perms, stream=None, wait_current=True):
         """First half of build(): enqueue the sync-free device pipeline (grid coordinates, codes, sorts,
         pooling of every level) and the asynchronous device->host copy of the per-level counts.  With
         `stream` (a side stream) the work is ordered after everything already enqueued on the current stream
@@ -56,7 +56,8 @@ class FrontEnd:
         the NEXT batch can be prefetched under the backward pass of the current one.  finish() completes it."""
         cur = torch.cuda.current_stream()
         if stream is not None:
-            stream.wait_stream(cur)
+            if wait_current:  # (not needed when pc_fts was produced on `stream` itself, e.g. uploaded there)
+                stream.wait_stream(cur)
             with torch.cuda.stream(stream):
                 pend = self._launch(pc_fts, counts, perms, ws_slot=5)
         else:

@@ -99,12 +99,24 @@ class SimplePolicyPTV3CA(BaseModel):
         """Optional input-pipeline hook (not in the reference): start the integer front-end of `batch` on a side
         stream.  Call it for the NEXT batch right after the forward of the current one; the following
         forward(batch) must get the same dict.  Purely an overlap device — results are identical."""
-        batch = self.prepare_batch(batch)
+        on_host = any(isinstance(v, torch.Tensor) and v.device.type == "cpu" for v in batch.values())
+        if on_host:
+            # a host batch (pinned tensors of data.ptv3_collate_fn(pin=True)): upload it on the front-end stream, so
+            # the H2D copies (24 MB of soft labels per 16 clouds) and the integer pipeline both run under the current
+            # step's backward instead of in front of the next forward (genrobo3d/models/base.py:29-34 uploads
+            # synchronously at the top of forward)
+            fe = self.ptv3_model.fe_stream()
+            with torch.cuda.stream(fe):
+                batch = self.prepare_batch(batch)
+            batch["_upload_stream"] = fe
+        else:
+            batch = self.prepare_batch(batch)
         if not batch["pc_fts"].is_contiguous():
             batch["pc_fts"] = batch["pc_fts"].contiguous()
         self.ptv3_model.prefetch({"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
                                   "offset": batch["offset"], "feat": batch["pc_fts"],
-                                  "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
+                                  "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])},
+                                 wait_current=not on_host)
 
     gemm_precision = None  # 'fp32' | 'bf16x3' | 'bf16': operand precision of THIS model's products (None = ops default)
 
@@ -114,6 +126,13 @@ class SimplePolicyPTV3CA(BaseModel):
 
     def _forward(self, batch, compute_loss=False, **kwargs):
         batch = self.prepare_batch(batch)
+        up = batch.pop("_upload_stream", None)
+        if up is not None:  # uploaded by prefetch() on the front-end stream: order this stream after it, tell the allocator
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(up)
+            for v in batch.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
         dev = batch["pc_fts"].device
         if dev.type != "cuda":
             raise RuntimeError("lotus-hip runs on a HIP device only (no CPU fallback); move the model and batch to cuda")

@@ -261,21 +261,25 @@ class PointTransformerV3CA(nn.Module):
         self.frontend.grid_size = float(np.float32(data_dict.get("grid_size", 0.01)))
         return feat, src, counts, ctx_counts, context
 
+    def fe_stream(self):
+        if self._fe_stream is None:
+            self._fe_stream = torch.cuda.Stream()
+        return self._fe_stream
+
     @torch.no_grad()
-    def prefetch(self, data_dict):
+    def prefetch(self, data_dict, wait_current=True):
         """Start the integer front-end (serialisation, sorts, pooling tables) of `data_dict` on a side stream.
         It depends on the input cloud only, so a trainer can call this for batch i + 1 right after the forward
         of batch i: the work then hides under the backward pass, and the next forward(data_dict) — which must
         receive the very same dict — finds its tables without draining the GPU.  The order permutations are drawn
         here (same count and order of torch.randperm calls as the reference's forward)."""
-        if self._fe_stream is None:
-            self._fe_stream = torch.cuda.Stream()
+        self.fe_stream()
         feat, src, counts, ctx_counts, context = self._front_inputs(data_dict)
         perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
         data_dict["feat"] = feat  # keep the tensors forward() will look at identical
         if src is not feat:
             data_dict["coord"] = src
-        self._pending = self.frontend.launch(src, counts, perms, stream=self._fe_stream)
+        self._pending = self.frontend.launch(src, counts, perms, stream=self._fe_stream, wait_current=wait_current)
 
     def forward(self, data_dict, return_dec_layers=False):
         """data_dict keys as in the reference: coord / feat / offset / context / context_offset
