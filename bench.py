@@ -212,7 +212,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, "
                          f"or start bench.py bare and let it spawn its ranks)")
-    rccl_ranks = world if (world > 1 and dist.get_backend() == "nccl") else 0
+    rccl_ranks = world if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -226,7 +226,7 @@ def main():
     else:
         model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
     reducer = None
-    if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1":  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
+    if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1" or dist.is_initialized():  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
         parallel.enable_sync_batchnorm()
     host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank)
@@ -393,7 +393,7 @@ def main():
             "config": {"workload": f"3D-LOTUS v1 (68.18M params), {args.batch} key-step clouds x {args.npoints} pts "
                                    f"per GPU, fwd+loss+bwd, train mode (dropout on), fp32 exact (MFMA f32)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
-                       "dist_backend": dist.get_backend() if world > 1 else None,
+                       "dist_backend": dist.get_backend() if dist.is_initialized() else None,
                        "model_gflop_per_sample": GFLOP_PER_SAMPLE,
                        "model_tflops": round(value * GFLOP_PER_SAMPLE / 1e3, 2)},
         }
@@ -471,7 +471,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only (the other ranks would idle in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -22,6 +22,15 @@ from . import ops
 def init_distributed(backend=None):
     """env:// rendezvous as torchrun sets it up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and os.environ.get("LOTUS_FORCE_COLLECTIVES") == "1" and torch.cuda.is_available():
+        # single-GPU rehearsal of the multi-GPU path: a one-rank RCCL communicator, so that every collective of the
+        # data-parallel step (gradient AVG all-reduce on the comm stream, fp64 SyncBN messages on their own communicator,
+        # the parameter broadcast) goes through the real library on a box with one device
+        if not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
+            dist.init_process_group(backend=backend or "nccl", init_method="env://", rank=0, world_size=1)
+        return 0, 0, 1
     if world == 1:
         return 0, 0, 1
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
@@ -59,8 +68,9 @@ class GradReducer:
     def __init__(self, module, bucket_mb=32.0, group=None, broadcast=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._force = dist.is_initialized() and os.environ.get("LOTUS_FORCE_COLLECTIVES") == "1"  # world-1 rehearsal
         self.params = [p for p in module.parameters() if p.requires_grad]
-        if broadcast and self.world > 1:
+        if broadcast and (self.world > 1 or self._force):
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=group)
         dev, total = self.params[0].device, sum(p.numel() for p in self.params)
@@ -68,7 +78,7 @@ class GradReducer:
         self._cap = int(bucket_mb * (1 << 20) / 4)
         self._layout(list(reversed(self.params)), [])
         self._handles = []
-        self._avg = self.world > 1 and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
+        self._avg = (self.world > 1 or self._force) and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
         self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
         self._sync = True
@@ -179,7 +189,7 @@ class GradReducer:
                 p.grad = v
 
     def _reduce(self, buf):
-        if self.world > 1:
+        if self.world > 1 or self._force:
             if self._avg:
                 self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
             else:
@@ -231,7 +241,7 @@ def enable_sync_batchnorm(group=None):
     critical path of forward and backward, and on the communicator of the gradient buckets they would queue behind a
     32+ MB all-reduce that is itself waiting for lagging weight gradients."""
     global _BN_GROUP
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("LOTUS_FORCE_COLLECTIVES") != "1"):
         ops.BnState.reduce = None
         return
     if group is None:

@@ -160,3 +160,23 @@ def test_bench_self_launches_its_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["scaling"] == "weak"
     assert out["rccl_ranks"] in (0, 2) and out["value"] > 0
+
+
+def test_one_rank_rccl_rehearsal_of_the_data_parallel_step():
+    """Only one device is reachable here, and RCCL refuses two ranks on one device — but a ONE-rank RCCL communicator
+    still sends every collective of the data-parallel step through the real library: parameter broadcast, bucketed AVG
+    all-reduce launched from backward hooks on the communication stream, fp64 SyncBN messages on their own communicator
+    (LOTUS_FORCE_COLLECTIVES=1).  The step must run and report rccl_ranks = 1."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LOTUS_FORCE_COLLECTIVES"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "4",
+                        "--npoints", "1024", "--no-roofline", "--no-other-modes", "--no-cpu-baseline", "--no-fresh-batches"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["rccl_ranks"] == 1 and out["config"]["dist_backend"] == "nccl" and out["value"] > 0
