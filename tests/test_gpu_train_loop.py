@@ -68,3 +68,59 @@ def test_resume_from_reference_format_checkpoint(tmp_path):
     opt2.load_state_dict(ock["optimizer"])
     resumed = _train(m2, opt2, init2, batch2, loptim, step, 3)
     assert resumed == cont, (resumed, cont)
+
+
+def test_episode_reader_to_training_step(tmp_path):
+    """The whole input path on real-format records: episode store -> KeystepDataset (table / robot-box removal, z rotation
+    + jitter, centring) -> DataLoader with the collate function (pinned, workers) -> prefetch()/forward/backward with the
+    optimiser.  The soft position labels built on the device from gt_actions give the same loss as the host-built
+    `disc_pos_probs` of the reference dataset (1e-5), for both heatmap types."""
+    import json
+    import random
+    import numpy as np
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import config as lcfg, data as ld, dataset as ds, optim as loptim
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+
+    rng = np.random.default_rng(0)
+    store = ds.DirStore(str(tmp_path / "eps"))
+    tv = "open_drawer+1"
+    for e in range(4):
+        store.write(tv, f"episode{e}".encode(), ds.synth_episode(rng, steps=4, points=1500))
+    instrs = {tv: ["open the drawer"]}
+    (tmp_path / "i.json").write_text(json.dumps(instrs))
+    np.save(tmp_path / "e.npy", {"open the drawer": rng.standard_normal((7, 512)).astype(np.float32)}, allow_pickle=True)
+    kw = dict(num_points=800, xyz_shift="center", xyz_norm=False, use_height=True, instr_embed_type="all", rm_robot="box_keep_gripper",
+              augment_pc=True, aug_max_rot=180, pos_bins=15, pos_bin_size=0.01, store=store)
+    torch.manual_seed(0)
+    m = SimplePolicyPTV3CA(lcfg.preset("tiny")).cuda().train()
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0
+    m.act_proj_head.dropout = 0.0
+    for kind in ("plain", "dist"):
+        host = ds.KeystepDataset(None, str(tmp_path / "e.npy"), str(tmp_path / "i.json"), host_labels=True, pos_heatmap_type=kind, **kw)
+        devl = ds.KeystepDataset(None, str(tmp_path / "e.npy"), str(tmp_path / "i.json"), pos_heatmap_type=kind, **kw)
+        random.seed(3); np.random.seed(3)
+        a = ld.ptv3_collate_fn([host[0], host[1]])
+        random.seed(3); np.random.seed(3)
+        b = ld.ptv3_collate_fn([devl[0], devl[1]])
+        b["pos_heatmap_type"] = kind
+        assert "disc_pos_probs" in a and "disc_pos_probs" not in b and torch.equal(a["pc_fts"], b["pc_fts"])
+        m.ptv3_model.order_perms = [[0, 1, 2, 3], [2, 3, 0, 1]]
+        _, la = m(a, compute_loss=True, compute_final_action=False)
+        _, lb = m(b, compute_loss=True, compute_final_action=False)
+        assert abs(la["pos"].item() - lb["pos"].item()) < 1e-5 * max(1.0, abs(la["pos"].item())), (kind, la["pos"].item(), lb["pos"].item())
+    # a short training run fed by a DataLoader
+    m.ptv3_model.order_perms = None
+    opt, init_lrs = loptim.build_optimizer(m, TOPTS)
+    loader = torch.utils.data.DataLoader(devl, batch_size=2, shuffle=True, num_workers=2, collate_fn=lambda x: ld.ptv3_collate_fn(x, pin=False))
+    losses = []
+    for epoch in range(3):
+        for step, batch in enumerate(loader):
+            opt.zero_grad(set_to_none=True)
+            _, l = m(batch, compute_loss=True, compute_final_action=False)
+            l["total"].backward()
+            loptim.set_lr(opt, init_lrs, len(losses) + 1, TOPTS)
+            opt.clip_grad_norm_(TOPTS.grad_norm)
+            opt.step()
+            losses.append(l["total"].item())
+    assert all(np.isfinite(losses)) and np.mean(losses[-2:]) < np.mean(losses[:2]), losses

@@ -1,0 +1,213 @@
+"""Episode reader, robot-box removal and augmentation: record format round trip, geometry
+known answers, item invariants; value-identical items against the imported reference dataset where the reference
+tree exists (build container; lmdb / msgpack_numpy / open3d are replaced by in-memory stand-ins for the import)."""
+import json
+import os
+import random
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import robot_3dlotus_amd  # noqa: F401
+from robot_3dlotus_amd import data as ld, dataset as ds
+
+HAVE_REF = os.path.isdir("/root/reference/genrobo3d")
+
+
+def _make_store(tmp_path, seed=3, episodes=3):
+    rng = np.random.default_rng(seed)
+    store = ds.DirStore(str(tmp_path / "eps"))
+    taskvars = ["push_button+0", "close_jar+3"]
+    for tv in taskvars:
+        for e in range(episodes):
+            store.write(tv, f"episode{e}".encode(), ds.synth_episode(rng, steps=int(rng.integers(3, 6)), points=1200))
+    instrs = {tv: [f"do {tv} please", f"{tv} now"] for tv in taskvars}
+    embeds = {s: rng.standard_normal((int(rng.integers(4, 9)), 16)).astype(np.float32) for v in instrs.values() for s in v}
+    (tmp_path / "instr.json").write_text(json.dumps(instrs))
+    np.save(tmp_path / "embeds.npy", embeds, allow_pickle=True)
+    return store, str(tmp_path / "instr.json"), str(tmp_path / "embeds.npy")
+
+
+def test_record_format_round_trip():
+    rng = np.random.default_rng(0)
+    ep = ds.synth_episode(rng, steps=3, points=500)
+    back = ds.unpack_episode(ds.pack_episode(ep))
+    assert set(back) == set(ep)
+    for a, b in zip(ep["xyz"], back["xyz"]):
+        assert b.dtype == a.dtype and np.array_equal(a, b)
+    assert np.array_equal(back["action"], ep["action"]) and back["action"].shape == (3, 8)
+    assert all(np.array_equal(back["bbox_info"][k], v) for k, v in ep["bbox_info"].items())
+
+
+def test_robot_box_geometry_known_answers():
+    """A box of extent (0.2, 0.4, 0.6) centred at (1, 2, 3), turned 90 deg about z: its long x/y axes swap."""
+    from scipy.spatial.transform import Rotation
+
+    q = Rotation.from_euler("z", 90, degrees=True).as_quat()
+    bbox, pose = {}, {}
+    for link in ds._ARM_LINKS + ds._GRIPPER_LINKS:
+        kind = "visual" if link in ds._VISUAL_LINKS else "respondable"
+        bbox[f"{link}_{kind}_bbox"] = np.array([-1e-3, 1e-3] * 3)                       # everything else: tiny boxes far away
+        pose[f"{link}_{kind}_pose"] = np.array([50.0, 50.0, 50.0, 0, 0, 0, 1])
+    bbox["Panda_link3_respondable_bbox"] = np.array([-0.1, 0.1, -0.2, 0.2, -0.3, 0.3])
+    pose["Panda_link3_respondable_pose"] = np.concatenate([[1.0, 2.0, 3.0], q])
+    box = ds.RobotBox((bbox, pose), keep_gripper=True)
+    pts = np.array([[1.0, 2.0, 3.0], [1.19, 2.0, 3.0], [1.21, 2.0, 3.0], [1.0, 2.09, 3.0], [1.0, 2.11, 3.0], [1.0, 2.0, 3.31]])
+    assert box.inside(pts).tolist() == [True, True, False, True, False, False]
+    bbox["Panda_gripper_visual_bbox"] = np.array([-0.05, 0.05] * 3)
+    pose["Panda_gripper_visual_pose"] = np.array([0.0, 0.0, 1.0, 0, 0, 0, 1])
+    p = np.array([[0.0, 0.0, 1.01]])
+    assert ds.RobotBox((bbox, pose), keep_gripper=False).inside(p)[0] and not ds.RobotBox((bbox, pose), keep_gripper=True).inside(p)[0]
+
+
+def test_items_feed_the_collate_function(tmp_path):
+    store, instr_file, embed_file = _make_store(tmp_path)
+    kw = dict(num_points=600, xyz_shift="center", xyz_norm=False, use_height=True, instr_embed_type="all", rm_robot="box_keep_gripper",
+              augment_pc=True, aug_max_rot=180, pos_bins=15, pos_bin_size=0.01, store=store)
+    d = ds.KeystepDataset(None, embed_file, instr_file, **kw)
+    assert len(d) == 6
+    random.seed(1); np.random.seed(1)
+    item = d[2]
+    T = len(item["pc_fts"])
+    assert T >= 2 and item["step_ids"] == list(range(T)) and "disc_pos_probs" not in item      # labels are built on the device
+    for pc, gt, ee in zip(item["pc_fts"], item["gt_actions"], item["ee_poses"]):
+        assert pc.shape[1] == 7 and pc.dtype == torch.float32 and 0 < pc.shape[0] <= 600
+        assert torch.allclose(pc[:, :3].mean(0), torch.zeros(3), atol=1e-5)                       # centred
+        assert float(pc[:, 3:6].abs().max()) <= 1.0 and float(pc[:, 6].min()) > 0.0                # rgb in [-1, 1]; above the table
+        assert gt.shape == (7,) and ee.shape == (8,) and all(0 <= int(b) < 72 for b in gt[3:6])
+    batch = ld.ptv3_collate_fn([d[0], d[1]], pin=False)
+    assert batch["pc_fts"].shape[0] == sum(batch["npoints_in_batch"]) and batch["gt_actions"].shape[1] == 7
+    h = ds.KeystepDataset(None, embed_file, instr_file, host_labels=True, pos_heatmap_no_robot=True, **kw)
+    random.seed(1); np.random.seed(1)
+    hi = h[2]
+    assert torch.equal(hi["pc_fts"][0], item["pc_fts"][0])                                       # same draws, labels added
+    for pc, pr in zip(hi["pc_fts"], hi["disc_pos_probs"]):
+        assert pr.shape == (3, pc.shape[0] * 30) and torch.allclose(pr.sum(1), torch.ones(3, dtype=pr.dtype), atol=1e-5)
+
+
+def _install_reference_standins():
+    """lmdb / msgpack_numpy / open3d stand-ins, just enough for `import genrobo3d.train.datasets.simple_policy_dataset`."""
+    import msgpack
+
+    class _Cursor:
+        def __init__(self, store, tv):
+            self.store, self.tv = store, tv
+
+        def iternext(self, values=False):
+            return iter(self.store.keys(self.tv))
+
+        def __iter__(self):
+            return iter((k, self.store.get(self.tv, k)) for k in self.store.keys(self.tv))
+
+    class _Txn:
+        def __init__(self, path):
+            self.store, self.tv = ds.DirStore(os.path.dirname(path)), os.path.basename(path)
+
+        def get(self, key):
+            return self.store.get(self.tv, key)
+
+        def cursor(self):
+            return _Cursor(self.store, self.tv)
+
+    class _Env:
+        def __init__(self, path, **kw):
+            self.path = path
+
+        def begin(self):
+            return _Txn(self.path)
+
+        def close(self):
+            pass
+
+    lmdb = types.ModuleType("lmdb")
+    lmdb.open = lambda path, **kw: _Env(path, **kw)
+    mn = types.ModuleType("msgpack_numpy")
+    orig = msgpack.unpackb
+    mn.patch = lambda: setattr(msgpack, "unpackb", lambda b, **kw: orig(b, **{"object_hook": ds._decode_nd, "strict_map_key": False, **kw}))
+
+    class _OBB:
+        def __init__(self, center, R, extent):
+            self.c, self.R, self.h = np.asarray(center, float), np.asarray(R, float), 0.5 * np.asarray(extent, float)
+
+        def get_point_indices_within_bounding_box(self, pts):
+            return np.nonzero(np.all(np.abs((np.asarray(pts) - self.c) @ self.R) <= self.h, axis=1))[0].tolist()
+
+    o3d = types.ModuleType("open3d")
+    o3d.geometry = types.SimpleNamespace(OrientedBoundingBox=_OBB)
+    o3d.utility = types.SimpleNamespace(Vector3dVector=lambda x: np.asarray(x))
+    for name, mod in (("lmdb", lmdb), ("msgpack_numpy", mn), ("open3d", o3d)):
+        sys.modules[name] = mod
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+
+
+@pytest.mark.reference
+@pytest.mark.skipif(not HAVE_REF, reason="reference tree is only present in the build container")
+@pytest.mark.parametrize("opts", [
+    dict(rm_robot="box_keep_gripper", augment_pc=True, aug_max_rot=180, xyz_shift="center", xyz_norm=False, use_height=True,
+         instr_embed_type="all", num_points=500, pos_heatmap_type="plain"),
+    dict(rm_robot="box", augment_pc=False, xyz_shift="gripper", xyz_norm=True, use_height=False, instr_embed_type="last",
+         num_points=4096, pos_heatmap_type="dist", pos_heatmap_no_robot=True, all_step_in_batch=False, include_last_step=True),
+    dict(rm_robot="none", augment_pc=True, aug_max_rot=45, xyz_shift="none", xyz_norm=False, use_height=True,
+         instr_embed_type="all", num_points=300, sample_points_by_distance=True, same_npoints_per_example=True),
+])
+def test_items_match_the_reference_dataset(tmp_path, opts):
+    """Same records, same seeds -> the item dictionaries of the imported `SimplePolicyDataset` (job-script options of
+    train_3dlotus_policy.sh / _peract.sh and two off-default mixes), value for value including the host-built labels."""
+    store, instr_file, embed_file = _make_store(tmp_path, seed=11)
+    _install_reference_standins()
+    from genrobo3d.train.datasets.simple_policy_dataset import SimplePolicyDataset
+
+    common = dict(rot_type="euler_disc", pos_type="disc", pos_bins=15, pos_bin_size=0.01, euler_resolution=5, **opts)
+    ref = SimplePolicyDataset(store.root, embed_file, instr_file, **common)
+    got = ds.KeystepDataset(store.root, embed_file, instr_file, host_labels=True, **common)
+    assert len(ref) == len(got) > 0 and [tuple(x[:2]) for x in got.ids] == [tuple(x[:2]) for x in ref.data_ids]
+    for idx in range(0, len(ref), max(1, len(ref) // 5)):
+        random.seed(100 + idx); np.random.seed(100 + idx)
+        want = ref[idx]
+        random.seed(100 + idx); np.random.seed(100 + idx)
+        have = got[idx]
+        assert set(want) == set(have) and len(want["pc_fts"]) > 0
+        for k in want:
+            assert len(want[k]) == len(have[k]), k
+            for a, b in zip(want[k], have[k]):
+                if isinstance(a, torch.Tensor):
+                    assert a.dtype == b.dtype and a.shape == b.shape, k
+                    assert torch.allclose(a.double(), b.double(), rtol=0, atol=1e-6 if k != "disc_pos_probs" else 1e-9), k
+                elif isinstance(a, np.ndarray):
+                    np.testing.assert_allclose(a, b, rtol=0, atol=1e-9, err_msg=k)
+                else:
+                    assert a == pytest.approx(b) if isinstance(a, float) else a == b, k
+
+
+def test_items_match_the_golden_fixture(tmp_path):
+    """tests/golden/dataset_items.npz (made by make_golden_dataset.py from the imported reference): the records in the
+    fixture, read back through this module with the recorded seeds, give the recorded items — runs on any box."""
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_items.npz"), allow_pickle=False)
+    opts, taskvar = json.loads(str(fx["opts"])), str(fx["taskvar"])
+    root = tmp_path / "eps" / taskvar
+    root.mkdir(parents=True)
+    for k in fx.files:
+        if k.startswith("rec/"):
+            (root / (k[4:] + ".msgpack")).write_bytes(fx[k].tobytes())
+    (tmp_path / "instr.json").write_text(str(fx["instrs"]))
+    np.save(tmp_path / "embeds.npy", {k[6:]: fx[k] for k in fx.files if k.startswith("embed/")}, allow_pickle=True)
+    d = ds.KeystepDataset(str(tmp_path / "eps"), str(tmp_path / "embeds.npy"), str(tmp_path / "instr.json"), host_labels=True, **opts)
+    n_items = len({k.split("/")[0] for k in fx.files if k.startswith("item")})
+    assert len(d) == n_items == 2
+    for idx in range(n_items):
+        random.seed(7 + idx); np.random.seed(7 + idx)
+        item = d[idx]
+        keys = {k.split("/")[1] for k in fx.files if k.startswith(f"item{idx}/")}
+        assert keys == set(item)
+        for k in keys:
+            for j, v in enumerate(item[k]):
+                want = fx[f"item{idx}/{k}/{j}"]
+                have = np.asarray(v.numpy() if hasattr(v, "numpy") else v)
+                if want.dtype.kind in "fc":
+                    np.testing.assert_allclose(have, want, rtol=0, atol=1e-6, err_msg=k)
+                else:
+                    assert np.array_equal(have, want), k
