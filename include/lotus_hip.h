@@ -222,6 +222,15 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
 int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream);
 int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
                      const float* g, int B, int n, int nb, float* dxt, void* stream);
+/* Trajectory head of the motion planner, genrobo3d/models/motion_planner_ptv3.py:88-97,113-114: hidden layer of step t =
+ * dropout(act(base + bias_t)) with base [M][C] shared by the steps and bias_t [C] = step-embedding part of the first
+ * Linear.  bwd: dpre = dh * act'(base + bias_t) * mask; dbase (+)= dpre (accumulate over the steps), dbias_t = colsum. */
+int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, int C, int act, float drop_p,
+                       unsigned long long drop_seed, void* stream);
+size_t lotus_step_act_bwd_workspace(int M, int C);
+int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, float* dbase, float* dbias, int M, int C, int act,
+                       float drop_p, unsigned long long drop_seed, int accumulate, void* workspace, size_t workspace_bytes,
+                       void* stream);
 /* elementwise plumbing */
 int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */

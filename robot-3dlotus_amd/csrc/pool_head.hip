@@ -299,6 +299,74 @@ __global__ void dropout_mask_kernel(const float* __restrict__ x, float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Trajectory head of the motion planner (genrobo3d/models/motion_planner_ptv3.py:88-97,113-114): the hidden layer of
+// step t is dropout(LeakyReLU(base + bias_t)) where base = x W_x^T is shared by all steps and bias_t carries the step
+// embedding.  Forward: one elementwise pass per step.  Backward: dpre_t = dh_t * act'(base + bias_t) * mask, accumulated
+// over the steps into dbase, with per-block column sums (-> dbias_t) reduced in fixed order.
+#define SA_ROWS 64  // rows per block of the backward pass
+__global__ void step_act_fwd_kernel(const float* __restrict__ base, const float* __restrict__ bias, float* __restrict__ out,
+                                    long total4, int c4n, int act, unsigned long long seed, unsigned thresh, float inv_keep) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const float4 b = reinterpret_cast<const float4*>(base)[i];
+    const float4 s = reinterpret_cast<const float4*>(bias)[i % c4n];
+    float v[4] = {b.x + s.x, b.y + s.y, b.z + s.z, b.w + s.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = act_f(v[e], act);
+      if (thresh) v[e] *= dropout_scale(seed, (unsigned long long)(4 * i + e), thresh, inv_keep);
+    }
+    reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+// block = 256 threads = (256 / c4n) row lanes x c4n column quads; rows [blockIdx.x * SA_ROWS, +SA_ROWS)
+__global__ __launch_bounds__(256) void step_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ base,
+                                                           const float* __restrict__ bias, float* __restrict__ dacc,
+                                                           float* __restrict__ part, int M, int c4n, int act, int accumulate,
+                                                           unsigned long long seed, unsigned thresh, float inv_keep) {
+  extern __shared__ float4 red[];  // [row lanes][c4n]
+  const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n, lanes = 256 / c4n;
+  const float4 s = reinterpret_cast<const float4*>(bias)[q];
+  float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int r1 = min(M, (int)(blockIdx.x + 1) * SA_ROWS);
+  for (int row = blockIdx.x * SA_ROWS + rl; row < r1; row += lanes) {
+    const long i = (long)row * c4n + q;
+    const float4 b = reinterpret_cast<const float4*>(base)[i];
+    const float4 g = reinterpret_cast<const float4*>(dh)[i];
+    const float pre[4] = {b.x + s.x, b.y + s.y, b.z + s.z, b.w + s.w};
+    float d[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d[e] *= act_grad_f(pre[e], act);
+      if (thresh) d[e] *= dropout_scale(seed, (unsigned long long)(4 * i + e), thresh, inv_keep);
+    }
+    cs.x += d[0]; cs.y += d[1]; cs.z += d[2]; cs.w += d[3];
+    float4 o = make_float4(d[0], d[1], d[2], d[3]);
+    if (accumulate) {
+      const float4 a = reinterpret_cast<const float4*>(dacc)[i];
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    reinterpret_cast<float4*>(dacc)[i] = o;
+  }
+  red[rl * c4n + q] = cs;
+  __syncthreads();
+  if (rl == 0) {
+    float4 t = red[q];
+    for (int k = 1; k < lanes; ++k) {
+      const float4 v = red[k * c4n + q];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    reinterpret_cast<float4*>(part)[(long)blockIdx.x * c4n + q] = t;
+  }
+}
+__global__ void step_act_colsum_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nb, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
+  dbias[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Soft position targets and arg-max position decoding on the device (SURVEY.md 8f rank 2;
 // genrobo3d/utils/action_position_utils.py:7-46 and :48-64 best='max').  Candidate coordinate of (point n, axis c,
 // bin j): xyz[n][c] + (j - pos_bins) * pos_bin_size, evaluated in double exactly like the reference's numpy code.
@@ -564,6 +632,46 @@ int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long 
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
                      1.f / (1.f - p));
   LOTUS_LAUNCH_CHECK("lotus_dropout");
+  return LOTUS_OK;
+}
+
+static void drop_params(float p, unsigned* th, float* inv) {
+  *th = (unsigned)(p * 4294967296.0);
+  if (p > 0.f && *th == 0) *th = 1;
+  *inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
+}
+
+int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, int C, int act, float drop_p,
+                       unsigned long long drop_seed, void* stream) {
+  LOTUS_CHECK_ARG(base && bias && out && M >= 0 && C > 0 && C % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "lotus_step_act_fwd: bad arguments");
+  if (M == 0) return LOTUS_OK;
+  unsigned th; float inv;
+  drop_params(drop_p, &th, &inv);
+  const long total4 = (long)M * C / 4;
+  const int g = cdiv(total4, 256);
+  hipLaunchKernelGGL(step_act_fwd_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, (hipStream_t)stream, base, bias, out, total4, C / 4,
+                     act, drop_seed, th, inv);
+  LOTUS_LAUNCH_CHECK("lotus_step_act_fwd");
+  return LOTUS_OK;
+}
+
+size_t lotus_step_act_bwd_workspace(int M, int C) { return (size_t)cdiv(M > 0 ? M : 1, SA_ROWS) * C * sizeof(float); }
+
+int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, float* dbase, float* dbias, int M, int C, int act,
+                       float drop_p, unsigned long long drop_seed, int accumulate, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+  LOTUS_CHECK_ARG(dh && base && bias && dbase && dbias && M >= 0 && C > 0 && C % 4 == 0 && 256 % (C / 4) == 0 && drop_p >= 0.f && drop_p < 1.f,
+                  "lotus_step_act_bwd: bad arguments (C / 4 must divide 256)");
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_step_act_bwd_workspace(M, C), "lotus_step_act_bwd: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) { (void)hipMemsetAsync(dbias, 0, C * sizeof(float), st); return LOTUS_OK; }
+  unsigned th; float inv;
+  drop_params(drop_p, &th, &inv);
+  const int nb = cdiv(M, SA_ROWS), c4n = C / 4;
+  hipLaunchKernelGGL(step_act_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float4), st, dh, base, bias, dbase, (float*)workspace, M,
+                     c4n, act, accumulate, drop_seed, th, inv);
+  hipLaunchKernelGGL(step_act_colsum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const float*)workspace, dbias, nb, C);
+  LOTUS_LAUNCH_CHECK("lotus_step_act_bwd");
   return LOTUS_OK;
 }
 

@@ -106,10 +106,8 @@ class MotionPlannerPTV3CA(BaseModel):
         # point-feature product is shared by all T steps and the step only shifts the bias.
         base = ops.LinearFn.apply(x, hm[0].weight[:, :C].contiguous(), None)                       # [N, C]
         step_bias = F.linear(te, hm[0].weight[:, C:], hm[0].bias)                                  # [T, C]
-        xts = []
-        for t in range(T):
-            h = F.dropout(F.leaky_relu(base + step_bias[t], 0.02), p, self.training)
-            xts.append(ops.LinearFn.apply(h, hm[3].weight, hm[3].bias))                            # [N, 3*nb]
+        xts = list(ops.StepHeadFn.apply(base, step_bias.contiguous(), hm[3].weight, hm[3].bias, p,
+                                        ops.mix_seed(self.ptv3_model.last_seed, 2000)))         # T x [N, 3*nb]
         # action branch, :116-120,139-146: max over points commutes with the concatenated step embedding
         pc = ops.CloudMaxFn.apply(x, lvl)                                                         # [B, C]
         pcs = torch.cat([pc.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(B, -1, -1)], -1).reshape(B * T, -1)

@@ -312,20 +312,25 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0, pr
     return dx
 
 
-def linear_wgrad(dy, x, need_bias=True, prec=None):
+def linear_wgrad(dy, x, need_bias=True, prec=None, into=None):
+    """dw = dy^T x, db = colsum(dy) on the weight-gradient stream.  `into` = (dw, db) of an earlier call: accumulate
+    into them (ordered on that stream; adding the results on the main stream would race with the side stream)."""
     M, N = dy.shape
     K = x.shape[1]
-    buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
-    dw = buf[:N * K].view(N, K)              # one contiguous gradient slab -> a single split-K reduce launch
-    db = buf[N * K:] if need_bias else None
+    if into is None:
+        buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
+        dw = buf[:N * K].view(N, K)              # one contiguous gradient slab -> a single split-K reduce launch
+        db = buf[N * K:] if need_bias else None
+    else:
+        dw, db = into
     if CALL_LOG is not None:
         CALL_LOG.append(("wgrad", M, N, K))
     nbytes = query("lotus_linear_wgrad_workspace", M, N, K)
     with _OnSide(dy, x):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         with _Timed(("wgrad", M, N, K)):
-            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0, _PREC if prec is None else prec, ws, ws.numel(),
-                 _counters(dy.device))
+            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0 if into is None else 1, _PREC if prec is None else prec, ws,
+                 ws.numel(), _counters(dy.device))
     return dw, db
 
 
@@ -934,6 +939,53 @@ class HeadLossFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         call("lotus_cloud_max_bwd", dpc, arg, lvl.batch, N, C, dxh, dx)
         return (dx, dhw0, dhb0, dhw3, dhb3, daw0, dab0, daw3, dab3) + (None,) * 8
+
+
+class StepHeadFn(torch.autograd.Function):
+    """Heat-map branch of the trajectory head for ALL steps (motion_planner_ptv3.py:88-97,113-114):
+    xt_t = Linear3(dropout(LeakyReLU(base + step_bias[t]))), t = 0..T-1, with `base` = the point-feature part of the first
+    Linear (shared by the steps).  The hidden layers are never kept: backward regenerates them (same counter-hash masks),
+    accumulates d base over the steps in the activation-backward kernel and sums the weight gradients of the T products."""
+
+    @_fwd
+    def forward(ctx, base, step_bias, w3, b3, drop_p, seed):
+        T = step_bias.shape[0]
+        M, C = base.shape
+        outs = []
+        for t in range(T):
+            h = torch.empty_like(base)
+            call("lotus_step_act_fwd", base, step_bias[t], h, M, C, ACT_LEAKY, float(drop_p), mix_seed(seed, t))
+            outs.append(linear_fwd(h, w3, b3)[0])
+        ctx.save_for_backward(base, step_bias, w3)
+        ctx.meta = (float(drop_p), int(seed))
+        return tuple(outs)
+
+    @_joined
+    def backward(ctx, *dxts):
+        base, step_bias, w3 = ctx.saved_tensors
+        p, seed = ctx.meta
+        T = step_bias.shape[0]
+        M, C = base.shape
+        dbase = torch.empty_like(base)
+        dsb = torch.empty_like(step_bias)
+        dw3 = db3 = None
+        ws = _ws(query("lotus_step_act_bwd_workspace", M, C), base.device)
+        first = True
+        for t in range(T):
+            if dxts[t] is None:
+                dsb[t].zero_()
+                continue
+            dxt = dxts[t].contiguous()
+            h = torch.empty_like(base)
+            call("lotus_step_act_fwd", base, step_bias[t], h, M, C, ACT_LEAKY, p, mix_seed(seed, t))
+            dw3, db3 = linear_wgrad(dxt, h, into=None if dw3 is None else (dw3, db3))
+            dh = linear_dgrad(dxt, w3)
+            call("lotus_step_act_bwd", dh, base, step_bias[t], dbase, dsb[t], M, C, ACT_LEAKY, p, mix_seed(seed, t),
+                 0 if first else 1, ws, ws.numel())
+            first = False
+        if first:
+            dbase.zero_()
+        return dbase, dsb, dw3, db3, None, None
 
 
 class PosCEFn(torch.autograd.Function):
