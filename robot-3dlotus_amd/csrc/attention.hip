@@ -119,17 +119,19 @@ __device__ __forceinline__ AttnSmem carve(float* base, bool bwd) {
   s.S = nullptr;  // scores live in registers (transposed-accumulator formulation)
   s.qrstd = p; p += AT;
   s.krstd = p; p += AT;
-  s.Dv = p; p += AT;
-  s.lse = p; p += AT;
+  s.Dv = p; if (bwd) p += AT;   // (backward only: the forward block must stay under 160 KB / 3)
+  s.lse = p; if (bwd) p += AT;
   s.gq = p; p += 32; s.bq = p; p += 32; s.gk = p; p += 32; s.bk = p; p += 32;
   s.qrow = (int*)p; p += AT;
   s.krow = (int*)p; p += AT;
   s.qown = (int*)p; p += AT;
-  s.kext = (int*)p; p += AT;
+  s.kext = (int*)p; if (bwd) p += AT;
   return s;
 }
 static size_t attn_smem_bytes(bool bwd) {
-  return (size_t)((bwd ? 4 : 3) * AT * ALD + 4 * AT + 4 * 32 + 4 * AT) * sizeof(float);
+  // forward: 3 row images + 2 + 3 small arrays = 53 760 B -> THREE blocks per CU (with the backward-only arrays it was
+  // 55 296 B: 3 x 55 296 > 160 KB, i.e. two)
+  return (size_t)((bwd ? 4 : 3) * AT * ALD + (bwd ? 4 : 2) * AT + 4 * 32 + (bwd ? 4 : 3) * AT) * sizeof(float);
 }
 
 __device__ __forceinline__ void load_affine(const AttnP& p, AttnSmem& s) {
