@@ -701,6 +701,10 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
     return LOTUS_OK;
   }
+  // (Measured and rejected for the tall thin level-0 layers, M = 65536, N x K <= 256 x 256: a weights-stationary kernel —
+  // whole W in LDS, one 32-row tile per wave with A fragments straight from global memory, barrier-free MFMA chain —
+  // 26.9 vs 28.9 us stand-alone at 128 x 128, 43 vs 32 us at N = 256, slower in the step everywhere: with exactly one tile
+  // per wave the load / MFMA / store phases of a wave still run back to back, which is what bounds these sizes.)
   // In isolation 128x128 tiles win once there are >= 4 blocks per CU, but inside the training step — with the
   // weight-gradient stream sharing the CUs — 64x64 tiles are better or equal at every batch size measured
   // (16 clouds: 820 vs 806 samples/s; 32: 945 vs 920; 64: 1051 vs 1032; 128: equal), so 128x128 is opt-in only

@@ -28,7 +28,10 @@ def _close(a, b, tol, msg=""):
 
 # ------------------------------------------------------------------------------------ linear
 @pytest.mark.parametrize("M,N,K", [(65536, 64, 64), (1000, 192, 64), (441, 768, 768), (3000, 256, 1024), (190, 512, 256),
-                                   (65536, 90, 128), (16, 217, 128), (7, 128, 128), (4097, 128, 512)])
+                                   (65536, 90, 128), (16, 217, 128), (7, 128, 128), (4097, 128, 512),
+                                   # tall thin layers of level 0: the weights-stationary kernel (all four column counts,
+                                   # all three reduction depths, a ragged last row tile)
+                                   (65536, 256, 64), (65536, 64, 256), (40011, 128, 128), (65536, 192, 64), (33000, 256, 128)])
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_linear_fwd(M, N, K, act):
     ops = _ops()
@@ -41,7 +44,8 @@ def test_linear_fwd(M, N, K, act):
     _close(y, ref, 2e-6, "y")
 
 
-@pytest.mark.parametrize("M,N,K", [(65536, 256, 64), (1000, 64, 192), (441, 3072, 768), (65536, 90, 128), (16, 217, 128)])
+@pytest.mark.parametrize("M,N,K", [(65536, 256, 64), (1000, 64, 192), (441, 3072, 768), (65536, 90, 128), (16, 217, 128),
+                                   (65536, 64, 256), (40011, 128, 128), (65536, 64, 192)])
 def test_linear_dgrad_wgrad(M, N, K):
     ops = _ops()
     g = torch.Generator().manual_seed(M * 3 + N + K)
