@@ -194,6 +194,94 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
                         int precision, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- composite entry points (csrc/blocks.cpp): ONE call enqueues the whole forward / backward of a sub-block by chaining
+ * the entry points above in the order the per-launch host path uses (bit-identical results).  The caller passes three flat
+ * fp32 buffers whose sizes come from the *_floats() queries — `saved` (activations kept for backward), `grads` (all
+ * parameter gradients of the sub-block, dw | db contiguous per layer) and `tmp` (scratch that must stay alive until the
+ * enqueued work is done) — plus one workspace / counter buffer per stream.  Weight gradients are enqueued on `side` after
+ * lotus_streamlink_wait(link, stream, side) (side == NULL: everything on `stream`); join != 0 orders `stream` after `side`
+ * at the end.  MLP: y = x + drop(fc2(drop(GELU(fc1(LN(x)))))), PointTransformerV3/model.py:577-583,669-673.
+ *   saved [n M*C | hpre M*Hd | a M*Hd | mean M | rstd M], grads [dg C | db C | dw1 Hd*C + db1 Hd | dw2 C*Hd + db2 C], every
+ *   slice rounded up to 4 floats. */
+size_t lotus_ffn_saved_floats(int M, int C, int Hd);
+size_t lotus_ffn_grads_floats(int C, int Hd);
+size_t lotus_ffn_tmp_floats(int M, int C, int Hd);
+size_t lotus_ffn_ws_main_bytes(int M, int C, int Hd);
+size_t lotus_ffn_ws_side_bytes(int M, int C, int Hd);
+int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
+                  unsigned long long seed2, int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
+/* dz_in (optional): dy times the fc2 dropout mask, handed over by the next sub-block; dz_out (optional, dz_out_p > 0):
+ * dx times the dropout mask (dz_out_p, dz_out_seed) of the previous sub-block (see lotus_layernorm_bwd). */
+int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* w1, const float* w2,
+                  const float* saved, float* dx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
+                  float* tmp, int M, int C, int Hd, float drop_p, unsigned long long seed1, unsigned long long seed2,
+                  int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                  void* counters_side, unsigned long long link, int join, void* stream, void* side);
+
+/* Patch self-attention sub-block, y = x + drop(proj(PatchAttention(qkv(LN(x))))), model.py:468-557,664-667.
+ *   saved [n M*C | qkv M*3C | att M*C | lse npad*H | mean M | rstd M]
+ *   grads [dg C | db C | dwqkv 3C*C + dbqkv 3C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]   (d = C / H)
+ * gidx / owner / tiles / blocks / kext / ext_pos: the level's patch tables (lotus_fe_patch + host tile lists). */
+size_t lotus_selfattn_saved_floats(int M, int C, int H, int npad);
+size_t lotus_selfattn_grads_floats(int C, int H);
+size_t lotus_selfattn_tmp_floats(int M, int C, int n_extra);
+size_t lotus_selfattn_ws_main_bytes(int M, int C, int H, int nblocks);
+size_t lotus_selfattn_ws_side_bytes(int M, int C);
+int lotus_selfattn_fwd(const float* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, float* y,
+                       float* saved, const int* gidx, const int* owner, const int* tiles, int ntiles, int npad, int M, int C,
+                       int H, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                       int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
+int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* wqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, float* dx,
+                       float* grads, float* tmp, const int* gidx, const int* owner, const int* tiles, const int* blocks, int nblocks,
+                       const int* kext, const int* ext_pos, int n_extra, int npad, int M, int C, int H, float scale, float drop_p,
+                       unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, void* ws_main,
+                       size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
+                       unsigned long long link, int join, void* stream, void* side);
+/* Cross-attention sub-block, y = x + drop(proj(CrossAttention(q(LN(x)), kv(context)))), model_ca.py:46-101,135-140.
+ *   saved [n M*C | q M*C | kv L*2C | att M*C | lse M*H | mean M | rstd M]
+ *   grads [dg C | db C | dwq C*C + dbq C | dwkv 2C*Cc + dbkv 2C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
+ * L = context rows, Cc = context channels, G = key-side partial slots of the backward tile lists. */
+size_t lotus_crossattn_saved_floats(int M, int C, int H, int L);
+size_t lotus_crossattn_grads_floats(int C, int H, int Cc);
+size_t lotus_crossattn_tmp_floats(int M, int C, int L, int G);
+size_t lotus_crossattn_ws_main_bytes(int M, int C, int H, int L, int Cc, int nblocks);
+size_t lotus_crossattn_ws_side_bytes(int M, int C, int L, int Cc);
+int lotus_crossattn_fwd(const float* x, const float* context, const float* g, const float* b, const float* wq, const float* bq,
+                        const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
+                        const float* wp, const float* bp, float* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
+                        int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
+int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, const float* context, const float* g, const float* wq,
+                        const float* wkv, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
+                        const float* saved, float* dx, float* dctx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed,
+                        float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
+                        int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                        int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                        void* counters_side, unsigned long long link, int join, void* stream, void* side);
+/* Conditional positional encoding, y = x + LN(Linear(SubMConv3d_3(xs))), model.py:615-625,660-662 (xs == x in the encoder,
+ * the stale skip branch in the decoder).  cw_packed: lotus_conv_weight_transpose output for `precision`.
+ *   saved [c n*C | l n*C | mean n | rstd n], grads [dg C | db C | dlw C*C + dlb C | dcw C*27*C + dcb C].
+ * bwd: dx_conv = conv input gradient (+ dy when add_dy); n_dup != 0 selects the duplicate-voxel passes (lotus_conv_dup_*). */
+size_t lotus_cpe_saved_floats(int n, int C);
+size_t lotus_cpe_grads_floats(int C);
+size_t lotus_cpe_tmp_floats(int n, int C);
+size_t lotus_cpe_ws_main_bytes(int n, int C);
+size_t lotus_cpe_ws_conv_bytes(int n, int C);
+size_t lotus_cpe_ws_side_bytes(int n, int C);
+int lotus_cpe_fwd(const float* x, const float* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
+                  const float* lb, const float* g, const float* b, float* y, float* saved, const int* nbr27, const int* order0, int n,
+                  int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream);
+int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
+                  const float* saved, float* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
+                  const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
+                  size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
+                  unsigned long long link, int join, void* stream, void* side);
+/* out[e] = sum_z part[z * stride + e] in fixed order (e.g. the key-side partial slots of the cross-attention backward) */
+int lotus_sum_slabs(const float* part, float* out, long n, long stride, int nz, void* stream);
+
 /* ---- pooling, head, losses ---------------------------------------------------------------- */
 /* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */
 int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,

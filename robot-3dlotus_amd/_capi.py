@@ -154,7 +154,10 @@ def call(name, *args):
 def call_raw(name, *args):
     """Entry points without a trailing stream parameter (stream link)."""
     F = _FAST if _FAST_TRIED else fastcall()
-    rc = getattr(F, name)(*args) if F is not None else lib().fn[name](*args)
+    if F is not None:
+        rc = getattr(F, name)(*args)
+    else:
+        rc = lib().fn[name](*[a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args])
     if rc != 0:
         raise LotusError(f"{name} failed ({rc}): {lib().last_error()}")
 

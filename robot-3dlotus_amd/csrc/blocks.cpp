@@ -1,0 +1,452 @@
+// lotus-hip: composite entry points — one C call enqueues the whole forward or backward of a transformer sub-block.
+//
+// The Python host used to issue the 3-11 launches of a sub-block one C-ABI call at a time (allocation, argument
+// conversion and bookkeeping per launch: ~8 us of interpreter time each, ~1000 launches per step).  These functions
+// chain the SAME entry points in the SAME order on the same streams, so results are bit-identical to the per-launch
+// path (tests/test_gpu_blocks.py); the host allocates three flat buffers per call (saved activations, gradients,
+// temporaries) whose layouts are defined here.
+//
+// Weight gradients go to `side` (0 = same stream as everything else) after `lotus_streamlink_wait(link, main, side)`,
+// exactly like ops._OnSide; join != 0 orders `main` after `side` at the end (ops "node" join mode).
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/lotus_hip.h"
+
+#define CHECK(x)        \
+  do {                  \
+    int rc_ = (x);      \
+    if (rc_) return rc_; \
+  } while (0)
+
+static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }  // keep every slice 16-byte aligned
+
+static inline int fork_side(unsigned long long link, void* main_s, void* side) {
+  return side ? lotus_streamlink_wait(link, main_s, side) : 0;
+}
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------
+// MLP sub-block: y = x + drop(fc2(drop(GELU(fc1(LN(x))))))   (PointTransformerV3/model.py:577-583, :669-673)
+//   saved  [n M*C | hpre M*Hd | a M*Hd | mean M | rstd M]
+//   grads  [dg C | db C | dw1 Hd*C | db1 Hd | dw2 C*Hd | db2 C]          (dw | db contiguous per layer)
+//   tmp    [dz2 M*C | dh M*Hd | dn M*C | ln partials]
+size_t lotus_ffn_saved_floats(int M, int C, int Hd) { return al4((size_t)M * C) + 2 * al4((size_t)M * Hd) + 2 * al4((size_t)M); }
+size_t lotus_ffn_grads_floats(int C, int Hd) { return 2 * al4(C) + al4((size_t)Hd * C + Hd) + al4((size_t)C * Hd + C); }
+size_t lotus_ffn_tmp_floats(int M, int C, int Hd) {
+  return 2 * al4((size_t)M * C) + al4((size_t)M * Hd) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+}
+size_t lotus_ffn_ws_main_bytes(int M, int C, int Hd) {
+  const size_t a = lotus_linear_workspace(M, Hd, C), b = lotus_linear_workspace(M, C, Hd);
+  return a > b ? a : b;
+}
+size_t lotus_ffn_ws_side_bytes(int M, int C, int Hd) {
+  const size_t a = lotus_linear_wgrad_workspace(M, Hd, C), b = lotus_linear_wgrad_workspace(M, C, Hd);
+  return a > b ? a : b;
+}
+
+int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
+                  const float* b2, float* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
+                  unsigned long long seed2, int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
+  float* n = saved;
+  float* hpre = n + al4((size_t)M * C);
+  float* a = hpre + al4((size_t)M * Hd);
+  float* mean = a + al4((size_t)M * Hd);
+  float* rstd = mean + al4((size_t)M);
+  const bool big = M > 8192;  // (the per-launch path only offers a split-K workspace to the small-M layers)
+  CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
+  CHECK(lotus_linear_fwd(n, w1, b1, nullptr, a, hpre, M, Hd, C, LOTUS_ACT_GELU, drop_p, seed1, precision, big ? nullptr : ws,
+                         big ? 0 : ws_bytes, big ? nullptr : counters, stream));
+  return lotus_linear_fwd(a, w2, b2, x, y, nullptr, M, C, Hd, LOTUS_ACT_NONE, drop_p, seed2, precision, big ? nullptr : ws,
+                          big ? 0 : ws_bytes, big ? nullptr : counters, stream);
+}
+
+// dz_in (optional): dy already multiplied by the fc2 dropout mask (handed over by the next sub-block's backward).
+// dz_out (optional, with dz_out_p > 0): dx times the dropout mask (dz_out_p, dz_out_seed) of the PREVIOUS sub-block.
+int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* w1, const float* w2,
+                  const float* saved, float* dx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
+                  float* tmp, int M, int C, int Hd, float drop_p, unsigned long long seed1, unsigned long long seed2,
+                  int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                  void* counters_side, unsigned long long link, int join, void* stream, void* side) {
+  const float* n = saved;
+  const float* hpre = n + al4((size_t)M * C);
+  const float* a = hpre + al4((size_t)M * Hd);
+  const float* mean = a + al4((size_t)M * Hd);
+  const float* rstd = mean + al4((size_t)M);
+  float* dg = grads;
+  float* db = dg + al4(C);
+  float* dw1 = db + al4(C);
+  float* db1 = dw1 + (size_t)Hd * C;
+  float* dw2 = dw1 + al4((size_t)Hd * C + Hd);
+  float* db2 = dw2 + (size_t)C * Hd;
+  float* dz2 = tmp;
+  float* dh = dz2 + al4((size_t)M * C);
+  float* dn = dh + al4((size_t)M * Hd);
+  float* lnp = dn + al4((size_t)M * C);
+  const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
+  void* sw = side ? side : stream;                                   // stream of the weight gradients
+  void* wws = side ? ws_side : ws_main;                              // ... and their workspace / counters
+  const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
+  void* wcnt = side ? counters_side : counters_main;
+  const bool big = M > 8192;
+  const float* dz = dz_in;
+  if (!dz) {
+    if (drop_p > 0.f) {
+      CHECK(lotus_dropout(dy, dz2, (long)M * C, drop_p, seed2, stream));
+      dz = dz2;
+    } else {
+      dz = dy;
+    }
+  }
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dz, a, dw2, db2, M, C, Hd, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dz, w2, dh, hpre, nullptr, M, C, Hd, LOTUS_ACT_GELU, drop_p, seed1, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dh, n, dw1, db1, M, Hd, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dh, w1, dn, nullptr, nullptr, M, Hd, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  if (side) {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p,
+                              dz_out_seed, lnp, lnp_bytes, stream));
+    CHECK(fork_side(link, stream, side));
+    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
+    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
+  } else {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
+                              lnp, lnp_bytes, stream));
+  }
+  return LOTUS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Patch self-attention sub-block: y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (model.py:468-557, :664-667)
+//   saved [n M*C | qkv M*3C | att M*C | lse npad*H | mean M | rstd M]
+//   grads [dg C | db C | dwqkv 3C*C + dbqkv 3C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
+//   tmp   [dz M*C | datt M*C | dqkv M*3C | extra max(n_extra,1)*2C | dn M*C | ln partials]
+size_t lotus_selfattn_saved_floats(int M, int C, int H, int npad) {
+  return 2 * al4((size_t)M * C) + al4((size_t)M * 3 * C) + al4((size_t)npad * H) + 2 * al4((size_t)M);
+}
+size_t lotus_selfattn_grads_floats(int C, int H) {
+  return 2 * al4(C) + al4((size_t)3 * C * C + 3 * C) + 4 * al4(C / H) + al4((size_t)C * C + C);
+}
+size_t lotus_selfattn_tmp_floats(int M, int C, int n_extra) {
+  return 3 * al4((size_t)M * C) + al4((size_t)M * 3 * C) + al4((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C) +
+         lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+}
+size_t lotus_selfattn_ws_main_bytes(int M, int C, int H, int nblocks) {
+  size_t a = lotus_linear_workspace(M, 3 * C, C), b = lotus_linear_workspace(M, C, C), c = lotus_attention_bwd_workspace(nblocks, H);
+  if (b > a) a = b;
+  return c > a ? c : a;
+}
+size_t lotus_selfattn_ws_side_bytes(int M, int C) {
+  const size_t a = lotus_linear_wgrad_workspace(M, 3 * C, C), b = lotus_linear_wgrad_workspace(M, C, C);
+  return a > b ? a : b;
+}
+
+int lotus_selfattn_fwd(const float* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, float* y,
+                       float* saved, const int* gidx, const int* owner, const int* tiles, int ntiles, int npad, int M, int C,
+                       int H, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                       int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
+  const int d = C / H;
+  float* n = saved;
+  float* qkv = n + al4((size_t)M * C);
+  float* att = qkv + al4((size_t)M * 3 * C);
+  float* lse = att + al4((size_t)M * C);
+  float* mean = lse + al4((size_t)npad * H);
+  float* rstd = mean + al4((size_t)M);
+  const bool big = M > 8192;
+  CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
+  CHECK(lotus_linear_fwd(n, wqkv, bqkv, nullptr, qkv, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws,
+                         big ? 0 : ws_bytes, big ? nullptr : counters, stream));
+  CHECK(lotus_attention_fwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse,
+                            H, d, scale, 1e-6f, attn_p, attn_seed, precision, stream));
+  return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
+                          big ? 0 : ws_bytes, big ? nullptr : counters, stream);
+}
+
+int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* wqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, float* dx,
+                       float* grads, float* tmp, const int* gidx, const int* owner, const int* tiles, const int* blocks, int nblocks,
+                       const int* kext, const int* ext_pos, int n_extra, int npad, int M, int C, int H, float scale, float drop_p,
+                       unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, void* ws_main,
+                       size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
+                       unsigned long long link, int join, void* stream, void* side) {
+  const int d = C / H;
+  const float* n = saved;
+  const float* qkv = n + al4((size_t)M * C);
+  const float* att = qkv + al4((size_t)M * 3 * C);
+  const float* lse = att + al4((size_t)M * C);
+  const float* mean = lse + al4((size_t)npad * H);
+  const float* rstd = mean + al4((size_t)M);
+  float* dg = grads;
+  float* db = dg + al4(C);
+  float* dwqkv = db + al4(C);
+  float* dbqkv = dwqkv + (size_t)3 * C * C;
+  float* gq = dwqkv + al4((size_t)3 * C * C + 3 * C);
+  float* bq = gq + al4(d);
+  float* gk = bq + al4(d);
+  float* bk = gk + al4(d);
+  float* dwp = bk + al4(d);
+  float* dbp = dwp + (size_t)C * C;
+  float* dzb = tmp;
+  float* datt = dzb + al4((size_t)M * C);
+  float* dqkv = datt + al4((size_t)M * C);
+  float* extra = dqkv + al4((size_t)M * 3 * C);
+  float* dn = extra + al4((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C);
+  float* lnp = dn + al4((size_t)M * C);
+  const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
+  void* sw = side ? side : stream;
+  void* wws = side ? ws_side : ws_main;
+  const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
+  void* wcnt = side ? counters_side : counters_main;
+  const bool big = M > 8192;
+  const float* dz = dz_in;
+  if (!dz) {
+    if (drop_p > 0.f) {
+      CHECK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
+      dz = dzb;
+    } else {
+      dz = dy;
+    }
+  }
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  CHECK(lotus_attention_bwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, blocks, nblocks, qnw, qnb, knw, knb, att, datt,
+                            (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra, gq, bq, gk, bk, 0, H, d,
+                            scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dqkv, n, dwqkv, dbqkv, M, 3 * C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dqkv, wqkv, dn, nullptr, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  if (side) {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
+    CHECK(fork_side(link, stream, side));
+    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
+    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
+  } else {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
+  }
+  return LOTUS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention sub-block: y = x + drop(proj(CrossAttention(q(LN(x)), kv(context))))   (model_ca.py:46-101, :135-140)
+//   saved [n M*C | q M*C | kv L*2C | att M*C | lse M*H | mean M | rstd M]
+//   grads [dg C | db C | dwq C*C + dbq C | dwkv 2C*Cc + dbkv 2C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
+//   tmp   [dz M*C | datt M*C | dq M*C | dkv_part G*L*2C | dkv L*2C | dn M*C | ln partials]
+size_t lotus_crossattn_saved_floats(int M, int C, int H, int L) {
+  return 3 * al4((size_t)M * C) + al4((size_t)L * 2 * C) + al4((size_t)M * H) + 2 * al4((size_t)M);
+}
+size_t lotus_crossattn_grads_floats(int C, int H, int Cc) {
+  return 2 * al4(C) + 2 * al4((size_t)C * C + C) + al4((size_t)2 * C * Cc + 2 * C) + 4 * al4(C / H);
+}
+size_t lotus_crossattn_tmp_floats(int M, int C, int L, int G) {
+  return 4 * al4((size_t)M * C) + al4((size_t)G * L * 2 * C) + al4((size_t)L * 2 * C) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+}
+size_t lotus_crossattn_ws_main_bytes(int M, int C, int H, int L, int Cc, int nblocks) {
+  size_t a = lotus_linear_workspace(M, C, C), b = lotus_linear_workspace(L, 2 * C, Cc), c = lotus_attention_bwd_workspace(nblocks, H);
+  if (b > a) a = b;
+  return c > a ? c : a;
+}
+size_t lotus_crossattn_ws_side_bytes(int M, int C, int L, int Cc) {
+  const size_t a = lotus_linear_wgrad_workspace(M, C, C), b = lotus_linear_wgrad_workspace(L, 2 * C, Cc);
+  return a > b ? a : b;
+}
+
+int lotus_crossattn_fwd(const float* x, const float* context, const float* g, const float* b, const float* wq, const float* bq,
+                        const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
+                        const float* wp, const float* bp, float* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
+                        int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
+  const int d = C / H;
+  float* n = saved;
+  float* q = n + al4((size_t)M * C);
+  float* kv = q + al4((size_t)M * C);
+  float* att = kv + al4((size_t)L * 2 * C);
+  float* lse = att + al4((size_t)M * C);
+  float* mean = lse + al4((size_t)M * H);
+  float* rstd = mean + al4((size_t)M);
+  const bool big = M > 8192, bigL = L > 8192;
+  CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
+  CHECK(lotus_linear_fwd(n, wq, bq, nullptr, q, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
+                         big ? nullptr : counters, stream));
+  CHECK(lotus_linear_fwd(context, wkv, bkv, nullptr, kv, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws,
+                         bigL ? 0 : ws_bytes, bigL ? nullptr : counters, stream));
+  CHECK(lotus_attention_fwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse, H,
+                            d, scale, 1e-6f, attn_p, attn_seed, precision, stream));
+  return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
+                          big ? 0 : ws_bytes, big ? nullptr : counters, stream);
+}
+
+// dctx (optional): gradient of the context [L][Cc].  G = key-side partial slots of the attention backward.
+int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, const float* context, const float* g, const float* wq,
+                        const float* wkv, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
+                        const float* saved, float* dx, float* dctx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed,
+                        float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
+                        int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
+                        int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                        void* counters_side, unsigned long long link, int join, void* stream, void* side) {
+  const int d = C / H;
+  const float* n = saved;
+  const float* q = n + al4((size_t)M * C);
+  const float* kv = q + al4((size_t)M * C);
+  const float* att = kv + al4((size_t)L * 2 * C);
+  const float* lse = att + al4((size_t)M * C);
+  const float* mean = lse + al4((size_t)M * H);
+  const float* rstd = mean + al4((size_t)M);
+  float* dg = grads;
+  float* db = dg + al4(C);
+  float* dwq = db + al4(C);
+  float* dbq = dwq + (size_t)C * C;
+  float* dwkv = dwq + al4((size_t)C * C + C);
+  float* dbkv = dwkv + (size_t)2 * C * Cc;
+  float* gq = dwkv + al4((size_t)2 * C * Cc + 2 * C);
+  float* bq_ = gq + al4(d);
+  float* gk = bq_ + al4(d);
+  float* bk_ = gk + al4(d);
+  float* dwp = bk_ + al4(d);
+  float* dbp = dwp + (size_t)C * C;
+  float* dzb = tmp;
+  float* datt = dzb + al4((size_t)M * C);
+  float* dq = datt + al4((size_t)M * C);
+  float* dkv_part = dq + al4((size_t)M * C);
+  float* dkv = dkv_part + al4((size_t)G * L * 2 * C);
+  float* dn = dkv + al4((size_t)L * 2 * C);
+  float* lnp = dn + al4((size_t)M * C);
+  const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
+  void* sw = side ? side : stream;
+  void* wws = side ? ws_side : ws_main;
+  const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
+  void* wcnt = side ? counters_side : counters_main;
+  const bool big = M > 8192, bigL = L > 8192;
+  const float* dz = dz_in;
+  if (!dz) {
+    if (drop_p > 0.f) {
+      CHECK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
+      dz = dzb;
+    } else {
+      dz = dy;
+    }
+  }
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att, datt,
+                            (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq, bq_, gk,
+                            bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
+  const float* dkv_f = dkv_part;
+  if (G > 1) {  // fixed-order sum of the key-side partial slots
+    CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));
+    dkv_f = dkv;
+  }
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dkv_f, context, dwkv, dbkv, L, 2 * C, Cc, 0, precision, wws, wws_bytes, wcnt, sw));
+  if (dctx)
+    CHECK(lotus_linear_dgrad(dkv_f, wkv, dctx, nullptr, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws_main,
+                             bigL ? 0 : ws_main_bytes, bigL ? nullptr : counters_main, stream));
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  if (side) {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p,
+                              dz_out_seed, lnp, lnp_bytes, stream));
+    CHECK(fork_side(link, stream, side));
+    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
+    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
+  } else {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
+                              lnp, lnp_bytes, stream));
+  }
+  return LOTUS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Conditional positional encoding: y = x + LN(Linear(SubMConv3d_3(xs)))   (model.py:615-625, :660-662); xs == x in the
+// encoder, the stale skip branch in the decoder (SURVEY.md Trap 3).
+//   saved [c n*C | l n*C | mean n | rstd n]
+//   grads [dg C | db C | dlw C*C + dlb C | dcw C*27*C + dcb C]
+//   tmp   [dl n*C | dc n*C | dyr n*C | ln partials]
+size_t lotus_cpe_saved_floats(int n, int C) { return 2 * al4((size_t)n * C) + 2 * al4((size_t)n); }
+size_t lotus_cpe_grads_floats(int C) { return 2 * al4(C) + al4((size_t)C * C + C) + al4((size_t)C * 27 * C + C); }
+size_t lotus_cpe_tmp_floats(int n, int C) { return 3 * al4((size_t)n * C) + lotus_layernorm_bwd_workspace(n, C) / sizeof(float); }
+size_t lotus_cpe_ws_main_bytes(int n, int C) { return lotus_linear_workspace(n, C, C); }
+size_t lotus_cpe_ws_conv_bytes(int n, int C) { return lotus_subm_conv_workspace(n, C, C); }
+size_t lotus_cpe_ws_side_bytes(int n, int C) {
+  const size_t a = lotus_linear_wgrad_workspace(n, C, C), b = lotus_subm_conv_wgrad_workspace(n, 27, C, C);
+  return a > b ? a : b;
+}
+
+int lotus_cpe_fwd(const float* x, const float* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
+                  const float* lb, const float* g, const float* b, float* y, float* saved, const int* nbr27, const int* order0, int n,
+                  int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream) {
+  float* c = saved;
+  float* l = c + al4((size_t)n * C);
+  float* mean = l + al4((size_t)n * C);
+  float* rstd = mean + al4((size_t)n);
+  const bool big = n > 8192;
+  CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, precision, ws_conv, ws_conv_bytes, stream));
+  CHECK(lotus_linear_fwd(c, lw, lb, nullptr, l, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
+                         big ? nullptr : counters, stream));
+  return lotus_layernorm_fwd(l, x, g, b, y, mean, rstd, n, C, 1e-5f, stream);
+}
+
+// dx_conv = input gradient of the convolution (+ dy when add_dy: the encoder case, where it IS d x).  n_dup != 0: the
+// level holds several points per voxel (code0 / order0 of the level drive the fold, nbr27[13] the mask).
+int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
+                  const float* saved, float* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
+                  const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
+                  size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
+                  unsigned long long link, int join, void* stream, void* side) {
+  const float* c = saved;
+  const float* l = c + al4((size_t)n * C);
+  const float* mean = l + al4((size_t)n * C);
+  const float* rstd = mean + al4((size_t)n);
+  float* dg = grads;
+  float* db = dg + al4(C);
+  float* dlw = db + al4(C);
+  float* dlb = dlw + (size_t)C * C;
+  float* dcw = dlw + al4((size_t)C * C + C);
+  float* dcb = dcw + (size_t)C * 27 * C;
+  float* dl = tmp;
+  float* dc = dl + al4((size_t)n * C);
+  float* dyr = dc + al4((size_t)n * C);
+  float* lnp = dyr + al4((size_t)n * C);
+  const size_t lnp_bytes = lotus_layernorm_bwd_workspace(n, C);
+  void* sw = side ? side : stream;
+  void* wws = side ? ws_side : ws_main;
+  const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
+  void* wcnt = side ? counters_side : counters_main;
+  const bool big = n > 8192;
+  if (side) {
+    CHECK(lotus_layernorm_bwd(dy, l, mean, rstd, g, nullptr, dl, nullptr, nullptr, n, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
+    CHECK(fork_side(link, stream, side));
+    CHECK(lotus_layernorm_bwd_params(lnp, n, C, dg, db, 0, side));
+  } else {
+    CHECK(lotus_layernorm_bwd(dy, l, mean, rstd, g, nullptr, dl, dg, db, n, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
+  }
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_linear_wgrad(dl, c, dlw, dlb, n, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  CHECK(fork_side(link, stream, side));
+  CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, wws, wws_bytes, sw));
+  const float* dsrc = dc;
+  if (n_dup != 0) {
+    CHECK(lotus_conv_dup_fold(dc, code0, order0, n, C, dyr, stream));
+    dsrc = dyr;
+  }
+  CHECK(lotus_subm_conv(1, dsrc, cw, cw_packed, nullptr, add_dy ? dy : nullptr, dx_conv, nbr27, order0, n, 27, C, C, precision, ws_conv,
+                        ws_conv_bytes, stream));
+  if (n_dup != 0) CHECK(lotus_conv_dup_mask(dx_conv, add_dy ? dy : nullptr, nbr27 + (size_t)13 * n, n, C, stream));
+  if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
+  return LOTUS_OK;
+}
+
+}  // extern "C"

@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["lotus_capi.cpp", "gemm.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
+SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
 HEADERS = ["common.h", "mma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 LIB = os.path.join(HERE, "liblotus_hip.so")

@@ -658,6 +658,13 @@ int lotus_reduce_parts(const float* part, float* out, long n, long stride, int n
   return LOTUS_OK;
 }
 
+// out[e] = sum_z part[z * stride + e], z = 0 .. nz-1 in fixed order (e.g. the key-side partial slots of the
+// cross-attention backward)
+extern "C" int lotus_sum_slabs(const float* part, float* out, long n, long stride, int nz, void* stream) {
+  LOTUS_CHECK_ARG(part && out && n >= 0 && nz >= 1, "lotus_sum_slabs: bad arguments");
+  return lotus_reduce_parts(part, out, n, stride, nz, 0, (hipStream_t)stream);
+}
+
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
 
 static int tune_env(const char* name) {

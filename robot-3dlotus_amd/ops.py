@@ -503,6 +503,16 @@ def pos_decode_max(xt, pc_fts, off, B, nb, bin_size):
     return out
 
 
+def sum_slabs(part):
+    """part [G, ...] -> sum over G in fixed order (one launch; G == 1: the slab itself)."""
+    if part.shape[0] == 1:
+        return part[0]
+    out = torch.empty_like(part[0])
+    n = out.numel()
+    call("lotus_sum_slabs", part, out, n, n, part.shape[0])
+    return out
+
+
 def add(a, b):
     y = torch.empty_like(a)
     call("lotus_add", a, b, y, a.numel())
@@ -627,6 +637,74 @@ def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, ti
     return grads
 
 
+# ------------------------------------------------------------------------------------ composite fast path
+# One C call per sub-block direction (csrc/blocks.cpp) instead of one per launch: same entry points, same order, same
+# streams -> bit-identical results (tests/test_gpu_blocks.py), ~70 % less interpreter time inside the sub-blocks.  The
+# per-launch bodies below stay as the readable reference and serve the diagnostics (bench.py's per-launch event log).
+_COMPOSITE = os.environ.get("LOTUS_PY_BLOCKS", "0") != "1"
+_SIZE_CACHE = {}
+
+
+def composites_enabled():
+    return _COMPOSITE and CALL_LOG is None and EVENT_LOG is None
+
+
+def set_composites(on):
+    global _COMPOSITE
+    _COMPOSITE = bool(on)
+
+
+def _sizes(kind, *dims):
+    key = (kind,) + dims
+    v = _SIZE_CACHE.get(key)
+    if v is None:
+        if kind == "ffn":
+            M, C, Hd = dims
+            v = (query("lotus_ffn_saved_floats", M, C, Hd), query("lotus_ffn_grads_floats", C, Hd),
+                 query("lotus_ffn_tmp_floats", M, C, Hd), query("lotus_ffn_ws_main_bytes", M, C, Hd),
+                 query("lotus_ffn_ws_side_bytes", M, C, Hd))
+        elif kind == "self":
+            M, C, H, npad, nblocks, n_extra = dims
+            v = (query("lotus_selfattn_saved_floats", M, C, H, npad), query("lotus_selfattn_grads_floats", C, H),
+                 query("lotus_selfattn_tmp_floats", M, C, n_extra), query("lotus_selfattn_ws_main_bytes", M, C, H, nblocks),
+                 query("lotus_selfattn_ws_side_bytes", M, C))
+        elif kind == "cross":
+            M, C, H, L, Cc, nblocks, G = dims
+            v = (query("lotus_crossattn_saved_floats", M, C, H, L), query("lotus_crossattn_grads_floats", C, H, Cc),
+                 query("lotus_crossattn_tmp_floats", M, C, L, G), query("lotus_crossattn_ws_main_bytes", M, C, H, L, Cc, nblocks),
+                 query("lotus_crossattn_ws_side_bytes", M, C, L, Cc))
+        elif kind == "cpe":
+            n, C = dims
+            v = (query("lotus_cpe_saved_floats", n, C), query("lotus_cpe_grads_floats", C), query("lotus_cpe_tmp_floats", n, C),
+                 query("lotus_cpe_ws_main_bytes", n, C), query("lotus_cpe_ws_side_bytes", n, C), query("lotus_cpe_ws_conv_bytes", n, C))
+        _SIZE_CACHE[key] = v
+    return v
+
+
+def _al4(n):
+    return (n + 3) & ~3
+
+
+def _side_ctx(dev, ws_side_bytes, reads):
+    """(side stream pointer or 0, its workspace, its counters) for a composite backward; in the deferred-join mode the
+    tensors the side stream reads are announced to the allocator (as _OnSide does)."""
+    global _CUR
+    if _side() is None:
+        return 0, None, None
+    _CUR = 0
+    st, ptr = _SIDES[0]
+    if _JOIN == "end":
+        for t in reads:
+            if t is not None:
+                t.record_stream(st)
+    ws = _side_ws(ws_side_bytes, dev)
+    key = (dev, ptr)
+    c = _COUNTERS.get(key)
+    if c is None:
+        c = _COUNTERS[key] = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
+    return ptr, ws, c
+
+
 # ------------------------------------------------------------------------------------ sub-blocks
 class CpeFn(torch.autograd.Function):
     """x1 = x + LN(Linear(SubMConv3d_3(xs))).  In the encoder xs is x; in the decoder xs is the
@@ -637,18 +715,52 @@ class CpeFn(torch.autograd.Function):
         same = xs is x
         if wt is None:
             wt = conv_weight_t(cw)
+        ctx.lvl, ctx.same = lvl, same
+        n_, C = x.shape
+        ctx.comp = composites_enabled() and C % 64 == 0 and (C == 64 or C % 128 == 0) and cw.shape[0] == C and cw.shape[-1] == C
+        if ctx.comp:
+            n_saved, _, _, ws_main, _, ws_conv = _sizes("cpe", n_, C)
+            saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            ws = _ws(ws_main, x.device)
+            wc = WS.get(ws_conv, x.device, slot=2)
+            _capi.call_raw("lotus_cpe_fwd", x, xs, cw, wt, cb, lw, lb, g, b, y, saved, lvl.nbr27, lvl.order[0], n_, C, _PREC, ws,
+                           ws.numel(), wc, wc.numel(), _counters(x.device), _capi.stream_ptr())
+            ctx.save_for_backward(xs, cw, lw, g, saved, wt)
+            return y
         c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt)
         l, _ = linear_fwd(c, lw, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
         ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd, wt)
-        ctx.lvl, ctx.same = lvl, same
         return y
 
     @_joined
     def backward(ctx, dy):
-        xs, cw, lw, g, c, l, mean, rstd, wt = ctx.saved_tensors
         lvl = ctx.lvl
         dy = dy.contiguous()
+        if ctx.comp:
+            xs, cw, lw, g, saved, wt = ctx.saved_tensors
+            n_, C = xs.shape
+            dev = xs.device
+            _, n_grads, n_tmp, ws_main, ws_side, ws_conv = _sizes("cpe", n_, C)
+            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+            dxc = torch.empty_like(xs)
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27))
+            wsm = _ws(ws_main, dev)
+            wc = WS.get(ws_conv, dev, slot=2)
+            _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, lw, g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
+                           lvl.order[0], lvl.code[0], lvl.n_dup, n_, C, _PREC, wsm, wsm.numel(), wc, wc.numel(), wss,
+                           wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
+            o1 = 2 * _al4(C)
+            o2 = o1 + _al4(C * C + C)
+            dg, db = grads[:C], grads[_al4(C):_al4(C) + C]
+            dlw, dlb = grads[o1:o1 + C * C].view(C, C), grads[o1 + C * C:o1 + C * C + C]
+            dcw, dcb = grads[o2:o2 + C * 27 * C].view(cw.shape), grads[o2 + C * 27 * C:o2 + C * 27 * C + C]
+            if ctx.same:
+                return dxc, None, dcw, dcb, dlw, dlb, dg, db, None, None
+            return dy, dxc, dcw, dcb, dlw, dlb, dg, db, None, None
+        xs, cw, lw, g, c, l, mean, rstd, wt = ctx.saved_tensors
         dl, dg, db = ln_bwd(dy, l, mean, rstd, g)
         dlw, dlb = linear_wgrad(dl, c)
         dc = linear_dgrad(dl, lw)
@@ -665,22 +777,57 @@ class FfnFn(torch.autograd.Function):
 
     @_fwd
     def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed, hand_in=None, hand_out=None):
-        n, mean, rstd = ln_fwd(x, g, b)
-        a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
-        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
-        ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         ctx.drop = (drop_p, seed)
         ctx.hands = (hand_in, hand_out)
         if hand_in is not None:
             hand_in.arm(drop_p, mix_seed(seed, 1))
+        ctx.comp = composites_enabled() and x.shape[1] % 4 == 0
+        if ctx.comp:
+            M, C = x.shape
+            Hd = w1.shape[0]
+            n_saved, _, _, ws_main, _ = _sizes("ffn", M, C, Hd)
+            saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            ws = _ws(ws_main, x.device)
+            _capi.call_raw("lotus_ffn_fwd", x, g, b, w1, b1, w2, b2, y, saved, M, C, Hd, float(drop_p), int(seed),
+                           mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+            ctx.save_for_backward(x, g, w1, w2, saved)
+            return y
+        n, mean, rstd = ln_fwd(x, g, b)
+        a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
+        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
+        ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         return y
 
     @_joined
     def backward(ctx, dy):
-        x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
         p, seed = ctx.drop
         hand_in, hand_out = ctx.hands
         dy = dy.contiguous()
+        if ctx.comp:
+            x, g, w1, w2, saved = ctx.saved_tensors
+            M, C = x.shape
+            Hd, dev = w1.shape[0], x.device
+            _, n_grads, n_tmp, ws_main, ws_side = _sizes("ffn", M, C, Hd)
+            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x)
+            dz_in = hand_in.take(dy) if hand_in is not None else None
+            dz_out, po, so = None, 0.0, 0
+            if hand_out is not None and hand_out.drop is not None:
+                po, so = hand_out.drop
+                dz_out = torch.empty_like(x)
+                hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
+            wsm = _ws(ws_main, dev)
+            _capi.call_raw("lotus_ffn_bwd", dy, dz_in, x, g, w1, w2, saved, dx, dz_out, po, so, grads, tmp, M, C, Hd, float(p),
+                           int(seed), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss, wss.numel() if wss is not None else 0,
+                           _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
+            o1 = 2 * _al4(C)
+            o2 = o1 + _al4(Hd * C + Hd)
+            return (dx, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + Hd * C].view(Hd, C), grads[o1 + Hd * C:o1 + Hd * C + Hd],
+                    grads[o2:o2 + C * Hd].view(C, Hd), grads[o2 + C * Hd:o2 + C * Hd + C], None, None, None, None)
+        x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
         dz2 = _masked(dy, p, mix_seed(seed, 1), hand_in)
         dw2, db2 = linear_wgrad(dz2, a)
         dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
@@ -697,6 +844,21 @@ class SelfAttnFn(torch.autograd.Function):
     def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0, hand_in=None):
         N, C = x.shape
         d = C // H
+        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
+        ctx.hand_in = hand_in
+        if hand_in is not None:
+            hand_in.arm(drop_p, seed)
+        ctx.comp = composites_enabled() and C % 4 == 0
+        if ctx.comp:
+            n_saved, _, _, ws_main, _ = _sizes("self", N, C, H, lvl.npad, lvl.n_self_tiles, lvl.n_extra)
+            saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            ws = _ws(ws_main, x.device)
+            _capi.call_raw("lotus_selfattn_fwd", x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, y, saved, lvl.gidx, lvl.owner,
+                           lvl.self_tiles, lvl.n_self_tiles, lvl.npad, N, C, H, float(d ** -0.5), float(drop_p), int(seed),
+                           float(attn_p), mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+            ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, saved)
+            return y
         n, mean, rstd = ln_fwd(x, g, b)
         qkv, _ = linear_fwd(n, wqkv, bqkv)
         att = torch.empty(N, C, dtype=torch.float32, device=x.device)
@@ -705,18 +867,37 @@ class SelfAttnFn(torch.autograd.Function):
                       lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, mix_seed(seed, 1))
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
-        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
-        ctx.hand_in = hand_in
-        if hand_in is not None:
-            hand_in.arm(drop_p, seed)
         return y
 
     @_joined
     def backward(ctx, dy):
-        x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
         lvl, H, d, p, seed, attn_p = ctx.meta
-        N, C = x.shape
         dy = dy.contiguous()
+        if ctx.comp:
+            x, g, wqkv, qnw, qnb, knw, knb, wp, saved = ctx.saved_tensors
+            N, C = x.shape
+            dev = x.device
+            _, n_grads, n_tmp, ws_main, ws_side = _sizes("self", N, C, H, lvl.npad, lvl.n_self_tiles, lvl.n_extra)
+            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x)
+            dz_in = ctx.hand_in.take(dy) if ctx.hand_in is not None else None
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
+            wsm = _ws(ws_main, dev)
+            _capi.call_raw("lotus_selfattn_bwd", dy, dz_in, x, g, wqkv, qnw, qnb, knw, knb, wp, saved, dx, grads, tmp, lvl.gidx,
+                           lvl.owner, lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, lvl.kext, lvl.ext_pos, lvl.n_extra, lvl.npad,
+                           N, C, H, float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(),
+                           wss, wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
+            d4 = _al4(d)
+            o1 = 2 * _al4(C)
+            o2 = o1 + _al4(3 * C * C + 3 * C)
+            o3 = o2 + 4 * d4
+            return (dx, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + 3 * C * C].view(3 * C, C),
+                    grads[o1 + 3 * C * C:o1 + 3 * C * C + 3 * C], grads[o2:o2 + d], grads[o2 + d4:o2 + d4 + d],
+                    grads[o2 + 2 * d4:o2 + 2 * d4 + d], grads[o2 + 3 * d4:o2 + 3 * d4 + d], grads[o3:o3 + C * C].view(C, C),
+                    grads[o3 + C * C:o3 + C * C + C], None, None, None, None, None, None)
+        x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
+        N, C = x.shape
         dz = _masked(dy, p, seed, ctx.hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
@@ -742,6 +923,22 @@ class CrossAttnFn(torch.autograd.Function):
                 hand_in=None, hand_out=None):
         N, C = x.shape
         d = C // H
+        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
+        ctx.hands = (hand_in, hand_out)
+        if hand_in is not None:
+            hand_in.arm(drop_p, seed)
+        ctx.comp = composites_enabled() and C % 4 == 0
+        if ctx.comp:
+            L, Cc = context.shape
+            n_saved, _, _, ws_main, _ = _sizes("cross", N, C, H, L, Cc, lvl.n_ca_blocks, lvl.ca_groups)
+            saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            ws = _ws(ws_main, x.device)
+            _capi.call_raw("lotus_crossattn_fwd", x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, y, saved,
+                           lvl.ca_tiles, lvl.n_ca_tiles, N, C, H, L, Cc, float(d ** -0.5), float(drop_p), int(seed), float(attn_p),
+                           mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+            ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved)
+            return y
         n, mean, rstd = ln_fwd(x, g, b)
         q, _ = linear_fwd(n, wq, bq)
         kv, _ = linear_fwd(context, wkv, bkv)
@@ -751,20 +948,47 @@ class CrossAttnFn(torch.autograd.Function):
                       att, lse, H, d, attn_p, mix_seed(seed, 1))
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
-        ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
-        ctx.hands = (hand_in, hand_out)
-        if hand_in is not None:
-            hand_in.arm(drop_p, seed)
         return y
 
     @_joined
     def backward(ctx, dy):
-        x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd = ctx.saved_tensors
         lvl, H, d, p, seed, attn_p = ctx.meta
-        N, C = x.shape
-        dev = x.device
         hand_in, hand_out = ctx.hands
         dy = dy.contiguous()
+        if ctx.comp:
+            x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved = ctx.saved_tensors
+            N, C = x.shape
+            L, Cc = context.shape
+            dev, G = x.device, lvl.ca_groups
+            _, n_grads, n_tmp, ws_main, ws_side = _sizes("cross", N, C, H, L, Cc, lvl.n_ca_blocks, G)
+            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x)
+            dctx = torch.empty_like(context) if ctx.needs_input_grad[1] else None
+            dz_in = hand_in.take(dy) if hand_in is not None else None
+            dz_out, po, so = None, 0.0, 0
+            if hand_out is not None and hand_out.drop is not None:
+                po, so = hand_out.drop
+                dz_out = torch.empty_like(x)
+                hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in, context))
+            wsm = _ws(ws_main, dev)
+            _capi.call_raw("lotus_crossattn_bwd", dy, dz_in, x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved, dx, dctx, dz_out,
+                           po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L, Cc, float(d ** -0.5),
+                           float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss,
+                           wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
+            d4 = _al4(d)
+            o1 = 2 * _al4(C)
+            o2 = o1 + _al4(C * C + C)
+            o3 = o2 + _al4(2 * C * Cc + 2 * C)
+            o4 = o3 + 4 * d4
+            return (dx, dctx, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + C * C].view(C, C), grads[o1 + C * C:o1 + C * C + C],
+                    grads[o2:o2 + 2 * C * Cc].view(2 * C, Cc), grads[o2 + 2 * C * Cc:o2 + 2 * C * Cc + 2 * C], grads[o3:o3 + d],
+                    grads[o3 + d4:o3 + d4 + d], grads[o3 + 2 * d4:o3 + 2 * d4 + d], grads[o3 + 3 * d4:o3 + 3 * d4 + d],
+                    grads[o4:o4 + C * C].view(C, C), grads[o4 + C * C:o4 + C * C + C], None, None, None, None, None, None, None)
+        x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd = ctx.saved_tensors
+        N, C = x.shape
+        dev = x.device
         dz = _masked(dy, p, seed, hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
@@ -774,7 +998,7 @@ class CrossAttnFn(torch.autograd.Function):
         gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
                                          lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
                                          2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1))
-        dkv = dkv_part[0] if G == 1 else dkv_part.sum(0)
+        dkv = sum_slabs(dkv_part)
         dwkv, dbkv = linear_wgrad(dkv, context)
         dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
         dwq, dbq = linear_wgrad(dq, n)

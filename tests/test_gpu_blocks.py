@@ -1,0 +1,152 @@
+"""The composite entry points (csrc/blocks.cpp: one C call per sub-block direction) against the per-launch host path:
+same kernels in the same order on the same streams, so outputs and every gradient must be BIT-identical — in both
+weight-gradient join modes, with dropout on, with and without the dropout hand-over."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import ops
+
+    return ops
+
+
+def _run_ffn(ops, composite, M, C, join, hand):
+    ops.set_composites(composite)
+    ops.set_wgrad_join(join)
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).cuda().requires_grad_(True)
+    ps = [t.cuda().requires_grad_(True) for t in (1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g),
+                                                  torch.randn(4 * C, C, generator=g) / C ** 0.5, 0.1 * torch.randn(4 * C, generator=g),
+                                                  torch.randn(C, 4 * C, generator=g) / (4 * C) ** 0.5, 0.1 * torch.randn(C, generator=g))]
+    dy = torch.randn(M, C, generator=g).cuda()
+    h_in, h_out = (ops.Handoff(), ops.Handoff()) if hand else (None, None)
+    if hand:
+        h_out.arm(0.1, 777)          # the previous sub-block wants dx pre-masked with (0.1, 777)
+    y = ops.FfnFn.apply(x, *ps, 0.1, 12345, h_in, h_out)
+    y.backward(dy)
+    torch.cuda.synchronize()
+    out = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ps]
+    if hand:
+        out.append(h_out.dz.clone())
+    return out
+
+
+@pytest.mark.parametrize("M,C", [(65536, 64), (6077, 256), (361, 768), (1450, 512)])
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("hand", [False, True])
+def test_ffn_composite_is_bit_identical(M, C, join, hand):
+    ops = _ops()
+    try:
+        ref = _run_ffn(ops, False, M, C, join, hand)
+        got = _run_ffn(ops, True, M, C, join, hand)
+    finally:
+        ops.set_composites(True)
+        ops.set_wgrad_join("node")
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+def _levels(dup):
+    import numpy as np  # noqa: F401
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.synth_batch(3, 1500, ragged=True, seed=11)
+    if dup:
+        batch = synth.augment_clouds(batch, seed=12)
+    perms = [[0, 1, 2, 3]] * 2
+    lv = FrontEnd(2).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], perms)
+    return batch, lv
+
+
+def _params(g, shapes):
+    return [(torch.randn(*s, generator=g) * (0.1 if len(s) == 1 else 1.0 / s[-1] ** 0.5)).cuda().requires_grad_(True) for s in shapes]
+
+
+def _grads(out, inputs):
+    torch.cuda.synchronize()
+    return [out.detach().clone()] + [t.grad.clone() for t in inputs if t.grad is not None]
+
+
+def _ab(fn, join):
+    ops = _ops()
+    try:
+        ops.set_wgrad_join(join)
+        ops.set_composites(False)
+        ref = fn(ops)
+        ops.set_composites(True)
+        got = fn(ops)
+    finally:
+        ops.set_composites(True)
+        ops.set_wgrad_join("node")
+    assert len(ref) == len(got)
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("C,H", [(64, 2), (128, 4)])
+def test_selfattn_composite_is_bit_identical(C, H, join):
+    batch, lv = _levels(False)
+    lvl, d = lv[0], C // H
+
+    def run(ops):
+        g = torch.Generator().manual_seed(C)
+        x = torch.randn(lvl.n, C, generator=g).cuda().requires_grad_(True)
+        ps = _params(g, [(C,), (C,), (3 * C, C), (3 * C,), (d,), (d,), (d,), (d,), (C, C), (C,)])
+        dy = torch.randn(lvl.n, C, generator=g).cuda()
+        hand = ops.Handoff()
+        y = ops.SelfAttnFn.apply(x, *ps, lvl, H, 0.1, 4242, 0.1, hand)
+        y.backward(dy)
+        return _grads(y, [x] + ps)
+
+    _ab(run, join)
+
+
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("C,H", [(64, 2), (256, 8)])
+def test_crossattn_composite_is_bit_identical(C, H, join):
+    batch, lv = _levels(False)
+    lvl, d, Cc = lv[0], C // H, 256
+    L = sum(batch["txt_lens"])
+
+    def run(ops):
+        g = torch.Generator().manual_seed(C + 1)
+        x = torch.randn(lvl.n, C, generator=g).cuda().requires_grad_(True)
+        ctxt = torch.randn(L, Cc, generator=g).cuda().requires_grad_(True)
+        ps = _params(g, [(C,), (C,), (C, C), (C,), (2 * C, Cc), (2 * C,), (d,), (d,), (d,), (d,), (C, C), (C,)])
+        dy = torch.randn(lvl.n, C, generator=g).cuda()
+        h_in, h_out = ops.Handoff(), ops.Handoff()
+        h_out.arm(0.1, 99)
+        y = ops.CrossAttnFn.apply(x, ctxt, *ps, lvl, H, 0.1, 777, 0.1, h_in, h_out)
+        y.backward(dy)
+        return _grads(y, [x, ctxt] + ps) + [h_out.dz.clone()]
+
+    _ab(run, join)
+
+
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("dup", [False, True])
+@pytest.mark.parametrize("C,same", [(64, True), (128, False)])
+def test_cpe_composite_is_bit_identical(C, same, dup, join):
+    batch, lv = _levels(dup)
+    lvl = lv[0]
+    assert (lvl.n_dup > 0) == dup
+
+    def run(ops):
+        g = torch.Generator().manual_seed(C + 2)
+        x = torch.randn(lvl.n, C, generator=g).cuda().requires_grad_(True)
+        xs = x if same else torch.randn(lvl.n, C, generator=g).cuda().requires_grad_(True)
+        cw = (torch.randn(C, 3, 3, 3, C, generator=g) / (C * 9) ** 0.5).cuda().requires_grad_(True)
+        ps = _params(g, [(C,), (C, C), (C,), (C,), (C,)])
+        dy = torch.randn(lvl.n, C, generator=g).cuda()
+        wt = ops.conv_weight_t(cw.detach())
+        y = ops.CpeFn.apply(x, xs, cw, *ps, lvl, wt)
+        y.backward(dy)
+        return _grads(y, [x] + ([] if same else [xs]) + [cw] + ps)
+
+    _ab(run, join)
