@@ -140,6 +140,8 @@ def _install_reference_standins():
     o3d.utility = types.SimpleNamespace(Vector3dVector=lambda x: np.asarray(x))
     for name, mod in (("lmdb", lmdb), ("msgpack_numpy", mn), ("open3d", o3d)):
         sys.modules[name] = mod
+    for name in ("genrobo3d.train.datasets.simple_policy_dataset", "genrobo3d.utils.robot_box"):
+        sys.modules.pop(name, None)  # (another test may have imported them against its own, smaller stand-ins)
     if "/root/reference" not in sys.path:
         sys.path.insert(0, "/root/reference")
 
