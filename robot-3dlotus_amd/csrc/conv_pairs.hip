@@ -91,8 +91,27 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1;
   const int rt = wave / NCS, cs = wave % NCS;
   const int gt = tid - rt * GT;
-  const int n0 = blockIdx.x * NW;
-  const int m0 = (blockIdx.y * NRT + rt) * BM;
+  // XCD-aware tile order: hardware block ids go to the 8 XCDs round-robin, each XCD has its own L2.  Consecutive row
+  // tiles (consecutive along the space-filling curve) share most of their halo rows, so give every XCD a CONTIGUOUS run
+  // of the (row tile, column block) list of this tap group instead of every 8th tile.
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, total = gx * (int)gridDim.y;
+    const int lin = by * gx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    if (gx == 1) {
+      by = t;
+    } else {
+      // several column blocks (C >= 256, the deep levels): a block's weight slices (taps x C x 128 columns) outweigh its
+      // rows, so the run of an XCD walks the row tiles of ONE column block before moving to the next
+      const int gy = gridDim.y;
+      bx = t / gy;
+      by = t - bx * gy;
+    }
+  }
+  const int n0 = bx * NW;
+  const int m0 = (by * NRT + rt) * BM;
   const int z_beg = blockIdx.z * p.tpz, z_end = min(p.T, z_beg + p.tpz);
   float* my_xs = xs_s + rt * HT * XLD;
   int* my_hkey = hkey_s + rt * HT;
