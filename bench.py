@@ -447,10 +447,28 @@ def main():
             # level 0 are HBM-bound, not MFMA-bound
             roof_ms = sum(max(2.0 * M * N * K / (MFMA_F32_PEAK_TFLOPS * 1e12), 4.0 * (M * K + N * K + M * N) / 6.3e12)
                           for _, M, N, K, _, _ in events) * 1e3
-            traffic = None  # HBM bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/pmc_summary.py)
+            # HBM bytes per GEMM launch and the two counters north_star names, from the committed rocprofv3 PMC passes
+            # (profiles/pmc_passes.sh + pmc_report.py).  Only trusted when they were taken on THIS build of the library.
+            traffic, evidence = None, None
             try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_hbm.json")))
-                traffic = pmc["kernels"]["gemm_kernel"]["hbm_bytes_per_launch"]
+                import hashlib
+                from robot_3dlotus_amd import _capi as _lc
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+                sha = hashlib.sha256(open(_lc.LIB_PATH, "rb").read()).hexdigest()[:16]
+                if pmc.get("library_sha256_16") == sha:
+                    k = pmc["kernels"]
+                    traffic = k["gemm_kernel"]["hbm_bytes_per_launch"]
+                    evidence = {"source": "profiles/r02_pmc.json, profiles/r02_sq.md (rocprofv3 --pmc, kernels serialised, this library build)",
+                                "attention_mfma_util": {"attn_fwd_kernel": k["attn_fwd_kernel"]["mfma_util"],
+                                                        "attn_bwd_kernel": k["attn_bwd_kernel"]["mfma_util"]},
+                                "gemm_mfma_util": k["gemm_kernel"]["mfma_util"],
+                                "neighbour_gather_GBps": {"conv_pairs_kernel (row-image fill + weights)": k["conv_pairs_kernel"]["achieved_GBps"],
+                                                          "fe_neighbour_kernel (hash probe -> table)": k["fe_neighbour_kernel"]["achieved_GBps"]},
+                                "conv_pairs_fetch_bytes_per_launch": k["conv_pairs_kernel"]["fetch_bytes_per_launch"],
+                                "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300}
+                else:
+                    evidence = {"note": f"profiles/r02_pmc.json was collected on library {pmc.get('library_sha256_16')}, this run loaded {sha}: "
+                                        "counter figures withheld (re-run profiles/pmc_passes.sh)"}
             except (OSError, KeyError, ValueError):
                 pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
@@ -468,6 +486,8 @@ def main():
                                "isolated": {"achieved": round(ach_iso, 2), "frac": round(ach_iso / MFMA_F32_PEAK_TFLOPS, 4),
                                             "ms_per_step": round(gms, 3),
                                             "note": "same launches replayed one shape at a time on an otherwise idle GPU"}}
+        if not args.no_roofline and evidence is not None:
+            out["counters"] = evidence
         if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only (the other ranks would idle in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
