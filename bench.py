@@ -206,6 +206,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
+    # stdout carries exactly ONE line, the JSON of rank 0: native libraries write banners to file descriptor 1 (RCCL prints
+    # its version block there when the communicator is torn down — after our line), so everything else goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if args.gpus > 1 and torch.cuda.device_count() < args.gpus and "LOTUS_DIST_BACKEND" not in os.environ:
         os.environ["LOTUS_DIST_BACKEND"] = "gloo"  # ranks share a device: RCCL needs one device per rank
     rank, local, world = parallel.init_distributed()
@@ -490,10 +495,15 @@ def main():
             out["counters"] = evidence
         if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only (the other ranks would idle in the barrier)
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        final_line = json.dumps(out)
+    else:
+        final_line = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if final_line is not None:
+        os.write(json_fd, (final_line + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
