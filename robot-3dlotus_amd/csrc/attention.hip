@@ -77,6 +77,39 @@ __device__ __forceinline__ void load_rows(float* img, const float* base, long ld
   }
 }
 
+// The same for N images at once with ALL global loads issued before the first LDS store: load_rows called N times
+// runs N x 4 load -> s_waitcnt -> store round trips back to back (measured: ~13 serialised HBM latencies = most of a
+// forward block's 23 us); here they are 4 N independent loads in flight.
+struct RowSrc {
+  float* img;
+  const float* base;
+  long ld;
+  int coff;
+  const int* rows_s;
+  int len;
+};
+template <int N>
+__device__ __forceinline__ void load_rows_batch(const RowSrc (&src)[N], int d) {
+  const int sub = threadIdx.x & 7, r0 = threadIdx.x >> 3;
+  float4 v[N][4];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + 32 * j;
+      v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < src[i].len && sub * 4 < d)
+        v[i][j] = *reinterpret_cast<const float4*>(src[i].base + (long)src[i].rows_s[r] * src[i].ld + src[i].coff + sub * 4);
+    }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float* o = src[i].img + (r0 + 32 * j) * ALD + sub * 4;
+      o[0] = v[i][j].x; o[1] = v[i][j].y; o[2] = v[i][j].z; o[3] = v[i][j].w;
+    }
+}
+
 // Per-row LayerNorm over d of img rows [0, len): img <- xhat (AFFINE=false) or xhat*g+b.
 template <bool AFFINE>
 __device__ __forceinline__ void ln_rows(float* img, float* rstd_s, int row, int len, int d, float eps,
@@ -201,9 +234,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
   }
   load_affine(p, s);
   __syncthreads();
-  load_rows(s.Q, p.q, p.q_ld, p.q_off + h * d, s.qrow, q_len, d);
-  load_rows(s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len, d);
-  load_rows(s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len, d);
+  {
+    const RowSrc src[3] = {{s.Q, p.q, p.q_ld, p.q_off + h * d, s.qrow, q_len}, {s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len},
+                           {s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len}};
+    load_rows_batch<3>(src, d);
+  }
   __syncthreads();
   if (tid < AT) ln_rows<true>(s.Q, s.qrstd, tid, q_len, d, p.eps, s.gq, s.bq);
   else ln_rows<true>(s.K, s.krstd, tid - AT, k_len, d, p.eps, s.gk, s.bk);
@@ -389,8 +424,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   if (tid < 4 * 32) lnacc[tid >> 5][tid & 31] = 0.f;
   load_affine(p, s);
   __syncthreads();
-  load_rows(s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len, d);
-  load_rows(s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len, d);
+  {
+    const RowSrc src[2] = {{s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len}, {s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len}};
+    load_rows_batch<2>(src, d);
+  }
   __syncthreads();
   if (tid >= AT) ln_rows<false>(s.K, s.krstd, tid - AT, k_len, d, p.eps, nullptr, nullptr);
   __syncthreads();
@@ -407,20 +444,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
       s.lse[tid] = tid < q_len ? p.lse[(long)(q_start + tid) * p.H + h] : 0.f;
     }
     __syncthreads();
-    load_rows(s.Q, p.q, p.q_ld, p.q_off + h * d, s.qrow, q_len, d);
-    {  // dO rows (zero for non-owners) and D = rowsum(dO * O)
-      const int sub = tid & 7;
-      for (int r = tid >> 3; r < AT; r += 32) {
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        float dsum = 0.f;
-        if (r < q_len && s.qown[r] && sub * 4 < d) {
-          const long o = (long)s.qrow[r] * p.out_ld + h * d + sub * 4;
-          g = *reinterpret_cast<const float4*>(p.dout + o);
-          const float4 ov = *reinterpret_cast<const float4*>(p.out + o);
-          dsum = g.x * ov.x + g.y * ov.y + g.z * ov.z + g.w * ov.w;
+    {  // Q rows, dO rows (zero for non-owners) and D = rowsum(dO * O): twelve independent 16-byte loads per thread in flight
+      const int sub = tid & 7, rr0 = tid >> 3;
+      float4 qv[4], gv[4], ov[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rr0 + 32 * j;
+        qv[j] = gv[j] = ov[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < q_len && sub * 4 < d) {
+          qv[j] = *reinterpret_cast<const float4*>(p.q + (long)s.qrow[r] * p.q_ld + p.q_off + h * d + sub * 4);
+          if (s.qown[r]) {
+            const long o = (long)s.qrow[r] * p.out_ld + h * d + sub * 4;
+            gv[j] = *reinterpret_cast<const float4*>(p.dout + o);
+            ov[j] = *reinterpret_cast<const float4*>(p.out + o);
+          }
         }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rr0 + 32 * j;
+        float* oq = s.Q + r * ALD + sub * 4;
+        oq[0] = qv[j].x; oq[1] = qv[j].y; oq[2] = qv[j].z; oq[3] = qv[j].w;
         float* o = s.dO + r * ALD + sub * 4;
-        o[0] = g.x; o[1] = g.y; o[2] = g.z; o[3] = g.w;
+        o[0] = gv[j].x; o[1] = gv[j].y; o[2] = gv[j].z; o[3] = gv[j].w;
+        float dsum = gv[j].x * ov[j].x + gv[j].y * ov[j].y + gv[j].z * ov[j].z + gv[j].w * ov[j].w;
         dsum += __shfl_xor(dsum, 1, 64);
         dsum += __shfl_xor(dsum, 2, 64);
         dsum += __shfl_xor(dsum, 4, 64);
