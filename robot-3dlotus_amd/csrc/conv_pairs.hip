@@ -128,11 +128,24 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   // neighbour ids of the whole tile with independent (batched) loads -> LDS, then an ordered in-place
   // compaction of the active output rows of every tap (wave ballot + popcount)
   {
+    // every load of the team is issued before the first result is stored: written as load -> store per iteration the
+    // loop runs its MAXT * BM / GT (7 or 14) global loads one latency after the other at the head of every block
     const int total = (z_end - z_beg) * BM;
-#pragma unroll 4
-    for (int i = gt; i < total; i += GT) {
-      const int pr = prow_s[rt * BM + (i % BM)];
-      src_tmp[i] = pr >= 0 ? p.nbr[(long)(z_beg + i / BM) * p.n + pr] : -1;
+    constexpr int NL = (MAXT * BM + GT - 1) / GT;
+    int vals[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = gt + j * GT;
+      vals[j] = -1;
+      if (i < total) {
+        const int pr = prow_s[rt * BM + (i % BM)];
+        if (pr >= 0) vals[j] = p.nbr[(long)(z_beg + i / BM) * p.n + pr];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = gt + j * GT;
+      if (i < total) src_tmp[i] = vals[j];
     }
   }
   __syncthreads();
@@ -447,7 +460,13 @@ __global__ void conv_part_reduce_kernel(const float* __restrict__ part, long str
                                         const float* __restrict__ add, float* __restrict__ y, long total4, int nd4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(part)[i];
-    for (int z = 1; z < nz; ++z) {
+    int z = 1;
+    for (; z + 1 < nz; z += 2) {  // nz is 3 or 9: two independent loads in flight, summed in z order
+      const float4 v0 = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
+      const float4 v1 = reinterpret_cast<const float4*>(part + (long)(z + 1) * stride)[i];
+      s.x = (s.x + v0.x) + v1.x; s.y = (s.y + v0.y) + v1.y; s.z = (s.z + v0.z) + v1.z; s.w = (s.w + v0.w) + v1.w;
+    }
+    for (; z < nz; ++z) {
       const float4 v = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
