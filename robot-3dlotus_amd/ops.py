@@ -747,7 +747,7 @@ class CpeFn(torch.autograd.Function):
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dxc = torch.empty_like(xs)
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27))
-            wsm = _ws(ws_main, dev)
+            wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             wc = WS.get(ws_conv, dev, slot=2)
             _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, lw, g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
                            lvl.order[0], lvl.code[0], lvl.n_dup, n_, C, _PREC, wsm, wsm.numel(), wc, wc.numel(), wss,
@@ -819,7 +819,7 @@ class FfnFn(torch.autograd.Function):
                 dz_out = torch.empty_like(x)
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
-            wsm = _ws(ws_main, dev)
+            wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_ffn_bwd", dy, dz_in, x, g, w1, w2, saved, dx, dz_out, po, so, grads, tmp, M, C, Hd, float(p),
                            int(seed), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss, wss.numel() if wss is not None else 0,
                            _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
@@ -883,7 +883,7 @@ class SelfAttnFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             dz_in = ctx.hand_in.take(dy) if ctx.hand_in is not None else None
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
-            wsm = _ws(ws_main, dev)
+            wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_selfattn_bwd", dy, dz_in, x, g, wqkv, qnw, qnb, knw, knb, wp, saved, dx, grads, tmp, lvl.gidx,
                            lvl.owner, lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, lvl.kext, lvl.ext_pos, lvl.n_extra, lvl.npad,
                            N, C, H, float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(),
@@ -972,7 +972,7 @@ class CrossAttnFn(torch.autograd.Function):
                 dz_out = torch.empty_like(x)
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in, context))
-            wsm = _ws(ws_main, dev)
+            wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_crossattn_bwd", dy, dz_in, x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved, dx, dctx, dz_out,
                            po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L, Cc, float(d ** -0.5),
                            float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss,

@@ -280,7 +280,8 @@ def test_prefetch_is_bit_identical():
 
 def test_deferred_wgrad_join_is_bit_identical():
     """ops.set_wgrad_join("end") (one join of the weight-gradient stream per backward pass instead of one per
-    autograd node) must not change a single bit of the gradients."""
+    autograd node) and running without the weight-gradient stream at all must not change a single bit of the
+    gradients."""
     import robot_3dlotus_amd  # noqa: F401
     from robot_3dlotus_amd import config as lcfg, ops, synth
     from weights_util import seeded_state_dict
@@ -290,7 +291,8 @@ def test_deferred_wgrad_join_is_bit_identical():
     batches = [_dev_batch(synth.synth_batch(4, 900, ragged=True, seed=s)) for s in (11, 12, 13)]
 
     def run(mode):
-        ops.set_wgrad_join(mode)
+        ops.set_wgrad_join("node" if mode == "single" else mode)
+        ops.enable_side_stream(mode != "single")
         try:
             m = _build(cfg, sd, True)
             m.ptv3_model.order_perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
@@ -305,11 +307,12 @@ def test_deferred_wgrad_join_is_bit_identical():
             return out
         finally:
             ops.set_wgrad_join("node")
+            ops.enable_side_stream(True)
 
-    a, b = run("node"), run("end")
-    for ga, gb in zip(a, b):
-        for u, v in zip(ga, gb):
-            assert torch.equal(u, v)
+    a, b, c = run("node"), run("end"), run("single")  # "single": LOTUS_SIDE_STREAM=0, everything on one stream
+    for ga, gb, gc in zip(a, b, c):
+        for u, v, w in zip(ga, gb, gc):
+            assert torch.equal(u, v) and torch.equal(u, w)
 
 
 def test_models_of_different_precisions_coexist():
