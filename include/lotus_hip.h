@@ -198,9 +198,10 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
  * the entry points above in the order the per-launch host path uses (bit-identical results).  The caller passes three flat
  * fp32 buffers whose sizes come from the *_floats() queries — `saved` (activations kept for backward), `grads` (all
  * parameter gradients of the sub-block, dw | db contiguous per layer) and `tmp` (scratch that must stay alive until the
- * enqueued work is done) — plus one workspace / counter buffer per stream.  Weight gradients are enqueued on `side` after
- * lotus_streamlink_wait(link, stream, side) (side == NULL: everything on `stream`); join != 0 orders `stream` after `side`
- * at the end.  MLP: y = x + drop(fc2(drop(GELU(fc1(LN(x)))))), PointTransformerV3/model.py:577-583,669-673.
+ * enqueued work is done) — plus one workspace / counter buffer per stream.  Weight gradients are enqueued on `side`
+ * (side == NULL: everything on `stream`), ordered after the launch that produces their operand by an event of `link` bound
+ * to that launch as its completion event (no marker packet in `stream`), or after lotus_streamlink_wait(link, stream, side)
+ * when the operand comes from the caller; join != 0 orders `stream` after `side` at the end.  MLP: y = x + drop(fc2(drop(GELU(fc1(LN(x)))))), PointTransformerV3/model.py:577-583,669-673.
  *   saved [n M*C | hpre M*Hd | a M*Hd | mean M | rstd M], grads [dg C | db C | dw1 Hd*C + db1 Hd | dw2 C*Hd + db2 C], every
  *   slice rounded up to 4 floats. */
 size_t lotus_ffn_saved_floats(int M, int C, int Hd);
@@ -211,8 +212,10 @@ size_t lotus_ffn_ws_side_bytes(int M, int C, int Hd);
 int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
                   const float* b2, float* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
                   unsigned long long seed2, int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
-/* dz_in (optional): dy times the fc2 dropout mask, handed over by the next sub-block; dz_out (optional, dz_out_p > 0):
- * dx times the dropout mask (dz_out_p, dz_out_seed) of the previous sub-block (see lotus_layernorm_bwd). */
+/* dz_in (optional): dy times the fc2 dropout mask, handed over by the next sub-block — i.e. the dz_out of a lotus_*_bwd
+ * call issued earlier with the same (stream, side) pair; `side` is already ordered after that launch and is NOT ordered
+ * after `stream` again for it.  dz_out (optional, dz_out_p > 0): dx times the dropout mask (dz_out_p, dz_out_seed) of the
+ * previous sub-block (see lotus_layernorm_bwd). */
 int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* w1, const float* w2,
                   const float* saved, float* dx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
                   float* tmp, int M, int C, int Hd, float drop_p, unsigned long long seed1, unsigned long long seed2,

@@ -871,13 +871,13 @@ int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, l
   const int prec = precision;
   if (prec == 3) {
     { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a1 = true; } }
-    hipLaunchKernelGGL(attn_fwd_kernel<3>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+    LOTUS_LAUNCH(attn_fwd_kernel<3>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   } else if (prec == 1) {
     { static bool a2 = false; if (!a2) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a2 = true; } }
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+    LOTUS_LAUNCH(attn_fwd_kernel<1>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   } else {
     { static bool a3 = false; if (!a3) { (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a3 = true; } }
-    hipLaunchKernelGGL(attn_fwd_kernel<0>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
+    LOTUS_LAUNCH(attn_fwd_kernel<0>, dim3(ntiles, H), dim3(256), sm, (hipStream_t)stream, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_attention_fwd");
   return LOTUS_OK;
@@ -920,20 +920,20 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   const int prec = precision;
   if (prec == 3) {
     { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a4 = true; } }
-    hipLaunchKernelGGL(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
+    LOTUS_LAUNCH(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else if (prec == 1) {
     { static bool a5 = false; if (!a5) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a5 = true; } }
-    hipLaunchKernelGGL(attn_bwd_kernel<1>, dim3(nblocks, H), dim3(256), sm, st, p);
+    LOTUS_LAUNCH(attn_bwd_kernel<1>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else {
     { static bool a6 = false; if (!a6) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a6 = true; } }
-    hipLaunchKernelGGL(attn_bwd_kernel<0>, dim3(nblocks, H), dim3(256), sm, st, p);
+    LOTUS_LAUNCH(attn_bwd_kernel<0>, dim3(nblocks, H), dim3(256), sm, st, p);
   }
   if (p.dkv_extra) {
     const int w4 = 2 * H * d / 4;
-    hipLaunchKernelGGL(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,
+    LOTUS_LAUNCH(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,
                        ext_pos, kidx, n_extra, w4, dkv, dkv_ld, dk_off);
   }
-  hipLaunchKernelGGL(attn_ln_reduce_kernel, dim3(4), dim3(1024), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
+  LOTUS_LAUNCH(attn_ln_reduce_kernel, dim3(4), dim3(1024), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
                      nblocks * H, d, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_attention_bwd");
   return LOTUS_OK;

@@ -11,7 +11,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/lotus_hip.h"
+
+extern thread_local hipEvent_t lotus_tls_stop_event;        // common.h: LOTUS_LAUNCH
+hipEvent_t lotus_link_next_event(unsigned long long link);  // lotus_capi.cpp
+void lotus_set_error(const char* fmt, ...);
 
 #define CHECK(x)        \
   do {                  \
@@ -24,6 +30,34 @@ static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }  // keep eve
 static inline int fork_side(unsigned long long link, void* main_s, void* side) {
   return side ? lotus_streamlink_wait(link, main_s, side) : 0;
 }
+
+// Fork bound to a producer: the kernels enqueued while a ForkAfter lives carry one of the link's events as their stop
+// event (the last launch wins, like re-recording), and wait() orders `side` after it.  Unlike fork_side() this puts no
+// event-record marker between the producer and the next kernel of the critical stream.
+struct ForkAfter {
+  hipEvent_t ev;
+  void* side;
+  ForkAfter(unsigned long long link, void* side_) : ev(side_ ? lotus_link_next_event(link) : nullptr), side(side_) {
+    lotus_tls_stop_event = ev;
+  }
+  ~ForkAfter() { lotus_tls_stop_event = nullptr; }
+  int wait() {
+    lotus_tls_stop_event = nullptr;
+    if (!side) return 0;
+    hipError_t e = hipStreamWaitEvent((hipStream_t)side, ev, 0);
+    if (e != hipSuccess) {
+      lotus_set_error("lotus composite: hipStreamWaitEvent: %s", hipGetErrorString(e));
+      return LOTUS_E_LAUNCH;
+    }
+    return 0;
+  }
+};
+#define PRODUCE_THEN_FORK(call) \
+  do {                          \
+    ForkAfter fa_(link, side);  \
+    CHECK(call);                \
+    CHECK(fa_.wait());          \
+  } while (0)
 
 extern "C" {
 
@@ -90,27 +124,27 @@ int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const flo
   const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
   void* wcnt = side ? counters_side : counters_main;
   const bool big = M > 8192;
+  // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
+  // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
   const float* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
-      CHECK(lotus_dropout(dy, dz2, (long)M * C, drop_p, seed2, stream));
+      PRODUCE_THEN_FORK(lotus_dropout(dy, dz2, (long)M * C, drop_p, seed2, stream));
       dz = dz2;
     } else {
       dz = dy;
+      CHECK(fork_side(link, stream, side));
     }
   }
-  CHECK(fork_side(link, stream, side));
   CHECK(lotus_linear_wgrad(dz, a, dw2, db2, M, C, Hd, 0, precision, wws, wws_bytes, wcnt, sw));
-  CHECK(lotus_linear_dgrad(dz, w2, dh, hpre, nullptr, M, C, Hd, LOTUS_ACT_GELU, drop_p, seed1, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(fork_side(link, stream, side));
+  PRODUCE_THEN_FORK(lotus_linear_dgrad(dz, w2, dh, hpre, nullptr, M, C, Hd, LOTUS_ACT_GELU, drop_p, seed1, precision,
+                                       big ? nullptr : ws_main, big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   CHECK(lotus_linear_wgrad(dh, n, dw1, db1, M, Hd, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dh, w1, dn, nullptr, nullptr, M, Hd, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   if (side) {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p,
-                              dz_out_seed, lnp, lnp_bytes, stream));
-    CHECK(fork_side(link, stream, side));
+    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
+                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
     CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
     if (join) CHECK(lotus_streamlink_wait(link, side, stream));
   } else {
@@ -203,29 +237,29 @@ int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, cons
   const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
   void* wcnt = side ? counters_side : counters_main;
   const bool big = M > 8192;
+  // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
+  // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
   const float* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
-      CHECK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
+      PRODUCE_THEN_FORK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
       dz = dzb;
     } else {
       dz = dy;
+      CHECK(fork_side(link, stream, side));
     }
   }
-  CHECK(fork_side(link, stream, side));
   CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(lotus_attention_bwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, blocks, nblocks, qnw, qnb, knw, knb, att, datt,
-                            (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra, gq, bq, gk, bk, 0, H, d,
-                            scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
-  CHECK(fork_side(link, stream, side));
+  PRODUCE_THEN_FORK(lotus_attention_bwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, blocks, nblocks, qnw, qnb, knw, knb,
+                                        att, datt, (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra,
+                                        gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
   CHECK(lotus_linear_wgrad(dqkv, n, dwqkv, dbqkv, M, 3 * C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dqkv, wqkv, dn, nullptr, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   if (side) {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
-    CHECK(fork_side(link, stream, side));
+    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
     CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
     if (join) CHECK(lotus_streamlink_wait(link, side, stream));
   } else {
@@ -324,40 +358,43 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
   const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
   void* wcnt = side ? counters_side : counters_main;
   const bool big = M > 8192, bigL = L > 8192;
+  // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
+  // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
   const float* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
-      CHECK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
+      PRODUCE_THEN_FORK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
       dz = dzb;
     } else {
       dz = dy;
+      CHECK(fork_side(link, stream, side));
     }
   }
-  CHECK(fork_side(link, stream, side));
   CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att, datt,
-                            (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq, bq_, gk,
-                            bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
   const float* dkv_f = dkv_part;
-  if (G > 1) {  // fixed-order sum of the key-side partial slots
-    CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));
-    dkv_f = dkv;
+  {
+    ForkAfter fa(link, side);  // dq and d kv: the last launch in here carries the fork event
+    CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att,
+                              datt, (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq,
+                              bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
+    if (G > 1) {  // fixed-order sum of the key-side partial slots
+      CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));
+      dkv_f = dkv;
+    }
+    CHECK(fa.wait());
   }
-  CHECK(fork_side(link, stream, side));
   CHECK(lotus_linear_wgrad(dkv_f, context, dwkv, dbkv, L, 2 * C, Cc, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   if (dctx)
     CHECK(lotus_linear_dgrad(dkv_f, wkv, dctx, nullptr, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws_main,
                              bigL ? 0 : ws_main_bytes, bigL ? nullptr : counters_main, stream));
-  CHECK(fork_side(link, stream, side));
-  CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   if (side) {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p,
-                              dz_out_seed, lnp, lnp_bytes, stream));
-    CHECK(fork_side(link, stream, side));
+    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
+                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
     CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
     if (join) CHECK(lotus_streamlink_wait(link, side, stream));
   } else {
@@ -425,17 +462,14 @@ int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float
   void* wcnt = side ? counters_side : counters_main;
   const bool big = n > 8192;
   if (side) {
-    CHECK(lotus_layernorm_bwd(dy, l, mean, rstd, g, nullptr, dl, nullptr, nullptr, n, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
-    CHECK(fork_side(link, stream, side));
+    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dy, l, mean, rstd, g, nullptr, dl, nullptr, nullptr, n, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
     CHECK(lotus_layernorm_bwd_params(lnp, n, C, dg, db, 0, side));
   } else {
     CHECK(lotus_layernorm_bwd(dy, l, mean, rstd, g, nullptr, dl, dg, db, n, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
   }
-  CHECK(fork_side(link, stream, side));
   CHECK(lotus_linear_wgrad(dl, c, dlw, dlb, n, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
-  CHECK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(fork_side(link, stream, side));
+  PRODUCE_THEN_FORK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                                       big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, wws, wws_bytes, sw));
   const float* dsrc = dc;
   if (n_dup != 0) {

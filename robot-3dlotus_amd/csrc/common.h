@@ -1,9 +1,23 @@
 // lotus-hip: shared device/host helpers (gfx950 / CDNA4 only, wave64).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+
+// Every kernel of the library is launched through LOTUS_LAUNCH.  Normally that is hipLaunchKernelGGL; while a composite
+// entry point (blocks.cpp) has armed `lotus_tls_stop_event`, the launch carries that event as its completion ("stop")
+// event instead, so another stream can be ordered after THIS kernel without an event-record marker packet in the
+// launching queue (a marker between two dependent kernels of the critical stream costs it 5-10 us; measured).
+extern thread_local hipEvent_t lotus_tls_stop_event;
+#define LOTUS_LAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
+  do {                                                                                                                   \
+    if (lotus_tls_stop_event)                                                                                            \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, lotus_tls_stop_event, 0, __VA_ARGS__);            \
+    else                                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                 \
+  } while (0)
 
 #define LOTUS_OK 0
 #define LOTUS_E_ARG (-1)

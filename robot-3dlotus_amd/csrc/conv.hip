@@ -410,10 +410,10 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
       ((uintptr_t)workspace) % 16 == 0 && workspace_bytes >= (size_t)T * cin * cout * sizeof(float)) {
     // thin-input stem: VALU kernel over the active pairs (rows are independent, so the processing order is moot);
     // the workspace receives the weights transposed to [T][cin][cout]
-    hipLaunchKernelGGL(conv_stem_wt_kernel, dim3(cdiv((long)cout * T * cin, 256)), dim3(256), 0, st, w, (float*)workspace, cout, T,
+    LOTUS_LAUNCH(conv_stem_wt_kernel, dim3(cdiv((long)cout * T * cin, 256)), dim3(256), 0, st, w, (float*)workspace, cout, T,
                        cin);
     p.w = (const float*)workspace;
-    hipLaunchKernelGGL(conv_smallcin_kernel, dim3(cout / 64, cdiv(n, STEM_ROWS)), dim3(256), 0, st, p, 0);
+    LOTUS_LAUNCH(conv_smallcin_kernel, dim3(cout / 64, cdiv(n, STEM_ROWS)), dim3(256), 0, st, p, 0);
     LOTUS_LAUNCH_CHECK("lotus_subm_conv(stem)");
     return LOTUS_OK;
   }
@@ -424,19 +424,19 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
     dim3 grid(cdiv(p.ND, 64), cdiv(n, 128));
     if (mode == 0) {
       { static bool a1 = false; if (!a1) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a1 = true; } }
-      hipLaunchKernelGGL((conv_kernel<128, 64, true>), grid, block, dyn, st, p);
+      LOTUS_LAUNCH((conv_kernel<128, 64, true>), grid, block, dyn, st, p);
     } else {
       { static bool a2 = false; if (!a2) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a2 = true; } }
-      hipLaunchKernelGGL((conv_kernel<128, 64, false>), grid, block, dyn, st, p);
+      LOTUS_LAUNCH((conv_kernel<128, 64, false>), grid, block, dyn, st, p);
     }
   } else {
     dim3 grid(cdiv(p.ND, 128), cdiv(n, 128));
     if (mode == 0) {
       { static bool a3 = false; if (!a3) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a3 = true; } }
-      hipLaunchKernelGGL((conv_kernel<128, 128, true>), grid, block, dyn, st, p);
+      LOTUS_LAUNCH((conv_kernel<128, 128, true>), grid, block, dyn, st, p);
     } else {
       { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn); a4 = true; } }
-      hipLaunchKernelGGL((conv_kernel<128, 128, false>), grid, block, dyn, st, p);
+      LOTUS_LAUNCH((conv_kernel<128, 128, false>), grid, block, dyn, st, p);
     }
   }
   LOTUS_LAUNCH_CHECK("lotus_subm_conv");
@@ -534,7 +534,7 @@ int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* orde
   LOTUS_CHECK_ARG(dy && code0 && order0 && dyr && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_fold: bad arguments");
   if (n == 0) return LOTUS_OK;
   const long total = (long)n * (C / 4);
-  hipLaunchKernelGGL(conv_dup_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, code0, order0, n,
+  LOTUS_LAUNCH(conv_dup_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, code0, order0, n,
                      C / 4, dyr);
   LOTUS_LAUNCH_CHECK("lotus_conv_dup_fold");
   return LOTUS_OK;
@@ -543,7 +543,7 @@ int lotus_conv_dup_mask(float* dx, const float* add, const int* rep, int n, int 
   LOTUS_CHECK_ARG(dx && rep && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_mask: bad arguments");
   if (n == 0) return LOTUS_OK;
   const long total = (long)n * (C / 4);
-  hipLaunchKernelGGL(conv_dup_mask_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, add, rep, n, C / 4);
+  LOTUS_LAUNCH(conv_dup_mask_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dx, add, rep, n, C / 4);
   LOTUS_LAUNCH_CHECK("lotus_conv_dup_mask");
   return LOTUS_OK;
 }
@@ -575,10 +575,10 @@ int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db,
     p.bias_part = db ? p.part + wsz : nullptr;
   }
   if (cin <= 8 && cout % 64 == 0 && !db) {  // thin-input stem: VALU kernel over the active pairs
-    hipLaunchKernelGGL(conv_smallcin_wgrad_kernel, dim3(cout / 64, T, nsplit), dim3(256), 0, st, p);
+    LOTUS_LAUNCH(conv_smallcin_wgrad_kernel, dim3(cout / 64, T, nsplit), dim3(256), 0, st, p);
   } else {
     dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+    LOTUS_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_subm_conv_wgrad");
   if (direct) return LOTUS_OK;

@@ -555,7 +555,7 @@ static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
   static bool attr_set = false;  // per instantiation; the attribute call costs host time on every launch otherwise
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
-  hipLaunchKernelGGL((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
+  LOTUS_LAUNCH((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
@@ -581,9 +581,9 @@ int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T,
   if (prec != 0) {
     const long tuples = 2L * cout * T * cin / 8;
     const int g = (int)((tuples + 255) / 256);
-    hipLaunchKernelGGL(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin);
+    LOTUS_LAUNCH(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin);
   } else {
-    hipLaunchKernelGGL(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
+    LOTUS_LAUNCH(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
   }
   LOTUS_LAUNCH_CHECK("lotus_conv_weight_transpose");
   return LOTUS_OK;
@@ -611,7 +611,7 @@ int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* 
   if (*rc == 0 && nz > 1) {
     const long total4 = (long)n * ND / 4;
     int g = cdiv(total4, 256);
-    hipLaunchKernelGGL(conv_part_reduce_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, (const float*)workspace,
+    LOTUS_LAUNCH(conv_part_reduce_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, (const float*)workspace,
                        (long)n * ND, nz, bias, add, y, total4, ND / 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { lotus_set_error("conv_part_reduce: %s", hipGetErrorString(e)); *rc = LOTUS_E_LAUNCH; }

@@ -445,8 +445,8 @@ int lotus_fe_grid(const float* coord, long ld, int n, float grid_size, int* grid
   (void)hipMemsetAsync(scratch, 0xff, 4 * sizeof(unsigned), st);
   (void)hipMemsetAsync(gmax, 0, sizeof(int), st);
   int g = cdiv(n, 256);
-  hipLaunchKernelGGL(fe_min_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, coord, ld, n, scratch);
-  hipLaunchKernelGGL(fe_grid_kernel, dim3(g), dim3(256), 0, st, coord, ld, n, scratch, grid_size, grid, gmax);
+  LOTUS_LAUNCH(fe_min_kernel, dim3(g > 1024 ? 1024 : g), dim3(256), 0, st, coord, ld, n, scratch);
+  LOTUS_LAUNCH(fe_grid_kernel, dim3(g), dim3(256), 0, st, coord, ld, n, scratch, grid_size, grid, gmax);
   LOTUS_LAUNCH_CHECK("lotus_fe_grid");
   return LOTUS_OK;
 }
@@ -457,7 +457,7 @@ int lotus_fe_encode(const int* grid, const int* batch, int n, const int* gmax, c
                     int* state, long long* code, long slot_stride, void* stream) {
   LOTUS_CHECK_ARG(grid && batch && gmax && perm4 && state && code && n > 0, "lotus_fe_encode: bad arguments");
   int4 pm = make_int4(perm4[0], perm4[1], perm4[2], perm4[3]);
-  hipLaunchKernelGGL(fe_encode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid, batch, n, gmax, pm,
+  LOTUS_LAUNCH(fe_encode_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, grid, batch, n, gmax, pm,
                      depth_bound, state, code, slot_stride);
   LOTUS_LAUNCH_CHECK("lotus_fe_encode");
   return LOTUS_OK;
@@ -492,15 +492,15 @@ int lotus_fe_sort(const long long* code, long slot_stride, const int* n_ptr, int
     int* vout = to_final ? order : vb;
     // both buffers use the same row stride when slot_stride == n_max; enforce it
     LOTUS_CHECK_ARG(slot_stride == (long)n_max, "lotus_fe_sort: slot_stride must equal n_max");
-    hipLaunchKernelGGL(rs_hist_kernel, dim3(ntiles4 / 4, 4), dim3(256), 0, st, kin, (long)n_max, n_ptr, ps * 8, ntiles4, hist);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(4), dim3(1024), 0, st, hist, ntiles4);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(ntiles, 4), dim3(64), 0, st, kin, vin, kout, vout, (long)n_max, n_ptr,
+    LOTUS_LAUNCH(rs_hist_kernel, dim3(ntiles4 / 4, 4), dim3(256), 0, st, kin, (long)n_max, n_ptr, ps * 8, ntiles4, hist);
+    LOTUS_LAUNCH(rs_scan_kernel, dim3(4), dim3(1024), 0, st, hist, ntiles4);
+    LOTUS_LAUNCH(rs_scatter_kernel, dim3(ntiles, 4), dim3(64), 0, st, kin, vin, kout, vout, (long)n_max, n_ptr,
                        ps * 8, ntiles4, hist, ps == 0 ? 1 : 0);
     kin = kout;
     vin = vout;
   }
   if (inverse)
-    hipLaunchKernelGGL(fe_inverse_kernel, dim3(cdiv(n_max, 256), 4), dim3(256), 0, st, order, inverse, (long)n_max, n_ptr);
+    LOTUS_LAUNCH(fe_inverse_kernel, dim3(cdiv(n_max, 256), 4), dim3(256), 0, st, order, inverse, (long)n_max, n_ptr);
   LOTUS_LAUNCH_CHECK("lotus_fe_sort");
   return LOTUS_OK;
 }
@@ -521,10 +521,10 @@ int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* ord
   // cbatch doubles as the per-block head-count scratch until fe_pool_child_kernel overwrites it
   const int nblk = cdiv(n_max, 1024);
   LOTUS_CHECK_ARG(nblk <= n_max, "lotus_fe_pool: n_max too small");
-  hipLaunchKernelGGL(fe_pool_count_kernel, dim3(nblk), dim3(1024), 0, st, skey0, n_ptr, cbatch, n_dup);
-  hipLaunchKernelGGL(fe_pool_scan_kernel, dim3(nblk), dim3(1024), 0, st, skey0, order0, n_ptr, (const int*)cbatch, cluster,
+  LOTUS_LAUNCH(fe_pool_count_kernel, dim3(nblk), dim3(1024), 0, st, skey0, n_ptr, cbatch, n_dup);
+  LOTUS_LAUNCH(fe_pool_scan_kernel, dim3(nblk), dim3(1024), 0, st, skey0, order0, n_ptr, (const int*)cbatch, cluster,
                      seg_start, n_child);
-  hipLaunchKernelGGL(fe_pool_child_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, pcode, (long)n_max, order0,
+  LOTUS_LAUNCH(fe_pool_child_kernel, dim3(cdiv(n_max, 256)), dim3(256), 0, st, pcode, (long)n_max, order0,
                      seg_start, pgrid, pbatch, n_child, pm, ccode, (long)n_max, cgrid, cbatch, ccounts, 1);
   LOTUS_LAUNCH_CHECK("lotus_fe_pool");
   return LOTUS_OK;
@@ -533,7 +533,7 @@ int lotus_fe_pool(const long long* pcode, const long long* skey0, const int* ord
 int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_start, int n_child, float* ccoord,
                         void* stream) {
   if (n_child == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(fe_pool_coord_kernel, dim3(cdiv(n_child, 256)), dim3(256), 0, (hipStream_t)stream, pcoord, order0,
+  LOTUS_LAUNCH(fe_pool_coord_kernel, dim3(cdiv(n_child, 256)), dim3(256), 0, (hipStream_t)stream, pcoord, order0,
                      seg_start, n_child, ccoord);
   LOTUS_LAUNCH_CHECK("lotus_fe_pool_coord");
   return LOTUS_OK;
@@ -544,7 +544,7 @@ int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int
                    int* kext, int* ext_pos, void* stream) {
   LOTUS_CHECK_ARG(order && off && offp && gidx && owner && B > 0 && K > 0, "lotus_fe_patch: bad arguments");
   if (npad == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(fe_patch_kernel, dim3(cdiv(npad, 256)), dim3(256), 0, (hipStream_t)stream, order, off, offp, B, K,
+  LOTUS_LAUNCH(fe_patch_kernel, dim3(cdiv(npad, 256)), dim3(256), 0, (hipStream_t)stream, order, off, offp, B, K,
                      npad, gidx, owner, kext, ext_pos);
   LOTUS_LAUNCH_CHECK("lotus_fe_patch");
   return LOTUS_OK;
@@ -569,8 +569,8 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
   int* hv = (int*)(hk + cap);
   (void)hipMemsetAsync(hk, 0xff, cap * sizeof(unsigned long long), st);
   (void)hipMemsetAsync(hv, 0x7f, cap * sizeof(int), st);
-  hipLaunchKernelGGL(fe_hash_build_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, grid, batch, n, hk, hv, (unsigned)(cap - 1));
-  hipLaunchKernelGGL(fe_neighbour_kernel, dim3(cdiv(n, 256), ksize * ksize * ksize), dim3(256), 0, st, grid, batch, n,
+  LOTUS_LAUNCH(fe_hash_build_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, grid, batch, n, hk, hv, (unsigned)(cap - 1));
+  LOTUS_LAUNCH(fe_neighbour_kernel, dim3(cdiv(n, 256), ksize * ksize * ksize), dim3(256), 0, st, grid, batch, n,
                      ksize, hk, hv, (unsigned)(cap - 1), nbr);
   LOTUS_LAUNCH_CHECK("lotus_fe_neighbours");
   return LOTUS_OK;

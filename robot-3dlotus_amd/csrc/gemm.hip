@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st) {
   if (n <= 0) return LOTUS_OK;
-  hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
+  LOTUS_LAUNCH(reduce_parts_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_reduce_parts");
   return LOTUS_OK;
 }
@@ -688,8 +688,8 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
     dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if constexpr (SUM_A && !A_KC && !B_KC && FAST) {
-      if (g_prec == 1) hipLaunchKernelGGL((gemm_kernel<64, 64, 32, false, false, true, true, 1>), g64, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, false, false, true, true, 3>), g64, block, 0, st, p);
+      if (g_prec == 1) LOTUS_LAUNCH((gemm_kernel<64, 64, 32, false, false, true, true, 1>), g64, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, false, false, true, true, 3>), g64, block, 0, st, p);
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
     return LOTUS_OK;
@@ -699,11 +699,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     const bool big = tile == 1;  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
     dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if (g_prec == 1) {
-      if (big) hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 1>), g128, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 1>), g64, block, 0, st, p);
+      if (big) LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 1>), g128, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 1>), g64, block, 0, st, p);
     } else {
-      if (big) hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 3>), g128, block, 0, st, p);
-      else hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 3>), g64, block, 0, st, p);
+      if (big) LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 3>), g128, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 3>), g64, block, 0, st, p);
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
     return LOTUS_OK;
@@ -719,11 +719,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   (void)blocks128; (void)small_n;
   if (tile == 1) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
-    hipLaunchKernelGGL((gemm_kernel<128, 128, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else if (tile == 2 && !SUM_A && p.M >= 2048) {  // experimental: 128 x 64 tiles (wave tile 64 x 32)
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
-    if (g_force_bk == 32) hipLaunchKernelGGL((gemm_kernel<128, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((gemm_kernel<128, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    if (g_force_bk == 32) LOTUS_LAUNCH((gemm_kernel<128, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    else LOTUS_LAUNCH((gemm_kernel<128, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
   } else {
     // slab depth (tools/gemm_sweep.py): with <= 2 blocks per CU nothing else hides the global-load latency,
     // so run deep slabs (4x the MFMA work and bytes in flight per barrier); large grids keep BK = 16 for
@@ -732,11 +732,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     if (!bk) bk = SUM_A ? 32 : (blocks64 * nz <= 512 ? 64 : (blocks64 * nz <= 2048 ? 32 : 16));
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if (bk == 64) {
-      hipLaunchKernelGGL((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+      LOTUS_LAUNCH((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
     } else if (bk == 32) {
-      hipLaunchKernelGGL((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+      LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
     } else {
-      hipLaunchKernelGGL((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+      LOTUS_LAUNCH((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
     }
   }
   LOTUS_LAUNCH_CHECK("lotus_gemm");
@@ -857,7 +857,7 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
   if (rc) return rc;
   const long total4 = (long)p.M * p.N / 4;
   int g = cdiv(total4, 256);
-  hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, p, (const float*)workspace,
+  LOTUS_LAUNCH(splitk_epilogue_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, p, (const float*)workspace,
                      (long)p.M * p.N, nz);
   LOTUS_LAUNCH_CHECK("lotus_gemm(split-K epilogue)");
   return LOTUS_OK;

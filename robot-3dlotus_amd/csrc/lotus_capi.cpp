@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
+thread_local hipEvent_t lotus_tls_stop_event = nullptr;  // see LOTUS_LAUNCH (common.h)
 
 void lotus_set_error(const char* fmt, ...) {
   va_list ap;
@@ -19,7 +20,7 @@ const char* lotus_last_error(void) { return g_err; }
 int lotus_abi_version(void) { return 1; }
 
 // Stream link: a caller-owned ring of timing-less events used to order one stream after another without a host
-// round trip ("to" waits for everything enqueued on "from" so far).  Re-recording a ring event later is safe:
+// round trip ("to" waits for everything enqueued on "from" so far, or — lotus_link_next_event — for one launch).  Re-recording a ring event later is safe:
 // hipStreamWaitEvent captures the event's state at the time of the call.
 struct StreamLink {
   int n, next;
@@ -35,7 +36,10 @@ unsigned long long lotus_streamlink_create(int nevents) {
   l->n = nevents;
   l->next = 0;
   for (int i = 0; i < nevents; ++i) {
-    hipError_t e = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming);
+    // Device-side ordering only (hipStreamWaitEvent / stop events; never inspected from the host), so the system-scope
+    // fence a recorded event performs by default is dropped: kernels of one device synchronise through their own
+    // agent-scope acquire / release.  Measured +0.5-1.3 % step throughput.
+    hipError_t e = hipEventCreateWithFlags(&l->ev[i], hipEventDisableTiming | hipEventDisableSystemFence);
     if (e != hipSuccess) {
       lotus_set_error("lotus_streamlink_create: %s", hipGetErrorString(e));
       for (int j = 0; j < i; ++j) (void)hipEventDestroy(l->ev[j]);
@@ -61,6 +65,16 @@ int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_s
   }
   return 0;
 }
+}  // extern "C"
+// internal (blocks.cpp): the ring's next event, to be bound to a kernel launch as its stop event
+hipEvent_t lotus_link_next_event(unsigned long long link) {
+  StreamLink* l = (StreamLink*)(uintptr_t)link;
+  if (!l) return nullptr;
+  hipEvent_t ev = l->ev[l->next];
+  l->next = (l->next + 1) % l->n;
+  return ev;
+}
+extern "C" {
 int lotus_streamlink_destroy(unsigned long long link) {
   StreamLink* l = (StreamLink*)(uintptr_t)link;
   if (!l) return 0;

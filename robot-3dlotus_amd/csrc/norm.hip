@@ -496,7 +496,7 @@ int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, co
   LOTUS_CHECK_ARG(x && gamma && beta && y && M >= 0, "lotus_layernorm_fwd: bad arguments");
   LOTUS_CHECK_ARG(ln_geometry(C, &p.LPR, &p.NV) == 0, "lotus_layernorm_fwd: unsupported C=%d", C);
   if (M == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(M, 256 / p.LPR)), dim3(256), 0, (hipStream_t)stream, p);
+  LOTUS_LAUNCH(ln_fwd_kernel, dim3(cdiv(M, 256 / p.LPR)), dim3(256), 0, (hipStream_t)stream, p);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_fwd");
   return LOTUS_OK;
 }
@@ -531,9 +531,9 @@ int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)grid * 2 * C * sizeof(float),
                   "lotus_layernorm_bwd: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * 2 * C * sizeof(float), st, p);
+  LOTUS_LAUNCH(ln_bwd_kernel, dim3(grid), dim3(256), (size_t)rpb * 2 * C * sizeof(float), st, p);
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, st, p.part, dgamma, dbeta, grid, C,
+    LOTUS_LAUNCH(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, st, p.part, dgamma, dbeta, grid, C,
                        accumulate);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd");
   return LOTUS_OK;
@@ -547,7 +547,7 @@ int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamm
   LOTUS_CHECK_ARG(workspace && dgamma && dbeta && M >= 0, "lotus_layernorm_bwd_params: bad arguments");
   LOTUS_CHECK_ARG(ln_geometry_bwd(C, &lpr, &nv) == 0, "lotus_layernorm_bwd_params: unsupported C=%d", C);
   const int grid = ln_bwd_grid(M, 256 / lpr);
-  hipLaunchKernelGGL(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream,
+  LOTUS_LAUNCH(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, dgamma, dbeta, grid, C, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd_params");
   return LOTUS_OK;
@@ -566,8 +566,8 @@ int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* work
   memset(&p, 0, sizeof(p));
   p.x = x; p.part = (double*)workspace; p.M = M; p.C = C;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
-  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
+  LOTUS_LAUNCH(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_stats");
   return LOTUS_OK;
 }
@@ -576,7 +576,7 @@ int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* work
 int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, float* running_mean,
                              float* running_var, int C, float eps, float momentum, void* stream) {
   LOTUS_CHECK_ARG(sums && mean && invstd, "lotus_batchnorm_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
+  LOTUS_LAUNCH(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, mean,
                      invstd, running_mean, running_var, C, eps, momentum);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_finalize");
   return LOTUS_OK;
@@ -584,7 +584,7 @@ int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, flo
 
 int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                                float eps, void* stream) {
-  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
+  LOTUS_LAUNCH(bn_eval_stats_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, running_mean,
                      running_var, mean, invstd, C, eps);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_eval_stats");
   return LOTUS_OK;
@@ -600,7 +600,7 @@ int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd
   p.x = x; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta; p.y = y;
   p.total4 = (long)M * C / 4; p.C = C; p.act = act;
   const int grid = bn_apply_grid(p.total4, C);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  LOTUS_LAUNCH(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_apply");
   return LOTUS_OK;
 }
@@ -618,8 +618,8 @@ int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean
   p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
   p.part = (double*)workspace; p.M = M; p.C = C; p.act = act;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
-  hipLaunchKernelGGL(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
+  LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
+  LOTUS_LAUNCH(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats");
   return LOTUS_OK;
 }
@@ -642,12 +642,12 @@ int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean
     BnApplyP q = p;
     q.sums = nullptr;
     q.dgamma = nullptr;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, q);
+    LOTUS_LAUNCH(bn_apply_kernel, dim3(grid), dim3(256), 0, st, q);
     BnApplyP g = p;
     g.total4 = 0;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(1), dim3(256), 0, st, g);
+    LOTUS_LAUNCH(bn_apply_kernel, dim3(1), dim3(256), 0, st, g);
   } else {
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), 0, st, p);
+    LOTUS_LAUNCH(bn_apply_kernel, dim3(grid), dim3(256), 0, st, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_apply");
   return LOTUS_OK;

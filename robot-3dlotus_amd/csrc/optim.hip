@@ -115,8 +115,8 @@ int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, in
   LOTUS_CHECK_ARG(g_ptrs && numel && chunks && partial && norm_out && nchunks >= 0, "lotus_grad_norm: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (nchunks > 0)
-    hipLaunchKernelGGL(mt_sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, (const float* const*)g_ptrs, numel, chunks, partial);
-  hipLaunchKernelGGL(mt_norm_finish_kernel, dim3(1), dim3(1024), 0, st, (const double*)partial, nchunks, max_norm, norm_out);
+    LOTUS_LAUNCH(mt_sqnorm_kernel, dim3(nchunks), dim3(256), 0, st, (const float* const*)g_ptrs, numel, chunks, partial);
+  LOTUS_LAUNCH(mt_norm_finish_kernel, dim3(1), dim3(1024), 0, st, (const double*)partial, nchunks, max_norm, norm_out);
   LOTUS_LAUNCH_CHECK("lotus_grad_norm");
   return LOTUS_OK;
 }
@@ -133,7 +133,7 @@ int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs,
   a.p = (float* const*)p_ptrs; a.g = (const float* const*)g_ptrs; a.m = (float* const*)m_ptrs; a.v = (float* const*)v_ptrs;
   a.numel = numel; a.step_size = step_size; a.decay = decay; a.chunks = chunks; a.clip = clip_coef;
   a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-  hipLaunchKernelGGL(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
+  LOTUS_LAUNCH(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
   LOTUS_LAUNCH_CHECK("lotus_adamw_step");
   return LOTUS_OK;
 }

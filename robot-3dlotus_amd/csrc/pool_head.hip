@@ -514,7 +514,7 @@ int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int n
                        void* stream) {
   LOTUS_CHECK_ARG(x && members && seg && y && arg && C % 4 == 0, "lotus_pool_max_fwd: bad arguments");
   if (nc == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(pool_max_fwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
+  LOTUS_LAUNCH(pool_max_fwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      members, seg, nc, C, y, arg);
   LOTUS_LAUNCH_CHECK("lotus_pool_max_fwd");
   return LOTUS_OK;
@@ -522,7 +522,7 @@ int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int n
 int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int n, int C, float* dx, void* stream) {
   LOTUS_CHECK_ARG(dy && arg && cluster && dx && C % 4 == 0, "lotus_pool_max_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(pool_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
+  LOTUS_LAUNCH(pool_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
                      cluster, n, C, dx);
   LOTUS_LAUNCH_CHECK("lotus_pool_max_bwd");
   return LOTUS_OK;
@@ -530,7 +530,7 @@ int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int 
 int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream) {
   LOTUS_CHECK_ARG(skip && up && cluster && x && C % 4 == 0, "lotus_unpool_fwd: bad arguments");
   if (n == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(unpool_fwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, skip, up,
+  LOTUS_LAUNCH(unpool_fwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, skip, up,
                      cluster, n, C, x);
   LOTUS_LAUNCH_CHECK("lotus_unpool_fwd");
   return LOTUS_OK;
@@ -538,7 +538,7 @@ int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int
 int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream) {
   LOTUS_CHECK_ARG(dx && members && seg && dup && C % 4 == 0, "lotus_unpool_bwd: bad arguments");
   if (nc == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(unpool_bwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dx,
+  LOTUS_LAUNCH(unpool_bwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dx,
                      members, seg, nc, C, dup);
   LOTUS_LAUNCH_CHECK("lotus_unpool_bwd");
   return LOTUS_OK;
@@ -546,7 +546,7 @@ int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc
 // per-cloud max over the contiguous row ranges [off[b], off[b+1])
 int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream) {
   LOTUS_CHECK_ARG(x && off && y && arg && B > 0, "lotus_cloud_max_fwd: bad arguments");
-  hipLaunchKernelGGL(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, x, off, C, y, arg);
+  LOTUS_LAUNCH(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, x, off, C, y, arg);
   LOTUS_LAUNCH_CHECK("lotus_cloud_max_fwd");
   return LOTUS_OK;
 }
@@ -554,7 +554,7 @@ int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n
                         void* stream) {
   LOTUS_CHECK_ARG(dy && arg && batch && dx && C % 4 == 0, "lotus_cloud_max_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
-  hipLaunchKernelGGL(cloud_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
+  LOTUS_LAUNCH(cloud_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
                      batch, n, C, add, dx);
   LOTUS_LAUNCH_CHECK("lotus_cloud_max_bwd");
   return LOTUS_OK;
@@ -571,9 +571,9 @@ int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const flo
   LOTUS_CHECK_ARG(xt && ae && tgt && gt && off && losses && pos_stats && B > 0, "lotus_loss_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   float* part = pos_stats + (size_t)B * 3 * 4;  // slice partials live behind the per-(cloud, axis) stats
-  hipLaunchKernelGGL(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
-  hipLaunchKernelGGL(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
-  hipLaunchKernelGGL(small_loss_kernel, dim3(1), dim3(256), 0, st, ae, gt, pos_stats, B, nrot, ga, pos_w, rot_w, losses, dae);
+  LOTUS_LAUNCH(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
+  LOTUS_LAUNCH(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
+  LOTUS_LAUNCH(small_loss_kernel, dim3(1), dim3(256), 0, st, ae, gt, pos_stats, B, nrot, ga, pos_w, rot_w, losses, dae);
   LOTUS_LAUNCH_CHECK("lotus_loss_fwd");
   return LOTUS_OK;
 }
@@ -584,10 +584,10 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
   LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && dae_saved && gl && dxt && dae_out, "lotus_loss_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)n * 3 * nb;
-  hipLaunchKernelGGL(pos_ce_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xt, tgt, off, batch, pos_stats, gl,
+  LOTUS_LAUNCH(pos_ce_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, xt, tgt, off, batch, pos_stats, gl,
                      pos_w, B, n, nb, dxt);
   const int W = nrot * 3 + 1;
-  hipLaunchKernelGGL(ae_grad_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, st, dae_saved, gl, rot_w, W,
+  LOTUS_LAUNCH(ae_grad_kernel, dim3(cdiv((long)B * W, 256)), dim3(256), 0, st, dae_saved, gl, rot_w, W,
                      (long)B * W, dae_out);
   LOTUS_LAUNCH_CHECK("lotus_loss_bwd");
   return LOTUS_OK;
@@ -598,8 +598,8 @@ int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, i
   LOTUS_CHECK_ARG(xt && tgt && off && pos_stats && B > 0 && nb > 0, "lotus_pos_ce_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   float* part = pos_stats + (size_t)B * 3 * 4;
-  hipLaunchKernelGGL(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
-  hipLaunchKernelGGL(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
+  LOTUS_LAUNCH(pos_ce_part_kernel, dim3(POS_CE_SPLITS, B * 3), dim3(256), 0, st, xt, tgt, off, nb, part);
+  LOTUS_LAUNCH(pos_ce_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const float*)part, pos_stats);
   LOTUS_LAUNCH_CHECK("lotus_pos_ce_fwd");
   return LOTUS_OK;
 }
@@ -608,7 +608,7 @@ int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const in
   LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && g && dxt && B > 0, "lotus_pos_ce_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
   const long total = (long)n * 3 * nb;
-  hipLaunchKernelGGL(pos_ce_bwd_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xt, tgt, off, batch,
+  LOTUS_LAUNCH(pos_ce_bwd_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xt, tgt, off, batch,
                      pos_stats, g, n, nb, dxt);
   LOTUS_LAUNCH_CHECK("lotus_pos_ce_bwd");
   return LOTUS_OK;
@@ -618,7 +618,7 @@ int lotus_add(const float* a, const float* b, float* y, long n, void* stream) {
   LOTUS_CHECK_ARG(a && b && y && n % 4 == 0, "lotus_add: bad arguments");
   if (n == 0) return LOTUS_OK;
   int g = cdiv(n / 4, 256);
-  hipLaunchKernelGGL(add_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 4);
+  LOTUS_LAUNCH(add_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, a, b, y, n / 4);
   LOTUS_LAUNCH_CHECK("lotus_add");
   return LOTUS_OK;
 }
@@ -629,7 +629,7 @@ int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long 
   unsigned th = (unsigned)(p * 4294967296.0);
   if (p > 0.f && th == 0) th = 1;
   int g = cdiv(n, 256);
-  hipLaunchKernelGGL(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
+  LOTUS_LAUNCH(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
                      1.f / (1.f - p));
   LOTUS_LAUNCH_CHECK("lotus_dropout");
   return LOTUS_OK;
@@ -649,7 +649,7 @@ int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, 
   drop_params(drop_p, &th, &inv);
   const long total4 = (long)M * C / 4;
   const int g = cdiv(total4, 256);
-  hipLaunchKernelGGL(step_act_fwd_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, (hipStream_t)stream, base, bias, out, total4, C / 4,
+  LOTUS_LAUNCH(step_act_fwd_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, (hipStream_t)stream, base, bias, out, total4, C / 4,
                      act, drop_seed, th, inv);
   LOTUS_LAUNCH_CHECK("lotus_step_act_fwd");
   return LOTUS_OK;
@@ -668,9 +668,9 @@ int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, fl
   unsigned th; float inv;
   drop_params(drop_p, &th, &inv);
   const int nb = cdiv(M, SA_ROWS), c4n = C / 4;
-  hipLaunchKernelGGL(step_act_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float4), st, dh, base, bias, dbase, (float*)workspace, M,
+  LOTUS_LAUNCH(step_act_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float4), st, dh, base, bias, dbase, (float*)workspace, M,
                      c4n, act, accumulate, drop_seed, th, inv);
-  hipLaunchKernelGGL(step_act_colsum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const float*)workspace, dbias, nb, C);
+  LOTUS_LAUNCH(step_act_colsum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const float*)workspace, dbias, nb, C);
   LOTUS_LAUNCH_CHECK("lotus_step_act_bwd");
   return LOTUS_OK;
 }
@@ -689,9 +689,9 @@ int lotus_pos_targets(const float* pc, long ld, const int* off, const int* batch
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)workspace;
   double* stats = part + (size_t)B * 3 * PT_SPLITS * 3;
-  hipLaunchKernelGGL(pos_tgt_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, pc, ld, off, gt, ga, robot, nb, bin_size, kind, part);
-  hipLaunchKernelGGL(pos_tgt_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, stats);
-  hipLaunchKernelGGL(pos_tgt_write_kernel, dim3(cdiv((long)n * 3 * nb, 256)), dim3(256), 0, st, pc, ld, off, batch, gt, ga, robot, n,
+  LOTUS_LAUNCH(pos_tgt_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, pc, ld, off, gt, ga, robot, nb, bin_size, kind, part);
+  LOTUS_LAUNCH(pos_tgt_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, stats);
+  LOTUS_LAUNCH(pos_tgt_write_kernel, dim3(cdiv((long)n * 3 * nb, 256)), dim3(256), 0, st, pc, ld, off, batch, gt, ga, robot, n,
                      nb, bin_size, kind, (const double*)stats, tgt);
   LOTUS_LAUNCH_CHECK("lotus_pos_targets");
   return LOTUS_OK;
@@ -704,8 +704,8 @@ int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* o
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_pos_workspace(B), "lotus_pos_decode_max: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   double* part = (double*)workspace;
-  hipLaunchKernelGGL(pos_argmax_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, xt, off, nb, part);
-  hipLaunchKernelGGL(pos_argmax_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, pc, ld, off, nb, bin_size, best_pos);
+  LOTUS_LAUNCH(pos_argmax_part_kernel, dim3(PT_SPLITS, B * 3), dim3(256), 0, st, xt, off, nb, part);
+  LOTUS_LAUNCH(pos_argmax_merge_kernel, dim3(B * 3), dim3(64), 0, st, (const double*)part, pc, ld, off, nb, bin_size, best_pos);
   LOTUS_LAUNCH_CHECK("lotus_pos_decode_max");
   return LOTUS_OK;
 }

@@ -646,7 +646,8 @@ _SIZE_CACHE = {}
 
 
 def composites_enabled():
-    return _COMPOSITE and CALL_LOG is None and EVENT_LOG is None
+    # (one weight-gradient stream: a handed-over dz is only known to be ordered on the stream its producer forked to)
+    return _COMPOSITE and CALL_LOG is None and EVENT_LOG is None and _NSIDE == 1
 
 
 def set_composites(on):
