@@ -918,6 +918,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   hipStream_t st = (hipStream_t)stream;
   const size_t sm = attn_smem_bytes(true);
   const int prec = precision;
+  StopEventOnLast stop_ev;
   if (prec == 3) {
     { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a4 = true; } }
     LOTUS_LAUNCH(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
@@ -933,6 +934,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
     LOTUS_LAUNCH(attn_extra_fixup_kernel, dim3(cdiv((long)n_extra * w4, 256)), dim3(256), 0, st, dkv_extra, 2L * H * d,
                        ext_pos, kidx, n_extra, w4, dkv, dkv_ld, dk_off);
   }
+  stop_ev.last();
   LOTUS_LAUNCH(attn_ln_reduce_kernel, dim3(4), dim3(1024), 0, st, p.ln_part, dqn_w, dqn_b, dkn_w, dkn_b,
                      nblocks * H, d, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_attention_bwd");

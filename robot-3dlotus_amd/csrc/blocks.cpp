@@ -376,10 +376,12 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
   const float* dkv_f = dkv_part;
   {
     ForkAfter fa(link, side);  // dq and d kv: the last launch in here carries the fork event
+    if (G > 1) lotus_tls_stop_event = nullptr;
     CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att,
                               datt, (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq,
                               bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
     if (G > 1) {  // fixed-order sum of the key-side partial slots
+      lotus_tls_stop_event = fa.ev;
       CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));
       dkv_f = dkv;
     }

@@ -18,6 +18,14 @@ extern thread_local hipEvent_t lotus_tls_stop_event;
     else                                                                                                                 \
       hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                 \
   } while (0)
+// An entry point with several launches hands an armed stop event to its LAST launch only (a completion event costs the
+// launching queue ~4 us per kernel that carries it): hold it on entry, call last() right before the final launch.
+struct StopEventOnLast {
+  hipEvent_t ev;
+  StopEventOnLast() : ev(lotus_tls_stop_event) { lotus_tls_stop_event = nullptr; }
+  void last() { lotus_tls_stop_event = ev; }
+  ~StopEventOnLast() { lotus_tls_stop_event = ev; }  // (the owner of the event disarms it)
+};
 
 #define LOTUS_OK 0
 #define LOTUS_E_ARG (-1)

@@ -853,10 +853,12 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
   q.C = (float*)workspace; q.part_stride = (long)p.M * p.N;
   q.bias = nullptr; q.residual = nullptr; q.pre = nullptr; q.mulpre = nullptr; q.act = LOTUS_ACT_NONE; q.drop_thresh = 0;
   q.klen = klen;
+  StopEventOnLast stop_ev;
   int rc = launch_gemm<A_KC, B_KC, false>(q, nz, st);
   if (rc) return rc;
   const long total4 = (long)p.M * p.N / 4;
   int g = cdiv(total4, 256);
+  stop_ev.last();
   LOTUS_LAUNCH(splitk_epilogue_kernel, dim3(g > 2048 ? 2048 : g), dim3(256), 0, st, p, (const float*)workspace,
                      (long)p.M * p.N, nz);
   LOTUS_LAUNCH_CHECK("lotus_gemm(split-K epilogue)");
