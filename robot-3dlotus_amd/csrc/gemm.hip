@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     for (int t = 0; t < B4; ++t) rb[t] = *reinterpret_cast<const float4*>(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
   };
 
-  // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs
+  // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs.  (Measured and rejected:
+  // a second staging register set with the loads issued TWO slabs ahead and both prologue slabs in flight at once —
+  // 5.91 vs 5.81 ms over the forward / input-gradient launches of a step, stand-alone: with 4 blocks per CU the other
+  // waves already cover the load latency; what these launches pay is a fixed ~6 us each, see DESIGN.md.)
   if (kbeg < kend) {
     gload(kbeg);
     lstore(As, Bs);
