@@ -315,6 +315,50 @@ def test_deferred_wgrad_join_is_bit_identical():
             assert torch.equal(u, v) and torch.equal(u, w)
 
 
+def test_full_size_stream_modes_bit_identical():
+    """The bench configuration (v1, 16 x 4096, high-priority step stream, prefetched front-end) over several steps with
+    the weight gradients (a) on their own stream joined once per backward pass — ordered by completion events bound
+    to the producing launches, created without the system-scope fence — and (b) on the step stream itself: a missing
+    ordering or a stale cache line shows up as a differing gradient bit.  All 460 gradients of every step must be
+    equal."""
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+
+    batches = [_dev_batch(synth.synth_batch(16, 4096, seed=s)) for s in (0, 1)]
+    torch.manual_seed(0)
+    sd = {k: v.clone() for k, v in SimplePolicyPTV3CA(lcfg.preset("v1")).state_dict().items()}
+
+    def run(side):
+        ops.enable_side_stream(side)
+        ops.set_wgrad_join("end" if side else "node")
+        hi = torch.cuda.Stream(priority=-1)
+        try:
+            torch.manual_seed(1)
+            m = SimplePolicyPTV3CA(lcfg.preset("v1"))
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            sums = []
+            with torch.cuda.stream(hi):
+                m.prefetch(batches[0])
+                for i in range(6):
+                    for p in m.parameters():
+                        p.grad = None
+                    _, losses = m(batches[i % 2], compute_loss=True, compute_final_action=False)
+                    m.prefetch(batches[(i + 1) % 2])
+                    losses["total"].backward()
+                    hi.synchronize()
+                    sums.append([p.grad.clone() for p in m.parameters()])
+            return sums
+        finally:
+            ops.set_wgrad_join("node")
+            ops.enable_side_stream(True)
+
+    a, b = run(True), run(False)
+    for step, (ga, gb) in enumerate(zip(a, b)):
+        for k, (u, v) in enumerate(zip(ga, gb)):
+            assert torch.equal(u, v), (step, k)
+
+
 def test_models_of_different_precisions_coexist():
     """Operand precision is per call (captured per autograd node): an fp32 model and a bf16 model interleaved in one
     process — forward of one, forward of the other, then both backward passes — give bit-identically the results of
