@@ -309,7 +309,10 @@ __global__ void conv_stem_wt_kernel(const float* __restrict__ w, float* __restri
   wt[i] = w[(long)c * T * cin + rem];
 }
 
-__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
+}  // extern "C"
+// CIN: compile-time input width (0 = runtime p.cin): with it the 2 * CIN weight loads of a pair are issued together.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
   __shared__ int list_nb[STEM_ROWS * STEM_TP];
   __shared__ unsigned char list_t[STEM_ROWS * STEM_TP];
   __shared__ int cnt_s[STEM_ROWS];
@@ -352,16 +355,44 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
   // no chunk barriers and only 20 KB of LDS: occupancy, not a software pipeline, hides the load latency.
   // Lane j fetches input channel j of the neighbour row; the row's 8 lanes share it through 8-wide shuffles.
   const float* wbase = p.w + cb * 64 + j * 8;
+  const int cin = CIN ? CIN : p.cin;
+  // Every global load of a pair used to sit behind the previous one (the neighbour's x, then one weight row per input
+  // channel: ~8 serialised L2 latencies per pair, 23 pairs per row).  Now the next pair's tap / x are fetched while this
+  // pair's weight rows — all issued at once — are in flight.  The FMA order per accumulator is unchanged.
+  int t = 0;
+  float xl = 0.f;
+  if (len > 0) {
+    t = list_t[r * STEM_TP];
+    xl = j < cin ? p.x[(long)list_nb[r * STEM_TP] * cin + j] : 0.f;
+  }
   for (int cur = 0; cur < len; ++cur) {
-    const int t = list_t[r * STEM_TP + cur];
-    const float xl = j < p.cin ? p.x[(long)list_nb[r * STEM_TP + cur] * p.cin + j] : 0.f;
-    const float* wr = wbase + (long)t * p.cin * p.cout;
-    for (int ci = 0; ci < p.cin; ++ci) {
-      const float4 w0 = *reinterpret_cast<const float4*>(wr + ci * p.cout);
-      const float4 w1 = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
-      const float xv = __shfl(xl, ci, 8);
-      acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
-      acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+    const float* wr = wbase + (long)t * cin * p.cout;
+    const float xc = xl;
+    if (cur + 1 < len) {
+      t = list_t[r * STEM_TP + cur + 1];
+      xl = j < cin ? p.x[(long)list_nb[r * STEM_TP + cur + 1] * cin + j] : 0.f;
+    }
+    if (CIN) {
+      float4 w0[CIN ? CIN : 1], w1[CIN ? CIN : 1];
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        w0[ci] = *reinterpret_cast<const float4*>(wr + ci * p.cout);
+        w1[ci] = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
+      }
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci) {
+        const float xv = __shfl(xc, ci, 8);
+        acc[0] = fmaf(xv, w0[ci].x, acc[0]); acc[1] = fmaf(xv, w0[ci].y, acc[1]); acc[2] = fmaf(xv, w0[ci].z, acc[2]); acc[3] = fmaf(xv, w0[ci].w, acc[3]);
+        acc[4] = fmaf(xv, w1[ci].x, acc[4]); acc[5] = fmaf(xv, w1[ci].y, acc[5]); acc[6] = fmaf(xv, w1[ci].z, acc[6]); acc[7] = fmaf(xv, w1[ci].w, acc[7]);
+      }
+    } else {
+      for (int ci = 0; ci < cin; ++ci) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + ci * p.cout);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
+        const float xv = __shfl(xc, ci, 8);
+        acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+        acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+      }
     }
   }
   if (valid) {
@@ -375,6 +406,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p, int tch) {
     *reinterpret_cast<float4*>(yo + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
   }
 }
+
+extern "C" {
 
 // w_t [2][cout*T*cin]: MFMA-fragment-packed copies of w for the forward and the input-gradient direction
 // (layout: conv_pairs.hip); cin and cout must be multiples of 32
@@ -413,7 +446,12 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
     LOTUS_LAUNCH(conv_stem_wt_kernel, dim3(cdiv((long)cout * T * cin, 256)), dim3(256), 0, st, w, (float*)workspace, cout, T,
                        cin);
     p.w = (const float*)workspace;
-    LOTUS_LAUNCH(conv_smallcin_kernel, dim3(cout / 64, cdiv(n, STEM_ROWS)), dim3(256), 0, st, p, 0);
+    const dim3 sg(cout / 64, cdiv(n, STEM_ROWS));
+    if (cin == 7) LOTUS_LAUNCH((conv_smallcin_kernel<7>), sg, dim3(256), 0, st, p);
+    else if (cin == 8) LOTUS_LAUNCH((conv_smallcin_kernel<8>), sg, dim3(256), 0, st, p);
+    else if (cin == 6) LOTUS_LAUNCH((conv_smallcin_kernel<6>), sg, dim3(256), 0, st, p);
+    else if (cin == 4) LOTUS_LAUNCH((conv_smallcin_kernel<4>), sg, dim3(256), 0, st, p);
+    else LOTUS_LAUNCH((conv_smallcin_kernel<0>), sg, dim3(256), 0, st, p);
     LOTUS_LAUNCH_CHECK("lotus_subm_conv(stem)");
     return LOTUS_OK;
   }
@@ -448,43 +486,79 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
 // compacted in row order (wave ballots), their input rows staged in LDS; wave g takes pairs g, g+4, ... and the four
 // waves are summed in fixed order -> deterministic.  Same partial-slab layout as conv_wgrad_kernel.
 __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
-  __shared__ int prow_s[256];
-  __shared__ int pnb_s[256];
-  __shared__ __attribute__((aligned(16))) float xs[256][8];
+  // All pairs of the block's row range (<= WG_MAX_PAIRS rows) are compacted first — the neighbour ids of every
+  // 256-row window are loaded up front, so the windows cost one memory latency together instead of one each — then
+  // the list is consumed in batches of SB pairs: gather their input rows into LDS, accumulate with 8 dy loads in
+  // flight per lane.  (Per 256-row window: load ids, compact, gather, accumulate, each behind a barrier, left the
+  // kernel at 213 us for 1.4 GFLOP; it runs alone at the very end of backward, so its time is step time.)  Pair order
+  // = row order, wave g takes pairs g, g + 4, ... of the list and the four waves are summed in fixed order.
+  constexpr int NW = WG_MAX_PAIRS / 256, SB = 512;
+  __shared__ int prow_s[WG_MAX_PAIRS];
+  __shared__ int pnb_s[WG_MAX_PAIRS];
+  __shared__ __attribute__((aligned(16))) float xs[SB][8];
   __shared__ float red[4][64][8];
-  __shared__ int wcnt[4];
+  __shared__ int wcnt[NW][4];
   const int tid = threadIdx.x, c = tid & 63, g = tid >> 6, lane = tid & 63;
   const int cb = blockIdx.x, t = blockIdx.y, z = blockIdx.z;
   const int rbeg = z * p.chunk, rend = min(p.n, rbeg + p.chunk);
+  int total = 0;
+  {
+    int nbv[NW];
+    unsigned long long mv[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int row = rbeg + w * 256 + tid;
+      nbv[w] = row < rend ? p.nbr[(long)t * p.n + row] : -1;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      mv[w] = __ballot(nbv[w] >= 0);
+      if (lane == 0) wcnt[w][g] = __popcll(mv[w]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int base = total;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q < g) base += wcnt[w][q];
+        total += wcnt[w][q];
+      }
+      if (nbv[w] >= 0) {
+        const int pos = base + __popcll(mv[w] & ((1ull << lane) - 1ull));
+        prow_s[pos] = rbeg + w * 256 + tid;
+        pnb_s[pos] = nbv[w];
+      }
+    }
+  }
+  __syncthreads();
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  for (int r0 = rbeg; r0 < rend; r0 += 256) {
-    const int row = r0 + tid;
-    const int nb = row < rend ? p.nbr[(long)t * p.n + row] : -1;
-    const unsigned long long m = __ballot(nb >= 0);
-    if (lane == 0) wcnt[g] = __popcll(m);
-    __syncthreads();
-    int base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < g) base += wcnt[w];
-      total += wcnt[w];
-    }
-    if (nb >= 0) {
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      prow_s[pos] = row;
-      pnb_s[pos] = nb;
-    }
-    __syncthreads();
-    for (int i = tid; i < total * 8; i += 256) {
-      const int pi = i >> 3, ci = i & 7;
-      xs[pi][ci] = ci < p.cin ? p.x[(long)pnb_s[pi] * p.cin + ci] : 0.f;
-    }
-    __syncthreads();
+  const float* dyc = p.dy + cb * 64 + c;
+  for (int b0 = 0; b0 < total; b0 += SB) {
+    const int nb = min(SB, total - b0);
 #pragma unroll 4
-    for (int pi = g; pi < total; pi += 4) {
-      const float dyv = p.dy[(long)prow_s[pi] * p.cout + cb * 64 + c];
+    for (int i = tid; i < nb * 8; i += 256) {
+      const int pi = i >> 3, ci = i & 7;
+      xs[pi][ci] = ci < p.cin ? p.x[(long)pnb_s[b0 + pi] * p.cin + ci] : 0.f;
+    }
+    __syncthreads();
+    int pi = g;
+    for (; pi + 28 < nb; pi += 32) {  // 8 pairs of this wave per trip: their dy loads are issued together
+      float dyv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dyv[u] = dyc[(long)prow_s[b0 + pi + 4 * u] * p.cout];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float4 xa = *reinterpret_cast<const float4*>(&xs[pi + 4 * u][0]);
+        const float4 xb = *reinterpret_cast<const float4*>(&xs[pi + 4 * u][4]);
+        acc[0] = fmaf(dyv[u], xa.x, acc[0]); acc[1] = fmaf(dyv[u], xa.y, acc[1]); acc[2] = fmaf(dyv[u], xa.z, acc[2]); acc[3] = fmaf(dyv[u], xa.w, acc[3]);
+        acc[4] = fmaf(dyv[u], xb.x, acc[4]); acc[5] = fmaf(dyv[u], xb.y, acc[5]); acc[6] = fmaf(dyv[u], xb.z, acc[6]); acc[7] = fmaf(dyv[u], xb.w, acc[7]);
+      }
+    }
+    for (; pi < nb; pi += 4) {
+      const float dyv = dyc[(long)prow_s[b0 + pi] * p.cout];
       const float4 xa = *reinterpret_cast<const float4*>(&xs[pi][0]);
       const float4 xb = *reinterpret_cast<const float4*>(&xs[pi][4]);
       acc[0] = fmaf(dyv, xa.x, acc[0]); acc[1] = fmaf(dyv, xa.y, acc[1]); acc[2] = fmaf(dyv, xa.z, acc[2]); acc[3] = fmaf(dyv, xa.w, acc[3]);
