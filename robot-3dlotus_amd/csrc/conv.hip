@@ -197,8 +197,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
   __shared__ float Bs[LOTUS_BK * BN];
   __shared__ int pair_p[WG_MAX_PAIRS + LOTUS_BK];
   __shared__ int pair_q[WG_MAX_PAIRS + LOTUS_BK];
-  __shared__ int wave_cnt[4];
-  __shared__ int total_s;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tiles_ci = (p.cin + BN - 1) / BN;
@@ -207,26 +205,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
   const int p0 = blockIdx.z * p.chunk, p1 = min(p.n, p0 + p.chunk);
   const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
 
-  // ordered compaction of the active (p, q = nbr[t][p]) pairs of this split
-  if (tid == 0) total_s = 0;
-  __syncthreads();
-  for (int base = p0; base < p1; base += 256) {
-    const int pp = base + tid;
-    const int q = pp < p1 ? p.nbr[(long)t * p.n + pp] : -1;
-    const unsigned long long b = __ballot(q >= 0);
-    const int rank = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wave] = __popcll(b);
-    __syncthreads();
-    int off = total_s;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-    if (q >= 0) {
-      pair_p[off + rank] = pp;
-      pair_q[off + rank] = q;
+  // ordered compaction of the active (p, q = nbr[t][p]) pairs of this split: the neighbour ids of all its 256-row
+  // windows are loaded up front (one memory latency for the split instead of one per window plus three barriers each)
+  constexpr int NW = WG_MAX_PAIRS / 256;
+  __shared__ int wcnt[NW][4];
+  int total_r = 0;
+  {
+    int qv[NW];
+    unsigned long long bv[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int pp = p0 + w * 256 + tid;
+      qv[w] = pp < p1 ? p.nbr[(long)t * p.n + pp] : -1;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      bv[w] = __ballot(qv[w] >= 0);
+      if (lane == 0) wcnt[w][wave] = __popcll(bv[w]);
     }
     __syncthreads();
-    if (tid == 0) total_s += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int off = total_r;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < wave) off += wcnt[w][k];
+        total_r += wcnt[w][k];
+      }
+      if (qv[w] >= 0) {
+        const int rank = __popcll(bv[w] & ((1ull << lane) - 1ull));
+        pair_p[off + rank] = p0 + w * 256 + tid;
+        pair_q[off + rank] = qv[w];
+      }
+    }
   }
+  __syncthreads();
+  const int total_s = total_r;
   const int total = total_s;
   for (int i = total + tid; i < total + LOTUS_BK; i += 256) {
     pair_p[i] = -1;
