@@ -4,6 +4,8 @@
 // produced by the front-end, so every reduction is an ordered loop: no atomics, deterministic.
 #include "common.h"
 
+int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);  // gemm.hip
+
 // ---------------------------------------------------------------- segment max over cluster members
 // y[c][:] = max_{i in [seg[c], seg[c+1])} x[members[i]][:]   ; arg = winning parent row
 __global__ void pool_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ members,
@@ -358,14 +360,6 @@ __global__ __launch_bounds__(256) void step_act_bwd_kernel(const float* __restri
     reinterpret_cast<float4*>(part)[(long)blockIdx.x * c4n + q] = t;
   }
 }
-__global__ void step_act_colsum_kernel(const float* __restrict__ part, float* __restrict__ dbias, int nb, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(long)b * C + c];
-  dbias[c] = s;
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Soft position targets and arg-max position decoding on the device (SURVEY.md 8f rank 2;
 // genrobo3d/utils/action_position_utils.py:7-46 and :48-64 best='max').  Candidate coordinate of (point n, axis c,
@@ -670,9 +664,10 @@ int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, fl
   const int nb = cdiv(M, SA_ROWS), c4n = C / 4;
   LOTUS_LAUNCH(step_act_bwd_kernel, dim3(nb), dim3(256), 256 * sizeof(float4), st, dh, base, bias, dbase, (float*)workspace, M,
                      c4n, act, accumulate, drop_seed, th, inv);
-  LOTUS_LAUNCH(step_act_colsum_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, (const float*)workspace, dbias, nb, C);
   LOTUS_LAUNCH_CHECK("lotus_step_act_bwd");
-  return LOTUS_OK;
+  // column sums of the per-block partials: the parallel fixed-order reduction of gemm.hip (one thread per column over
+  // all nb partials took 226 us per step head, 1.1 ms of a motion-planner step)
+  return lotus_reduce_parts((const float*)workspace, dbias, (long)C, (long)C, nb, 0, st);
 }
 
 size_t lotus_pos_workspace(int B) { return (size_t)B * 3 * (PT_SPLITS * 3 + 2) * sizeof(double); }
