@@ -313,6 +313,16 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
 int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream);
 int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
                      const float* g, int B, int n, int nb, float* dxt, void* stream);
+/* Trajectory losses of the motion planner on its [B, T]-sized tensors, genrobo3d/models/motion_planner_ptv3.py:327-397
+ * (heatmap_disc / euler_disc), one launch.  Row r = b * T + t: ae [B*T][nrot*3 + 2] = rotation logits (bin, axis) at
+ * bin*3 + axis | openness logit | stop logit; gt [B*T][ga] = gt_trajs (rotation bins at 3..5, openness at ga-1);
+ * stop [B*T] = gt_trajs_stop; mask [B*T] = traj_masks; ce [B*T][3] = heatmap cross entropy per (cloud, step, axis)
+ * (lotus_pos_ce_fwd).  losses[5] = pos, rot, open, stop, total (= pos_w pos + rot_w rot + open + stop).  dae / dce keep the
+ * partial derivatives for lotus_mp_loss_bwd, which scales them by the upstream gradient g[5] (device). */
+int lotus_mp_loss_fwd(const float* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
+                      int nrot, int ga, float pos_w, float rot_w, float* losses, float* dae, float* dce, void* stream);
+int lotus_mp_loss_bwd(const float* dae, const float* dce, const float* g, float pos_w, float rot_w, int B, int T, int nrot,
+                      float* dae_out, float* dce_out, void* stream);
 /* Trajectory head of the motion planner, genrobo3d/models/motion_planner_ptv3.py:88-97,113-114: hidden layer of step t =
  * dropout(act(base + bias_t)) with base [M][C] shared by the steps and bias_t [C] = step-embedding part of the first
  * Linear.  bwd: dpre = dh * act'(base + bias_t) * mask; dbase (+)= dpre (accumulate over the steps), dbias_t = colsum. */

@@ -287,6 +287,91 @@ __global__ void ae_grad_kernel(const float* __restrict__ x, const float* __restr
   y[i] = x[i] * (open_col ? gl[2] + gl[3] : gl[1] + rot_w * gl[3]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Trajectory losses of the motion planner on the [B, T]-sized tensors, motion_planner_ptv3.py:327-397 (heatmap_disc /
+// euler_disc): one block.  Row r = b * T + t.  ae [B*T][W], W = nrot * 3 + 2 (rotation logits (bin, axis) at bin*3+axis,
+// openness logit, stop logit); gt [B*T][ga] (rotation bins at 3..5, openness at ga-1); stop [B*T]; mask [B*T];
+// ce [B*T][3] = heatmap cross entropy per (cloud, step, axis).
+//   pos  = mean_b ( sum_t mask * sum_c ce / (3 * sum_t mask) )        rot = sum mask * CE_rot / sum mask / 3
+//   open = sum mask * BCE(open) / sum mask                             stop likewise
+// losses[5] = pos, rot, open, stop, total.  dae [B*T][W] and dce [B*T][3] receive the partial derivatives of the loss
+// each column belongs to (the columns are disjoint), unscaled by the upstream gradient.
+__global__ __launch_bounds__(256) void mp_loss_kernel(const float* __restrict__ ae, const float* __restrict__ gt,
+                                                      const float* __restrict__ stop, const float* __restrict__ mask,
+                                                      const float* __restrict__ ce, int B, int T, int nrot, int ga, float pos_w,
+                                                      float rot_w, float* __restrict__ losses, float* __restrict__ dae,
+                                                      float* __restrict__ dce) {
+  extern __shared__ float msum_b[];  // [B] sum_t mask
+  __shared__ float red[4][4];
+  __shared__ float msum_s;
+  const int W = nrot * 3 + 2, R = B * T, tid = threadIdx.x;
+  for (int b = tid; b < B; b += 256) {
+    float s = 0.f;
+    for (int t = 0; t < T; ++t) s += mask[b * T + t];
+    msum_b[b] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += msum_b[b];
+    msum_s = s;
+  }
+  __syncthreads();
+  const float msum = msum_s;
+  float pos = 0.f, rot = 0.f, opn = 0.f, stp = 0.f;
+  for (int i = tid; i < R * 3; i += 256) {
+    const int r = i / 3, a = i % 3, b = r / T;
+    const float m = mask[r];
+    const float* row = ae + (long)r * W;
+    float mx = -INFINITY;
+    for (int k = 0; k < nrot; ++k) mx = fmaxf(mx, row[k * 3 + a]);
+    float se = 0.f;
+    for (int k = 0; k < nrot; ++k) se += expf(row[k * 3 + a] - mx);
+    const float lse = mx + logf(se);
+    const int tk = (int)gt[(long)r * ga + 3 + a];
+    rot += (lse - row[tk * 3 + a]) * m;
+    const float sc = m / msum / 3.f;
+    for (int k = 0; k < nrot; ++k) dae[(long)r * W + k * 3 + a] = (expf(row[k * 3 + a] - lse) - (k == tk ? 1.f : 0.f)) * sc;
+    const float cpos = m / (3.f * msum_b[b] * B);
+    pos += ce[i] * cpos;
+    dce[i] = cpos;
+  }
+  for (int r = tid; r < R; r += 256) {
+    const float m = mask[r], sc = m / msum;
+    const float xo = ae[(long)r * W + W - 2], to = gt[(long)r * ga + ga - 1];
+    opn += (fmaxf(xo, 0.f) - xo * to + log1pf(expf(-fabsf(xo)))) * m;
+    dae[(long)r * W + W - 2] = (1.f / (1.f + expf(-xo)) - to) * sc;
+    const float xs = ae[(long)r * W + W - 1], ts = stop[r];
+    stp += (fmaxf(xs, 0.f) - xs * ts + log1pf(expf(-fabsf(xs)))) * m;
+    dae[(long)r * W + W - 1] = (1.f / (1.f + expf(-xs)) - ts) * sc;
+  }
+  const float v4[4] = {pos, rot, opn, stp};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float w = wave_sum(v4[k]);
+    if ((tid & 63) == 0) red[k][tid >> 6] = w;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float t4[4];
+    for (int k = 0; k < 4; ++k) t4[k] = ((red[k][0] + red[k][1]) + red[k][2]) + red[k][3];
+    const float lp = t4[0], lr = t4[1] / msum / 3.f, lo = t4[2] / msum, ls = t4[3] / msum;
+    losses[0] = lp; losses[1] = lr; losses[2] = lo; losses[3] = ls; losses[4] = pos_w * lp + rot_w * lr + lo + ls;
+  }
+}
+// upstream gradient g[5] (device) of the five losses -> d ae, d ce
+__global__ void mp_loss_bwd_kernel(const float* __restrict__ dae, const float* __restrict__ dce, const float* __restrict__ g,
+                                   float pos_w, float rot_w, int W, long nae, long nce, float* __restrict__ dae_out,
+                                   float* __restrict__ dce_out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nae) {
+    const int col = (int)(i % W);
+    const float sc = col == W - 1 ? g[3] + g[4] : col == W - 2 ? g[2] + g[4] : g[1] + rot_w * g[4];
+    dae_out[i] = dae[i] * sc;
+  }
+  if (i < nce) dce_out[i] = dce[i] * (g[0] + pos_w * g[4]);
+}
+
 // elementwise helpers ---------------------------------------------------------------------------
 __global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -605,6 +690,27 @@ int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const in
   LOTUS_LAUNCH(pos_ce_bwd_w_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, xt, tgt, off, batch,
                      pos_stats, g, n, nb, dxt);
   LOTUS_LAUNCH_CHECK("lotus_pos_ce_bwd");
+  return LOTUS_OK;
+}
+
+// Trajectory losses of the motion planner ([B, T]-sized tensors), see mp_loss_kernel.
+int lotus_mp_loss_fwd(const float* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
+                      int nrot, int ga, float pos_w, float rot_w, float* losses, float* dae, float* dce, void* stream) {
+  LOTUS_CHECK_ARG(ae && gt && stop && mask && ce && losses && dae && dce && B > 0 && T > 0 && nrot > 0 && ga >= 7 && B <= 8192,
+                  "lotus_mp_loss_fwd: bad arguments");
+  LOTUS_LAUNCH(mp_loss_kernel, dim3(1), dim3(256), (size_t)B * sizeof(float), (hipStream_t)stream, ae, gt, stop, mask, ce, B, T,
+               nrot, ga, pos_w, rot_w, losses, dae, dce);
+  LOTUS_LAUNCH_CHECK("lotus_mp_loss_fwd");
+  return LOTUS_OK;
+}
+int lotus_mp_loss_bwd(const float* dae, const float* dce, const float* g, float pos_w, float rot_w, int B, int T, int nrot,
+                      float* dae_out, float* dce_out, void* stream) {
+  LOTUS_CHECK_ARG(dae && dce && g && dae_out && dce_out && B > 0 && T > 0 && nrot > 0, "lotus_mp_loss_bwd: bad arguments");
+  const int W = nrot * 3 + 2;
+  const long nae = (long)B * T * W, nce = (long)B * T * 3;
+  LOTUS_LAUNCH(mp_loss_bwd_kernel, dim3(cdiv(nae, 256)), dim3(256), 0, (hipStream_t)stream, dae, dce, g, pos_w, rot_w, W, nae, nce,
+               dae_out, dce_out);
+  LOTUS_LAUNCH_CHECK("lotus_mp_loss_bwd");
   return LOTUS_OK;
 }
 

@@ -119,7 +119,7 @@ class MotionPlannerPTV3CA(BaseModel):
 
         losses = None
         if compute_loss:
-            losses = self.compute_loss(xts, pred_rot, pred_open, pred_stop, batch, lvl)
+            losses = self._traj_losses(xts, ae, batch, lvl)
         decode = kwargs.get("compute_final_action", True)
         if compute_loss and self.training and not decode and not kwargs.get("decode_actions", False):
             return None, losses                                  # trainer discards the actions (see policy.py)
@@ -142,12 +142,17 @@ class MotionPlannerPTV3CA(BaseModel):
         return torch.stack([xt.view(-1, 3, nb).permute(1, 0, 2) for xt in self.last_pred[0]], 0)
 
     def compute_loss(self, xts, pred_rot, pred_open, pred_stop, batch, lvl):
-        """motion_planner_ptv3.py:307-397 (heatmap_disc / euler_disc)."""
-        dev = pred_rot.device
+        """motion_planner_ptv3.py:307-397 (heatmap_disc / euler_disc), reference argument list."""
         B, T = pred_rot.shape[:2]
+        ae = torch.cat([pred_rot.reshape(B, T, -1), pred_open.unsqueeze(-1), pred_stop.unsqueeze(-1)], -1)
+        return self._traj_losses(xts, ae, batch, lvl)
+
+    def _traj_losses(self, xts, ae, batch, lvl):
+        """ae [B, T, euler_bins * 3 + 2]: rotation logits (bin, axis) at bin * 3 + axis | openness | stop."""
+        dev = ae.device
+        B, T = ae.shape[:2]
         gt = batch["gt_trajs"].float()
         m = batch["traj_masks"].float()                                                  # [B, T]
-        msum = m.sum()
         dp = batch["gt_trajs_disc_pos_probs"]
         # per step t the targets in the layout the CE kernel reads: cloud-major, [3][n_b * nb] per cloud
         if isinstance(dp, torch.Tensor):
@@ -156,13 +161,10 @@ class MotionPlannerPTV3CA(BaseModel):
             tgts = torch.cat([d.to(dev).float().reshape(T, -1) for d in dp], 1)
         tgts = tgts.contiguous()
         ce = torch.stack([ops.PosCEFn.apply(xts[t], tgts[t], lvl) for t in range(T)], 1)  # [B, T, 3]
-        # sum_tc CE * mask / (3 * sum_t mask) per cloud, mean over clouds (:327-336)
-        pos = ((ce.sum(-1) * m).sum(1) / (3.0 * m.sum(1))).sum() / B
-        rl = F.cross_entropy(pred_rot.permute(0, 1, 3, 2).reshape(-1, pred_rot.shape[2]),
-                             gt[..., 3:-1].long().reshape(-1), reduction="none").view(B, T, 3)
-        rot = (rl * m.unsqueeze(-1)).sum() / msum / 3
-        opn = (F.binary_cross_entropy_with_logits(pred_open, gt[..., -1], reduction="none") * m).sum() / msum
-        stp = (F.binary_cross_entropy_with_logits(pred_stop, batch["gt_trajs_stop"].float(), reduction="none") * m).sum() / msum
+        # sum_tc CE * mask / (3 * sum_t mask) per cloud, mean over clouds (:327-336); masked rotation CE, openness and
+        # stop BCE (:338-383): one launch for the lot (the same arithmetic as ~40 small ATen kernels cost 2 ms per step)
         lc = self.config.loss_config
-        return {"pos": pos, "rot": rot, "open": opn, "stop": stp,
-                "total": lc.pos_weight * pos + lc.rot_weight * rot + opn + stp}
+        L = ops.TrajLossFn.apply(ae.reshape(B * T, -1), ce.reshape(B * T, 3), gt.reshape(B * T, -1).contiguous(),
+                                 batch["gt_trajs_stop"].float().reshape(-1).contiguous(), m.reshape(B, T).contiguous(),
+                                 (ae.shape[-1] - 2) // 3, lc.pos_weight, lc.rot_weight)
+        return {"pos": L[0], "rot": L[1], "open": L[2], "stop": L[3], "total": L[4]}

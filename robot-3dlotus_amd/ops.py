@@ -1237,6 +1237,32 @@ class PosCEFn(torch.autograd.Function):
         return dxt, None, None
 
 
+class TrajLossFn(torch.autograd.Function):
+    """The [B, T]-sized losses of the motion planner in one launch (motion_planner_ptv3.py:327-397): masked rotation
+    cross entropy, openness / stop BCE and the masked mean of the heatmap cross entropies ce [B, T, 3].  Returns the
+    vector (pos, rot, open, stop, total)."""
+
+    @staticmethod
+    def forward(ctx, ae, ce, gt, stop, mask, nrot, pos_w, rot_w):
+        B, T = mask.shape
+        ae, ce = ae.contiguous(), ce.contiguous()
+        losses = torch.empty(5, dtype=torch.float32, device=ae.device)
+        dae = torch.empty_like(ae)
+        dce = torch.empty_like(ce)
+        call("lotus_mp_loss_fwd", ae, gt, stop, mask, ce, B, T, nrot, gt.shape[-1], float(pos_w), float(rot_w), losses, dae, dce)
+        ctx.save_for_backward(dae, dce)
+        ctx.dims = (B, T, nrot, float(pos_w), float(rot_w))
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        dae, dce = ctx.saved_tensors
+        B, T, nrot, pos_w, rot_w = ctx.dims
+        dae_o, dce_o = torch.empty_like(dae), torch.empty_like(dce)
+        call("lotus_mp_loss_bwd", dae, dce, g.contiguous().float(), pos_w, rot_w, B, T, nrot, dae_o, dce_o)
+        return dae_o, dce_o, None, None, None, None, None, None
+
+
 class CloudMaxFn(torch.autograd.Function):
     """torch.stack([torch.max(x, 0)[0] for x in torch.split(feat, npoints_in_batch)]),
     motion_planner_ptv3.py:117-119 / simple_policy_ptv3.py:117-119."""

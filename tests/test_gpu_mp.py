@@ -128,3 +128,47 @@ def test_mp_train_step_is_deterministic():
     assert grads[0].keys() == grads[1].keys()
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
+
+
+def test_traj_loss_fn_matches_torch_expression():
+    """ops.TrajLossFn (one launch) against the reference's expression on the [B, T]-sized tensors
+    (motion_planner_ptv3.py:327-397): the five losses and the gradients w.r.t. the logits and the heatmap cross
+    entropies, ragged trajectory masks, non-unit loss weights."""
+    import torch.nn.functional as F
+    from robot_3dlotus_amd import ops
+
+    torch.manual_seed(3)
+    B, T, eb = 7, 5, 72
+    dev = torch.device("cuda")
+    ae = torch.randn(B, T, eb * 3 + 2, device=dev, requires_grad=True)
+    ce = (torch.rand(B, T, 3, device=dev) * 5).requires_grad_(True)
+    gt = torch.zeros(B, T, 7, device=dev)
+    gt[..., :3] = torch.randn(B, T, 3, device=dev)
+    gt[..., 3:6] = torch.randint(0, eb, (B, T, 3), device=dev).float()
+    gt[..., 6] = torch.randint(0, 2, (B, T), device=dev).float()
+    stop = torch.randint(0, 2, (B, T), device=dev).float()
+    lens = torch.tensor([5, 1, 3, 2, 5, 4, 1], device=dev)
+    m = (torch.arange(T, device=dev)[None] < lens[:, None]).float()
+    pos_w, rot_w = 1.5, 0.7
+
+    def ref(ae, ce):
+        pred_rot = ae[..., :eb * 3].reshape(B, T, eb, 3)
+        pred_open, pred_stop = ae[..., -2], ae[..., -1]
+        msum = m.sum()
+        pos = ((ce.sum(-1) * m).sum(1) / (3.0 * m.sum(1))).sum() / B
+        rl = F.cross_entropy(pred_rot.permute(0, 1, 3, 2).reshape(-1, eb), gt[..., 3:-1].long().reshape(-1),
+                             reduction="none").view(B, T, 3)
+        rot = (rl * m.unsqueeze(-1)).sum() / msum / 3
+        opn = (F.binary_cross_entropy_with_logits(pred_open, gt[..., -1], reduction="none") * m).sum() / msum
+        stp = (F.binary_cross_entropy_with_logits(pred_stop, stop, reduction="none") * m).sum() / msum
+        return torch.stack([pos, rot, opn, stp, pos_w * pos + rot_w * rot + opn + stp])
+
+    w = torch.tensor([0.3, -1.1, 0.9, 2.0, 1.0], device=dev)   # upstream gradient of all five outputs
+    Lr = ref(ae, ce)
+    gr = torch.autograd.grad((Lr * w).sum(), [ae, ce])
+    Lh = ops.TrajLossFn.apply(ae.reshape(B * T, -1), ce.reshape(B * T, 3), gt.reshape(B * T, -1).contiguous(),
+                              stop.reshape(-1).contiguous(), m.contiguous(), eb, pos_w, rot_w)
+    gh = torch.autograd.grad((Lh * w).sum(), [ae, ce])
+    assert torch.allclose(Lh, Lr, rtol=2e-6, atol=1e-6), (Lh, Lr)
+    for a, b in zip(gh, gr):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (a - b).abs().max()
