@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--episodes", type=int, default=96)
     ap.add_argument("--episodes-per-batch", type=int, default=3)   # x 5-6 key steps = 15-18 clouds per step
     ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup-steps", type=int, default=5000, help="lr warm-up of the schedule (reference: 5000)")
+    ap.add_argument("--curve", default=None, help="write the loss every 20 steps to this JSON file")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     tmp = tempfile.mkdtemp()
@@ -60,10 +62,11 @@ def main():
     torch.manual_seed(0)
     model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
     topts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.05, optim="adamw", betas=[0.9, 0.98], lr_sched="cosine",
-                            warmup_steps=5000, num_train_steps=150000, grad_norm=10.0)
+                            warmup_steps=args.warmup_steps, num_train_steps=150000, grad_norm=10.0)
     opt, init_lrs = loptim.build_optimizer(model, topts)
     torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
     step, seen, t1 = 0, 0, None
+    curve = []
     it = iter(loader)
     nxt = next(it)
     model.prefetch(nxt)
@@ -82,6 +85,8 @@ def main():
         opt.clip_grad_norm_(topts.grad_norm)
         opt.step()
         step += 1
+        if args.curve and step % 20 == 0:
+            curve.append((step, torch.stack([losses[k].detach() for k in ("total", "pos", "rot", "open")])))  # no host sync
         if step == 10:
             torch.cuda.synchronize()
             t1, seen = time.perf_counter(), 0
@@ -91,6 +96,14 @@ def main():
     print(json.dumps({"loader_only_keysteps_per_s": round(loader_rate, 1), "train_keysteps_per_s": round(rate, 1),
                       "workers": args.workers, "clouds_per_step": round(seen / (args.steps - 10), 1), "loss": round(losses["total"].item(), 4),
                       "note": "episode records -> KeystepDataset -> DataLoader(pin) -> prefetch/forward/backward/AdamW, v1 model, 4096-point clouds"}))
+    if args.curve:
+        write_curve(args.curve, curve, rate)
+
+
+def write_curve(path, curve, rate):
+    rows = [[st] + [round(float(v), 4) for v in t.cpu()] for st, t in curve]
+    json.dump({"columns": ["step", "total", "pos", "rot", "open"], "train_keysteps_per_s": round(rate, 1), "rows": rows},
+              open(path, "w"))
 
 
 if __name__ == "__main__":
