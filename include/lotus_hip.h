@@ -294,7 +294,9 @@ int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int 
 int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream);
 int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream);
 /* ActionHead reduce == 'max': per-cloud torch.max(x, 0), simple_policy_ptv3.py:117-119 */
-int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream);
+size_t lotus_cloud_max_workspace(int B, int C);
+int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* workspace, size_t workspace_bytes,
+                        void* stream);
 int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
                         void* stream);
 /* compute_loss (heatmap_disc / euler_disc), simple_policy_ptv3.py:322-373: losses[4] = pos, rot,

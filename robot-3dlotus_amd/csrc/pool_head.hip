@@ -75,38 +75,71 @@ __global__ void unpool_bwd_kernel(const float* __restrict__ dx, const int* __res
 }
 
 // ---------------------------------------------------------------- per-cloud max over contiguous rows
-// grid (B, C/32); block 256 = 32 columns x 8 row lanes
-__global__ __launch_bounds__(1024) void cloud_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ off,
-                                                             int C, float* __restrict__ y, int* __restrict__ arg) {
-  __shared__ float bv[32][33];
-  __shared__ int bi[32][33];
-  const int cl = threadIdx.x & 31, ry = threadIdx.x >> 5;
-  const int b = blockIdx.x, col = blockIdx.y * 32 + cl;
+// Two passes: (cloud, 128-column group, row split) blocks of 32 column quads x 32 row lanes keep the first-index maximum
+// of their rows (16-byte loads), then one thread per (cloud, column) merges the CM_SPLITS partials in split order — the
+// arg-max is the FIRST row attaining the maximum, as torch.max(x, 0) returns it.  (One block per (cloud, 32 columns)
+// with 4-byte loads: 64 blocks, 46 us for 33 MB.)
+#define CM_SPLITS 8
+__global__ __launch_bounds__(1024) void cloud_max_part_kernel(const float* __restrict__ x, const int* __restrict__ off, int C,
+                                                              float* __restrict__ pv, int* __restrict__ pi) {
+  __shared__ float4 bv[32][33];
+  __shared__ int4 bi[32][33];
+  const int cq = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int b = blockIdx.x, q = blockIdx.y * 32 + cq, sp = blockIdx.z;  // q: float4 column index
+  const int r0 = off[b], r1 = off[b + 1];
+  const int chunk = (r1 - r0 + CM_SPLITS - 1) / CM_SPLITS;
+  const int s0 = r0 + sp * chunk, s1 = min(r1, s0 + chunk);
+  float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  int idx[4] = {-1, -1, -1, -1};
+  if (q * 4 < C)
+    for (int r = s0 + ry; r < s1; r += 32) {
+      const float4 v4 = reinterpret_cast<const float4*>(x + (long)r * C)[q];
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > best[e]) {
+          best[e] = v[e];
+          idx[e] = r;
+        }
+    }
+  bv[ry][cq] = make_float4(best[0], best[1], best[2], best[3]);
+  bi[ry][cq] = make_int4(idx[0], idx[1], idx[2], idx[3]);
+  __syncthreads();
+  if (ry == 0 && q * 4 < C) {
+    for (int k = 1; k < 32; ++k) {
+      const float4 v4 = bv[k][cq];
+      const int4 i4 = bi[k][cq];
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+      const int ii[4] = {i4.x, i4.y, i4.z, i4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > best[e] || (v[e] == best[e] && ii[e] >= 0 && (idx[e] < 0 || ii[e] < idx[e]))) {
+          best[e] = v[e];
+          idx[e] = ii[e];
+        }
+    }
+    const long o = ((long)b * CM_SPLITS + sp) * C + q * 4;
+    *reinterpret_cast<float4*>(pv + o) = make_float4(best[0], best[1], best[2], best[3]);
+    *reinterpret_cast<int4*>(pi + o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+  }
+}
+__global__ void cloud_max_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int B, int C,
+                                       float* __restrict__ y, int* __restrict__ arg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
   float best = -INFINITY;
   int idx = -1;
-  if (col < C)
-    for (int r = off[b] + ry; r < off[b + 1]; r += 32) {
-      const float v = x[(long)r * C + col];
-      if (v > best) {
-        best = v;
-        idx = r;
-      }
+  for (int sp = 0; sp < CM_SPLITS; ++sp) {  // splits are ascending row ranges: strict > keeps the first maximum
+    const float v = pv[((long)b * CM_SPLITS + sp) * C + c];
+    const int ii = pi[((long)b * CM_SPLITS + sp) * C + c];
+    if (ii >= 0 && (idx < 0 || v > best)) {
+      best = v;
+      idx = ii;
     }
-  bv[ry][cl] = best;
-  bi[ry][cl] = idx;
-  __syncthreads();
-  if (ry == 0 && col < C) {
-    for (int k = 1; k < 32; ++k) {
-      const float v = bv[k][cl];
-      const int i = bi[k][cl];
-      if (v > best || (v == best && i >= 0 && i < idx)) {
-        best = v;
-        idx = i;
-      }
-    }
-    y[(long)b * C + col] = best;
-    arg[(long)b * C + col] = idx;
   }
+  y[i] = best;
+  arg[i] = idx;
 }
 
 __global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
@@ -623,9 +656,18 @@ int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc
   return LOTUS_OK;
 }
 // per-cloud max over the contiguous row ranges [off[b], off[b+1])
-int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* stream) {
-  LOTUS_CHECK_ARG(x && off && y && arg && B > 0, "lotus_cloud_max_fwd: bad arguments");
-  LOTUS_LAUNCH(cloud_max_fwd_kernel, dim3(B, cdiv(C, 32)), dim3(1024), 0, (hipStream_t)stream, x, off, C, y, arg);
+size_t lotus_cloud_max_workspace(int B, int C) { return (size_t)B * CM_SPLITS * C * (sizeof(float) + sizeof(int)); }
+int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  LOTUS_CHECK_ARG(x && off && y && arg && B > 0 && C > 0 && C % 4 == 0 && ((uintptr_t)x) % 16 == 0,
+                  "lotus_cloud_max_fwd: bad arguments (C must be a multiple of 4, x 16-byte aligned)");
+  LOTUS_CHECK_ARG(workspace && ((uintptr_t)workspace) % 16 == 0 && workspace_bytes >= lotus_cloud_max_workspace(B, C),
+                  "lotus_cloud_max_fwd: workspace too small");
+  float* pv = (float*)workspace;
+  int* pi = (int*)(pv + (size_t)B * CM_SPLITS * C);
+  hipStream_t st = (hipStream_t)stream;
+  LOTUS_LAUNCH(cloud_max_part_kernel, dim3(B, cdiv(C, 128), CM_SPLITS), dim3(1024), 0, st, x, off, C, pv, pi);
+  LOTUS_LAUNCH(cloud_max_merge_kernel, dim3(cdiv(B * C, 256)), dim3(256), 0, st, (const float*)pv, (const int*)pi, B, C, y, arg);
   LOTUS_LAUNCH_CHECK("lotus_cloud_max_fwd");
   return LOTUS_OK;
 }

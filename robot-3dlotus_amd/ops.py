@@ -1122,7 +1122,8 @@ class HeadLossFn(torch.autograd.Function):
         xt, _ = linear_fwd(h, hw3, hb3)
         pc = torch.empty(B, C, dtype=torch.float32, device=dev)
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
-        call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg)
+        ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
+        call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg, ws, ws.numel())
         a, apre = linear_fwd(pc, aw0, ab0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=mix_seed(seed, 1))
         ae, _ = linear_fwd(a, aw3, ab3)
         losses = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -1272,7 +1273,8 @@ class CloudMaxFn(torch.autograd.Function):
         B, C = len(lvl.counts), x.shape[1]
         y = torch.empty(B, C, dtype=torch.float32, device=x.device)
         arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
-        call("lotus_cloud_max_fwd", x, lvl.off, B, C, y, arg)
+        ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
+        call("lotus_cloud_max_fwd", x, lvl.off, B, C, y, arg, ws, ws.numel())
         ctx.save_for_backward(arg)
         ctx.lvl, ctx.n = lvl, x.shape[0]
         return y

@@ -550,3 +550,31 @@ def test_attention_dropout_mask_is_consistent_between_fwd_and_bwd():
     num = (((fwd(qkv + eps * uq)[0] - fwd(qkv - eps * uq)[0]) / (2 * eps)) * dout).double().sum().item()
     ana = (dqkv * uq).double().sum().item()
     assert abs(num - ana) <= 3e-2 * max(1.0, abs(ana)), (num, ana)
+
+
+def test_cloud_max_first_index_ties_and_ragged_clouds():
+    """lotus_cloud_max_fwd == torch.max(x_b, 0) per cloud, values AND indices (first row attaining the maximum), with
+    deliberate ties, clouds shorter than the row splits and non-finite rows; backward scatters to those rows."""
+    from types import SimpleNamespace
+    from robot_3dlotus_amd import ops
+
+    torch.manual_seed(5)
+    counts = [1, 7, 300, 4096, 33, 2050]
+    C = 128
+    x = torch.randn(sum(counts), C, device="cuda")
+    x = (x * 4).round() / 4                                   # coarse values: many exact ties inside every column
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device="cuda")
+    x[off[3] + 5, :] = float("-inf")
+    x[off[2]:off[2] + 300, 3] = 2.5                           # a whole column tied
+    batch = torch.repeat_interleave(torch.arange(len(counts), device="cuda", dtype=torch.int32), torch.tensor(counts, device="cuda"))
+    lvl = SimpleNamespace(counts=counts, off=off, batch=batch)
+    xr = x.clone().requires_grad_(True)
+    y = ops.CloudMaxFn.apply(xr, lvl)
+    ref_v, ref_i = zip(*[t.max(0) for t in torch.split(x, counts)])
+    assert torch.equal(y, torch.stack(ref_v))
+    g = torch.randn_like(y)
+    y.backward(g)
+    want = torch.zeros_like(x)
+    for b, (i, o) in enumerate(zip(ref_i, off[:-1].tolist())):
+        want[i + o, torch.arange(C, device="cuda")] += g[b]
+    assert torch.equal(xr.grad, want)
