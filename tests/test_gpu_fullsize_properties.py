@@ -1,0 +1,114 @@
+"""Size-independent properties of the hot-path kernels at the full bench size (16 clouds x 4096 points, every level
+of the v1 hierarchy) — where the CPU oracle is too slow to serve as the checker:
+
+* adjointness  <A x, y> == <x, A^T y>  of the sparse convolution (forward vs input gradient, and vs weight gradient) and
+  of the dense layers — the input / weight gradients are the transposes of the forward map, independent of any reference;
+* linearity of the convolution in x;
+* partition of unity of the patch attention (softmax rows sum to one: constant values come back unchanged at every
+  point, which exercises the padding / patch tables of all 65 536 points);
+* LayerNorm statistics, max-pool / unpool consistency.
+Tolerances are fp32 summation bounds (relative to the size of the inner products)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def levels():
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.synth_batch(16, 4096, seed=0)
+    perms = [[0, 1, 2, 3], [1, 0, 3, 2], [2, 3, 0, 1], [3, 2, 1, 0], [0, 2, 1, 3]]
+    return FrontEnd(5).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], perms)
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+def _rel(a, b, scale):
+    return abs(a - b) / max(scale, 1e-30)
+
+
+@pytest.mark.parametrize("lv,C", [(0, 64), (0, 128), (1, 128), (2, 256), (3, 512), (4, 768)])
+def test_sparse_conv_adjoint_and_linear(levels, lv, C):
+    from robot_3dlotus_amd import ops
+
+    L = levels[lv]
+    g = torch.Generator(device="cuda").manual_seed(100 * lv + C)
+    x = torch.randn(L.n, C, device="cuda", generator=g)
+    x2 = torch.randn(L.n, C, device="cuda", generator=g)
+    dy = torch.randn(L.n, C, device="cuda", generator=g)
+    w = torch.randn(C, 3, 3, 3, C, device="cuda", generator=g) / (13 * C) ** 0.5
+    wt = ops.conv_weight_t(w)
+    y = ops.conv_fwd(x, w, None, L.nbr27, L.order[0], w_t=wt)
+    # <conv(x), dy> == <x, conv^T(dy)> == <w, wgrad(dy, x)>
+    dx = ops.conv_dgrad(dy, w, L.nbr27, L.order[0], w_t=wt, lvl=L)
+    dw, _ = ops.conv_wgrad(dy, x, w.shape, L.nbr27, need_bias=False)
+    fwd = _dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert _rel(fwd, _dot(x, dx), scale) < 2e-6, "input gradient is not the transpose of the forward convolution"
+    assert _rel(fwd, _dot(w, dw), scale) < 2e-6, "weight gradient is not the transpose of the forward convolution"
+    # linearity in x
+    y2 = ops.conv_fwd(x2, w, None, L.nbr27, L.order[0], w_t=wt)
+    y12 = ops.conv_fwd(0.5 * x - 2.0 * x2, w, None, L.nbr27, L.order[0], w_t=wt)
+    err = float((y12 - (0.5 * y - 2.0 * y2)).abs().max())
+    assert err < 5e-6 * float(y.abs().max() + 2 * y2.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 512, 128), (65536, 128, 512), (65536, 128, 128), (23894, 512, 128), (6077, 1024, 256),
+                                   (1450, 2048, 512), (361, 3072, 768)])
+def test_dense_layer_adjoint(M, N, K):
+    from robot_3dlotus_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    y, _ = ops.linear_fwd(x, w, None)
+    dx = ops.linear_dgrad(dy, w)
+    dw, db = ops.linear_wgrad(dy, x)
+    torch.cuda.synchronize()
+    fwd = _dot(y, dy)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert _rel(fwd, _dot(x, dx), scale) < 2e-6
+    assert _rel(fwd, _dot(w, dw), scale) < 2e-6
+    assert torch.allclose(db.double(), dy.double().sum(0), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("lv,C,H", [(0, 64, 2), (0, 128, 4), (1, 128, 4), (2, 256, 8), (3, 512, 16), (4, 768, 24)])
+def test_patch_attention_partition_of_unity(levels, lv, C, H):
+    """softmax rows sum to one: with V constant over the points (one value per channel) the attention output is that
+    constant at EVERY point, whatever Q and K are — all padding slots, borrowed rows and patch tables of the level take
+    part."""
+    from robot_3dlotus_amd import ops
+
+    L = levels[lv]
+    d = C // H
+    g = torch.Generator(device="cuda").manual_seed(7 * lv + C)
+    qkv = torch.randn(L.n, 3 * C, device="cuda", generator=g)
+    vconst = torch.randn(C, device="cuda", generator=g)
+    qkv[:, 2 * C:] = vconst
+    qn = (torch.rand(d, device="cuda", generator=g) + 0.5, torch.randn(d, device="cuda", generator=g) * 0.2)
+    kn = (torch.rand(d, device="cuda", generator=g) + 0.5, torch.randn(d, device="cuda", generator=g) * 0.2)
+    out = torch.empty(L.n, C, device="cuda")
+    lse = torch.empty(L.npad, H, device="cuda")
+    ops.attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, L.gidx, L.gidx, L.owner, L.self_tiles, L.n_self_tiles, qn, kn, out, lse,
+                      H, d)
+    err = float((out - vconst).abs().max())
+    assert err < 2e-5 * float(vconst.abs().max()), err
+
+
+@pytest.mark.parametrize("M,C", [(65536, 64), (65536, 128), (23894, 128), (361, 768)])
+def test_layernorm_statistics(M, C):
+    from robot_3dlotus_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    x = torch.randn(M, C, device="cuda", generator=g) * 3 + 1.5
+    y, mean, rstd = ops.ln_fwd(x, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"))
+    assert float(y.mean(1).abs().max()) < 1e-5
+    assert float((y.var(1, unbiased=False) - 1).abs().max()) < 1e-3   # eps = 1e-5 against var ~ 9
+    assert torch.allclose(mean, x.mean(1), rtol=1e-5, atol=1e-5)
