@@ -394,7 +394,11 @@ __global__ void fe_hash_build_kernel(const int* __restrict__ grid, const int* __
     slot = (slot + 1) & mask;
   }
 }
-// nbr[t][i], t = ((dx+r)*k + (dy+r))*k + (dz+r)
+// nbr[t][i], t = ((dx+r)*k + (dy+r))*k + (dz+r).  One thread per (point, tap) and a fully scattering hash: ~19 M random
+// 8-byte probes per level-0 5^3 table, i.e. the kernel sits at the L2 random-access rate (540 GB/s of HBM-side traffic
+// is all it needs).  Measured and rejected: a z-local home slot (the 8 cells of a z octet in one 64-byte line) with one
+// thread probing the k cells of a (dx, dy) column — surface clouds fill whole octets, probe chains grow and the
+// per-thread chains serialise: 22 -> 65 us per launch, hash build 11 -> 28 us.
 __global__ void fe_neighbour_kernel(const int* __restrict__ grid, const int* __restrict__ batch, int n, int ksize,
                                     const unsigned long long* __restrict__ hkeys, const int* __restrict__ hvals,
                                     unsigned mask, int* __restrict__ nbr) {
