@@ -271,10 +271,23 @@ _COUNTERS = {}
 def _counters(dev):
     """Zeroed arrival counters of the fused split-K products, one buffer per stream that launches them (the kernels
     leave them zero)."""
-    key = (dev, _capi.STREAM_OVERRIDE or _capi.stream_ptr())
+    return _counters_for(dev, _capi.STREAM_OVERRIDE or _capi.stream_ptr())
+
+
+def _counters_for(dev, ptr):
+    """The counter buffer of the stream with raw handle `ptr`.  First use: the zero-fill is enqueued ON that stream (a
+    fill on torch's current stream would not be ordered before a side-stream launch whose fork event was already
+    recorded: a counter that starts non-zero never reaches gridDim.z - 1 and the tile is never written)."""
+    key = (dev, ptr)
     c = _COUNTERS.get(key)
     if c is None:
-        c = _COUNTERS[key] = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
+        owner = next((st for st, sp in _SIDES if sp == ptr), None)
+        if owner is not None and ptr != _capi.stream_ptr():
+            with torch.cuda.stream(owner):
+                c = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
+        else:
+            c = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
+        _COUNTERS[key] = c
     return c
 
 
@@ -699,11 +712,7 @@ def _side_ctx(dev, ws_side_bytes, reads):
             if t is not None:
                 t.record_stream(st)
     ws = _side_ws(ws_side_bytes, dev)
-    key = (dev, ptr)
-    c = _COUNTERS.get(key)
-    if c is None:
-        c = _COUNTERS[key] = torch.zeros(query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device=dev)
-    return ptr, ws, c
+    return ptr, ws, _counters_for(dev, ptr)
 
 
 # ------------------------------------------------------------------------------------ sub-blocks
@@ -1197,12 +1206,17 @@ class StepHeadFn(torch.autograd.Function):
         dw3 = db3 = None
         ws = _ws(query("lotus_step_act_bwd_workspace", M, C), base.device)
         first = True
+        keep = []  # everything the weight-gradient stream reads stays alive until the node's join (h_t and a contiguous
+        #            copy of dxt_t would otherwise be recycled by the allocator while wgrad_t is still in flight)
         for t in range(T):
             if dxts[t] is None:
                 dsb[t].zero_()
                 continue
             dxt = dxts[t].contiguous()
             h = torch.empty_like(base)
+            keep.append((dxt, h))
+            if _JOIN == "end" and _side() is not None:
+                dxt.record_stream(_SIDES[0][0]); h.record_stream(_SIDES[0][0])
             call("lotus_step_act_fwd", base, step_bias[t], h, M, C, ACT_LEAKY, p, mix_seed(seed, t))
             dw3, db3 = linear_wgrad(dxt, h, into=None if dw3 is None else (dw3, db3))
             dh = linear_dgrad(dxt, w3)
@@ -1211,6 +1225,7 @@ class StepHeadFn(torch.autograd.Function):
             first = False
         if first:
             dbase.zero_()
+        # `keep` dies with this frame: whatever re-uses the blocks is enqueued after the join `_joined` performs next
         return dbase, dsb, dw3, db3, None, None
 
 

@@ -62,8 +62,8 @@ class GradReducer:
     last micro-batch;  finish().  Every bucket is all-reduced exactly once per step on every rank — from its hook when
     all its gradients arrived, else in finish() with the slots of gradient-less parameters zeroed — so ranks whose
     parameter usage differs stay in lock-step (what DistributedDataParallel(find_unused_parameters=True) achieves with
-    its usage bitmap; the difference: a parameter no rank used ends with a zero gradient instead of None when
-    world > 1).  A backward that would add onto already averaged gradients raises instead of silently diverging."""
+    its usage bitmap, which finish() mirrors with one MAX all-reduce of a per-parameter flag: a parameter no rank
+    used ends with `.grad = None`, exactly as on one GPU).  A backward that would add onto already averaged gradients raises instead of silently diverging."""
 
     def __init__(self, module, bucket_mb=32.0, group=None, broadcast=True):
         self.group = group
@@ -82,6 +82,8 @@ class GradReducer:
         self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
         self._sync = True
+        self._index = {p: i for i, p in enumerate(self.params)}
+        self._used = torch.zeros(len(self.params), dtype=torch.int32)  # host bitmap: parameters with a gradient this step
         for p in self.params:
             p.grad = None
             p.register_post_accumulate_grad_hook(self._hook)
@@ -157,6 +159,8 @@ class GradReducer:
         ps, views = self._bparams[b], self._bviews[b]
         self._flushed[b] = True
         have = [i for i, p in enumerate(ps) if p.grad is not None]
+        for i in have:
+            self._used[self._index[ps[i]]] = 1
         lo, hi = self.buckets[b]
         buf = self.flat[lo:hi]
         grads = [ps[i].grad for i in have]
@@ -199,20 +203,26 @@ class GradReducer:
     def zero_grad(self):
         for p in self.params:
             p.grad = None
-        if self._learning and self._arrival:
+        if self._learning:
             # first backward seen: re-lay the flat buffer in arrival order.  The order is a property of the autograd
-            # graph, but ranks whose first batches exercised different modules would disagree: rank 0 decides.
+            # graph, but ranks whose first batches exercised different modules would disagree: rank 0 decides.  The
+            # broadcast is issued by EVERY rank on every zero_grad() while learning (a rank-local condition — "my first
+            # backward ran under no_sync / was skipped" — would leave the other ranks alone in the collective); an empty
+            # order from rank 0 keeps every rank in learning mode.
             index = {p: i for i, p in enumerate(self.params)}
             order = [index[p] for p in self._arrival]
             if self.world > 1:
                 t = torch.full((len(self.params),), -1, dtype=torch.int64, device=self.flat.device)
-                t[:len(order)] = torch.tensor(order, dtype=torch.int64)
+                if order:
+                    t[:len(order)] = torch.tensor(order, dtype=torch.int64)
                 dist.broadcast(t, 0, group=self.group)
                 order = [i for i in t.tolist() if i >= 0]
-            hot = [self.params[i] for i in order]
-            hot_set = set(hot)
-            self._layout(hot, [p for p in self.params if p not in hot_set])
-            self._arrival, self._seen, self._learning = [], set(), False
+            if order:
+                hot = [self.params[i] for i in order]
+                hot_set = set(hot)
+                self._layout(hot, [p for p in self.params if p not in hot_set])
+                self._learning = False
+            self._arrival, self._seen = [], set()
         self._rearm()
 
     def finish(self):
@@ -228,6 +238,18 @@ class GradReducer:
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
         self._keep = []
+        if self.world > 1:
+            # parameters NO rank used keep .grad None, as under DistributedDataParallel(find_unused_parameters=True) and
+            # as on one GPU: the optimiser skips them (no decoupled weight decay, no moment update for e.g. a head
+            # that never ran).  One tiny MAX all-reduce of the usage bitmap per step.
+            # (issued unconditionally: a rank-local "everything was used here" shortcut would mismatch the collective)
+            u = self._used.to(self.flat.device)
+            dist.all_reduce(u, op=dist.ReduceOp.MAX, group=self.group)
+            if int(u.min().item()) == 0:
+                for p, flag in zip(self.params, u.tolist()):
+                    if not flag:
+                        p.grad = None
+        self._used.zero_()
 
 
 _BN_GROUP = None

@@ -293,6 +293,7 @@ class PointTransformerV3CA(nn.Module):
         else:
             perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
             levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
+        self.last_n_dup = levels[0].n_dup  # points sharing a voxel with an earlier point (0 for voxel-unique batches)
         training = self.training
         if not self._sync_bn_checked:
             self._check_sync_bn()

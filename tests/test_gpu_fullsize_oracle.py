@@ -1,0 +1,102 @@
+"""Full-size parity of BASELINE configs[1] against the oracle: v1, 16 clouds x 4096 points, train mode (batch statistics in
+every BatchNorm, dropout 0 because the reference's RNG streams cannot be reproduced), injected order permutations.
+
+The oracle (oracle/model.py, torch-CPU fp32 under autograd) needs ~5-10 s for forward + backward at this size on the GPU
+box's host cores.  Compared: the action logits (absolute 1e-4 — the north-star bar — where |logit|max < 1, else relative to
+the largest logit), the four losses, and EVERY parameter gradient as a whole tensor, ||dg|| / (||g|| + floor).  This reaches
+the shapes no committed fixture reaches: 65 536 points, 512 patches per order at level 0, the split-K dense products and the
+tap-split convolutions of the deep levels.  A second case uses augmented clouds (rotation + jitter: 1-7 % duplicate voxels).
+
+The measured errors go to the ledger (tests/ledger.py -> profiles/rNN_parity.json)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+import ledger  # noqa: E402
+
+PERMS = [[1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 0, 2, 3]]
+GRAD_TOL = 1e-4      # ||dg|| <= GRAD_TOL * (||g|| + GRAD_FLOOR * max_p ||g_p||)
+GRAD_FLOOR = 1e-3
+LOGIT_TOL = 1e-4
+
+
+def _dev_batch(batch):
+    return {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v))
+            for k, v in batch.items()}
+
+
+def _run(variant, augment, seed, tag):
+    import robot_3dlotus_amd  # noqa: F401
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("v1")
+    sd = seeded_state_dict(gu.state_template(cfg), seed, variant)
+    batch = synth.synth_batch(16, 4096, seed=seed)
+    if augment:
+        batch = synth.augment_clouds(batch, seed=seed + 1)
+    torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(cfg), training=True).forward(batch, PERMS)
+    out["losses"]["total"].backward()
+
+    m = SimplePolicyPTV3CA(cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0
+    m.act_proj_head.dropout = 0.0
+    m.ptv3_model.order_perms = PERMS
+    _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    if augment:
+        assert m.ptv3_model.last_n_dup > 0, "the augmented clouds were meant to contain duplicate voxels"
+    rec = {"n_dup": int(m.ptv3_model.last_n_dup), "points": int(sum(batch["npoints_in_batch"])), "weights": variant, "augmented": bool(augment)}
+    fails = []
+    for name, got, ref in (("xt", m.last_pred[0], out["xt"]), ("xr", m.last_pred[1], out["xr"]), ("xo", m.last_pred[2], out["xo"])):
+        ref = ref.detach().numpy()
+        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        mag = float(np.abs(ref).max())
+        rec["logit_abs_err_" + name], rec["logit_max_" + name] = err, mag
+        if err > LOGIT_TOL * max(1.0, mag):
+            fails.append(f"{name}: max |diff| {err:.3e} (|logit|max {mag:.3g})")
+    for k in ("pos", "rot", "open", "total"):
+        ref = float(out["losses"][k])
+        err = abs(losses[k].item() - ref)
+        rec["loss_abs_err_" + k] = err
+        if err > 1e-4 * max(1.0, abs(ref)):
+            fails.append(f"loss {k}: {losses[k].item()} vs {ref}")
+    losses["total"].backward()
+    gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    worst, n = (0.0, None), 0
+    for name, p in m.named_parameters():
+        r = sdg[name].grad
+        assert p.grad is not None and r is not None, name
+        err = float((p.grad.cpu().double() - r.double()).norm())
+        rel = err / (float(r.norm()) + GRAD_FLOOR * gmax)
+        worst = max(worst, (rel, name))
+        n += 1
+        if rel > GRAD_TOL:
+            fails.append(f"grad {name}: ||dg|| {err:.3e} vs ||g|| {float(r.norm()):.3e} (rel {rel:.2e})")
+    rec.update(n_gradients=n, grad_rel_err_max=worst[0], grad_rel_err_argmax=worst[1], grad_norm_max=gmax,
+               grad_tol=GRAD_TOL, grad_floor=GRAD_FLOOR)
+    ledger.record("fullsize_oracle/" + tag, **rec)
+    assert not fails, "; ".join(fails[:8])
+
+
+def test_fullsize_v1_against_oracle_init_weights():
+    """Reference-initialisation weights: |logit|max < 1, so the 1e-4 bar is absolute."""
+    _run("init", False, 11, "v1_16x4096_init")
+
+
+def test_fullsize_v1_against_oracle_scaled_weights():
+    """x3 weights, non-trivial affine / running statistics (SURVEY Trap 2): softmax, qk-norm, GELU and BN leave their
+    linear regime."""
+    _run("scaled", False, 12, "v1_16x4096_scaled")
+
+
+def test_fullsize_v1_against_oracle_duplicate_voxels():
+    _run("scaled", True, 13, "v1_16x4096_scaled_augmented")

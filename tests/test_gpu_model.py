@@ -11,7 +11,13 @@ pytestmark = pytest.mark.gpu
 
 import golden_util as gu  # noqa: E402
 
+import ledger  # noqa: E402
+
 LOGIT_TOL = 1e-4
+# gradients: ||dg|| <= GRAD_TOL * (||g|| + GRAD_FLOOR * max_p ||g_p||) for every parameter, whole tensor (round 2 had 2e-3 on
+# the norm and the first 48 entries only); measured errors are in profiles/r03_parity.json
+GRAD_TOL = 1e-4
+GRAD_FLOOR = 1e-3
 
 
 def _build(cfg, sd, train):
@@ -43,27 +49,48 @@ def test_golden_fixture_parity(case):
     m.ptv3_model.order_perms = [p.tolist() for p in fx["perms"]]
     _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
     xt, xr, xo = m.last_pred
+    errs = {}
     for name, got in (("xt", xt), ("xr", xr), ("xo", xo)):
         ref = fx[name]
         tol = LOGIT_TOL * max(1.0, float(np.abs(ref).max()))
         err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        errs["logit_abs_err_" + name], errs["logit_max_" + name] = err, float(np.abs(ref).max())
         assert err <= tol, f"{case} {name}: max |diff| {err:.3e} > {tol:.3e}"
     for k in ("pos", "rot", "open", "total"):
         ref = float(fx["loss_" + k])
+        errs["loss_abs_err_" + k] = abs(losses[k].item() - ref)
         assert abs(losses[k].item() - ref) <= 1e-4 * max(1.0, abs(ref)), (k, losses[k].item(), ref)
     losses["total"].backward()
     gmax = max(float(fx[k]) for k in fx if k.startswith("gnorm/"))
-    worst = (0.0, None)
+    worst, worst_head = (0.0, None), (0.0, None)
     for name, p in m.named_parameters():
         assert p.grad is not None, f"no gradient for {name}"
         ref = float(fx["gnorm/" + name])
         got = p.grad.double().norm().item()
-        rel = abs(got - ref) / (ref + 1e-3 * gmax)
+        rel = abs(got - ref) / (ref + GRAD_FLOOR * gmax)
         worst = max(worst, (rel, name))
         head = fx["ghead/" + name]
-        np.testing.assert_allclose(p.grad.flatten()[:48].cpu().numpy(), head,
-                                   atol=2e-3 * float(np.abs(head).max()) + 2e-5 * gmax, rtol=0, err_msg=name)
-    assert worst[0] < 2e-3, f"gradient norm mismatch {worst}"
+        herr = float(np.abs(p.grad.flatten()[:48].cpu().numpy() - head).max()) / (float(np.abs(head).max()) + GRAD_FLOOR * gmax)
+        worst_head = max(worst_head, (herr, name))
+    # the fixture stores norms + leading entries of the reference's gradients; the WHOLE gradient of every parameter is
+    # compared with the oracle run live on the fixture's inputs (the oracle itself is pinned to the reference's gradients
+    # at 1e-4 by tests/test_oracle_vs_reference.py)
+    from oracle.model import Oracle
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(cfg), training=train).forward(batch, [p.tolist() for p in fx["perms"]])
+    out["losses"]["total"].backward()
+    og = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    worst_full = (0.0, None)
+    for name, p in m.named_parameters():
+        r = sdg[name].grad
+        rel = float((p.grad.cpu().double() - r.double()).norm()) / (float(r.norm()) + GRAD_FLOOR * og)
+        worst_full = max(worst_full, (rel, name))
+    ledger.record("golden_fixture/" + case, grad_norm_rel_err_max=worst[0], grad_norm_argmax=worst[1],
+                  grad_head_rel_err_max=worst_head[0], grad_head_argmax=worst_head[1],
+                  grad_full_vs_oracle_rel_err_max=worst_full[0], grad_full_argmax=worst_full[1], **errs)
+    assert worst[0] < GRAD_TOL, f"gradient norm mismatch {worst}"
+    assert worst_head[0] < GRAD_TOL, f"gradient entries mismatch {worst_head}"
+    assert worst_full[0] < GRAD_TOL, f"whole-gradient mismatch against the oracle {worst_full}"
     if train:
         sdn = m.state_dict()
         for k in fx:
@@ -119,10 +146,14 @@ def test_live_oracle_parity_with_duplicate_voxels_backward():
     assert abs(losses["total"].item() - out["losses"]["total"].item()) < 1e-4 * max(1.0, abs(out["losses"]["total"].item()))
     losses["total"].backward()
     gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
+    worst = (0.0, None)
     for name, p in m.named_parameters():
         r = sdg[name].grad
         err = float((p.grad.cpu() - r).norm())
-        assert err <= 2e-3 * (float(r.norm()) + 1e-3 * gmax), f"{name}: |dgrad| {err:.3e} vs |g| {float(r.norm()):.3e}"
+        worst = max(worst, (err / (float(r.norm()) + GRAD_FLOOR * gmax), name))
+    ledger.record("live_oracle/tiny_duplicate_voxels", grad_full_vs_oracle_rel_err_max=worst[0], grad_full_argmax=worst[1],
+                  n_dup=int(m.ptv3_model.last_n_dup))
+    assert worst[0] <= GRAD_TOL, f"whole-gradient mismatch against the oracle {worst}"
 
 
 @pytest.mark.parametrize("mode,tol", [("bf16x3", 1e-4), ("bf16", 3e-2)])
