@@ -100,8 +100,11 @@ def cross_attention(q, kv, counts, ctx_counts, H, qn_w, qn_b, kn_w, kn_b, fp16_a
 class Oracle:
     """sd: dict name -> tensor (reference key grammar).  cfg: dict(ptv3=..., action=..., loss=...)."""
 
-    def __init__(self, sd, cfg, training=False, fp16_attn=False, bn_momentum=0.01):
-        self.sd, self.cfg = sd, cfg
+    def __init__(self, sd, cfg, training=False, fp16_attn=False, bn_momentum=0.01, dtype=torch.float32):
+        # dtype: arithmetic type of the restatement.  float32 is the reference's; float64 (state dict given in float64)
+        # is the yardstick the full-size parity test measures BOTH fp32 implementations against — the integer front end
+        # always sees the float32 coordinates
+        self.sd, self.cfg, self.dt = sd, cfg, dtype
         self.training = training
         self.fp16_attn = fp16_attn
         self.bn_momentum = bn_momentum
@@ -161,10 +164,11 @@ class Oracle:
         """SimplePolicyPTV3AdaNorm.forward + SimplePolicyPTV3CA.prepare_ptv3_batch,
         simple_policy_ptv3.py:225-306, :403-431.  batch uses the reference schema
         (pc_fts, npoints_in_batch, txt_embeds, txt_lens, gt_actions, disc_pos_probs)."""
-        pc = batch["pc_fts"].float()
+        pc32 = batch["pc_fts"].float()
+        pc = pc32.to(self.dt)
         counts = list(batch["npoints_in_batch"])
-        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")  # simple_policy_ptv3.py:414
-        x, out = self.backbone(pc, pc[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        ctx = self.lin(batch["txt_embeds"].to(self.dt), "txt_fc")  # simple_policy_ptv3.py:414
+        x, out = self.backbone(pc, pc32[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
         return self.head(x, counts, batch, out, compute_loss)
 
     def backbone(self, feat, xyz, counts, ctx, ctx_counts, perms):
@@ -227,10 +231,10 @@ class Oracle:
         xo = ae[..., -1]
         out.update(xt=xt, xr=xr, xo=xo)
         if compute_loss:  # compute_loss, simple_policy_ptv3.py:308-373
-            gt = batch["gt_actions"].float()
+            gt = batch["gt_actions"].to(self.dt)
             pos = 0
             for i, (lg, tg) in enumerate(zip(torch.split(xt, counts, dim=1), batch["disc_pos_probs"])):
-                pos = pos + F.cross_entropy(lg.reshape(3, -1), tg.float(), reduction="mean")
+                pos = pos + F.cross_entropy(lg.reshape(3, -1), tg.to(self.dt), reduction="mean")
             pos = pos / len(counts)
             rot = F.cross_entropy(xr, gt[..., 3:-1].long(), reduction="mean")
             opn = F.binary_cross_entropy_with_logits(xo, gt[..., -1], reduction="mean")

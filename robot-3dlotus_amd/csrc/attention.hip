@@ -71,7 +71,7 @@ __device__ __forceinline__ void load_rows(float* img, const float* base, long ld
   const int sub = threadIdx.x & 7;
   for (int r = threadIdx.x >> 3; r < AT; r += 32) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < len && sub * 4 < d) v = *reinterpret_cast<const float4*>(base + (long)rows_s[r] * ld + coff + sub * 4);
+    if (r < len && sub * 4 < d) v = ld4(base + (long)rows_s[r] * ld + coff + sub * 4);
     float* o = img + r * ALD + sub * 4;
     o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
   }
@@ -99,7 +99,7 @@ __device__ __forceinline__ void load_rows_batch(const RowSrc (&src)[N], int d) {
       const int r = r0 + 32 * j;
       v[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < src[i].len && sub * 4 < d)
-        v[i][j] = *reinterpret_cast<const float4*>(src[i].base + (long)src[i].rows_s[r] * src[i].ld + src[i].coff + sub * 4);
+        v[i][j] = ld4(src[i].base + (long)src[i].rows_s[r] * src[i].ld + src[i].coff + sub * 4);
     }
 #pragma unroll
   for (int i = 0; i < N; ++i)
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int dc = 8 * q4 + 4 * hh;
-      if (dc < d) *reinterpret_cast<float4*>(orow + dc) = make_float4(o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]);
+      if (dc < d) st4(orow + dc, make_float4(o[4 * q4], o[4 * q4 + 1], o[4 * q4 + 2], o[4 * q4 + 3]));
     }
   }
 }
@@ -380,7 +380,7 @@ __device__ __forceinline__ void store_rows(const float* img, float* base, long l
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
     } else {
-      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      st4(o, make_float4(v[0], v[1], v[2], v[3]));
     }
   }
 }
@@ -452,11 +452,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         const int r = rr0 + 32 * j;
         qv[j] = gv[j] = ov[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < q_len && sub * 4 < d) {
-          qv[j] = *reinterpret_cast<const float4*>(p.q + (long)s.qrow[r] * p.q_ld + p.q_off + h * d + sub * 4);
+          qv[j] = ld4(p.q + (long)s.qrow[r] * p.q_ld + p.q_off + h * d + sub * 4);
           if (s.qown[r]) {
             const long o = (long)s.qrow[r] * p.out_ld + h * d + sub * 4;
-            gv[j] = *reinterpret_cast<const float4*>(p.dout + o);
-            ov[j] = *reinterpret_cast<const float4*>(p.out + o);
+            gv[j] = ld4(p.dout + o);
+            ov[j] = ld4(p.out + o);
           }
         }
       }
@@ -556,8 +556,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
         float lse4[16], d4[16];  // per-query scalars of this lane's 16 rows: four aligned runs of four queries
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          const float4 a = *reinterpret_cast<const float4*>(s.lse + qt * 32 + 8 * q4 + 4 * hh);
-          const float4 b = *reinterpret_cast<const float4*>(s.Dv + qt * 32 + 8 * q4 + 4 * hh);
+          const float4 a = ld4(s.lse + qt * 32 + 8 * q4 + 4 * hh);
+          const float4 b = ld4(s.Dv + qt * 32 + 8 * q4 + 4 * hh);
           lse4[4 * q4] = a.x; lse4[4 * q4 + 1] = a.y; lse4[4 * q4 + 2] = a.z; lse4[4 * q4 + 3] = a.w;
           d4[4 * q4] = b.x; d4[4 * q4 + 1] = b.y; d4[4 * q4 + 2] = b.z; d4[4 * q4 + 3] = b.w;
         }
@@ -840,7 +840,7 @@ __global__ void attn_extra_fixup_kernel(const float* __restrict__ extra, long ex
   if (gid >= (long)n_extra * w4) return;
   const int e = (int)(gid / w4), c = (int)(gid % w4) * 4;
   const int point = kidx[ext_pos[e]];
-  const float4 a = *reinterpret_cast<const float4*>(extra + (long)e * extra_ld + c);
+  const float4 a = ld4(extra + (long)e * extra_ld + c);
   float4* o = reinterpret_cast<float4*>(dkv + (long)point * dkv_ld + dk_off + c);
   float4 v = *o;
   v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;

@@ -55,6 +55,50 @@ void lotus_set_error(const char* fmt, ...);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---- activation storage type.  Every [rows][channels] ACTIVATION tensor in HBM (layer inputs / outputs, saved
+// pre-activations, their gradients) is `act_t`; parameters, parameter gradients, statistics, logits of the losses'
+// reductions and all accumulation stay fp32.  The library is compiled twice from the same sources: act_t = float (entry
+// points lotus_*, the fp32 parity path) and, with -DLOTUS_ACT_BF16, act_t = bf16 (entry points lotus_b16_*: the
+// "bf16 activations / fp32 master weights / fp32 accumulate" mode of BASELINE configs[4]).  Kernels never spell the
+// width of an activation access: they go through ld4 / st4 (four consecutive channels: 16 bytes fp32, 8 bytes bf16,
+// round-to-nearest-even on store) and ld1 / st1, which are overloaded on the pointer type, so the fp32 instantiation is
+// token-for-token the code it was before.  All file-scope code of a translation unit lives in namespace LOTUS_NS so
+// that the two variants of a kernel template never share a symbol.
+#ifdef LOTUS_ACT_BF16
+typedef __bf16 act_t;
+#define LOTUS_NS lotus_b16
+#define LOTUS_ACT_IS_BF16 1
+#else
+typedef float act_t;
+#define LOTUS_NS lotus_f32
+#define LOTUS_ACT_IS_BF16 0
+#endif
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 lotus_bf16x2;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                     __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u));
+}
+__device__ __forceinline__ unsigned lotus_pack_bf16(float a, float b) {
+  const lotus_bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void st4(__bf16* p, float4 v) {
+  *reinterpret_cast<uint2*>(p) = make_uint2(lotus_pack_bf16(v.x, v.y), lotus_pack_bf16(v.z, v.w));
+}
+// group q of four consecutive elements
+template <typename T> __device__ __forceinline__ float4 ld4q(const T* p, long q) { return ld4(p + 4 * q); }
+template <typename T> __device__ __forceinline__ void st4q(T* p, long q, float4 v) { st4(p + 4 * q, v); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+// floats needed to hold n activation elements (host-side carving of flat float buffers)
+static inline size_t lotus_act_floats(size_t n) { return LOTUS_ACT_IS_BF16 ? (n + 1) / 2 : n; }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

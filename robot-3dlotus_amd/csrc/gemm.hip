@@ -10,17 +10,22 @@
 // fixed order by a second kernel (no float atomics).
 #include "mma.h"
 #include <stdlib.h>
+#include <type_traits>
+
+namespace LOTUS_NS {
 
 struct GemmP {
-  const float* A;
-  const float* B;
-  float* C;
+  // element types are template parameters of the kernel (EA, EB, EC): activations are act_t, weights / weight gradients /
+  // split-K partials are float (fwd, dgrad: act x float -> act; wgrad: act x act -> float)
+  const void* A;
+  const void* B;
+  void* C;
   int M, N, K;
   long lda, ldb, ldc;
   const float* bias;      // [N]
-  const float* residual;  // [M][ldc], added after the activation
-  float* pre;             // [M][ldc], pre-activation (after bias) saved for backward
-  const float* mulpre;    // [M][ldc], dgrad: multiply by act'(mulpre)
+  const act_t* residual;  // [M][ldc], added after the activation
+  act_t* pre;             // [M][ldc], pre-activation (after bias) saved for backward
+  const act_t* mulpre;    // [M][ldc], dgrad: multiply by act'(mulpre)
   int act;   // activation applied to the value
   int dact;  // derivative code used with mulpre
   int klen;          // K range per blockIdx.z (multiple of BK)
@@ -40,6 +45,7 @@ struct GemmP {
   unsigned* cnt;
   float* bias_out;   // wgrad, fused: final column sums (bias gradient)
   int accumulate;    // wgrad, fused: C / bias_out += result
+  int c_float;       // fwd / dgrad: C is an fp32 split-K partial slab, not an activation tensor
 };
 
 // Partial tiles of a fused split-K product travel between blocks that may sit on different XCDs (one L2 each).  An
@@ -62,18 +68,19 @@ __device__ __forceinline__ float4 ld_agent4(const float* p) {
 }
 
 // the full epilogue of one float4 of the output: bias, pre-activation copy, activation, act', dropout, residual
-__device__ __forceinline__ void gemm_epilogue4(const GemmP& p, float* __restrict__ C, long o, int col, float (&v)[4]) {
+template <typename TC>
+__device__ __forceinline__ void gemm_epilogue4(const GemmP& p, TC* __restrict__ C, long o, int col, float (&v)[4]) {
   if (p.bias) {
-    const float4 bv = *reinterpret_cast<const float4*>(p.bias + col);
+    const float4 bv = ld4(p.bias + col);
     v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
   }
-  if (p.pre) *reinterpret_cast<float4*>(p.pre + o) = make_float4(v[0], v[1], v[2], v[3]);
+  if (p.pre) st4(p.pre + o, make_float4(v[0], v[1], v[2], v[3]));
   if (p.act != LOTUS_ACT_NONE) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
   }
   if (p.mulpre) {
-    const float4 m4 = *reinterpret_cast<const float4*>(p.mulpre + o);
+    const float4 m4 = ld4(p.mulpre + o);
     const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
@@ -83,14 +90,14 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmP& p, float* __restrict
     for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
   }
   if (p.residual) {
-    const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
+    const float4 r4 = ld4(p.residual + o);
     v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
   }
   if (p.accumulate) {
-    const float4 c4 = *reinterpret_cast<const float4*>(C + o);
+    const float4 c4 = ld4(C + o);
     v[0] += c4.x; v[1] += c4.y; v[2] += c4.z; v[3] += c4.w;
   }
-  *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+  st4(C + o, make_float4(v[0], v[1], v[2], v[3]));
 }
 
 // FAST: operands are 16-byte aligned with ld % 4 == 0 and the contiguous extents are multiples of 4,
@@ -120,7 +127,7 @@ __device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const fl
       const float* row = As + (wr0 + tm * 32 + l31) * GTile<BM, true, BK>::kLd + h * KS;
 #pragma unroll
       for (int q = 0; q < KS / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        const float4 v = ld4(row + 4 * q);
         a[tm][4 * q] = v.x; a[tm][4 * q + 1] = v.y; a[tm][4 * q + 2] = v.z; a[tm][4 * q + 3] = v.w;
       }
     } else {
@@ -134,7 +141,7 @@ __device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const fl
       const float* row = Bs + (wc0 + tn * 32 + l31) * GTile<BN, true, BK>::kLd + h * KS;
 #pragma unroll
       for (int q = 0; q < KS / 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+        const float4 v = ld4(row + 4 * q);
         b[tn][4 * q] = v.x; b[tn][4 * q + 1] = v.y; b[tn][4 * q + 2] = v.z; b[tn][4 * q + 3] = v.w;
       }
     } else {
@@ -226,8 +233,11 @@ __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
-template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, int PREC = 0>
+template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, int PREC = 0, typename EA = float, typename EB = float,
+          typename EC = float>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  const EA* __restrict__ pA = static_cast<const EA*>(p.A);
+  const EB* __restrict__ pB = static_cast<const EB*>(p.B);
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
@@ -292,20 +302,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
-          const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4));
+          const float4 v = ld4(pA + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4));
           ra[t] = zsel(k < kend, v);
         } else {
-          ra[t] = load4_guard(p.A, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
+          ra[t] = load4_guard(pA, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
         }
       } else {
         const int f2 = PREC ? tid + (t >> 1) * 256 : f;  // bf16 path: registers 2p, 2p+1 hold k, k+1 of one row quad
         const int kr = PREC ? (f2 / (BM / 4)) * 2 + (t & 1) : f / (BM / 4), iq = f2 % (BM / 4);
         if (FAST) {
           const int k = k0 + kr;
-          const float4 v = *reinterpret_cast<const float4*>(p.A + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
+          const float4 v = ld4(pA + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
           ra[t] = zsel(k < kend, v);
         } else {
-          ra[t] = load4_guard(p.A, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
+          ra[t] = load4_guard(pA, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
         }
       }
     }
@@ -316,20 +326,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
-          const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4));
+          const float4 v = ld4(pB + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4));
           rb[t] = zsel(k < kend, v);
         } else {
-          rb[t] = load4_guard(p.B, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
+          rb[t] = load4_guard(pB, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
         }
       } else {
         const int f2 = PREC ? tid + (t >> 1) * 256 : f;
         const int kr = PREC ? (f2 / (BN / 4)) * 2 + (t & 1) : f / (BN / 4), jq = f2 % (BN / 4);
         if (FAST) {
           const int k = k0 + kr;
-          const float4 v = *reinterpret_cast<const float4*>(p.B + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
+          const float4 v = ld4(pB + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
           rb[t] = zsel(k < kend, v);
         } else {
-          rb[t] = load4_guard(p.B, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
+          rb[t] = load4_guard(pB, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
         }
       }
     }
@@ -412,10 +422,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const float v[4] = {ra[t].x, ra[t].y, ra[t].z, ra[t].w};
       if (A_KC) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
-        *reinterpret_cast<float4*>(&Ad[row * GTile<BM, true, BK>::kLd + kq * 4]) = ra[t];
+        st4(&Ad[row * GTile<BM, true, BK>::kLd + kq * 4], ra[t]);
       } else {
         const int kr = f / (BM / 4), iq = f % (BM / 4);
-        *reinterpret_cast<float4*>(&Ad[kr * BM + iq * 4]) = ra[t];
+        st4(&Ad[kr * BM + iq * 4], ra[t]);
       }
     }
 #pragma unroll
@@ -424,10 +434,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       const float v[4] = {rb[t].x, rb[t].y, rb[t].z, rb[t].w};
       if (B_KC) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
-        *reinterpret_cast<float4*>(&Bd[row * GTile<BN, true, BK>::kLd + kq * 4]) = rb[t];
+        st4(&Bd[row * GTile<BN, true, BK>::kLd + kq * 4], rb[t]);
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
-        *reinterpret_cast<float4*>(&Bd[kr * BN + jq * 4]) = rb[t];
+        st4(&Bd[kr * BN + jq * 4], rb[t]);
       }
     }
   };
@@ -436,29 +446,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // once) plus the slab offset — one 64-bit add per 16-byte load, no k clamp, no zero select.  Issued at the top of the
   // iteration and pinned there (sched_barrier), so the loads fly under the whole slab of MFMAs instead of being
   // sunk next to their consumers.
-  const float* pa[A4];
-  const float* pb[B4];
+  const EA* pa[A4];
+  const EB* pb[B4];
   if (FAST) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
-      if (A_KC) pa[t] = p.A + (long)min(m0 + f / (BK / 4), p.M - 1) * p.lda + (f % (BK / 4)) * 4;
-      else if (PREC) pa[t] = p.A + (long)(((tid + (t >> 1) * 256) / (BM / 4)) * 2 + (t & 1)) * p.lda + min(m0 + ((tid + (t >> 1) * 256) % (BM / 4)) * 4, p.M - 4);
-      else pa[t] = p.A + (long)(f / (BM / 4)) * p.lda + min(m0 + (f % (BM / 4)) * 4, p.M - 4);
+      if (A_KC) pa[t] = pA + (long)min(m0 + f / (BK / 4), p.M - 1) * p.lda + (f % (BK / 4)) * 4;
+      else if (PREC) pa[t] = pA + (long)(((tid + (t >> 1) * 256) / (BM / 4)) * 2 + (t & 1)) * p.lda + min(m0 + ((tid + (t >> 1) * 256) % (BM / 4)) * 4, p.M - 4);
+      else pa[t] = pA + (long)(f / (BM / 4)) * p.lda + min(m0 + (f % (BM / 4)) * 4, p.M - 4);
     }
 #pragma unroll
     for (int t = 0; t < B4; ++t) {
       const int f = tid + t * 256;
-      if (B_KC) pb[t] = p.B + (long)min(n0 + f / (BK / 4), p.N - 1) * p.ldb + (f % (BK / 4)) * 4;
-      else if (PREC) pb[t] = p.B + (long)(((tid + (t >> 1) * 256) / (BN / 4)) * 2 + (t & 1)) * p.ldb + min(n0 + ((tid + (t >> 1) * 256) % (BN / 4)) * 4, p.N - 4);
-      else pb[t] = p.B + (long)(f / (BN / 4)) * p.ldb + min(n0 + (f % (BN / 4)) * 4, p.N - 4);
+      if (B_KC) pb[t] = pB + (long)min(n0 + f / (BK / 4), p.N - 1) * p.ldb + (f % (BK / 4)) * 4;
+      else if (PREC) pb[t] = pB + (long)(((tid + (t >> 1) * 256) / (BN / 4)) * 2 + (t & 1)) * p.ldb + min(n0 + ((tid + (t >> 1) * 256) % (BN / 4)) * 4, p.N - 4);
+      else pb[t] = pB + (long)(f / (BN / 4)) * p.ldb + min(n0 + (f % (BN / 4)) * 4, p.N - 4);
     }
   }
   auto gload_full = [&](int k0) {
 #pragma unroll
-    for (int t = 0; t < A4; ++t) ra[t] = *reinterpret_cast<const float4*>(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
+    for (int t = 0; t < A4; ++t) ra[t] = ld4(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
 #pragma unroll
-    for (int t = 0; t < B4; ++t) rb[t] = *reinterpret_cast<const float4*>(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
+    for (int t = 0; t < B4; ++t) rb[t] = ld4(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
   };
 
   // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs.  (Measured and rejected:
@@ -487,7 +497,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
   // ---- epilogue
   const bool fused = FAST && p.cnt != nullptr && gridDim.z > 1;
-  float* __restrict__ C = fused ? p.part + (long)bz * p.part_stride : p.C + (long)bz * p.part_stride;
+  // (a fused split stores its raw partial into the fp32 `part` slabs; everything else goes to C)
+  EC* __restrict__ C = static_cast<EC*>(p.C) + (long)bz * p.part_stride;
+  float* __restrict__ Cp = fused ? p.part + (long)bz * p.part_stride : nullptr;
   if (FAST) {
     // Stage each wave's 32 x WN sub-tile through LDS and leave as float4 rows: 16 B per lane loads of
     // residual / pre-activation and 16 B stores (4 B-per-lane stores ran at ~1 TB/s, 4x below HBM).
@@ -512,9 +524,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           const int row = m0 + wr0 + tm * 32 + rl;
           if (row < p.M) {
             const long o = (long)row * p.ldc + col;
-            const float4 a4 = *reinterpret_cast<const float4*>(st + rl * SLD + c4 * 4);
+            const float4 a4 = ld4(st + rl * SLD + c4 * 4);
             if (fused) {
-              st_agent4(C + o, a4);  // raw partial of this split
+              st_agent4(Cp + o, a4);  // raw partial of this split
             } else {
               float v[4] = {a4.x, a4.y, a4.z, a4.w};
               gemm_epilogue4(p, C, o, col, v);
@@ -538,12 +550,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           if (row >= p.M) continue;
           const long o = (long)row * p.ldc + col;
           float v = acc[tm][tn][r] + bv;
-          if (p.pre) p.pre[o] = v;
+          if (p.pre) st1(p.pre + o, v);
           v = act_f(v, p.act);
-          if (p.mulpre) v *= act_grad_f(p.mulpre[o], p.dact);
+          if (p.mulpre) v *= act_grad_f(ld1(p.mulpre + o), p.dact);
           if (p.drop_thresh) v *= dropout_scale(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep);
-          if (p.residual) v += p.residual[o];
-          C[o] = v;
+          if (p.residual) v += ld1(p.residual + o);
+          st1(C + o, v);
         }
       }
   }
@@ -608,7 +620,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
       }
       float v[4] = {s4.x, s4.y, s4.z, s4.w};
-      gemm_epilogue4(p, p.C, o, col, v);
+      gemm_epilogue4(p, static_cast<EC*>(p.C), o, col, v);
     }
     if (SUM_A && p.bias_out && p.bias_part && bx == 0) {
       for (int i = tid; i < BM; i += 256) {
@@ -633,7 +645,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e + 3 < n) {
     for (int z = zl; z < nz; z += 16) {
-      const float4 v = *reinterpret_cast<const float4*>(part + (long)z * stride + e);
+      const float4 v = ld4(part + (long)z * stride + e);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   } else if (e < n) {
@@ -668,7 +680,7 @@ extern "C" int lotus_sum_slabs(const float* part, float* out, long n, long strid
   return lotus_reduce_parts(part, out, n, stride, nz, 0, (hipStream_t)stream);
 }
 
-static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }
+static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }  // (bf16 rows: 8-byte accesses, same rule)
 
 static int tune_env(const char* name) {
   const char* e = getenv(name);
@@ -677,11 +689,23 @@ static int tune_env(const char* name) {
 static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 3: 64x64), LOTUS_GEMM_NZ, LOTUS_GEMM_BK
 #define GEMM_KALIGN 64  // split-K ranges are multiples of the largest slab depth
 
+// Element types of a launch: A is always an activation; B is the weight matrix (fp32 master) except in the weight gradient
+// (both operands are activations); C is an activation except for the weight gradient and for split-K partial slabs
+// (p.c_float).  In the fp32 build every combination is <float, float, float>.
+#define GEMM_GO(BM_, BN_, BK_, PREC_, grid_)                                                                                     \
+  do {                                                                                                                           \
+    using TB_ = std::conditional_t<SUM_A, act_t, float>;                                                                         \
+    if constexpr (LOTUS_ACT_IS_BF16 && !SUM_A) {                                                                                 \
+      if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p); \
+      else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, act_t>), grid_, block, 0, st, p);   \
+    } else {                                                                                                                     \
+      LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p);      \
+    }                                                                                                                            \
+  } while (0)
+
 template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
-  const long blocks128 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
   const long blocks64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
-  const bool small_n = p.N <= 64;
   dim3 block(256);
   if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
   if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
@@ -691,22 +715,23 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
     dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if constexpr (SUM_A && !A_KC && !B_KC && FAST) {
-      if (g_prec == 1) LOTUS_LAUNCH((gemm_kernel<64, 64, 32, false, false, true, true, 1>), g64, block, 0, st, p);
-      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, false, false, true, true, 3>), g64, block, 0, st, p);
+      if (g_prec == 1) GEMM_GO(64, 64, 32, 1, g64);
+      else if constexpr (!LOTUS_ACT_IS_BF16) GEMM_GO(64, 64, 32, 3, g64);
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
     return LOTUS_OK;
   }
   if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
     // bf16 / bf16x3 operand path (forward and input-gradient products)
-    const bool big = tile == 1;  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
     dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    if (g_prec == 1) {
-      if (big) LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 1>), g128, block, 0, st, p);
-      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 1>), g64, block, 0, st, p);
-    } else {
-      if (big) LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, false, true, 3>), g128, block, 0, st, p);
-      else LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, false, true, 3>), g64, block, 0, st, p);
+    if constexpr (!SUM_A && FAST) {
+      if (g_prec == 1) {
+        if (tile == 1) GEMM_GO(128, 128, 16, 1, g128);  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
+        else GEMM_GO(64, 64, 32, 1, g64);
+      } else if constexpr (!LOTUS_ACT_IS_BF16) {
+        if (tile == 1) GEMM_GO(128, 128, 16, 3, g128);
+        else GEMM_GO(64, 64, 32, 3, g64);
+      }
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
     return LOTUS_OK;
@@ -719,14 +744,18 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   // weight-gradient stream sharing the CUs — 64x64 tiles are better or equal at every batch size measured
   // (16 clouds: 820 vs 806 samples/s; 32: 945 vs 920; 64: 1051 vs 1032; 128: equal), so 128x128 is opt-in only
   if (tile == 0) tile = 3;
-  (void)blocks128; (void)small_n;
-  if (tile == 1) {
+  if constexpr (LOTUS_ACT_IS_BF16) {
+    // bf16-storage build: the exact-fp32 product path only serves the shapes the vectorised bf16 path cannot take
+    // (odd widths such as the 90- and 217-wide head layers)
+    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
+    GEMM_GO(64, 64, 32, 0, grid);
+  } else if (tile == 1) {
     dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
-    LOTUS_LAUNCH((gemm_kernel<128, 128, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    GEMM_GO(128, 128, 16, 0, grid);
   } else if (tile == 2 && !SUM_A && p.M >= 2048) {  // experimental: 128 x 64 tiles (wave tile 64 x 32)
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
-    if (g_force_bk == 32) LOTUS_LAUNCH((gemm_kernel<128, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-    else LOTUS_LAUNCH((gemm_kernel<128, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
+    if (g_force_bk == 32) GEMM_GO(128, 64, 32, 0, grid);
+    else GEMM_GO(128, 64, 16, 0, grid);
   } else {
     // slab depth (tools/gemm_sweep.py): with <= 2 blocks per CU nothing else hides the global-load latency,
     // so run deep slabs (4x the MFMA work and bytes in flight per barrier); large grids keep BK = 16 for
@@ -734,13 +763,9 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     int bk = g_force_bk;
     if (!bk) bk = SUM_A ? 32 : (blocks64 * nz <= 512 ? 64 : (blocks64 * nz <= 2048 ? 32 : 16));
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    if (bk == 64) {
-      LOTUS_LAUNCH((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-    } else if (bk == 32) {
-      LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-    } else {
-      LOTUS_LAUNCH((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST>), grid, block, 0, st, p);
-    }
+    if (bk == 64) GEMM_GO(64, 64, 64, 0, grid);
+    else if (bk == 32) GEMM_GO(64, 64, 32, 0, grid);
+    else GEMM_GO(64, 64, 16, 0, grid);
   }
   LOTUS_LAUNCH_CHECK("lotus_gemm");
   return LOTUS_OK;
@@ -789,21 +814,21 @@ __global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int row = (int)(i / n4), col = (int)(i % n4) * 4;
     const long o = (long)row * p.ldc + col;
-    float4 s4 = *reinterpret_cast<const float4*>(part + o);
+    float4 s4 = ld4(part + o);
     for (int z = 1; z < nz; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(part + (long)z * stride + o);
+      const float4 v = ld4(part + (long)z * stride + o);
       s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
     }
     float v[4] = {s4.x, s4.y, s4.z, s4.w};
     if (p.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+      const float4 b = ld4(p.bias + col);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
-    if (p.pre) *reinterpret_cast<float4*>(p.pre + o) = make_float4(v[0], v[1], v[2], v[3]);
+    if (p.pre) st4(p.pre + o, make_float4(v[0], v[1], v[2], v[3]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
     if (p.mulpre) {
-      const float4 m4 = *reinterpret_cast<const float4*>(p.mulpre + o);
+      const float4 m4 = ld4(p.mulpre + o);
       const float mv[4] = {m4.x, m4.y, m4.z, m4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
@@ -813,10 +838,10 @@ __global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, 
       for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
     }
     if (p.residual) {
-      const float4 r4 = *reinterpret_cast<const float4*>(p.residual + o);
+      const float4 r4 = ld4(p.residual + o);
       v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
     }
-    *reinterpret_cast<float4*>(p.C + o) = make_float4(v[0], v[1], v[2], v[3]);
+    st4(static_cast<act_t*>(p.C) + o, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
@@ -853,7 +878,7 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
     if (fast_ok<A_KC, B_KC>(q)) return launch_gemm<A_KC, B_KC, false>(q, nz, st);
   }
   GemmP q = p;
-  q.C = (float*)workspace; q.part_stride = (long)p.M * p.N;
+  q.C = workspace; q.c_float = 1; q.part_stride = (long)p.M * p.N;
   q.bias = nullptr; q.residual = nullptr; q.pre = nullptr; q.mulpre = nullptr; q.act = LOTUS_ACT_NONE; q.drop_thresh = 0;
   q.klen = klen;
   StopEventOnLast stop_ev;
@@ -879,8 +904,8 @@ size_t lotus_linear_workspace(int M, int N, int K) {
   return wa > wb ? wa : wb;
 }
 
-int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                     float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
+int lotus_linear_fwd(const act_t* x, const float* w, const float* bias, const act_t* residual, act_t* y,
+                     act_t* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
                      int precision, void* workspace, size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_fwd: precision must be 0, 1 or 3");
@@ -899,7 +924,7 @@ int lotus_linear_fwd(const float* x, const float* w, const float* bias, const fl
 // dx = (dy w) * act'(pre) * dropmask + add.   dy [M,N], w [N,K], dx/pre/add [M,K].
 // `pre`/`act`/`drop_*` describe the layer that PRODUCED this layer's input (its pre-activation,
 // activation and output dropout), so the chain rule through it is fused into this epilogue.
-int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
+int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* pre, const act_t* add, int M,
                        int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
                        size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
@@ -938,7 +963,7 @@ size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
 // dw (+)= dy^T x ; db (+)= colsum(dy).   dy [M,N], x [M,K], dw [N,K], db [N] (optional).
 // When db == dw + N*K (one contiguous [N*K + N] gradient buffer) the split-K partials of both are
 // summed by a single launch; with one split and accumulate == 0 the GEMM writes dw/db directly.
-int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, int M, int N, int K,
                        int accumulate, int precision, void* workspace, size_t workspace_bytes, void* counters,
                        void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
@@ -983,3 +1008,5 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
 }
 
 }  // extern "C"
+
+}  // namespace LOTUS_NS

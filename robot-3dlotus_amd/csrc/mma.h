@@ -23,19 +23,20 @@ struct LdsTile {
   __device__ static __forceinline__ int idx(int r, int k) { return KC ? r * kStride + k : k * kStride + r; }
 };
 
-// Guarded 4-float global load of base[r * ld + c .. c + 3].
-__device__ __forceinline__ float4 load4_guard(const float* __restrict__ base, long ld, int r, int c, int rmax,
+// Guarded 4-element global load of base[r * ld + c .. c + 3] (fp32 or bf16 storage).
+template <typename T>
+__device__ __forceinline__ float4 load4_guard(const T* __restrict__ base, long ld, int r, int c, int rmax,
                                               int cmax, bool vec_ok) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r < rmax && c < cmax) {
-    const float* p = base + (long)r * ld + c;
+    const T* p = base + (long)r * ld + c;
     if (vec_ok && c + 3 < cmax) {
-      v = *reinterpret_cast<const float4*>(p);
+      v = ld4(p);
     } else {
-      v.x = p[0];
-      if (c + 1 < cmax) v.y = p[1];
-      if (c + 2 < cmax) v.z = p[2];
-      if (c + 3 < cmax) v.w = p[3];
+      v.x = ld1(p);
+      if (c + 1 < cmax) v.y = ld1(p + 1);
+      if (c + 2 < cmax) v.z = ld1(p + 2);
+      if (c + 3 < cmax) v.w = ld1(p + 3);
     }
   }
   return v;

@@ -5,14 +5,16 @@
 // column reductions go through per-block partials that a second tiny kernel sums in fixed order.
 #include "common.h"
 
+namespace LOTUS_NS {
+
 // --------------------------------------------------------------------------------- LayerNorm
 // A row is owned by LPR lanes (16/32/64); lane holds float4 #(l + j * LPR), j < NV <= 4.
 struct LnP {
-  const float* x;
-  const float* res;  // optional residual added AFTER the norm: y = LN(x) + res
+  const act_t* x;
+  const act_t* res;  // optional residual added AFTER the norm: y = LN(x) + res
   const float* gamma;
   const float* beta;
-  float* y;
+  act_t* y;
   float* mean;
   float* rstd;
   int M, C, LPR, NV;
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
     v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int q = l + j * p.LPR;
     if (valid && j < p.NV && q < c4) {
-      v[j] = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
+      v[j] = ld4q(p.x + (long)row * p.C, q);
       s += v[j].x + v[j].y + v[j].z + v[j].w;
     }
   }
@@ -61,35 +63,35 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
   for (int j = 0; j < 4; ++j) {
     const int q = l + j * p.LPR;
     if (j < p.NV && q < c4) {
-      const float4 g = reinterpret_cast<const float4*>(p.gamma)[q];
-      const float4 b = reinterpret_cast<const float4*>(p.beta)[q];
+      const float4 g = ld4q(p.gamma, q);
+      const float4 b = ld4q(p.beta, q);
       float4 o;
       o.x = (v[j].x - mean) * rstd * g.x + b.x;
       o.y = (v[j].y - mean) * rstd * g.y + b.y;
       o.z = (v[j].z - mean) * rstd * g.z + b.z;
       o.w = (v[j].w - mean) * rstd * g.w + b.w;
       if (p.res) {
-        const float4 r = reinterpret_cast<const float4*>(p.res + (long)row * p.C)[q];
+        const float4 r = ld4q(p.res + (long)row * p.C, q);
         o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
       }
-      reinterpret_cast<float4*>(p.y + (long)row * p.C)[q] = o;
+      st4q(p.y + (long)row * p.C, q, o);
     }
   }
 }
 
 struct LnBwdP {
-  const float* dy;
-  const float* x;
+  const act_t* dy;
+  const act_t* x;
   const float* mean;
   const float* rstd;
   const float* gamma;
-  const float* add;  // optional: dx += add
-  float* dx;
+  const act_t* add;  // optional: dx += add
+  act_t* dx;
   float* part;  // [gridDim.x][2][C]  (dgamma, dbeta partials)
   int M, C, LPR, NV;
   // optional second output: dz = dx * dropout mask of the layer that PRODUCED this block's input (its backward would
   // otherwise start with a stand-alone mask kernel over dx)
-  float* dz;
+  act_t* dz;
   unsigned long long drop_seed;
   unsigned drop_thresh;
   float drop_inv_keep;
@@ -114,10 +116,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
       const int q = l + j * p.LPR;
       xh[j] = g[j] = av[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (valid && j < p.NV && q < c4) {
-        const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
-        const float4 dv = reinterpret_cast<const float4*>(p.dy + (long)row * p.C)[q];
-        if (p.add) av[j] = reinterpret_cast<const float4*>(p.add + (long)row * p.C)[q];  // in flight with x / dy
-        const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
+        const float4 xv = ld4q(p.x + (long)row * p.C, q);
+        const float4 dv = ld4q(p.dy + (long)row * p.C, q);
+        if (p.add) av[j] = ld4q(p.add + (long)row * p.C, q);  // in flight with x / dy
+        const float4 gm = ld4q(p.gamma, q);
         xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
         pg[j].x += dv.x * xh[j].x; pg[j].y += dv.y * xh[j].y; pg[j].z += dv.z * xh[j].z; pg[j].w += dv.w * xh[j].w;
         pb[j].x += dv.x; pb[j].y += dv.y; pb[j].z += dv.z; pb[j].w += dv.w;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
         o.z = rstd * (g[j].z - s1 - xh[j].z * s2);
         o.w = rstd * (g[j].w - s1 - xh[j].w * s2);
         o.x += av[j].x; o.y += av[j].y; o.z += av[j].z; o.w += av[j].w;
-        reinterpret_cast<float4*>(p.dx + (long)row * p.C)[q] = o;
+        st4q(p.dx + (long)row * p.C, q, o);
         if (p.dz) {
           const unsigned long long e = (unsigned long long)row * p.C + 4 * q;
           float4 z;
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
           z.y = o.y * dropout_scale(p.drop_seed, e + 1, p.drop_thresh, p.drop_inv_keep);
           z.z = o.z * dropout_scale(p.drop_seed, e + 2, p.drop_thresh, p.drop_inv_keep);
           z.w = o.w * dropout_scale(p.drop_seed, e + 3, p.drop_thresh, p.drop_inv_keep);
-          reinterpret_cast<float4*>(p.dz + (long)row * p.C)[q] = z;
+          st4q(p.dz + (long)row * p.C, q, z);
         }
       }
     }
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   for (int j = 0; j < 4; ++j) {
     const int q = l + j * p.LPR;
     if (j < p.NV && q < c4) {
-      reinterpret_cast<float4*>(red + (long)(rslot * 2 + 0) * p.C)[q] = pg[j];
-      reinterpret_cast<float4*>(red + (long)(rslot * 2 + 1) * p.C)[q] = pb[j];
+      st4q(red + (long)(rslot * 2 + 0) * p.C, q, pg[j]);
+      st4q(red + (long)(rslot * 2 + 1) * p.C, q, pb[j]);
     }
   }
   __syncthreads();
@@ -226,8 +228,8 @@ static int ln_geometry_bwd(int C, int* LPR, int* NV) {
 // --------------------------------------------------------------------------------- BatchNorm
 // Column statistics in double: per-block partial (sum, sumsq) -> fixed-order reduction.
 struct BnStatP {
-  const float* x;     // [M][C]
-  const float* dy;    // backward: dy (stats of dz, dz*xhat), else null
+  const act_t* x;     // [M][C]
+  const act_t* dy;    // backward: dy (stats of dz, dz*xhat), else null
   const float* mean;  // backward
   const float* invstd;
   const float* gamma;
@@ -249,10 +251,10 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
     if (live && q < c4) {
       float4 mu, is, gm, bt;
       if (p.dy) {
-        mu = reinterpret_cast<const float4*>(p.mean)[q];
-        is = reinterpret_cast<const float4*>(p.invstd)[q];
-        gm = reinterpret_cast<const float4*>(p.gamma)[q];
-        bt = reinterpret_cast<const float4*>(p.beta)[q];
+        mu = ld4q(p.mean, q);
+        is = ld4q(p.invstd, q);
+        gm = ld4q(p.gamma, q);
+        bt = ld4q(p.beta, q);
       }
       const int stride = gridDim.x * rslots;
       int row = blockIdx.x * rslots + rslot;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
         for (; row + 3 * stride < p.M; row += 4 * stride) {
           float4 xv[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xv[u] = reinterpret_cast<const float4*>(p.x + (long)(row + u * stride) * p.C)[q];
+          for (int u = 0; u < 4; ++u) xv[u] = ld4q(p.x + (long)(row + u * stride) * p.C, q);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
           float4 xv[2], dv[2];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            xv[u] = reinterpret_cast<const float4*>(p.x + (long)(row + u * stride) * p.C)[q];
-            dv[u] = reinterpret_cast<const float4*>(p.dy + (long)(row + u * stride) * p.C)[q];
+            xv[u] = ld4q(p.x + (long)(row + u * stride) * p.C, q);
+            dv[u] = ld4q(p.dy + (long)(row + u * stride) * p.C, q);
           }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
         }
       }
       for (; row < p.M; row += stride) {
-        const float4 xv = reinterpret_cast<const float4*>(p.x + (long)row * p.C)[q];
+        const float4 xv = ld4q(p.x + (long)row * p.C, q);
         const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
         if (!p.dy) {
 #pragma unroll
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
             s1[e] += (double)xs[e] * xs[e];
           }
         } else {
-          const float4 dv = reinterpret_cast<const float4*>(p.dy + (long)row * p.C)[q];
+          const float4 dv = ld4q(p.dy + (long)row * p.C, q);
           const float ds[4] = {dv.x, dv.y, dv.z, dv.w};
           const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
           const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
@@ -383,14 +385,14 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ rm, const float* 
 }
 
 struct BnApplyP {
-  const float* x;
-  const float* dy;  // backward when non-null
+  const act_t* x;
+  const act_t* dy;  // backward when non-null
   const float* mean;
   const float* invstd;
   const float* gamma;
   const float* beta;
   const double* sums;  // backward (train): (sum dz, sum dz*xhat); null in eval mode
-  float* y;            // forward output or dx
+  act_t* y;            // forward output or dx
   float* dgamma;       // backward: written by block 0
   float* dbeta;
   long total4;  // M * C / 4
@@ -405,10 +407,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
   if (i0 < p.total4) {
     const int q = (int)(i0 % c4);
-    const float4 mu = reinterpret_cast<const float4*>(p.mean)[q];
-    const float4 is = reinterpret_cast<const float4*>(p.invstd)[q];
-    const float4 gm = reinterpret_cast<const float4*>(p.gamma)[q];
-    const float4 bt = reinterpret_cast<const float4*>(p.beta)[q];
+    const float4 mu = ld4q(p.mean, q);
+    const float4 is = ld4q(p.invstd, q);
+    const float4 gm = ld4q(p.gamma, q);
+    const float4 bt = ld4q(p.beta, q);
     const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
     const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
     float mdz[4] = {0.f, 0.f, 0.f, 0.f}, mdx[4] = {0.f, 0.f, 0.f, 0.f};
@@ -438,14 +440,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     long i = i0;
     for (; i + step < p.total4; i += 2 * step) {
-      const float4 xa = reinterpret_cast<const float4*>(p.x)[i], xb = reinterpret_cast<const float4*>(p.x)[i + step];
-      const float4 da = p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4;
-      const float4 db = p.dy ? reinterpret_cast<const float4*>(p.dy)[i + step] : z4;
-      reinterpret_cast<float4*>(p.y)[i] = one(xa, da);
-      reinterpret_cast<float4*>(p.y)[i + step] = one(xb, db);
+      const float4 xa = ld4q(p.x, i), xb = ld4q(p.x, i + step);
+      const float4 da = p.dy ? ld4q(p.dy, i) : z4;
+      const float4 db = p.dy ? ld4q(p.dy, i + step) : z4;
+      st4q(p.y, i, one(xa, da));
+      st4q(p.y, i + step, one(xb, db));
     }
     if (i < p.total4)
-      reinterpret_cast<float4*>(p.y)[i] = one(reinterpret_cast<const float4*>(p.x)[i], p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4);
+      st4q(p.y, i, one(reinterpret_cast<const float4*>(p.x)[i], p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4));
   }
   if (p.dy && p.dgamma && blockIdx.x == 0) {
     for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -488,7 +490,7 @@ static size_t bn_dyn_lds(int C) {
 extern "C" {
 
 // y = LayerNorm(x; gamma, beta, eps) (+ res).  mean/rstd [M] saved for backward (optional).
-int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+int lotus_layernorm_fwd(const act_t* x, const act_t* res, const float* gamma, const float* beta, act_t* y,
                         float* mean, float* rstd, int M, int C, float eps, void* stream) {
   LnP p;
   p.x = x; p.res = res; p.gamma = gamma; p.beta = beta; p.y = y; p.mean = mean; p.rstd = rstd;
@@ -511,9 +513,9 @@ size_t lotus_layernorm_bwd_workspace(int M, int C) { return (size_t)LN_BWD_MAX_G
 // dx = LN'(dy) (+ add); dgamma/dbeta (+)= column sums.  With dgamma == NULL only dx is produced and the
 // per-block column partials stay in `workspace` for lotus_layernorm_bwd_params (which a caller may run on
 // another stream: the parameter gradients are off the critical path of backward).
-int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
-                        float* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
+int lotus_layernorm_bwd(const act_t* dy, const act_t* x, const float* mean, const float* rstd, const float* gamma,
+                        const act_t* add, act_t* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
+                        act_t* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
                         void* stream) {
   LnBwdP p;
   p.dz = (dz && drop_p > 0.f) ? dz : nullptr;
@@ -556,7 +558,7 @@ int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamm
 size_t lotus_batchnorm_workspace(int M, int C) { return (size_t)512 * 2 * C * sizeof(double); }
 
 // Forward statistics: sums[2*C+1] (double) = (sum x, sum x^2, M) over the M local rows.
-int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
+int lotus_batchnorm_stats(const act_t* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
                           void* stream) {
   LOTUS_CHECK_ARG(x && sums && C % 4 == 0 && M >= 0, "lotus_batchnorm_stats: bad arguments (C=%d)", C);
   const int grid = bn_grid(M, C);
@@ -591,8 +593,8 @@ int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_v
 }
 
 // y = act((x - mean) * invstd * gamma + beta)
-int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
-                          const float* beta, float* y, int M, int C, int act, void* stream) {
+int lotus_batchnorm_apply(const act_t* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, act_t* y, int M, int C, int act, void* stream) {
   LOTUS_CHECK_ARG(x && y && C % 4 == 0, "lotus_batchnorm_apply: bad arguments");
   if (M == 0) return LOTUS_OK;
   BnApplyP p;
@@ -606,7 +608,7 @@ int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd
 }
 
 // Backward statistics: sums = (sum dz, sum dz * xhat), dz = dy * act'(z).
-int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean, const float* invstd,
+int lotus_batchnorm_bwd_stats(const act_t* dy, const act_t* x, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, double* sums, int M, int C, int act,
                               void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(dy && x && sums && C % 4 == 0, "lotus_batchnorm_bwd_stats: bad arguments");
@@ -626,8 +628,8 @@ int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean
 
 // dx from dy; train = 1 uses batch statistics (sums[2*C+1] incl. the row count, all-reduced when SyncBN),
 // train = 0 (eval) treats mean/invstd as constants.  dgamma/dbeta (+)= from sums.
-int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, const double* sums, float* dx, float* dgamma,
+int lotus_batchnorm_bwd_apply(const act_t* dy, const act_t* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const double* sums, act_t* dx, float* dgamma,
                               float* dbeta, int M, int C, int act, int train, int accumulate, void* stream) {
   LOTUS_CHECK_ARG(dy && x && dx && sums && C % 4 == 0, "lotus_batchnorm_bwd_apply: bad arguments");
   BnApplyP p;
@@ -654,3 +656,5 @@ int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean
 }
 
 }  // extern "C"
+
+}  // namespace LOTUS_NS

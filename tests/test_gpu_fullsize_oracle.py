@@ -1,8 +1,9 @@
 """Full-size parity of BASELINE configs[1] against the oracle: v1, 16 clouds x 4096 points, train mode (batch statistics in
 every BatchNorm, dropout 0 because the reference's RNG streams cannot be reproduced), injected order permutations.
 
-The oracle (oracle/model.py, torch-CPU fp32 under autograd) needs ~5-10 s for forward + backward at this size on the GPU
-box's host cores.  Compared: the action logits (absolute 1e-4 — the north-star bar — where |logit|max < 1, else relative to
+The oracle (oracle/model.py, torch-CPU under autograd) needs ~5-10 s for forward + backward at this size on the GPU
+box's host cores.  It is evaluated in float64 (the yardstick) and in float32 (the reference's arithmetic, whose own distance to
+the yardstick is recorded next to the HIP model's).  Compared: the action logits (absolute 1e-4 — the north-star bar — where |logit|max < 1, else relative to
 the largest logit), the four losses, and EVERY parameter gradient as a whole tensor, ||dg|| / (||g|| + floor).  This reaches
 the shapes no committed fixture reaches: 65 536 points, 512 patches per order at level 0, the split-K dense products and the
 tap-split convolutions of the deep levels.  A second case uses augmented clouds (rotation + jitter: 1-7 % duplicate voxels).
@@ -18,8 +19,15 @@ import golden_util as gu  # noqa: E402
 import ledger  # noqa: E402
 
 PERMS = [[1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 0, 2, 3]]
-GRAD_TOL = 1e-4      # ||dg|| <= GRAD_TOL * (||g|| + GRAD_FLOOR * max_p ||g_p||)
+# Gradients, per parameter, whole tensor: rel = ||g_hip - g_f64|| / (||g_f64|| + GRAD_FLOOR * max_p ||g_p||).  Bar: rel <= 1e-4,
+# or — for the handful of parameters where fp32 arithmetic itself cannot do that at 65 536 points (max-pool arg-max near-ties
+# in `down.proj`, BatchNorm-fed biases: the float32 oracle, i.e. the reference's own arithmetic, is 1.7e-4 ... 1.3e-3 away from
+# float64 there) — no worse than REF_SLACK x the float32 oracle's distance on the same parameter.  Measured (round 3): max
+# 1.6e-4 / 6.5e-4 / 2.2e-4 (init / scaled / augmented) against 1.7e-4 / 1.3e-3 / 1.3e-3 for the float32 oracle, median 1e-6 ... 4e-6.
+GRAD_TOL = 1e-4
 GRAD_FLOOR = 1e-3
+REF_SLACK = 2.0
+GRAD_MEDIAN_TOL = 2e-5
 LOGIT_TOL = 1e-4
 
 
@@ -41,9 +49,20 @@ def _run(variant, augment, seed, tag):
     if augment:
         batch = synth.augment_clouds(batch, seed=seed + 1)
     torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
-    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
-    out = Oracle(sdg, lcfg.plain(cfg), training=True).forward(batch, PERMS)
-    out["losses"]["total"].backward()
+
+    def oracle(dt):
+        sdg_ = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k, v in sdg_.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_(True)
+        out_ = Oracle(sdg_, lcfg.plain(cfg), training=True, dtype=dt).forward(batch, PERMS)
+        out_["losses"]["total"].backward()
+        return out_, sdg_
+
+    # the yardstick is the oracle evaluated in float64; the same oracle in float32 (the reference's arithmetic) is
+    # measured against it too, which shows how much of a difference is fp32 summation order rather than a defect
+    out, sdg = oracle(torch.float64)
+    out32, sdg32 = oracle(torch.float32)
 
     m = SimplePolicyPTV3CA(cfg)
     m.load_state_dict(sd, strict=True)
@@ -57,32 +76,42 @@ def _run(variant, augment, seed, tag):
     rec = {"n_dup": int(m.ptv3_model.last_n_dup), "points": int(sum(batch["npoints_in_batch"])), "weights": variant, "augmented": bool(augment)}
     fails = []
     for name, got, ref in (("xt", m.last_pred[0], out["xt"]), ("xr", m.last_pred[1], out["xr"]), ("xo", m.last_pred[2], out["xo"])):
+        o32 = float((out32[name].detach().double() - ref.detach()).abs().max())
         ref = ref.detach().numpy()
-        err = float(np.abs(got.detach().cpu().numpy() - ref).max())
+        err = float(np.abs(got.detach().cpu().double().numpy() - ref).max())
         mag = float(np.abs(ref).max())
-        rec["logit_abs_err_" + name], rec["logit_max_" + name] = err, mag
+        rec["logit_abs_err_" + name], rec["logit_max_" + name], rec["oracle32_logit_abs_err_" + name] = err, mag, o32
         if err > LOGIT_TOL * max(1.0, mag):
             fails.append(f"{name}: max |diff| {err:.3e} (|logit|max {mag:.3g})")
     for k in ("pos", "rot", "open", "total"):
-        ref = float(out["losses"][k])
+        ref = float(out["losses"][k].detach())
         err = abs(losses[k].item() - ref)
         rec["loss_abs_err_" + k] = err
         if err > 1e-4 * max(1.0, abs(ref)):
             fails.append(f"loss {k}: {losses[k].item()} vs {ref}")
     losses["total"].backward()
     gmax = max(float(v.grad.norm()) for v in sdg.values() if v.grad is not None)
-    worst, n = (0.0, None), 0
+    worst, worst32, n, rels, table = (0.0, None), (0.0, None), 0, [], []
     for name, p in m.named_parameters():
         r = sdg[name].grad
         assert p.grad is not None and r is not None, name
-        err = float((p.grad.cpu().double() - r.double()).norm())
-        rel = err / (float(r.norm()) + GRAD_FLOOR * gmax)
-        worst = max(worst, (rel, name))
+        err = float((p.grad.cpu().double() - r).norm())
+        den = float(r.norm()) + GRAD_FLOOR * gmax
+        rel, rel32 = err / den, float((sdg32[name].grad.double() - r).norm()) / den
+        worst, worst32 = max(worst, (rel, name)), max(worst32, (rel32, name))
+        rels.append(rel)
         n += 1
-        if rel > GRAD_TOL:
-            fails.append(f"grad {name}: ||dg|| {err:.3e} vs ||g|| {float(r.norm()):.3e} (rel {rel:.2e})")
-    rec.update(n_gradients=n, grad_rel_err_max=worst[0], grad_rel_err_argmax=worst[1], grad_norm_max=gmax,
-               grad_tol=GRAD_TOL, grad_floor=GRAD_FLOOR)
+        table.append((rel, rel32, name))
+        if rel > max(GRAD_TOL, REF_SLACK * rel32):
+            fails.append(f"grad {name}: ||dg|| {err:.3e} vs ||g|| {float(r.norm()):.3e} (rel {rel:.2e}; oracle fp32 {rel32:.2e})")
+    table.sort(reverse=True)
+    rec["grad_worst5"] = [dict(name=t[2], hip=float("%.3g" % t[0]), oracle_fp32=float("%.3g" % t[1])) for t in table[:5]]
+    rec["n_gradients_above_1e-4"] = sum(1 for t in table if t[0] > GRAD_TOL)
+    if float(np.median(rels)) > GRAD_MEDIAN_TOL:
+        fails.append(f"median gradient error {float(np.median(rels)):.2e}")
+    rec.update(n_gradients=n, grad_rel_err_max=worst[0], grad_rel_err_argmax=worst[1], grad_rel_err_median=float(np.median(rels)),
+               oracle32_grad_rel_err_max=worst32[0], oracle32_grad_rel_err_argmax=worst32[1], grad_norm_max=gmax,
+               grad_tol=GRAD_TOL, grad_floor=GRAD_FLOOR, ref_slack=REF_SLACK, yardstick="oracle/model.py evaluated in float64")
     ledger.record("fullsize_oracle/" + tag, **rec)
     assert not fails, "; ".join(fails[:8])
 
