@@ -181,6 +181,8 @@ def main():
     ap.add_argument("--with-optimizer", action="store_true",
                     help="also run lr schedule + clip_grad_norm_(10) + fused AdamW inside every step (SURVEY 8f rank 1); "
                          "the headline metric of BASELINE.json is forward + backward only, so this is off by default")
+    ap.add_argument("--act-storage", choices=["fp32", "bf16"], default="bf16",
+                    help="peract workload only: storage type of the activation tensors in HBM (bf16 = BASELINE configs[4])")
     ap.add_argument("--workload", choices=["policy", "mp", "peract"], default="policy",
                     help="policy = 3D-LOTUS v1 (BASELINE configs[1], the headline metric); mp = the 3D-LOTUS++ motion "
                          "planner (configs[3]); peract = RLBench-18task config (configs[4]): the v1 network on dense 4096-point "
@@ -230,6 +232,8 @@ def main():
         model = MotionPlannerPTV3CA(lcfg.preset("mp")).to(dev).train()
     else:
         model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
+        if peract and args.act_storage == "bf16":
+            model.act_storage = "bf16"  # activations stored in bf16 (lotus_b16_* twins), fp32 master weights / gradients
     reducer = None
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1" or dist.is_initialized():  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
@@ -413,7 +417,11 @@ def main():
             out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"
             out["config"]["workload"] = (f"3D-LOTUS v1 network, PerAct preset (BASELINE configs[4]), {args.batch} dense clouds x {args.npoints} pts "
                                          f"per GPU after aug_max_rot 45 + jitter (duplicate voxels present), fwd+loss+bwd, train mode; "
-                                         f"products with {args.gemm_precision} operands and fp32 accumulate, activations / weights stored in fp32")
+                                         f"products with {args.gemm_precision} operands and fp32 accumulate, " +
+                                         ("activations stored in bf16 (every [N, C] tensor in HBM; lotus_b16_* entry points), fp32 master "
+                                          "weights, fp32 parameter gradients and statistics" if args.act_storage == "bf16" else
+                                          "activations / weights stored in fp32"))
+            out["config"]["act_storage"] = args.act_storage
             out["dtype"] = "bf16" if args.gemm_precision == "bf16" else args.gemm_precision
         if other:
             out["opt_in_modes"] = {"unit": "keystep-samples/s", **other,

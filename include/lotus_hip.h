@@ -10,7 +10,7 @@
  *   - every function returns 0 on success or a negative LOTUS_E_* code; lotus_last_error() returns a
  *     thread-local message.  Nothing throws, allocates device memory or synchronises the stream.
  *   - all pointers are DEVICE pointers borrowed for the duration of the enqueue, unless marked
- *     "host".  Tensors are dense row-major fp32; indices are int32; curve codes are int64.
+ *     "host".  Tensors are dense row-major (activations `lotus_act_t`, everything else fp32); indices are int32; curve codes are int64.
  *   - `stream` is a hipStream_t (the caller's current stream; 0 = default stream).
  *   - workspaces are caller-allocated; sizes come from the matching *_workspace() function.
  */
@@ -26,6 +26,16 @@ extern "C" {
 #define LOTUS_E_LAUNCH (-2)
 #define LOTUS_E_UNSUPPORTED (-3)
 #define LOTUS_E_WORKSPACE (-4)
+/* Activation storage type.  Every [rows][channels] activation tensor (layer inputs / outputs, saved pre-activations, their
+ * gradients) is `lotus_act_t`: float in this header's entry points.  The same sources are compiled a second time with bf16
+ * storage; those twins (lotus_b16_<name>, pointers to 16-bit bf16) are declared in lotus_hip_b16.h.  Weights, biases,
+ * parameter gradients, statistics and accumulation are fp32 in both. */
+#ifdef LOTUS_ACT_BF16 /* internal: the second compilation of the library */
+typedef unsigned short lotus_act_t;
+#else
+typedef float lotus_act_t;
+#endif
+
 #define LOTUS_ACT_NONE 0
 #define LOTUS_ACT_GELU 1  /* nn.GELU() exact erf form */
 #define LOTUS_ACT_LEAKY 2 /* nn.LeakyReLU(0.02), simple_policy_ptv3.py:42 */
@@ -99,16 +109,16 @@ size_t lotus_linear_workspace(int M, int N, int K); /* optional split-K scratch 
  * tile, the last block to arrive at a tile sums the partials in fixed order and applies the epilogue, and resets the
  * tile's counter (so the buffer stays zero between calls).  Without it the reduction is a second launch. */
 size_t lotus_splitk_counters_bytes(void);
-int lotus_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
-                     float* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
+int lotus_linear_fwd(const lotus_act_t* x, const float* w, const float* bias, const lotus_act_t* residual, lotus_act_t* y,
+                     lotus_act_t* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
                      int precision, void* workspace, size_t workspace_bytes, void* counters, void* stream);
 /* dx = (dy w) * act'(pre) * dropmask + add : chain rule through the producer of this layer's input */
-int lotus_linear_dgrad(const float* dy, const float* w, float* dx, const float* pre, const float* add, int M,
+int lotus_linear_dgrad(const lotus_act_t* dy, const float* w, lotus_act_t* dx, const lotus_act_t* pre, const lotus_act_t* add, int M,
                        int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
                        size_t workspace_bytes, void* counters, void* stream);
 size_t lotus_linear_wgrad_workspace(int M, int N, int K);
 /* dw (+)= dy^T x, db (+)= colsum(dy); deterministic split-K */
-int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, int M, int N, int K,
+int lotus_linear_wgrad(const lotus_act_t* dy, const lotus_act_t* x, float* dw, float* db, int M, int N, int K,
                        int accumulate, int precision, void* workspace, size_t workspace_bytes, void* counters,
                        void* stream);
 
@@ -121,32 +131,32 @@ int lotus_linear_wgrad(const float* dy, const float* x, float* dw, float* db, in
  * of >= T*cin*cout floats selects the active-pair VALU kernel. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
 int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, int precision, void* stream);
-int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
+int lotus_subm_conv(int mode, const lotus_act_t* x, const float* w, const float* w_t, const float* bias, const lotus_act_t* add,
+                    lotus_act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* Duplicate voxels (several points in one cell; the neighbour tables name the lowest index, `rep[p]` = centre tap
  * row nbr[T/2][p]): the true input gradient of mode 0 is dx[q] = [rep[q] == q] * sum_t W_t^T sum_{p in voxel(q) - d_t} dy[p].
  * lotus_conv_dup_fold writes dyr[r] = sum of dy over the points of r's voxel for representatives r (0 elsewhere), walking
  * the points in sorted (code, index) order `order0` (code0 = curve code per point; fixed order -> deterministic); mode 1
  * on dyr then yields the gradient for representatives, and lotus_conv_dup_mask resets the other rows to `add` (or 0). */
-int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* order0, int n, int C, float* dyr,
+int lotus_conv_dup_fold(const lotus_act_t* dy, const long long* code0, const int* order0, int n, int C, lotus_act_t* dyr,
                         void* stream);
-int lotus_conv_dup_mask(float* dx, const float* add, const int* rep, int n, int C, void* stream);
+int lotus_conv_dup_mask(lotus_act_t* dx, const lotus_act_t* add, const int* rep, int n, int C, void* stream);
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout);
-int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
+int lotus_subm_conv_wgrad(const lotus_act_t* dy, const lotus_act_t* x, float* dw, float* db, const int* nbr, int n, int T,
                           int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------ */
 /* nn.LayerNorm (model.py:624,627,645; model_ca.py:114,124): y = LN(x) (+ res) */
-int lotus_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+int lotus_layernorm_fwd(const lotus_act_t* x, const lotus_act_t* res, const float* gamma, const float* beta, lotus_act_t* y,
                         float* mean, float* rstd, int M, int C, float eps, void* stream);
 size_t lotus_layernorm_bwd_workspace(int M, int C);
 /* dz (optional, with drop_p > 0): second output dz = dx * mask(drop_seed), the nn.Dropout mask (same element index and
  * hash as the forward epilogue) of the layer that produced this block's input — its backward then needs no mask pass. */
-int lotus_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        const float* add, float* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
-                        float* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
+int lotus_layernorm_bwd(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* rstd, const float* gamma,
+                        const lotus_act_t* add, lotus_act_t* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
+                        lotus_act_t* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
                         void* stream);
 /* second half of the above when it was called with dgamma == NULL: reduce the column partials left in workspace */
 int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamma, float* dbeta, int accumulate,
@@ -155,19 +165,19 @@ int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamm
  * double sums[2*C+1] = (sum, sumsq, row count) so that a caller can all-reduce them across ranks (SyncBatchNorm,
  * train_simple_policy.py:116-117) between _stats and _finalize. */
 size_t lotus_batchnorm_workspace(int M, int C);
-int lotus_batchnorm_stats(const float* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
+int lotus_batchnorm_stats(const lotus_act_t* x, double* sums, int M, int C, void* workspace, size_t workspace_bytes,
                           void* stream);
 int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, float* running_mean,
                              float* running_var, int C, float eps, float momentum, void* stream);
 int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                                float eps, void* stream);
-int lotus_batchnorm_apply(const float* x, const float* mean, const float* invstd, const float* gamma,
-                          const float* beta, float* y, int M, int C, int act, void* stream);
-int lotus_batchnorm_bwd_stats(const float* dy, const float* x, const float* mean, const float* invstd,
+int lotus_batchnorm_apply(const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, lotus_act_t* y, int M, int C, int act, void* stream);
+int lotus_batchnorm_bwd_stats(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, double* sums, int M, int C, int act,
                               void* workspace, size_t workspace_bytes, void* stream);
-int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, const double* sums, float* dx, float* dgamma,
+int lotus_batchnorm_bwd_apply(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd,
+                              const float* gamma, const float* beta, const double* sums, lotus_act_t* dx, float* dgamma,
                               float* dbeta, int M, int C, int act, int train, int accumulate, void* stream);
 
 /* ---- attention ---------------------------------------------------------------------------- */
@@ -176,21 +186,21 @@ int lotus_batchnorm_bwd_apply(const float* dy, const float* x, const float* mean
  * model_ca.py:52-53), in fp32.  tiles: int32 [ntiles][4] = q_start, q_len, k_start, k_len (<= 128).
  * Row r of q lives at q + r*q_ld + q_off + h*d; k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d.
  * drop_p / drop_seed: dropout on the probabilities (flash-attn dropout_p), regenerated in backward. */
-int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+int lotus_attention_fwd(const lotus_act_t* q, long q_ld, int q_off, const lotus_act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
-                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
+                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, lotus_act_t* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
                         unsigned long long drop_seed, int precision, void* stream);
 size_t lotus_attention_bwd_workspace(int nblocks, int H);
 /* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.  kext / ext_pos /
  * dkv_extra (optional, from lotus_fe_patch): k/v gradients of the borrowed tail-patch copies go to a side
  * buffer [n_extra][2*H*d] and are added to their point afterwards (no atomics, no zero-fill of dkv). */
-int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+int lotus_attention_bwd(const lotus_act_t* q, long q_ld, int q_off, const lotus_act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, const int* blocks,
                         int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
-                        const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
-                        int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
-                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        const lotus_act_t* out, const lotus_act_t* dout, long out_ld, const float* lse, lotus_act_t* dq, long dq_ld,
+                        int dq_off, lotus_act_t* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
+                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, lotus_act_t* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
                         int precision, void* workspace, size_t workspace_bytes, void* stream);
 
@@ -209,15 +219,15 @@ size_t lotus_ffn_grads_floats(int C, int Hd);
 size_t lotus_ffn_tmp_floats(int M, int C, int Hd);
 size_t lotus_ffn_ws_main_bytes(int M, int C, int Hd);
 size_t lotus_ffn_ws_side_bytes(int M, int C, int Hd);
-int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
-                  const float* b2, float* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
+int lotus_ffn_fwd(const lotus_act_t* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
+                  const float* b2, lotus_act_t* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
                   unsigned long long seed2, int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
 /* dz_in (optional): dy times the fc2 dropout mask, handed over by the next sub-block — i.e. the dz_out of a lotus_*_bwd
  * call issued earlier with the same (stream, side) pair; `side` is already ordered after that launch and is NOT ordered
  * after `stream` again for it.  dz_out (optional, dz_out_p > 0): dx times the dropout mask (dz_out_p, dz_out_seed) of the
  * previous sub-block (see lotus_layernorm_bwd). */
-int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* w1, const float* w2,
-                  const float* saved, float* dx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
+int lotus_ffn_bwd(const lotus_act_t* dy, const lotus_act_t* dz_in, const lotus_act_t* x, const float* g, const float* w1, const float* w2,
+                  const float* saved, lotus_act_t* dx, lotus_act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
                   float* tmp, int M, int C, int Hd, float drop_p, unsigned long long seed1, unsigned long long seed2,
                   int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
                   void* counters_side, unsigned long long link, int join, void* stream, void* side);
@@ -231,13 +241,13 @@ size_t lotus_selfattn_grads_floats(int C, int H);
 size_t lotus_selfattn_tmp_floats(int M, int C, int n_extra);
 size_t lotus_selfattn_ws_main_bytes(int M, int C, int H, int nblocks);
 size_t lotus_selfattn_ws_side_bytes(int M, int C);
-int lotus_selfattn_fwd(const float* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
-                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, float* y,
+int lotus_selfattn_fwd(const lotus_act_t* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, lotus_act_t* y,
                        float* saved, const int* gidx, const int* owner, const int* tiles, int ntiles, int npad, int M, int C,
                        int H, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
-int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* wqkv, const float* qnw,
-                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, float* dx,
+int lotus_selfattn_bwd(const lotus_act_t* dy, const lotus_act_t* dz_in, const lotus_act_t* x, const float* g, const float* wqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, lotus_act_t* dx,
                        float* grads, float* tmp, const int* gidx, const int* owner, const int* tiles, const int* blocks, int nblocks,
                        const int* kext, const int* ext_pos, int n_extra, int npad, int M, int C, int H, float scale, float drop_p,
                        unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, void* ws_main,
@@ -252,14 +262,14 @@ size_t lotus_crossattn_grads_floats(int C, int H, int Cc);
 size_t lotus_crossattn_tmp_floats(int M, int C, int L, int G);
 size_t lotus_crossattn_ws_main_bytes(int M, int C, int H, int L, int Cc, int nblocks);
 size_t lotus_crossattn_ws_side_bytes(int M, int C, int L, int Cc);
-int lotus_crossattn_fwd(const float* x, const float* context, const float* g, const float* b, const float* wq, const float* bq,
+int lotus_crossattn_fwd(const lotus_act_t* x, const lotus_act_t* context, const float* g, const float* b, const float* wq, const float* bq,
                         const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
-                        const float* wp, const float* bp, float* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
+                        const float* wp, const float* bp, lotus_act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
                         int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                         int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
-int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, const float* context, const float* g, const float* wq,
+int lotus_crossattn_bwd(const lotus_act_t* dy, const lotus_act_t* dz_in, const lotus_act_t* x, const lotus_act_t* context, const float* g, const float* wq,
                         const float* wkv, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
-                        const float* saved, float* dx, float* dctx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed,
+                        const float* saved, lotus_act_t* dx, lotus_act_t* dctx, lotus_act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed,
                         float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
                         int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                         int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
@@ -274,70 +284,70 @@ size_t lotus_cpe_tmp_floats(int n, int C);
 size_t lotus_cpe_ws_main_bytes(int n, int C);
 size_t lotus_cpe_ws_conv_bytes(int n, int C);
 size_t lotus_cpe_ws_side_bytes(int n, int C);
-int lotus_cpe_fwd(const float* x, const float* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
-                  const float* lb, const float* g, const float* b, float* y, float* saved, const int* nbr27, const int* order0, int n,
+int lotus_cpe_fwd(const lotus_act_t* x, const lotus_act_t* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
+                  const float* lb, const float* g, const float* b, lotus_act_t* y, float* saved, const int* nbr27, const int* order0, int n,
                   int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream);
-int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
-                  const float* saved, float* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
+int lotus_cpe_bwd(const lotus_act_t* dy, const lotus_act_t* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
+                  const float* saved, lotus_act_t* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
                   const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
                   size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                   unsigned long long link, int join, void* stream, void* side);
 /* out[e] = sum_z part[z * stride + e] in fixed order (e.g. the key-side partial slots of the cross-attention backward) */
-int lotus_sum_slabs(const float* part, float* out, long n, long stride, int nz, void* stream);
+int lotus_sum_slabs(const lotus_act_t* part, lotus_act_t* out, long n, long stride, int nz, void* stream);
 
 /* ---- pooling, head, losses ---------------------------------------------------------------- */
 /* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */
-int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,
+int lotus_pool_max_fwd(const lotus_act_t* x, const int* members, const int* seg, int nc, int C, lotus_act_t* y, int* arg,
                        void* stream);
-int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int n, int C, float* dx, void* stream);
+int lotus_pool_max_bwd(const lotus_act_t* dy, const int* arg, const int* cluster, int n, int C, lotus_act_t* dx, void* stream);
 /* SerializedUnpooling: parent.feat + point.feat[inverse], model.py:824 */
-int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream);
-int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream);
+int lotus_unpool_fwd(const lotus_act_t* skip, const lotus_act_t* up, const int* cluster, int n, int C, lotus_act_t* x, void* stream);
+int lotus_unpool_bwd(const lotus_act_t* dx, const int* members, const int* seg, int nc, int C, lotus_act_t* dup, void* stream);
 /* ActionHead reduce == 'max': per-cloud torch.max(x, 0), simple_policy_ptv3.py:117-119 */
 size_t lotus_cloud_max_workspace(int B, int C);
-int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* workspace, size_t workspace_bytes,
+int lotus_cloud_max_fwd(const lotus_act_t* x, const int* off, int B, int C, lotus_act_t* y, int* arg, void* workspace, size_t workspace_bytes,
                         void* stream);
-int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
+int lotus_cloud_max_bwd(const lotus_act_t* dy, const int* arg, const int* batch, int n, int C, const lotus_act_t* add, lotus_act_t* dx,
                         void* stream);
 /* compute_loss (heatmap_disc / euler_disc), simple_policy_ptv3.py:322-373: losses[4] = pos, rot,
  * open, total.  xt [n][3*nb]; ae [B][nrot*3+1]; tgt = concatenated disc_pos_probs; gt [B][ga].
  * pos_stats: lotus_loss_stats_floats(B) floats (statistics [B*3][4] followed by slice partials). */
 size_t lotus_loss_stats_floats(int B);
-int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
+int lotus_loss_fwd(const lotus_act_t* xt, const lotus_act_t* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
                    int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
                    void* stream);
-int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+int lotus_loss_bwd(const lotus_act_t* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
                    const float* dae_saved, const float* gl, float pos_w, float rot_w, int B, int n, int nb, int nrot,
-                   float* dxt, float* dae_out, void* stream);
+                   lotus_act_t* dxt, lotus_act_t* dae_out, void* stream);
 /* heatmap cross entropy alone, for the trajectory head (one call per trajectory step; per-cloud step masks enter as
  * the upstream gradients g[B*3]), genrobo3d/models/motion_planner_ptv3.py:327-336.  pos_stats as for lotus_loss_fwd;
  * pos_stats[(b*3+c)*4] = CE of cloud b, axis c. */
-int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream);
-int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
-                     const float* g, int B, int n, int nb, float* dxt, void* stream);
+int lotus_pos_ce_fwd(const lotus_act_t* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream);
+int lotus_pos_ce_bwd(const lotus_act_t* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                     const float* g, int B, int n, int nb, lotus_act_t* dxt, void* stream);
 /* Trajectory losses of the motion planner on its [B, T]-sized tensors, genrobo3d/models/motion_planner_ptv3.py:327-397
  * (heatmap_disc / euler_disc), one launch.  Row r = b * T + t: ae [B*T][nrot*3 + 2] = rotation logits (bin, axis) at
  * bin*3 + axis | openness logit | stop logit; gt [B*T][ga] = gt_trajs (rotation bins at 3..5, openness at ga-1);
  * stop [B*T] = gt_trajs_stop; mask [B*T] = traj_masks; ce [B*T][3] = heatmap cross entropy per (cloud, step, axis)
  * (lotus_pos_ce_fwd).  losses[5] = pos, rot, open, stop, total (= pos_w pos + rot_w rot + open + stop).  dae / dce keep the
  * partial derivatives for lotus_mp_loss_bwd, which scales them by the upstream gradient g[5] (device). */
-int lotus_mp_loss_fwd(const float* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
+int lotus_mp_loss_fwd(const lotus_act_t* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
                       int nrot, int ga, float pos_w, float rot_w, float* losses, float* dae, float* dce, void* stream);
 int lotus_mp_loss_bwd(const float* dae, const float* dce, const float* g, float pos_w, float rot_w, int B, int T, int nrot,
-                      float* dae_out, float* dce_out, void* stream);
+                      lotus_act_t* dae_out, float* dce_out, void* stream);
 /* Trajectory head of the motion planner, genrobo3d/models/motion_planner_ptv3.py:88-97,113-114: hidden layer of step t =
  * dropout(act(base + bias_t)) with base [M][C] shared by the steps and bias_t [C] = step-embedding part of the first
  * Linear.  bwd: dpre = dh * act'(base + bias_t) * mask; dbase (+)= dpre (accumulate over the steps), dbias_t = colsum. */
-int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, int C, int act, float drop_p,
+int lotus_step_act_fwd(const lotus_act_t* base, const float* bias, lotus_act_t* out, int M, int C, int act, float drop_p,
                        unsigned long long drop_seed, void* stream);
 size_t lotus_step_act_bwd_workspace(int M, int C);
-int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, float* dbase, float* dbias, int M, int C, int act,
+int lotus_step_act_bwd(const lotus_act_t* dh, const lotus_act_t* base, const float* bias, lotus_act_t* dbase, float* dbias, int M, int C, int act,
                        float drop_p, unsigned long long drop_seed, int accumulate, void* workspace, size_t workspace_bytes,
                        void* stream);
 /* elementwise plumbing */
-int lotus_add(const float* a, const float* b, float* y, long n, void* stream);
+int lotus_add(const lotus_act_t* a, const lotus_act_t* b, lotus_act_t* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */
-int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream);
+int lotus_dropout(const lotus_act_t* x, lotus_act_t* y, long n, float p, unsigned long long seed, void* stream);
 
 /* ---- soft position targets / arg-max position decode: get_disc_gt_pos_prob and
  * get_best_pos_from_disc_pos(best='max'), genrobo3d/utils/action_position_utils.py:7-46, :48-64.  pc = point rows whose
@@ -346,7 +356,7 @@ size_t lotus_pos_workspace(int B);
 int lotus_pos_targets(const float* pc, long ld, const int* off, const int* batch, const float* gt, int ga,
                       const unsigned char* robot, int B, int n, int nb, double bin_size, int kind, float* tgt, void* workspace,
                       size_t workspace_bytes, void* stream);
-int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
+int lotus_pos_decode_max(const lotus_act_t* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
                          double* best_pos, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- optimiser step: genrobo3d/train/optim/adamw.py:53-112 (HF AdamW: eps outside the bias

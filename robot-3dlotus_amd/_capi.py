@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liblotus_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lotus_hip.h")
+TWIN_HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lotus_hip_b16.h")  # bf16-storage twins (generated)
 
 _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
@@ -20,9 +21,12 @@ _CTYPES = {
 }
 
 
-def parse_header(path=HEADER_PATH):
-    """-> {name: (restype, [argtypes], [argnames])} for every `lotus_*` prototype."""
-    src = open(path).read()
+def parse_header(path=None):
+    """-> {name: (restype, [argtypes], [argnames])} for every `lotus_*` prototype (both headers when path is None)."""
+    if path is None:
+        src = open(HEADER_PATH).read() + (open(TWIN_HEADER_PATH).read() if os.path.exists(TWIN_HEADER_PATH) else "")
+    else:
+        src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"([A-Za-z_][\w \*]*?)\s*\b(lotus_\w+)\s*\(([^;{]*?)\)\s*;", src):
@@ -136,9 +140,24 @@ def fastcall():
 # weight-gradient stream).  Cheaper than switching torch's current stream, which nothing inside those blocks needs.
 STREAM_OVERRIDE = 0
 
+# Activation storage of the calls being issued: False = fp32 entry points (lotus_*), True = their bf16-storage twins
+# (lotus_b16_*, include/lotus_hip_b16.h).  Set per forward pass / per autograd node by ops (like the operand precision).
+BF16 = False
+_TWIN = {}
+
+
+def _twin(name):
+    t = _TWIN.get(name)
+    if t is None:
+        cand = "lotus_b16_" + name[6:]
+        t = _TWIN[name] = cand if cand in lib().protos else name  # entry points without activations have no twin
+    return t
+
 
 def call(name, *args):
     """Call an int-returning entry point; tensors -> device pointers; appends the current stream."""
+    if BF16:
+        name = _TWIN.get(name) or _twin(name)
     F = _FAST if _FAST_TRIED else fastcall()
     if F is not None:
         rc = getattr(F, name)(*args, STREAM_OVERRIDE or _raw_stream(_get_dev()))
@@ -153,6 +172,8 @@ def call(name, *args):
 
 def call_raw(name, *args):
     """Entry points without a trailing stream parameter (stream link)."""
+    if BF16:
+        name = _TWIN.get(name) or _twin(name)
     F = _FAST if _FAST_TRIED else fastcall()
     if F is not None:
         rc = getattr(F, name)(*args)
@@ -164,6 +185,8 @@ def call_raw(name, *args):
 
 def query(name, *args):
     """Call a size_t-returning *_workspace() function."""
+    if BF16:
+        name = _TWIN.get(name) or _twin(name)
     F = _FAST if _FAST_TRIED else fastcall()
     if F is not None:
         return getattr(F, name)(*args)

@@ -14,29 +14,31 @@
 #include "common.h"
 #include <stdlib.h>
 
+namespace LOTUS_NS {
+
 #define AT 128        // tile rows (queries) and max keys
 #define ALD 33        // row stride of the [128][d<=32] images
 #define SLD 129       // row stride of the score image
 
 struct AttnP {
-  const float* q; long q_ld; int q_off;
-  const float* kv; long kv_ld; int k_off, v_off;
+  const act_t* q; long q_ld; int q_off;
+  const act_t* kv; long kv_ld; int k_off, v_off;
   const int* qidx;    // row gather for the q side (null = identity)
   const int* kidx;    // row gather for the k/v side (null = identity)
   const int* owner;   // per q position: write/use this row (null = all)
   const int* tiles;   // [ntiles][4] = q_start, q_len, k_start, k_len
   const int* blocks;  // bwd: [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len
   const float* qn_w; const float* qn_b; const float* kn_w; const float* kn_b;
-  float* out; long out_ld;   // fwd output rows (indexed like q rows)
+  act_t* out; long out_ld;   // fwd output rows (indexed like q rows)
   float* lse;                // [npos][H]
   // backward
-  const float* dout;         // gradient of out (same indexing as out)
-  float* dq; long dq_ld; int dq_off;
-  float* dkv; long dkv_ld; int dk_off, dv_off; long dkv_part_stride;
+  const act_t* dout;         // gradient of out (same indexing as out)
+  act_t* dq; long dq_ld; int dq_off;
+  act_t* dkv; long dkv_ld; int dk_off, dv_off; long dkv_part_stride;
   float* ln_part;            // [nblocks * H][4][32]  dgamma_q, dbeta_q, dgamma_k, dbeta_k
   int atomic_out;            // 1: atomicAdd into dq/dkv (kept for generality; unused by the model)
   const int* kext;           // per k position: -1 = owner row, else row of dkv_extra (borrowed copy of a tail patch)
-  float* dkv_extra;          // [n_extra][dkv_extra_ld] k | v gradients of the borrowed copies
+  act_t* dkv_extra;          // [n_extra][dkv_extra_ld] k | v gradients of the borrowed copies
   long dkv_extra_ld;
   int H, d;
   float scale, eps;
@@ -66,7 +68,7 @@ __device__ __forceinline__ f32x16 zero16() {
 
 // Load `len` rows (gathered through idx) of d floats at column offset coff into img[128][ALD];
 // rows >= len and columns >= d are zero.  8 threads per row, float4 each.
-__device__ __forceinline__ void load_rows(float* img, const float* base, long ld, int coff, const int* rows_s,
+__device__ __forceinline__ void load_rows(float* img, const act_t* base, long ld, int coff, const int* rows_s,
                                           int len, int d) {
   const int sub = threadIdx.x & 7;
   for (int r = threadIdx.x >> 3; r < AT; r += 32) {
@@ -82,7 +84,7 @@ __device__ __forceinline__ void load_rows(float* img, const float* base, long ld
 // forward block's 23 us); here they are 4 N independent loads in flight.
 struct RowSrc {
   float* img;
-  const float* base;
+  const act_t* base;
   long ld;
   int coff;
   const int* rows_s;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
       }
     }
   if (qi < q_len && s.qown[qi]) {
-    float* orow = p.out + (long)s.qrow[qi] * p.out_ld + h * d;
+    act_t* orow = p.out + (long)s.qrow[qi] * p.out_ld + h * d;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int dc = 8 * q4 + 4 * hh;
@@ -366,22 +368,24 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
 }
 
 // ------------------------------------------------------------------------------------ backward
-__device__ __forceinline__ void store_rows(const float* img, float* base, long ld, int coff, const int* rows_s,
+__device__ __forceinline__ void store_rows(const float* img, act_t* base, long ld, int coff, const int* rows_s,
                                            const int* own_s, int len, int d, int atomic, const int* ext_s = nullptr,
-                                           float* ext_base = nullptr, long ext_ld = 0, int ext_coff = 0) {
+                                           act_t* ext_base = nullptr, long ext_ld = 0, int ext_coff = 0) {
   const int sub = threadIdx.x & 7;
   for (int r = threadIdx.x >> 3; r < len; r += 32) {
     if (own_s && !own_s[r]) continue;
     if (sub * 4 >= d) continue;
     const float* v = img + r * ALD + sub * 4;
-    float* o = base + (long)rows_s[r] * ld + coff + sub * 4;
+    act_t* o = base + (long)rows_s[r] * ld + coff + sub * 4;
     if (ext_s && ext_s[r] >= 0) o = ext_base + (long)ext_s[r] * ext_ld + ext_coff + sub * 4;  // borrowed copy
+#if !LOTUS_ACT_IS_BF16  // (generality only: the model never asks for atomic accumulation)
     if (atomic) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) atomicAdd(o + e, v[e]);
-    } else {
-      st4(o, make_float4(v[0], v[1], v[2], v[3]));
+      continue;
     }
+#endif
+    st4(o, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   }
   if (tid < AT) ln_rows_bwd(s.dO, s.K, s.krstd, tid, k_len, d, s.gk);
   __syncthreads();
-  float* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
   store_rows(s.dO, dkv, p.dkv_ld, p.dk_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
              p.dkv_extra, p.dkv_extra_ld, h * d);
   store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
@@ -833,18 +837,18 @@ static void set_attn_drop(AttnP& p, float drop_p, unsigned long long seed) {
 }
 
 // dqkv[point][k|v columns] += extra[e]  for every borrowed copy e (each point is borrowed at most once)
-__global__ void attn_extra_fixup_kernel(const float* __restrict__ extra, long extra_ld, const int* __restrict__ ext_pos,
-                                        const int* __restrict__ kidx, int n_extra, int w4, float* __restrict__ dkv,
+__global__ void attn_extra_fixup_kernel(const act_t* __restrict__ extra, long extra_ld, const int* __restrict__ ext_pos,
+                                        const int* __restrict__ kidx, int n_extra, int w4, act_t* __restrict__ dkv,
                                         long dkv_ld, int dk_off) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n_extra * w4) return;
   const int e = (int)(gid / w4), c = (int)(gid % w4) * 4;
   const int point = kidx[ext_pos[e]];
   const float4 a = ld4(extra + (long)e * extra_ld + c);
-  float4* o = reinterpret_cast<float4*>(dkv + (long)point * dkv_ld + dk_off + c);
-  float4 v = *o;
+  act_t* o = dkv + (long)point * dkv_ld + dk_off + c;
+  float4 v = ld4(o);
   v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-  *o = v;
+  st4(o, v);
 }
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
@@ -853,9 +857,9 @@ extern "C" {
 
 // Forward.  tiles: int32 [ntiles][4] (device).  Rows: q row r lives at q + r*q_ld + q_off + h*d;
 // k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d; out rows are indexed like q rows.
-int lotus_attention_fwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+int lotus_attention_fwd(const act_t* q, long q_ld, int q_off, const act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
-                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, float* out,
+                        const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, act_t* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
                         unsigned long long drop_seed, int precision, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && out && check_geom(H, d) == 0, "lotus_attention_fwd: bad arguments (H=%d d=%d)", H, d);
@@ -888,12 +892,12 @@ size_t lotus_attention_bwd_workspace(int nblocks, int H) { return (size_t)nblock
 // Backward.  blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.
 // dq/dkv must be zero-initialised by the caller when atomic_out = 1.  With atomic_out = 0 every
 // (part_slot, key row, head) is written exactly once (plain stores, deterministic).
-int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, long kv_ld, int k_off, int v_off,
+int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, const int* blocks,
                         int nblocks, const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b,
-                        const float* out, const float* dout, long out_ld, const float* lse, float* dq, long dq_ld,
-                        int dq_off, float* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
-                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, float* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
+                        const act_t* out, const act_t* dout, long out_ld, const float* lse, act_t* dq, long dq_ld,
+                        int dq_off, act_t* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
+                        int atomic_out, const int* kext, const int* ext_pos, int n_extra, act_t* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
                         int precision, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
@@ -906,7 +910,7 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
   p.q = q; p.q_ld = q_ld; p.q_off = q_off; p.kv = kv; p.kv_ld = kv_ld; p.k_off = k_off; p.v_off = v_off;
   p.qidx = qidx; p.kidx = kidx; p.owner = owner; p.tiles = tiles; p.blocks = blocks;
   p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
-  p.out = (float*)out; p.dout = dout; p.out_ld = out_ld; p.lse = (float*)lse;
+  p.out = (act_t*)out; p.dout = dout; p.out_ld = out_ld; p.lse = (float*)lse;
   p.dq = dq; p.dq_ld = dq_ld; p.dq_off = dq_off;
   p.dkv = dkv; p.dkv_ld = dkv_ld; p.dk_off = dk_off; p.dv_off = dv_off; p.dkv_part_stride = dkv_part_stride;
   p.atomic_out = atomic_out; p.ln_part = (float*)workspace;
@@ -942,3 +946,5 @@ int lotus_attention_bwd(const float* q, long q_ld, int q_off, const float* kv, l
 }
 
 }  // extern "C"
+
+}  // namespace LOTUS_NS

@@ -27,6 +27,19 @@ void lotus_set_error(const char* fmt, ...);
 
 static inline size_t al4(size_t n) { return (n + 3) & ~(size_t)3; }  // keep every slice 16-byte aligned
 
+// Activation element type of this build (include/lotus_hip.h: float, or 16-bit bf16 storage in the lotus_b16_* twin).  The
+// flat `saved` / `tmp` buffers are carved in bytes: activation slices take n * sizeof(act_t), statistics n * 4, each rounded
+// up to 16 bytes; their sizes are still reported in floats (the host allocates fp32 words).  In the fp32 build the
+// layout is what it always was.
+typedef lotus_act_t act_t;
+static inline size_t actf(size_t n) { return al4((n * sizeof(act_t) + 3) / 4); }  // floats holding n activations
+struct Carve {
+  char* p;
+  explicit Carve(const void* base) : p((char*)base) {}
+  act_t* act(size_t n) { act_t* r = (act_t*)p; p += actf(n) * 4; return r; }
+  float* f32(size_t n) { float* r = (float*)p; p += al4(n) * 4; return r; }
+};
+
 static inline int fork_side(unsigned long long link, void* main_s, void* side) {
   return side ? lotus_streamlink_wait(link, main_s, side) : 0;
 }
@@ -66,10 +79,10 @@ extern "C" {
 //   saved  [n M*C | hpre M*Hd | a M*Hd | mean M | rstd M]
 //   grads  [dg C | db C | dw1 Hd*C | db1 Hd | dw2 C*Hd | db2 C]          (dw | db contiguous per layer)
 //   tmp    [dz2 M*C | dh M*Hd | dn M*C | ln partials]
-size_t lotus_ffn_saved_floats(int M, int C, int Hd) { return al4((size_t)M * C) + 2 * al4((size_t)M * Hd) + 2 * al4((size_t)M); }
+size_t lotus_ffn_saved_floats(int M, int C, int Hd) { return actf((size_t)M * C) + 2 * actf((size_t)M * Hd) + 2 * al4((size_t)M); }
 size_t lotus_ffn_grads_floats(int C, int Hd) { return 2 * al4(C) + al4((size_t)Hd * C + Hd) + al4((size_t)C * Hd + C); }
 size_t lotus_ffn_tmp_floats(int M, int C, int Hd) {
-  return 2 * al4((size_t)M * C) + al4((size_t)M * Hd) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+  return 2 * actf((size_t)M * C) + actf((size_t)M * Hd) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
 }
 size_t lotus_ffn_ws_main_bytes(int M, int C, int Hd) {
   const size_t a = lotus_linear_workspace(M, Hd, C), b = lotus_linear_workspace(M, C, Hd);
@@ -80,14 +93,15 @@ size_t lotus_ffn_ws_side_bytes(int M, int C, int Hd) {
   return a > b ? a : b;
 }
 
-int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
-                  const float* b2, float* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
+int lotus_ffn_fwd(const act_t* x, const float* g, const float* b, const float* w1, const float* b1, const float* w2,
+                  const float* b2, act_t* y, float* saved, int M, int C, int Hd, float drop_p, unsigned long long seed1,
                   unsigned long long seed2, int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
-  float* n = saved;
-  float* hpre = n + al4((size_t)M * C);
-  float* a = hpre + al4((size_t)M * Hd);
-  float* mean = a + al4((size_t)M * Hd);
-  float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  act_t* n = sv.act((size_t)M * C);
+  act_t* hpre = sv.act((size_t)M * Hd);
+  act_t* a = sv.act((size_t)M * Hd);
+  float* mean = sv.f32(M);
+  float* rstd = sv.f32(M);
   const bool big = M > 8192;  // (the per-launch path only offers a split-K workspace to the small-M layers)
   CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
   CHECK(lotus_linear_fwd(n, w1, b1, nullptr, a, hpre, M, Hd, C, LOTUS_ACT_GELU, drop_p, seed1, precision, big ? nullptr : ws,
@@ -98,26 +112,28 @@ int lotus_ffn_fwd(const float* x, const float* g, const float* b, const float* w
 
 // dz_in (optional): dy already multiplied by the fc2 dropout mask (handed over by the next sub-block's backward).
 // dz_out (optional, with dz_out_p > 0): dx times the dropout mask (dz_out_p, dz_out_seed) of the PREVIOUS sub-block.
-int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* w1, const float* w2,
-                  const float* saved, float* dx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
+int lotus_ffn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, const float* g, const float* w1, const float* w2,
+                  const float* saved, act_t* dx, act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed, float* grads,
                   float* tmp, int M, int C, int Hd, float drop_p, unsigned long long seed1, unsigned long long seed2,
                   int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
                   void* counters_side, unsigned long long link, int join, void* stream, void* side) {
-  const float* n = saved;
-  const float* hpre = n + al4((size_t)M * C);
-  const float* a = hpre + al4((size_t)M * Hd);
-  const float* mean = a + al4((size_t)M * Hd);
-  const float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  const act_t* n = sv.act((size_t)M * C);
+  const act_t* hpre = sv.act((size_t)M * Hd);
+  const act_t* a = sv.act((size_t)M * Hd);
+  const float* mean = sv.f32(M);
+  const float* rstd = sv.f32(M);
   float* dg = grads;
   float* db = dg + al4(C);
   float* dw1 = db + al4(C);
   float* db1 = dw1 + (size_t)Hd * C;
   float* dw2 = dw1 + al4((size_t)Hd * C + Hd);
   float* db2 = dw2 + (size_t)C * Hd;
-  float* dz2 = tmp;
-  float* dh = dz2 + al4((size_t)M * C);
-  float* dn = dh + al4((size_t)M * Hd);
-  float* lnp = dn + al4((size_t)M * C);
+  Carve tp(tmp);
+  act_t* dz2 = tp.act((size_t)M * C);
+  act_t* dh = tp.act((size_t)M * Hd);
+  act_t* dn = tp.act((size_t)M * C);
+  float* lnp = tp.f32(0);
   const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
   void* sw = side ? side : stream;                                   // stream of the weight gradients
   void* wws = side ? ws_side : ws_main;                              // ... and their workspace / counters
@@ -126,7 +142,7 @@ int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const flo
   const bool big = M > 8192;
   // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
   // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
-  const float* dz = dz_in;
+  const act_t* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
       PRODUCE_THEN_FORK(lotus_dropout(dy, dz2, (long)M * C, drop_p, seed2, stream));
@@ -160,13 +176,13 @@ int lotus_ffn_bwd(const float* dy, const float* dz_in, const float* x, const flo
 //   grads [dg C | db C | dwqkv 3C*C + dbqkv 3C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
 //   tmp   [dz M*C | datt M*C | dqkv M*3C | extra max(n_extra,1)*2C | dn M*C | ln partials]
 size_t lotus_selfattn_saved_floats(int M, int C, int H, int npad) {
-  return 2 * al4((size_t)M * C) + al4((size_t)M * 3 * C) + al4((size_t)npad * H) + 2 * al4((size_t)M);
+  return 2 * actf((size_t)M * C) + actf((size_t)M * 3 * C) + al4((size_t)npad * H) + 2 * al4((size_t)M);
 }
 size_t lotus_selfattn_grads_floats(int C, int H) {
   return 2 * al4(C) + al4((size_t)3 * C * C + 3 * C) + 4 * al4(C / H) + al4((size_t)C * C + C);
 }
 size_t lotus_selfattn_tmp_floats(int M, int C, int n_extra) {
-  return 3 * al4((size_t)M * C) + al4((size_t)M * 3 * C) + al4((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C) +
+  return 3 * actf((size_t)M * C) + actf((size_t)M * 3 * C) + actf((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C) +
          lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
 }
 size_t lotus_selfattn_ws_main_bytes(int M, int C, int H, int nblocks) {
@@ -179,18 +195,19 @@ size_t lotus_selfattn_ws_side_bytes(int M, int C) {
   return a > b ? a : b;
 }
 
-int lotus_selfattn_fwd(const float* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
-                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, float* y,
+int lotus_selfattn_fwd(const act_t* x, const float* g, const float* b, const float* wqkv, const float* bqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp, act_t* y,
                        float* saved, const int* gidx, const int* owner, const int* tiles, int ntiles, int npad, int M, int C,
                        int H, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
   const int d = C / H;
-  float* n = saved;
-  float* qkv = n + al4((size_t)M * C);
-  float* att = qkv + al4((size_t)M * 3 * C);
-  float* lse = att + al4((size_t)M * C);
-  float* mean = lse + al4((size_t)npad * H);
-  float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  act_t* n = sv.act((size_t)M * C);
+  act_t* qkv = sv.act((size_t)M * 3 * C);
+  act_t* att = sv.act((size_t)M * C);
+  float* lse = sv.f32((size_t)npad * H);
+  float* mean = sv.f32(M);
+  float* rstd = sv.f32(M);
   const bool big = M > 8192;
   CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
   CHECK(lotus_linear_fwd(n, wqkv, bqkv, nullptr, qkv, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws,
@@ -201,20 +218,21 @@ int lotus_selfattn_fwd(const float* x, const float* g, const float* b, const flo
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
 
-int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, const float* g, const float* wqkv, const float* qnw,
-                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, float* dx,
+int lotus_selfattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, const float* g, const float* wqkv, const float* qnw,
+                       const float* qnb, const float* knw, const float* knb, const float* wp, const float* saved, act_t* dx,
                        float* grads, float* tmp, const int* gidx, const int* owner, const int* tiles, const int* blocks, int nblocks,
                        const int* kext, const int* ext_pos, int n_extra, int npad, int M, int C, int H, float scale, float drop_p,
                        unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, void* ws_main,
                        size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                        unsigned long long link, int join, void* stream, void* side) {
   const int d = C / H;
-  const float* n = saved;
-  const float* qkv = n + al4((size_t)M * C);
-  const float* att = qkv + al4((size_t)M * 3 * C);
-  const float* lse = att + al4((size_t)M * C);
-  const float* mean = lse + al4((size_t)npad * H);
-  const float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  const act_t* n = sv.act((size_t)M * C);
+  const act_t* qkv = sv.act((size_t)M * 3 * C);
+  const act_t* att = sv.act((size_t)M * C);
+  const float* lse = sv.f32((size_t)npad * H);
+  const float* mean = sv.f32(M);
+  const float* rstd = sv.f32(M);
   float* dg = grads;
   float* db = dg + al4(C);
   float* dwqkv = db + al4(C);
@@ -225,12 +243,13 @@ int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, cons
   float* bk = gk + al4(d);
   float* dwp = bk + al4(d);
   float* dbp = dwp + (size_t)C * C;
-  float* dzb = tmp;
-  float* datt = dzb + al4((size_t)M * C);
-  float* dqkv = datt + al4((size_t)M * C);
-  float* extra = dqkv + al4((size_t)M * 3 * C);
-  float* dn = extra + al4((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C);
-  float* lnp = dn + al4((size_t)M * C);
+  Carve tp(tmp);
+  act_t* dzb = tp.act((size_t)M * C);
+  act_t* datt = tp.act((size_t)M * C);
+  act_t* dqkv = tp.act((size_t)M * 3 * C);
+  act_t* extra = tp.act((size_t)(n_extra > 1 ? n_extra : 1) * 2 * C);
+  act_t* dn = tp.act((size_t)M * C);
+  float* lnp = tp.f32(0);
   const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
   void* sw = side ? side : stream;
   void* wws = side ? ws_side : ws_main;
@@ -239,7 +258,7 @@ int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, cons
   const bool big = M > 8192;
   // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
   // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
-  const float* dz = dz_in;
+  const act_t* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
       PRODUCE_THEN_FORK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
@@ -274,13 +293,13 @@ int lotus_selfattn_bwd(const float* dy, const float* dz_in, const float* x, cons
 //   grads [dg C | db C | dwq C*C + dbq C | dwkv 2C*Cc + dbkv 2C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
 //   tmp   [dz M*C | datt M*C | dq M*C | dkv_part G*L*2C | dkv L*2C | dn M*C | ln partials]
 size_t lotus_crossattn_saved_floats(int M, int C, int H, int L) {
-  return 3 * al4((size_t)M * C) + al4((size_t)L * 2 * C) + al4((size_t)M * H) + 2 * al4((size_t)M);
+  return 3 * actf((size_t)M * C) + actf((size_t)L * 2 * C) + al4((size_t)M * H) + 2 * al4((size_t)M);
 }
 size_t lotus_crossattn_grads_floats(int C, int H, int Cc) {
   return 2 * al4(C) + 2 * al4((size_t)C * C + C) + al4((size_t)2 * C * Cc + 2 * C) + 4 * al4(C / H);
 }
 size_t lotus_crossattn_tmp_floats(int M, int C, int L, int G) {
-  return 4 * al4((size_t)M * C) + al4((size_t)G * L * 2 * C) + al4((size_t)L * 2 * C) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+  return 4 * actf((size_t)M * C) + actf((size_t)G * L * 2 * C) + actf((size_t)L * 2 * C) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
 }
 size_t lotus_crossattn_ws_main_bytes(int M, int C, int H, int L, int Cc, int nblocks) {
   size_t a = lotus_linear_workspace(M, C, C), b = lotus_linear_workspace(L, 2 * C, Cc), c = lotus_attention_bwd_workspace(nblocks, H);
@@ -292,19 +311,20 @@ size_t lotus_crossattn_ws_side_bytes(int M, int C, int L, int Cc) {
   return a > b ? a : b;
 }
 
-int lotus_crossattn_fwd(const float* x, const float* context, const float* g, const float* b, const float* wq, const float* bq,
+int lotus_crossattn_fwd(const act_t* x, const act_t* context, const float* g, const float* b, const float* wq, const float* bq,
                         const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
-                        const float* wp, const float* bp, float* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
+                        const float* wp, const float* bp, act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
                         int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                         int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
   const int d = C / H;
-  float* n = saved;
-  float* q = n + al4((size_t)M * C);
-  float* kv = q + al4((size_t)M * C);
-  float* att = kv + al4((size_t)L * 2 * C);
-  float* lse = att + al4((size_t)M * C);
-  float* mean = lse + al4((size_t)M * H);
-  float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  act_t* n = sv.act((size_t)M * C);
+  act_t* q = sv.act((size_t)M * C);
+  act_t* kv = sv.act((size_t)L * 2 * C);
+  act_t* att = sv.act((size_t)M * C);
+  float* lse = sv.f32((size_t)M * H);
+  float* mean = sv.f32(M);
+  float* rstd = sv.f32(M);
   const bool big = M > 8192, bigL = L > 8192;
   CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
   CHECK(lotus_linear_fwd(n, wq, bq, nullptr, q, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
@@ -318,21 +338,22 @@ int lotus_crossattn_fwd(const float* x, const float* context, const float* g, co
 }
 
 // dctx (optional): gradient of the context [L][Cc].  G = key-side partial slots of the attention backward.
-int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, const float* context, const float* g, const float* wq,
+int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, const act_t* context, const float* g, const float* wq,
                         const float* wkv, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
-                        const float* saved, float* dx, float* dctx, float* dz_out, float dz_out_p, unsigned long long dz_out_seed,
+                        const float* saved, act_t* dx, act_t* dctx, act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed,
                         float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
                         int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
                         int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
                         void* counters_side, unsigned long long link, int join, void* stream, void* side) {
   const int d = C / H;
-  const float* n = saved;
-  const float* q = n + al4((size_t)M * C);
-  const float* kv = q + al4((size_t)M * C);
-  const float* att = kv + al4((size_t)L * 2 * C);
-  const float* lse = att + al4((size_t)M * C);
-  const float* mean = lse + al4((size_t)M * H);
-  const float* rstd = mean + al4((size_t)M);
+  Carve sv(saved);
+  const act_t* n = sv.act((size_t)M * C);
+  const act_t* q = sv.act((size_t)M * C);
+  const act_t* kv = sv.act((size_t)L * 2 * C);
+  const act_t* att = sv.act((size_t)M * C);
+  const float* lse = sv.f32((size_t)M * H);
+  const float* mean = sv.f32(M);
+  const float* rstd = sv.f32(M);
   float* dg = grads;
   float* db = dg + al4(C);
   float* dwq = db + al4(C);
@@ -345,13 +366,14 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
   float* bk_ = gk + al4(d);
   float* dwp = bk_ + al4(d);
   float* dbp = dwp + (size_t)C * C;
-  float* dzb = tmp;
-  float* datt = dzb + al4((size_t)M * C);
-  float* dq = datt + al4((size_t)M * C);
-  float* dkv_part = dq + al4((size_t)M * C);
-  float* dkv = dkv_part + al4((size_t)G * L * 2 * C);
-  float* dn = dkv + al4((size_t)L * 2 * C);
-  float* lnp = dn + al4((size_t)M * C);
+  Carve tp(tmp);
+  act_t* dzb = tp.act((size_t)M * C);
+  act_t* datt = tp.act((size_t)M * C);
+  act_t* dq = tp.act((size_t)M * C);
+  act_t* dkv_part = tp.act((size_t)G * L * 2 * C);
+  act_t* dkv = tp.act((size_t)L * 2 * C);
+  act_t* dn = tp.act((size_t)M * C);
+  float* lnp = tp.f32(0);
   const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
   void* sw = side ? side : stream;
   void* wws = side ? ws_side : ws_main;
@@ -360,7 +382,7 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
   const bool big = M > 8192, bigL = L > 8192;
   // dz_in was written by the LayerNorm backward of the sub-block that ran just before this one, and the weight-gradient
   // stream is already ordered after that launch (its parameter-gradient reduction waited for it): no fork needed
-  const float* dz = dz_in;
+  const act_t* dz = dz_in;
   if (!dz) {
     if (drop_p > 0.f) {
       PRODUCE_THEN_FORK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
@@ -373,7 +395,7 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
   CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  const float* dkv_f = dkv_part;
+  const act_t* dkv_f = dkv_part;
   {
     ForkAfter fa(link, side);  // dq and d kv: the last launch in here carries the fork event
     if (G > 1) lotus_tls_stop_event = nullptr;
@@ -412,9 +434,9 @@ int lotus_crossattn_bwd(const float* dy, const float* dz_in, const float* x, con
 //   saved [c n*C | l n*C | mean n | rstd n]
 //   grads [dg C | db C | dlw C*C + dlb C | dcw C*27*C + dcb C]
 //   tmp   [dl n*C | dc n*C | dyr n*C | ln partials]
-size_t lotus_cpe_saved_floats(int n, int C) { return 2 * al4((size_t)n * C) + 2 * al4((size_t)n); }
+size_t lotus_cpe_saved_floats(int n, int C) { return 2 * actf((size_t)n * C) + 2 * al4((size_t)n); }
 size_t lotus_cpe_grads_floats(int C) { return 2 * al4(C) + al4((size_t)C * C + C) + al4((size_t)C * 27 * C + C); }
-size_t lotus_cpe_tmp_floats(int n, int C) { return 3 * al4((size_t)n * C) + lotus_layernorm_bwd_workspace(n, C) / sizeof(float); }
+size_t lotus_cpe_tmp_floats(int n, int C) { return 3 * actf((size_t)n * C) + lotus_layernorm_bwd_workspace(n, C) / sizeof(float); }
 size_t lotus_cpe_ws_main_bytes(int n, int C) { return lotus_linear_workspace(n, C, C); }
 size_t lotus_cpe_ws_conv_bytes(int n, int C) { return lotus_subm_conv_workspace(n, C, C); }
 size_t lotus_cpe_ws_side_bytes(int n, int C) {
@@ -422,13 +444,14 @@ size_t lotus_cpe_ws_side_bytes(int n, int C) {
   return a > b ? a : b;
 }
 
-int lotus_cpe_fwd(const float* x, const float* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
-                  const float* lb, const float* g, const float* b, float* y, float* saved, const int* nbr27, const int* order0, int n,
+int lotus_cpe_fwd(const act_t* x, const act_t* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
+                  const float* lb, const float* g, const float* b, act_t* y, float* saved, const int* nbr27, const int* order0, int n,
                   int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream) {
-  float* c = saved;
-  float* l = c + al4((size_t)n * C);
-  float* mean = l + al4((size_t)n * C);
-  float* rstd = mean + al4((size_t)n);
+  Carve sv(saved);
+  act_t* c = sv.act((size_t)n * C);
+  act_t* l = sv.act((size_t)n * C);
+  float* mean = sv.f32(n);
+  float* rstd = sv.f32(n);
   const bool big = n > 8192;
   CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, precision, ws_conv, ws_conv_bytes, stream));
   CHECK(lotus_linear_fwd(c, lw, lb, nullptr, l, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
@@ -438,25 +461,27 @@ int lotus_cpe_fwd(const float* x, const float* xs, const float* cw, const float*
 
 // dx_conv = input gradient of the convolution (+ dy when add_dy: the encoder case, where it IS d x).  n_dup != 0: the
 // level holds several points per voxel (code0 / order0 of the level drive the fold, nbr27[13] the mask).
-int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
-                  const float* saved, float* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
+int lotus_cpe_bwd(const act_t* dy, const act_t* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
+                  const float* saved, act_t* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
                   const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
                   size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                   unsigned long long link, int join, void* stream, void* side) {
-  const float* c = saved;
-  const float* l = c + al4((size_t)n * C);
-  const float* mean = l + al4((size_t)n * C);
-  const float* rstd = mean + al4((size_t)n);
+  Carve sv(saved);
+  const act_t* c = sv.act((size_t)n * C);
+  const act_t* l = sv.act((size_t)n * C);
+  const float* mean = sv.f32(n);
+  const float* rstd = sv.f32(n);
   float* dg = grads;
   float* db = dg + al4(C);
   float* dlw = db + al4(C);
   float* dlb = dlw + (size_t)C * C;
   float* dcw = dlw + al4((size_t)C * C + C);
   float* dcb = dcw + (size_t)C * 27 * C;
-  float* dl = tmp;
-  float* dc = dl + al4((size_t)n * C);
-  float* dyr = dc + al4((size_t)n * C);
-  float* lnp = dyr + al4((size_t)n * C);
+  Carve tp(tmp);
+  act_t* dl = tp.act((size_t)n * C);
+  act_t* dc = tp.act((size_t)n * C);
+  act_t* dyr = tp.act((size_t)n * C);
+  float* lnp = tp.f32(0);
   const size_t lnp_bytes = lotus_layernorm_bwd_workspace(n, C);
   void* sw = side ? side : stream;
   void* wws = side ? ws_side : ws_main;
@@ -473,7 +498,7 @@ int lotus_cpe_bwd(const float* dy, const float* xs, const float* cw, const float
   PRODUCE_THEN_FORK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                                        big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, wws, wws_bytes, sw));
-  const float* dsrc = dc;
+  const act_t* dsrc = dc;
   if (n_dup != 0) {
     CHECK(lotus_conv_dup_fold(dc, code0, order0, n, C, dyr, stream));
     dsrc = dyr;

@@ -16,6 +16,11 @@ SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "conv.hip", "conv_pairs.h
 HEADERS = ["common.h", "mma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 LIB = os.path.join(HERE, "liblotus_hip.so")
+# The translation units that touch activation tensors are compiled twice: act_t = float (lotus_*) and, with
+# -DLOTUS_ACT_BF16 and the generated rename header, act_t = bf16 (lotus_b16_*, include/lotus_hip_b16.h) — gen_twin.py.
+ACT_SOURCES = ["blocks.cpp", "gemm.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "pool_head.hip"]
+RENAME = os.path.join(HERE, "lotus_rename_b16.h")
+PUBLIC = [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "lotus_hip.h")]
 
 
 def _stale(obj, deps):
@@ -25,12 +30,14 @@ def _stale(obj, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src):
-    obj = os.path.join(HERE, os.path.splitext(src)[0] + ".o")
-    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS]
+def _compile(job):
+    src, b16 = job
+    obj = os.path.join(HERE, os.path.splitext(src)[0] + ("_b16.o" if b16 else ".o"))
+    deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + PUBLIC + ([RENAME] if b16 else [])
     if not _stale(obj, deps):
         return obj, ""
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(HERE, src), "-o", obj]
+    extra = ["-DLOTUS_ACT_BF16", "-include", RENAME] if b16 else []
+    cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(HERE, src), "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -38,13 +45,18 @@ def _compile(src):
 
 
 def build(force=False):
+    sys.path.insert(0, HERE)
+    import gen_twin
+
+    gen_twin.generate()  # rename header + include/lotus_hip_b16.h (rewritten only when they change)
+    jobs = [(s, False) for s in SOURCES] + [(s, True) for s in ACT_SOURCES]
     if force:
-        for s in SOURCES:
-            o = os.path.join(HERE, os.path.splitext(s)[0] + ".o")
+        for s, b16 in jobs:
+            o = os.path.join(HERE, os.path.splitext(s)[0] + ("_b16.o" if b16 else ".o"))
             if os.path.exists(o):
                 os.remove(o)
-    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = [o for o, _ in ex.map(_compile, SOURCES)]
+    with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:
+        objs = [o for o, _ in ex.map(_compile, jobs)]
     if _stale(LIB, objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
                            capture_output=True, text=True)
@@ -64,8 +76,8 @@ def build_fastcall():
 
     src, _ = gen_fastcall.generate()
     out = os.path.join(HERE, "_lotus_fastcall.so")
-    hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "lotus_hip.h")
-    if _stale(out, [src, hdr, LIB]):
+    inc = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
+    if _stale(out, [src, os.path.join(inc, "lotus_hip.h"), os.path.join(inc, "lotus_hip_b16.h"), LIB]):
         cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], src, "-o", out,
                "-L" + HERE, "-llotus_hip", "-Wl,-rpath,$ORIGIN"]
         r = subprocess.run(cmd, capture_output=True, text=True)

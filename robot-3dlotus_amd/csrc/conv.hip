@@ -13,19 +13,21 @@
 // and per-wave 32-row groups skip their MFMAs through a ballot mask.
 #include "mma.h"
 
+namespace LOTUS_NS {
+
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);
-int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                         float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* w_t, const float* bias, const act_t* add,
+                         act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
                          size_t workspace_bytes, int prec, hipStream_t st, int* rc);
 size_t lotus_conv_pairs_workspace(int n, int ND);
 int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, int prec, hipStream_t st);
 
 struct ConvP {
-  const float* x;   // [n][KD] gathered operand (features, or dy for dgrad)
+  const act_t* x;   // [n][KD] gathered operand (features, or dy for dgrad)
   const float* w;   // [cout][T][cin]
-  float* y;         // [n][ND]
+  act_t* y;         // [n][ND]
   const float* bias;
-  const float* add;  // [n][ND] optional addend
+  const act_t* add;  // [n][ND] optional addend
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] processing order or null
   int n, T, cin, cout;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
         for (int e = 0; e < 4; ++e) Bs[LdsTile<BN, true>::idx(row, kq * 4 + e)] = v[e];
       } else {
         const int kr = f / (BN / 4), jq = f % (BN / 4);
-        *reinterpret_cast<float4*>(&Bs[kr * BN + jq * 4]) = rb[q];
+        st4(&Bs[kr * BN + jq * 4], rb[q]);
       }
     }
   };
@@ -181,8 +183,8 @@ __global__ __launch_bounds__(256) void conv_kernel(ConvP p) {
 
 // ------------------------------------------------------------------------------------ wgrad
 struct ConvWgP {
-  const float* dy;  // [n][cout]
-  const float* x;   // [n][cin]
+  const act_t* dy;  // [n][cout]
+  const act_t* x;   // [n][cin]
   const int* nbr;   // [T][n]
   float* part;      // [nsplit][cout][T][cin]
   float* bias_part; // slice z at bias_part + z * part_stride, or null
@@ -263,8 +265,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
     rb = qq >= 0 ? load4_guard(p.x, p.cin, qq, ci0 + cq * 4, p.n, p.cin, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
   auto lstore = [&]() {
-    *reinterpret_cast<float4*>(&As[kr * BM + cq * 4]) = ra;
-    *reinterpret_cast<float4*>(&Bs[kr * BN + cq * 4]) = rb;
+    st4(&As[kr * BM + cq * 4], ra);
+    st4(&Bs[kr * BN + cq * 4], rb);
   };
   if (total > 0) {
     gload(0);
@@ -315,6 +317,8 @@ size_t lotus_subm_conv_workspace(int n, int cin, int cout) {
 #define STEM_ROWS 32
 #define STEM_TP 128  // taps are scanned as 8 lanes x 16
 
+}  // extern "C"
+
 // wt[t][ci][c] = w[c][t][ci]
 __global__ void conv_stem_wt_kernel(const float* __restrict__ w, float* __restrict__ wt, int cout, int T, int cin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -323,7 +327,6 @@ __global__ void conv_stem_wt_kernel(const float* __restrict__ w, float* __restri
   wt[i] = w[(long)c * T * cin + rem];
 }
 
-}  // extern "C"
 // CIN: compile-time input width (0 = runtime p.cin): with it the 2 * CIN weight loads of a pair are issued together.
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
@@ -390,8 +393,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
       float4 w0[CIN ? CIN : 1], w1[CIN ? CIN : 1];
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci) {
-        w0[ci] = *reinterpret_cast<const float4*>(wr + ci * p.cout);
-        w1[ci] = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
+        w0[ci] = ld4(wr + ci * p.cout);
+        w1[ci] = ld4(wr + ci * p.cout + 4);
       }
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci) {
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
       }
     } else {
       for (int ci = 0; ci < cin; ++ci) {
-        const float4 w0 = *reinterpret_cast<const float4*>(wr + ci * p.cout);
-        const float4 w1 = *reinterpret_cast<const float4*>(wr + ci * p.cout + 4);
+        const float4 w0 = ld4(wr + ci * p.cout);
+        const float4 w1 = ld4(wr + ci * p.cout + 4);
         const float xv = __shfl(xc, ci, 8);
         acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
         acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
@@ -410,14 +413,14 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(ConvP p) {
     }
   }
   if (valid) {
-    float* yo = p.y + (long)m * p.ND + cb * 64 + j * 8;
+    act_t* yo = p.y + (long)m * p.ND + cb * 64 + j * 8;
     if (p.add) {
-      const float* ao = p.add + (long)m * p.ND + cb * 64 + j * 8;
+      const act_t* ao = p.add + (long)m * p.ND + cb * 64 + j * 8;
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc[k] += ao[k];
     }
-    *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    *reinterpret_cast<float4*>(yo + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    st4(yo, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    st4(yo + 4, make_float4(acc[4], acc[5], acc[6], acc[7]));
   }
 }
 
@@ -433,8 +436,8 @@ int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int
 
 // mode 0: fwd  (x [n][cin]  -> y [n][cout]);  mode 1: dgrad (x = dy [n][cout] -> y = dx [n][cin]).
 // w_t (optional) and workspace (optional) enable the pair-compacted tap-split fast path in both modes.
-int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                    float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
+int lotus_subm_conv(int mode, const act_t* x, const float* w, const float* w_t, const float* bias, const act_t* add,
+                    act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
                     void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_subm_conv: precision must be 0, 1 or 3");
@@ -499,7 +502,7 @@ int lotus_subm_conv(int mode, const float* x, const float* w, const float* w_t, 
 // dy[row][c] * x[nbr][ci].  Block = (64 output channels, tap t, row range z); the pairs of a 256-row window are
 // compacted in row order (wave ballots), their input rows staged in LDS; wave g takes pairs g, g+4, ... and the four
 // waves are summed in fixed order -> deterministic.  Same partial-slab layout as conv_wgrad_kernel.
-__global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
+static __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
   // All pairs of the block's row range (<= WG_MAX_PAIRS rows) are compacted first — the neighbour ids of every
   // 256-row window are loaded up front, so the windows cost one memory latency together instead of one each — then
   // the list is consumed in batches of SB pairs: gather their input rows into LDS, accumulate with 8 dy loads in
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  const float* dyc = p.dy + cb * 64 + c;
+  const act_t* dyc = p.dy + cb * 64 + c;
   for (int b0 = 0; b0 < total; b0 += SB) {
     const int nb = min(SB, total - b0);
 #pragma unroll 4
@@ -565,16 +568,16 @@ __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
       for (int u = 0; u < 8; ++u) dyv[u] = dyc[(long)prow_s[b0 + pi + 4 * u] * p.cout];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const float4 xa = *reinterpret_cast<const float4*>(&xs[pi + 4 * u][0]);
-        const float4 xb = *reinterpret_cast<const float4*>(&xs[pi + 4 * u][4]);
+        const float4 xa = ld4(&xs[pi + 4 * u][0]);
+        const float4 xb = ld4(&xs[pi + 4 * u][4]);
         acc[0] = fmaf(dyv[u], xa.x, acc[0]); acc[1] = fmaf(dyv[u], xa.y, acc[1]); acc[2] = fmaf(dyv[u], xa.z, acc[2]); acc[3] = fmaf(dyv[u], xa.w, acc[3]);
         acc[4] = fmaf(dyv[u], xb.x, acc[4]); acc[5] = fmaf(dyv[u], xb.y, acc[5]); acc[6] = fmaf(dyv[u], xb.z, acc[6]); acc[7] = fmaf(dyv[u], xb.w, acc[7]);
       }
     }
     for (; pi < nb; pi += 4) {
       const float dyv = dyc[(long)prow_s[b0 + pi] * p.cout];
-      const float4 xa = *reinterpret_cast<const float4*>(&xs[pi][0]);
-      const float4 xb = *reinterpret_cast<const float4*>(&xs[pi][4]);
+      const float4 xa = ld4(&xs[pi][0]);
+      const float4 xb = ld4(&xs[pi][4]);
       acc[0] = fmaf(dyv, xa.x, acc[0]); acc[1] = fmaf(dyv, xa.y, acc[1]); acc[2] = fmaf(dyv, xa.z, acc[2]); acc[3] = fmaf(dyv, xa.w, acc[3]);
       acc[4] = fmaf(dyv, xb.x, acc[4]); acc[5] = fmaf(dyv, xb.y, acc[5]); acc[6] = fmaf(dyv, xb.z, acc[6]); acc[7] = fmaf(dyv, xb.w, acc[7]);
     }
@@ -590,8 +593,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_wgrad_kernel(ConvWgP p) {
 }
 
 // ---- duplicate voxels: see include/lotus_hip.h.  One thread per (sorted position, float4 column).
-__global__ void conv_dup_fold_kernel(const float* __restrict__ dy, const long long* __restrict__ code0,
-                                     const int* __restrict__ order0, int n, int c4n, float* __restrict__ dyr) {
+static __global__ void conv_dup_fold_kernel(const act_t* __restrict__ dy, const long long* __restrict__ code0,
+                                     const int* __restrict__ order0, int n, int c4n, act_t* __restrict__ dyr) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int i = (int)(id / c4n), c4 = (int)(id % c4n);
   if (i >= n) return;
@@ -599,25 +602,25 @@ __global__ void conv_dup_fold_kernel(const float* __restrict__ dy, const long lo
   const long long key = code0[row];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (i == 0 || code0[order0[i - 1]] != key) {  // representative: lowest index of its voxel (stable sort)
-    acc = reinterpret_cast<const float4*>(dy)[(long)row * c4n + c4];
+    acc = ld4q(dy, (long)row * c4n + c4);
     for (int j = i + 1; j < n; ++j) {
       const int rj = order0[j];
       if (code0[rj] != key) break;
-      const float4 v = reinterpret_cast<const float4*>(dy)[(long)rj * c4n + c4];
+      const float4 v = ld4q(dy, (long)rj * c4n + c4);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
-  reinterpret_cast<float4*>(dyr)[(long)row * c4n + c4] = acc;
+  st4q(dyr, (long)row * c4n + c4, acc);
 }
-__global__ void conv_dup_mask_kernel(float* __restrict__ dx, const float* __restrict__ add, const int* __restrict__ rep,
+static __global__ void conv_dup_mask_kernel(act_t* __restrict__ dx, const act_t* __restrict__ add, const int* __restrict__ rep,
                                      int n, int c4n) {
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int i = (int)(id / c4n), c4 = (int)(id % c4n);
   if (i >= n || rep[i] == i) return;
-  reinterpret_cast<float4*>(dx)[id] = add ? reinterpret_cast<const float4*>(add)[id] : make_float4(0.f, 0.f, 0.f, 0.f);
+  st4q(dx, id, add ? ld4q(add, id) : make_float4(0.f, 0.f, 0.f, 0.f));
 }
 
-int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* order0, int n, int C, float* dyr,
+int lotus_conv_dup_fold(const act_t* dy, const long long* code0, const int* order0, int n, int C, act_t* dyr,
                         void* stream) {
   LOTUS_CHECK_ARG(dy && code0 && order0 && dyr && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_fold: bad arguments");
   if (n == 0) return LOTUS_OK;
@@ -627,7 +630,7 @@ int lotus_conv_dup_fold(const float* dy, const long long* code0, const int* orde
   LOTUS_LAUNCH_CHECK("lotus_conv_dup_fold");
   return LOTUS_OK;
 }
-int lotus_conv_dup_mask(float* dx, const float* add, const int* rep, int n, int C, void* stream) {
+int lotus_conv_dup_mask(act_t* dx, const act_t* add, const int* rep, int n, int C, void* stream) {
   LOTUS_CHECK_ARG(dx && rep && n >= 0 && C > 0 && C % 4 == 0, "lotus_conv_dup_mask: bad arguments");
   if (n == 0) return LOTUS_OK;
   const long total = (long)n * (C / 4);
@@ -642,7 +645,7 @@ size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout) {
 }
 
 // dw [cout][T][cin] (+)= sum_p dy[p] (x) x[nbr[t][p]] ;  db [cout] (+)= colsum(dy)
-int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db, const int* nbr, int n, int T,
+int lotus_subm_conv_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, const int* nbr, int n, int T,
                           int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
                           void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && nbr && n >= 0, "lotus_subm_conv_wgrad: bad arguments");
@@ -677,3 +680,5 @@ int lotus_subm_conv_wgrad(const float* dy, const float* x, float* dw, float* db,
 }
 
 }  // extern "C"
+
+}  // namespace LOTUS_NS

@@ -15,12 +15,15 @@
 #include <stdlib.h>
 #include <type_traits>
 
+namespace LOTUS_NS {
+
 struct ConvP2 {
-  const float* x;    // [n][KD]
+  const act_t* x;    // [n][KD]
   const float* w;    // packed B fragments: element (k, tap, j) at w[((tap * (KD / 4) + k / 4) * ND + j) * 4 + k % 4]
-  float* y;          // [n][ND]  (or partial slabs [nz][n][ND] when tap-split)
+  act_t* y;          // [n][ND]
+  float* ypart;      // fp32 partial slabs [nz][n][ND] when tap-split (part_stride != 0)
   const float* bias;
-  const float* add;
+  const act_t* add;
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] or null
   int n, T, KD, ND, mirror;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       for (int j = 0; j < FILL; ++j) {
         const int q = (gt + j * GT) % (KC / 4);
         vv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gs[j] >= 0) vv[j] = *reinterpret_cast<const float4*>(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
+        if (gs[j] >= 0) vv[j] = ld4(p.x + (long)gs[j] * p.KD + kc * KC + q * 4);
       }
     };
     auto store_fill = [&]() {
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
           ow[0] = h0; ow[1] = h1;
           if (PREC == 3) { ow[KC / 2] = l0; ow[KC / 2 + 1] = l1; }
         } else if (Cfg::AVEC) {
-          *reinterpret_cast<float4*>(o) = vv[j];
+          st4(o, vv[j]);
         } else {
           o[0] = vv[j].x; o[1] = vv[j].y; o[2] = vv[j].z; o[3] = vv[j].w;
         }
@@ -292,8 +295,8 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
 #pragma unroll
         for (int q2 = 0; q2 < KC / 16; ++q2) {
           if (Cfg::AVEC) {
-            dst[2 * q2] = *reinterpret_cast<const float4*>(my_xs + ab + q2 * 8);
-            if (PREC == 3) dst[2 * q2 + 1] = *reinterpret_cast<const float4*>(my_xs + ab + KC / 2 + q2 * 8);
+            dst[2 * q2] = ld4(my_xs + ab + q2 * 8);
+            if (PREC == 3) dst[2 * q2 + 1] = ld4(my_xs + ab + KC / 2 + q2 * 8);
           } else {
             const float* r = my_xs + ab + q2 * 8;
             dst[2 * q2] = make_float4(r[0], r[1], r[2], r[3]);
@@ -303,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
       } else if constexpr (Cfg::AVEC) {
 #pragma unroll
         for (int s4 = 0; s4 < KS / 4; ++s4) {
-          const float4 v4 = *reinterpret_cast<const float4*>(my_xs + ab + s4 * 4);
+          const float4 v4 = ld4(my_xs + ab + s4 * 4);
           dst[s4 * 4] = v4.x; dst[s4 * 4 + 1] = v4.y; dst[s4 * 4 + 2] = v4.z; dst[s4 * 4 + 3] = v4.w;
         }
       } else {
@@ -433,52 +436,53 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
 
   // epilogue: coalesced row stores (final result, or this tap group's partial slab)
   const bool final_out = p.part_stride == 0;
-  float* yo = p.y + (long)blockIdx.z * p.part_stride;
+  float* yo = p.ypart + (long)blockIdx.z * p.part_stride;
   for (int i = gt; i < BM * (NW / 4); i += GT) {
     const int r = i / (NW / 4), c4 = i % (NW / 4);
     const int pr = prow_s[rt * BM + r];
     if (pr < 0) continue;
-    float4 v = *reinterpret_cast<const float4*>(out_s + (rt * (BM + 1) + r) * OLD + c4 * 4);
+    float4 v = ld4(out_s + (rt * (BM + 1) + r) * OLD + c4 * 4);
     const int col = n0 + c4 * 4;
     const long o = (long)pr * p.ND + col;
     if (final_out) {
       if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b = ld4(p.bias + col);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
       }
       if (p.add) {
-        const float4 a = *reinterpret_cast<const float4*>(p.add + o);
+        const float4 a = ld4(p.add + o);
         v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
       }
     }
-    *reinterpret_cast<float4*>(yo + o) = v;
+    if (final_out) st4(p.y + o, v);
+    else st4(yo + o, v);
   }
 }
 
 // y = sum_z part[z] + bias + add   (fixed order -> deterministic)
 __global__ void conv_part_reduce_kernel(const float* __restrict__ part, long stride, int nz, const float* __restrict__ bias,
-                                        const float* __restrict__ add, float* __restrict__ y, long total4, int nd4) {
+                                        const act_t* __restrict__ add, act_t* __restrict__ y, long total4, int nd4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    float4 s = reinterpret_cast<const float4*>(part)[i];
+    float4 s = ld4q(part, i);
     int z = 1;
     for (; z + 1 < nz; z += 2) {  // nz is 3 or 9: two independent loads in flight, summed in z order
-      const float4 v0 = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
-      const float4 v1 = reinterpret_cast<const float4*>(part + (long)(z + 1) * stride)[i];
+      const float4 v0 = ld4q(part + (long)z * stride, i);
+      const float4 v1 = ld4q(part + (long)(z + 1) * stride, i);
       s.x = (s.x + v0.x) + v1.x; s.y = (s.y + v0.y) + v1.y; s.z = (s.z + v0.z) + v1.z; s.w = (s.w + v0.w) + v1.w;
     }
     for (; z < nz; ++z) {
-      const float4 v = reinterpret_cast<const float4*>(part + (long)z * stride)[i];
+      const float4 v = ld4q(part + (long)z * stride, i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     if (bias) {
-      const float4 b = reinterpret_cast<const float4*>(bias)[i % nd4];
+      const float4 b = ld4q(bias, i % nd4);
       s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
     }
     if (add) {
-      const float4 a = reinterpret_cast<const float4*>(add)[i];
+      const float4 a = ld4q(add, i);
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
-    reinterpret_cast<float4*>(y)[i] = s;
+    st4q(y, i, s);
   }
 }
 
@@ -591,8 +595,8 @@ int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T,
 
 // returns 1 if the pair-compacted path handled the call, 0 if the shape is not eligible.
 // Both modes read the packed weights w_t of lotus_conv_weight_transpose (fwd half / dgrad half).
-int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* w_t, const float* bias, const float* add,
-                         float* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
+int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* w_t, const float* bias, const act_t* add,
+                         act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, void* workspace,
                          size_t workspace_bytes, int prec, hipStream_t st, int* rc) {
   const int KD = mode == 0 ? cin : cout, ND = mode == 0 ? cout : cin;
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
@@ -605,7 +609,7 @@ int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* 
   p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
   p.w = w_t + (mode == 0 ? 0 : (long)cout * T * cin);
   p.tpz = cdiv(T, nz);
-  p.y = nz > 1 ? (float*)workspace : y;
+  p.y = y; p.ypart = nz > 1 ? (float*)workspace : nullptr;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
   *rc = ND == 64 ? launch_pairs<2>(p, nz, prec, st) : launch_pairs<4>(p, nz, prec, st);
   if (*rc == 0 && nz > 1) {
@@ -618,3 +622,5 @@ int lotus_conv_pairs_try(int mode, const float* x, const float* w, const float* 
   }
   return 1;
 }
+
+}  // namespace LOTUS_NS

@@ -637,7 +637,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 
 // out[e] = sum_z part[z * stride + e].  Block = 16 float4 columns x 16 z-lanes: coalesced 256-byte row
 // segments per z, 16 independent partial sums per column, fixed-order LDS tree -> deterministic.
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ part, float* __restrict__ out, long n,
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const T* __restrict__ part, T* __restrict__ out, long n,
                                                            long stride, int nz, int accumulate) {
   __shared__ float4 red[16][16];
   const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
   } else if (e < n) {
     float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int z = zl; z < nz; z += 16)
-      for (int k = 0; k < 4 && e + k < n; ++k) t[k] += part[(long)z * stride + e + k];
+      for (int k = 0; k < 4 && e + k < n; ++k) t[k] += ld1(part + (long)z * stride + e + k);
     s = make_float4(t[0], t[1], t[2], t[3]);
   }
   red[zl][q] = s;
@@ -662,22 +663,25 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
       t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w;
     }
     const float tv[4] = {t.x, t.y, t.z, t.w};
-    for (int k = 0; k < 4 && e + k < n; ++k) out[e + k] = accumulate ? out[e + k] + tv[k] : tv[k];
+    for (int k = 0; k < 4 && e + k < n; ++k) st1(out + e + k, accumulate ? ld1(out + e + k) + tv[k] : tv[k]);
   }
 }
 
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st) {
   if (n <= 0) return LOTUS_OK;
-  LOTUS_LAUNCH(reduce_parts_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
+  LOTUS_LAUNCH(reduce_parts_kernel<float>, dim3(cdiv(n, 64)), dim3(256), 0, st, part, out, n, stride, nz, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_reduce_parts");
   return LOTUS_OK;
 }
 
 // out[e] = sum_z part[z * stride + e], z = 0 .. nz-1 in fixed order (e.g. the key-side partial slots of the
 // cross-attention backward)
-extern "C" int lotus_sum_slabs(const float* part, float* out, long n, long stride, int nz, void* stream) {
+extern "C" int lotus_sum_slabs(const act_t* part, act_t* out, long n, long stride, int nz, void* stream) {
   LOTUS_CHECK_ARG(part && out && n >= 0 && nz >= 1, "lotus_sum_slabs: bad arguments");
-  return lotus_reduce_parts(part, out, n, stride, nz, 0, (hipStream_t)stream);
+  if (n <= 0) return LOTUS_OK;
+  LOTUS_LAUNCH(reduce_parts_kernel<act_t>, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, part, out, n, stride, nz, 0);
+  LOTUS_LAUNCH_CHECK("lotus_sum_slabs");
+  return LOTUS_OK;
 }
 
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }  // (bf16 rows: 8-byte accesses, same rule)

@@ -4,12 +4,14 @@
 // produced by the front-end, so every reduction is an ordered loop: no atomics, deterministic.
 #include "common.h"
 
+namespace LOTUS_NS {
+
 int lotus_reduce_parts(const float* part, float* out, long n, long stride, int nz, int accumulate, hipStream_t st);  // gemm.hip
 
 // ---------------------------------------------------------------- segment max over cluster members
 // y[c][:] = max_{i in [seg[c], seg[c+1])} x[members[i]][:]   ; arg = winning parent row
-__global__ void pool_max_fwd_kernel(const float* __restrict__ x, const int* __restrict__ members,
-                                    const int* __restrict__ seg, int nc, int C, float* __restrict__ y,
+__global__ void pool_max_fwd_kernel(const act_t* __restrict__ x, const int* __restrict__ members,
+                                    const int* __restrict__ seg, int nc, int C, act_t* __restrict__ y,
                                     int* __restrict__ arg) {
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -20,7 +22,7 @@ __global__ void pool_max_fwd_kernel(const float* __restrict__ x, const int* __re
   int bi[4] = {-1, -1, -1, -1};
   for (int i = a; i < b; ++i) {
     const int p = members[i];
-    const float4 v = reinterpret_cast<const float4*>(x + (long)p * C)[q];
+    const float4 v = ld4q(x + (long)p * C, q);
     const float vs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e)
@@ -29,49 +31,48 @@ __global__ void pool_max_fwd_kernel(const float* __restrict__ x, const int* __re
         bi[e] = p;
       }
   }
-  reinterpret_cast<float4*>(y + (long)c * C)[q] = make_float4(best[0], best[1], best[2], best[3]);
+  st4q(y + (long)c * C, q, make_float4(best[0], best[1], best[2], best[3]));
   reinterpret_cast<int4*>(arg + (long)c * C)[q] = make_int4(bi[0], bi[1], bi[2], bi[3]);
 }
 
 // dx[p][:] = (arg[cluster[p]][:] == p) ? dy[cluster[p]][:] : 0
-__global__ void pool_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
-                                    const int* __restrict__ cluster, int n, int C, float* __restrict__ dx) {
+__global__ void pool_max_bwd_kernel(const act_t* __restrict__ dy, const int* __restrict__ arg,
+                                    const int* __restrict__ cluster, int n, int C, act_t* __restrict__ dx) {
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c4) return;
   const int p = (int)(gid / c4), q = (int)(gid % c4);
   const int c = cluster[p];
-  const float4 g = reinterpret_cast<const float4*>(dy + (long)c * C)[q];
+  const float4 g = ld4q(dy + (long)c * C, q);
   const int4 a = reinterpret_cast<const int4*>(arg + (long)c * C)[q];
-  reinterpret_cast<float4*>(dx + (long)p * C)[q] =
-      make_float4(a.x == p ? g.x : 0.f, a.y == p ? g.y : 0.f, a.z == p ? g.z : 0.f, a.w == p ? g.w : 0.f);
+  st4q(dx + (long)p * C, q, make_float4(a.x == p ? g.x : 0.f, a.y == p ? g.y : 0.f, a.z == p ? g.z : 0.f, a.w == p ? g.w : 0.f));
 }
 
 // x[p][:] = skip[p][:] + up[cluster[p]][:]
-__global__ void unpool_fwd_kernel(const float* __restrict__ skip, const float* __restrict__ up,
-                                  const int* __restrict__ cluster, int n, int C, float* __restrict__ x) {
+__global__ void unpool_fwd_kernel(const act_t* __restrict__ skip, const act_t* __restrict__ up,
+                                  const int* __restrict__ cluster, int n, int C, act_t* __restrict__ x) {
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c4) return;
   const int p = (int)(gid / c4), q = (int)(gid % c4);
-  const float4 s = reinterpret_cast<const float4*>(skip + (long)p * C)[q];
-  const float4 u = reinterpret_cast<const float4*>(up + (long)cluster[p] * C)[q];
-  reinterpret_cast<float4*>(x + (long)p * C)[q] = make_float4(s.x + u.x, s.y + u.y, s.z + u.z, s.w + u.w);
+  const float4 s = ld4q(skip + (long)p * C, q);
+  const float4 u = ld4q(up + (long)cluster[p] * C, q);
+  st4q(x + (long)p * C, q, make_float4(s.x + u.x, s.y + u.y, s.z + u.z, s.w + u.w));
 }
 
 // dup[c][:] = sum over members of dx
-__global__ void unpool_bwd_kernel(const float* __restrict__ dx, const int* __restrict__ members,
-                                  const int* __restrict__ seg, int nc, int C, float* __restrict__ dup) {
+__global__ void unpool_bwd_kernel(const act_t* __restrict__ dx, const int* __restrict__ members,
+                                  const int* __restrict__ seg, int nc, int C, act_t* __restrict__ dup) {
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)nc * c4) return;
   const int c = (int)(gid / c4), q = (int)(gid % c4);
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int i = seg[c]; i < seg[c + 1]; ++i) {
-    const float4 v = reinterpret_cast<const float4*>(dx + (long)members[i] * C)[q];
+    const float4 v = ld4q(dx + (long)members[i] * C, q);
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   }
-  reinterpret_cast<float4*>(dup + (long)c * C)[q] = s;
+  st4q(dup + (long)c * C, q, s);
 }
 
 // ---------------------------------------------------------------- per-cloud max over contiguous rows
@@ -80,7 +81,7 @@ __global__ void unpool_bwd_kernel(const float* __restrict__ dx, const int* __res
 // arg-max is the FIRST row attaining the maximum, as torch.max(x, 0) returns it.  (One block per (cloud, 32 columns)
 // with 4-byte loads: 64 blocks, 46 us for 33 MB.)
 #define CM_SPLITS 8
-__global__ __launch_bounds__(1024) void cloud_max_part_kernel(const float* __restrict__ x, const int* __restrict__ off, int C,
+__global__ __launch_bounds__(1024) void cloud_max_part_kernel(const act_t* __restrict__ x, const int* __restrict__ off, int C,
                                                               float* __restrict__ pv, int* __restrict__ pi) {
   __shared__ float4 bv[32][33];
   __shared__ int4 bi[32][33];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(1024) void cloud_max_part_kernel(const float* __res
   int idx[4] = {-1, -1, -1, -1};
   if (q * 4 < C)
     for (int r = s0 + ry; r < s1; r += 32) {
-      const float4 v4 = reinterpret_cast<const float4*>(x + (long)r * C)[q];
+      const float4 v4 = ld4q(x + (long)r * C, q);
       const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e)
@@ -119,12 +120,12 @@ __global__ __launch_bounds__(1024) void cloud_max_part_kernel(const float* __res
         }
     }
     const long o = ((long)b * CM_SPLITS + sp) * C + q * 4;
-    *reinterpret_cast<float4*>(pv + o) = make_float4(best[0], best[1], best[2], best[3]);
+    st4(pv + o, make_float4(best[0], best[1], best[2], best[3]));
     *reinterpret_cast<int4*>(pi + o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
   }
 }
 __global__ void cloud_max_merge_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int B, int C,
-                                       float* __restrict__ y, int* __restrict__ arg) {
+                                       act_t* __restrict__ y, int* __restrict__ arg) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i % C;
@@ -142,22 +143,22 @@ __global__ void cloud_max_merge_kernel(const float* __restrict__ pv, const int* 
   arg[i] = idx;
 }
 
-__global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __restrict__ arg,
-                                     const int* __restrict__ batch, int n, int C, const float* __restrict__ add,
-                                     float* __restrict__ dx) {
+__global__ void cloud_max_bwd_kernel(const act_t* __restrict__ dy, const int* __restrict__ arg,
+                                     const int* __restrict__ batch, int n, int C, const act_t* __restrict__ add,
+                                     act_t* __restrict__ dx) {
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c4) return;
   const int p = (int)(gid / c4), q = (int)(gid % c4);
   const int b = batch[p];
-  const float4 g = reinterpret_cast<const float4*>(dy + (long)b * C)[q];
+  const float4 g = ld4q(dy + (long)b * C, q);
   const int4 a = reinterpret_cast<const int4*>(arg + (long)b * C)[q];
   float4 o = make_float4(a.x == p ? g.x : 0.f, a.y == p ? g.y : 0.f, a.z == p ? g.z : 0.f, a.w == p ? g.w : 0.f);
   if (add) {
-    const float4 v = reinterpret_cast<const float4*>(add + (long)p * C)[q];
+    const float4 v = ld4q(add + (long)p * C, q);
     o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
   }
-  reinterpret_cast<float4*>(dx + (long)p * C)[q] = o;
+  st4q(dx + (long)p * C, q, o);
 }
 
 // ---------------------------------------------------------------- losses (simple_policy_ptv3.py:308-373)
@@ -165,7 +166,7 @@ __global__ void cloud_max_bwd_kernel(const float* __restrict__ dy, const int* __
 // xt[n][3*nb] logits (n, c, bin); tgt: cloud b at tgt_off = 3*nb*off[b], laid out [3][n_b*nb].
 #define POS_CE_SPLITS 32
 // slice s of cloud b, axis c: partial (max, sum exp(x - max), sum t x, sum t) of the heatmap cross-entropy
-__global__ __launch_bounds__(256) void pos_ce_part_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+__global__ __launch_bounds__(256) void pos_ce_part_kernel(const act_t* __restrict__ xt, const float* __restrict__ tgt,
                                                           const int* __restrict__ off, int nb,
                                                           float* __restrict__ part /*[B*3][SPLITS][4]*/) {
   __shared__ float red[4];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void pos_ce_part_kernel(const float* __restric
   const int n0 = off[b], nn = off[b + 1] - n0;
   const int p0 = (int)((long)nn * s / POS_CE_SPLITS), p1 = (int)((long)nn * (s + 1) / POS_CE_SPLITS);
   const float* tb = tgt + (long)3 * nb * n0 + (long)c * nn * nb;
-  const float* xb = xt + (long)n0 * (3 * nb) + c * nb;
+  const act_t* xb = xt + (long)n0 * (3 * nb) + c * nb;
   // lanes 0..31 of a half-wave walk the bins of one point; 8 points per block step
   const int j0 = threadIdx.x & 31, g = threadIdx.x >> 5;
   float m = -INFINITY;
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(64) void pos_ce_merge_kernel(const float* __restric
 // Rotation CE + openness BCE on ae[B][nrot*3 + 1]; gt[B][ga] with rot bins at 3..5 and open at ga-1.
 // losses[4] = pos, rot, open, total.  dae = (d rot / d ae | d open / d ae) column-wise (rot logits and the
 // open logit are disjoint columns), unscaled by the upstream gradient.
-__global__ __launch_bounds__(256) void small_loss_kernel(const float* __restrict__ ae, const float* __restrict__ gt,
+__global__ __launch_bounds__(256) void small_loss_kernel(const act_t* __restrict__ ae, const float* __restrict__ gt,
                                                          const float* __restrict__ pos_stats, int B, int nrot, int ga,
                                                          float pos_w, float rot_w, float* __restrict__ losses,
                                                          float* __restrict__ dae) {
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void small_loss_kernel(const float* __restrict
   float rot = 0.f, opn = 0.f, pos = 0.f;
   for (int i = threadIdx.x; i < B * 3; i += 256) {
     const int b = i / 3, a = i % 3;
-    const float* row = ae + (long)b * W;
+    const act_t* row = ae + (long)b * W;
     float m = -INFINITY;
     for (int k = 0; k < nrot; ++k) m = fmaxf(m, row[k * 3 + a]);
     float se = 0.f;
@@ -278,10 +279,10 @@ __global__ __launch_bounds__(256) void small_loss_kernel(const float* __restrict
 }
 
 // dxt[n][c][bin] = coef * (softmax * tsum - t) / (3B), coef = g[0] + pos_w * g[3] (device scalars)
-__global__ void pos_ce_bwd_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+__global__ void pos_ce_bwd_kernel(const act_t* __restrict__ xt, const float* __restrict__ tgt,
                                   const int* __restrict__ off, const int* __restrict__ batch,
                                   const float* __restrict__ stats, const float* __restrict__ gl, float pos_w, int B,
-                                  int n, int nb, float* __restrict__ dxt) {
+                                  int n, int nb, act_t* __restrict__ dxt) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)n * 3 * nb;
   if (gid >= total) return;
@@ -296,10 +297,10 @@ __global__ void pos_ce_bwd_kernel(const float* __restrict__ xt, const float* __r
 
 // per-(cloud, axis) upstream gradients g[B*3] (trajectory heads weight each cloud by its step mask,
 // motion_planner_ptv3.py:327-336): dxt = g[b*3+c] * (softmax * tsum - t)
-__global__ void pos_ce_bwd_w_kernel(const float* __restrict__ xt, const float* __restrict__ tgt,
+__global__ void pos_ce_bwd_w_kernel(const act_t* __restrict__ xt, const float* __restrict__ tgt,
                                     const int* __restrict__ off, const int* __restrict__ batch,
                                     const float* __restrict__ stats, const float* __restrict__ g, int n, int nb,
-                                    float* __restrict__ dxt) {
+                                    act_t* __restrict__ dxt) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)n * 3 * nb;
   if (gid >= total) return;
@@ -313,7 +314,7 @@ __global__ void pos_ce_bwd_w_kernel(const float* __restrict__ xt, const float* _
 
 // dae_out = dae_saved * (upstream weight of its column): rot columns g[1] + rot_w * g[3], open column g[2] + g[3]
 __global__ void ae_grad_kernel(const float* __restrict__ x, const float* __restrict__ gl, float rot_w, int W, long n,
-                               float* __restrict__ y) {
+                               act_t* __restrict__ y) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool open_col = (i % W) == W - 1;
@@ -329,7 +330,7 @@ __global__ void ae_grad_kernel(const float* __restrict__ x, const float* __restr
 //   open = sum mask * BCE(open) / sum mask                             stop likewise
 // losses[5] = pos, rot, open, stop, total.  dae [B*T][W] and dce [B*T][3] receive the partial derivatives of the loss
 // each column belongs to (the columns are disjoint), unscaled by the upstream gradient.
-__global__ __launch_bounds__(256) void mp_loss_kernel(const float* __restrict__ ae, const float* __restrict__ gt,
+__global__ __launch_bounds__(256) void mp_loss_kernel(const act_t* __restrict__ ae, const float* __restrict__ gt,
                                                       const float* __restrict__ stop, const float* __restrict__ mask,
                                                       const float* __restrict__ ce, int B, int T, int nrot, int ga, float pos_w,
                                                       float rot_w, float* __restrict__ losses, float* __restrict__ dae,
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void mp_loss_kernel(const float* __restrict__ 
   for (int i = tid; i < R * 3; i += 256) {
     const int r = i / 3, a = i % 3, b = r / T;
     const float m = mask[r];
-    const float* row = ae + (long)r * W;
+    const act_t* row = ae + (long)r * W;
     float mx = -INFINITY;
     for (int k = 0; k < nrot; ++k) mx = fmaxf(mx, row[k * 3 + a]);
     float se = 0.f;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(256) void mp_loss_kernel(const float* __restrict__ 
 }
 // upstream gradient g[5] (device) of the five losses -> d ae, d ce
 __global__ void mp_loss_bwd_kernel(const float* __restrict__ dae, const float* __restrict__ dce, const float* __restrict__ g,
-                                   float pos_w, float rot_w, int W, long nae, long nce, float* __restrict__ dae_out,
+                                   float pos_w, float rot_w, int W, long nae, long nce, act_t* __restrict__ dae_out,
                                    float* __restrict__ dce_out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nae) {
@@ -406,13 +407,13 @@ __global__ void mp_loss_bwd_kernel(const float* __restrict__ dae, const float* _
 }
 
 // elementwise helpers ---------------------------------------------------------------------------
-__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long n4) {
+__global__ void add_kernel(const act_t* __restrict__ a, const act_t* __restrict__ b, act_t* __restrict__ y, long n4) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
-    reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    const float4 u = ld4q(a, i), v = ld4q(b, i);
+    st4q(y, i, make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w));
   }
 }
-__global__ void dropout_mask_kernel(const float* __restrict__ x, float* __restrict__ y, long n,
+__global__ void dropout_mask_kernel(const act_t* __restrict__ x, act_t* __restrict__ y, long n,
                                     unsigned long long seed, unsigned thresh, float inv_keep) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     y[i] = x[i] * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep);
@@ -424,34 +425,34 @@ __global__ void dropout_mask_kernel(const float* __restrict__ x, float* __restri
 // embedding.  Forward: one elementwise pass per step.  Backward: dpre_t = dh_t * act'(base + bias_t) * mask, accumulated
 // over the steps into dbase, with per-block column sums (-> dbias_t) reduced in fixed order.
 #define SA_ROWS 64  // rows per block of the backward pass
-__global__ void step_act_fwd_kernel(const float* __restrict__ base, const float* __restrict__ bias, float* __restrict__ out,
+__global__ void step_act_fwd_kernel(const act_t* __restrict__ base, const float* __restrict__ bias, act_t* __restrict__ out,
                                     long total4, int c4n, int act, unsigned long long seed, unsigned thresh, float inv_keep) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const float4 b = reinterpret_cast<const float4*>(base)[i];
-    const float4 s = reinterpret_cast<const float4*>(bias)[i % c4n];
+    const float4 b = ld4q(base, i);
+    const float4 s = ld4q(bias, i % c4n);
     float v[4] = {b.x + s.x, b.y + s.y, b.z + s.z, b.w + s.w};
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       v[e] = act_f(v[e], act);
       if (thresh) v[e] *= dropout_scale(seed, (unsigned long long)(4 * i + e), thresh, inv_keep);
     }
-    reinterpret_cast<float4*>(out)[i] = make_float4(v[0], v[1], v[2], v[3]);
+    st4q(out, i, make_float4(v[0], v[1], v[2], v[3]));
   }
 }
 // block = 256 threads = (256 / c4n) row lanes x c4n column quads; rows [blockIdx.x * SA_ROWS, +SA_ROWS)
-__global__ __launch_bounds__(256) void step_act_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ base,
-                                                           const float* __restrict__ bias, float* __restrict__ dacc,
+__global__ __launch_bounds__(256) void step_act_bwd_kernel(const act_t* __restrict__ dh, const act_t* __restrict__ base,
+                                                           const float* __restrict__ bias, act_t* __restrict__ dacc,
                                                            float* __restrict__ part, int M, int c4n, int act, int accumulate,
                                                            unsigned long long seed, unsigned thresh, float inv_keep) {
   extern __shared__ float4 red[];  // [row lanes][c4n]
   const int q = threadIdx.x % c4n, rl = threadIdx.x / c4n, lanes = 256 / c4n;
-  const float4 s = reinterpret_cast<const float4*>(bias)[q];
+  const float4 s = ld4q(bias, q);
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
   const int r1 = min(M, (int)(blockIdx.x + 1) * SA_ROWS);
   for (int row = blockIdx.x * SA_ROWS + rl; row < r1; row += lanes) {
     const long i = (long)row * c4n + q;
-    const float4 b = reinterpret_cast<const float4*>(base)[i];
-    const float4 g = reinterpret_cast<const float4*>(dh)[i];
+    const float4 b = ld4q(base, i);
+    const float4 g = ld4q(dh, i);
     const float pre[4] = {b.x + s.x, b.y + s.y, b.z + s.z, b.w + s.w};
     float d[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
@@ -462,10 +463,10 @@ __global__ __launch_bounds__(256) void step_act_bwd_kernel(const float* __restri
     cs.x += d[0]; cs.y += d[1]; cs.z += d[2]; cs.w += d[3];
     float4 o = make_float4(d[0], d[1], d[2], d[3]);
     if (accumulate) {
-      const float4 a = reinterpret_cast<const float4*>(dacc)[i];
+      const float4 a = ld4q(dacc, i);
       o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
     }
-    reinterpret_cast<float4*>(dacc)[i] = o;
+    st4q(dacc, i, o);
   }
   red[rl * c4n + q] = cs;
   __syncthreads();
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void step_act_bwd_kernel(const float* __restri
       const float4 v = red[k * c4n + q];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    reinterpret_cast<float4*>(part)[(long)blockIdx.x * c4n + q] = t;
+    st4q(part, (long)blockIdx.x * c4n + q, t);
   }
 }
 // ---------------------------------------------------------------------------------------------------------------
@@ -577,7 +578,7 @@ __global__ void pos_tgt_write_kernel(const float* __restrict__ pc, long ld, cons
 }
 
 // slice s of (cloud b, axis c): first arg-max of the position logits xt[n][c][j]
-__global__ __launch_bounds__(256) void pos_argmax_part_kernel(const float* __restrict__ xt, const int* __restrict__ off, int nb,
+__global__ __launch_bounds__(256) void pos_argmax_part_kernel(const act_t* __restrict__ xt, const int* __restrict__ off, int nb,
                                                               double* __restrict__ part) {
   __shared__ float rv[4];
   __shared__ long ri[4];
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(64) void pos_argmax_merge_kernel(const double* __re
 
 extern "C" {
 
-int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int nc, int C, float* y, int* arg,
+int lotus_pool_max_fwd(const act_t* x, const int* members, const int* seg, int nc, int C, act_t* y, int* arg,
                        void* stream) {
   LOTUS_CHECK_ARG(x && members && seg && y && arg && C % 4 == 0, "lotus_pool_max_fwd: bad arguments");
   if (nc == 0) return LOTUS_OK;
@@ -631,7 +632,7 @@ int lotus_pool_max_fwd(const float* x, const int* members, const int* seg, int n
   LOTUS_LAUNCH_CHECK("lotus_pool_max_fwd");
   return LOTUS_OK;
 }
-int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int n, int C, float* dx, void* stream) {
+int lotus_pool_max_bwd(const act_t* dy, const int* arg, const int* cluster, int n, int C, act_t* dx, void* stream) {
   LOTUS_CHECK_ARG(dy && arg && cluster && dx && C % 4 == 0, "lotus_pool_max_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
   LOTUS_LAUNCH(pool_max_bwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dy, arg,
@@ -639,7 +640,7 @@ int lotus_pool_max_bwd(const float* dy, const int* arg, const int* cluster, int 
   LOTUS_LAUNCH_CHECK("lotus_pool_max_bwd");
   return LOTUS_OK;
 }
-int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int n, int C, float* x, void* stream) {
+int lotus_unpool_fwd(const act_t* skip, const act_t* up, const int* cluster, int n, int C, act_t* x, void* stream) {
   LOTUS_CHECK_ARG(skip && up && cluster && x && C % 4 == 0, "lotus_unpool_fwd: bad arguments");
   if (n == 0) return LOTUS_OK;
   LOTUS_LAUNCH(unpool_fwd_kernel, dim3(cdiv((long)n * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, skip, up,
@@ -647,7 +648,7 @@ int lotus_unpool_fwd(const float* skip, const float* up, const int* cluster, int
   LOTUS_LAUNCH_CHECK("lotus_unpool_fwd");
   return LOTUS_OK;
 }
-int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc, int C, float* dup, void* stream) {
+int lotus_unpool_bwd(const act_t* dx, const int* members, const int* seg, int nc, int C, act_t* dup, void* stream) {
   LOTUS_CHECK_ARG(dx && members && seg && dup && C % 4 == 0, "lotus_unpool_bwd: bad arguments");
   if (nc == 0) return LOTUS_OK;
   LOTUS_LAUNCH(unpool_bwd_kernel, dim3(cdiv((long)nc * C / 4, 256)), dim3(256), 0, (hipStream_t)stream, dx,
@@ -657,7 +658,7 @@ int lotus_unpool_bwd(const float* dx, const int* members, const int* seg, int nc
 }
 // per-cloud max over the contiguous row ranges [off[b], off[b+1])
 size_t lotus_cloud_max_workspace(int B, int C) { return (size_t)B * CM_SPLITS * C * (sizeof(float) + sizeof(int)); }
-int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, int* arg, void* workspace, size_t workspace_bytes,
+int lotus_cloud_max_fwd(const act_t* x, const int* off, int B, int C, act_t* y, int* arg, void* workspace, size_t workspace_bytes,
                         void* stream) {
   LOTUS_CHECK_ARG(x && off && y && arg && B > 0 && C > 0 && C % 4 == 0 && ((uintptr_t)x) % 16 == 0,
                   "lotus_cloud_max_fwd: bad arguments (C must be a multiple of 4, x 16-byte aligned)");
@@ -671,7 +672,7 @@ int lotus_cloud_max_fwd(const float* x, const int* off, int B, int C, float* y, 
   LOTUS_LAUNCH_CHECK("lotus_cloud_max_fwd");
   return LOTUS_OK;
 }
-int lotus_cloud_max_bwd(const float* dy, const int* arg, const int* batch, int n, int C, const float* add, float* dx,
+int lotus_cloud_max_bwd(const act_t* dy, const int* arg, const int* batch, int n, int C, const act_t* add, act_t* dx,
                         void* stream) {
   LOTUS_CHECK_ARG(dy && arg && batch && dx && C % 4 == 0, "lotus_cloud_max_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
@@ -686,7 +687,7 @@ size_t lotus_loss_stats_floats(int B) { return (size_t)B * 3 * 4 * (1 + POS_CE_S
 
 // losses[4] = (pos, rot, open, total); pos_stats (lotus_loss_stats_floats(B) floats; the leading [B*3][4] are
 // what backward reads) and dae [B][nrot*3+1] are saved for backward.
-int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
+int lotus_loss_fwd(const act_t* xt, const act_t* ae, const float* tgt, const float* gt, const int* off, int B, int nb,
                    int nrot, int ga, float pos_w, float rot_w, float* losses, float* pos_stats, float* dae,
                    void* stream) {
   LOTUS_CHECK_ARG(xt && ae && tgt && gt && off && losses && pos_stats && B > 0, "lotus_loss_fwd: bad arguments");
@@ -699,9 +700,9 @@ int lotus_loss_fwd(const float* xt, const float* ae, const float* tgt, const flo
   return LOTUS_OK;
 }
 // dxt [n][3*nb] and dae_out [B][nrot*3+1] from the upstream gradient of the 4 losses (gl, device).
-int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+int lotus_loss_bwd(const act_t* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
                    const float* dae_saved, const float* gl, float pos_w, float rot_w, int B, int n, int nb, int nrot,
-                   float* dxt, float* dae_out, void* stream) {
+                   act_t* dxt, act_t* dae_out, void* stream) {
   LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && dae_saved && gl && dxt && dae_out, "lotus_loss_bwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   const long total = (long)n * 3 * nb;
@@ -715,7 +716,7 @@ int lotus_loss_bwd(const float* xt, const float* tgt, const int* off, const int*
 }
 
 // Heatmap cross entropy alone (trajectory heads call it once per step): pos_stats[(b*3+c)*4] = CE of cloud b, axis c
-int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream) {
+int lotus_pos_ce_fwd(const act_t* xt, const float* tgt, const int* off, int B, int nb, float* pos_stats, void* stream) {
   LOTUS_CHECK_ARG(xt && tgt && off && pos_stats && B > 0 && nb > 0, "lotus_pos_ce_fwd: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   float* part = pos_stats + (size_t)B * 3 * 4;
@@ -724,8 +725,8 @@ int lotus_pos_ce_fwd(const float* xt, const float* tgt, const int* off, int B, i
   LOTUS_LAUNCH_CHECK("lotus_pos_ce_fwd");
   return LOTUS_OK;
 }
-int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
-                     const float* g, int B, int n, int nb, float* dxt, void* stream) {
+int lotus_pos_ce_bwd(const act_t* xt, const float* tgt, const int* off, const int* batch, const float* pos_stats,
+                     const float* g, int B, int n, int nb, act_t* dxt, void* stream) {
   LOTUS_CHECK_ARG(xt && tgt && off && batch && pos_stats && g && dxt && B > 0, "lotus_pos_ce_bwd: bad arguments");
   if (n == 0) return LOTUS_OK;
   const long total = (long)n * 3 * nb;
@@ -736,7 +737,7 @@ int lotus_pos_ce_bwd(const float* xt, const float* tgt, const int* off, const in
 }
 
 // Trajectory losses of the motion planner ([B, T]-sized tensors), see mp_loss_kernel.
-int lotus_mp_loss_fwd(const float* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
+int lotus_mp_loss_fwd(const act_t* ae, const float* gt, const float* stop, const float* mask, const float* ce, int B, int T,
                       int nrot, int ga, float pos_w, float rot_w, float* losses, float* dae, float* dce, void* stream) {
   LOTUS_CHECK_ARG(ae && gt && stop && mask && ce && losses && dae && dce && B > 0 && T > 0 && nrot > 0 && ga >= 7 && B <= 8192,
                   "lotus_mp_loss_fwd: bad arguments");
@@ -746,7 +747,7 @@ int lotus_mp_loss_fwd(const float* ae, const float* gt, const float* stop, const
   return LOTUS_OK;
 }
 int lotus_mp_loss_bwd(const float* dae, const float* dce, const float* g, float pos_w, float rot_w, int B, int T, int nrot,
-                      float* dae_out, float* dce_out, void* stream) {
+                      act_t* dae_out, float* dce_out, void* stream) {
   LOTUS_CHECK_ARG(dae && dce && g && dae_out && dce_out && B > 0 && T > 0 && nrot > 0, "lotus_mp_loss_bwd: bad arguments");
   const int W = nrot * 3 + 2;
   const long nae = (long)B * T * W, nce = (long)B * T * 3;
@@ -756,7 +757,7 @@ int lotus_mp_loss_bwd(const float* dae, const float* dce, const float* g, float 
   return LOTUS_OK;
 }
 
-int lotus_add(const float* a, const float* b, float* y, long n, void* stream) {
+int lotus_add(const act_t* a, const act_t* b, act_t* y, long n, void* stream) {
   LOTUS_CHECK_ARG(a && b && y && n % 4 == 0, "lotus_add: bad arguments");
   if (n == 0) return LOTUS_OK;
   int g = cdiv(n / 4, 256);
@@ -765,7 +766,7 @@ int lotus_add(const float* a, const float* b, float* y, long n, void* stream) {
   return LOTUS_OK;
 }
 // y = x * dropmask(seed, p) / (1 - p): forward dropout and its backward (same mask from the same seed)
-int lotus_dropout(const float* x, float* y, long n, float p, unsigned long long seed, void* stream) {
+int lotus_dropout(const act_t* x, act_t* y, long n, float p, unsigned long long seed, void* stream) {
   LOTUS_CHECK_ARG(x && y && p >= 0.f && p < 1.f, "lotus_dropout: bad arguments");
   if (n == 0) return LOTUS_OK;
   unsigned th = (unsigned)(p * 4294967296.0);
@@ -783,7 +784,7 @@ static void drop_params(float p, unsigned* th, float* inv) {
   *inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
 }
 
-int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, int C, int act, float drop_p,
+int lotus_step_act_fwd(const act_t* base, const float* bias, act_t* out, int M, int C, int act, float drop_p,
                        unsigned long long drop_seed, void* stream) {
   LOTUS_CHECK_ARG(base && bias && out && M >= 0 && C > 0 && C % 4 == 0 && drop_p >= 0.f && drop_p < 1.f, "lotus_step_act_fwd: bad arguments");
   if (M == 0) return LOTUS_OK;
@@ -799,7 +800,7 @@ int lotus_step_act_fwd(const float* base, const float* bias, float* out, int M, 
 
 size_t lotus_step_act_bwd_workspace(int M, int C) { return (size_t)cdiv(M > 0 ? M : 1, SA_ROWS) * C * sizeof(float); }
 
-int lotus_step_act_bwd(const float* dh, const float* base, const float* bias, float* dbase, float* dbias, int M, int C, int act,
+int lotus_step_act_bwd(const act_t* dh, const act_t* base, const float* bias, act_t* dbase, float* dbias, int M, int C, int act,
                        float drop_p, unsigned long long drop_seed, int accumulate, void* workspace, size_t workspace_bytes,
                        void* stream) {
   LOTUS_CHECK_ARG(dh && base && bias && dbase && dbias && M >= 0 && C > 0 && C % 4 == 0 && 256 % (C / 4) == 0 && drop_p >= 0.f && drop_p < 1.f,
@@ -841,7 +842,7 @@ int lotus_pos_targets(const float* pc, long ld, const int* off, const int* batch
 }
 
 // best_pos[b][c] (double) = coordinate of the first arg-max of the position logits xt [n][3 * nb] of cloud b, axis c
-int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
+int lotus_pos_decode_max(const act_t* xt, const float* pc, long ld, const int* off, int B, int nb, double bin_size,
                          double* best_pos, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(xt && pc && off && best_pos && B > 0 && nb > 0 && nb % 2 == 0, "lotus_pos_decode_max: bad arguments");
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_pos_workspace(B), "lotus_pos_decode_max: workspace too small");
@@ -854,3 +855,5 @@ int lotus_pos_decode_max(const float* xt, const float* pc, long ld, const int* o
 }
 
 }  // extern "C"
+
+}  // namespace LOTUS_NS

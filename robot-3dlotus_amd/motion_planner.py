@@ -85,6 +85,8 @@ class MotionPlannerPTV3CA(BaseModel):
     gemm_precision = None  # as SimplePolicyPTV3CA.gemm_precision
 
     def forward(self, batch, compute_loss=False, **kwargs):
+        if getattr(self, "act_storage", None) == "bf16":
+            raise NotImplementedError("bf16 activation storage is built for SimplePolicyPTV3CA (BASELINE configs[4]) only")
         with ops.precision(self.gemm_precision):
             return self._forward(batch, compute_loss, **kwargs)
 

@@ -98,6 +98,31 @@ def _env_precision():
 _PREC = _env_precision()  # precision code the next forward pass captures (see set_gemm_precision / precision())
 
 
+class storage:
+    """Context manager: activation STORAGE type of the forward passes started inside.  torch.float32 (default) runs the
+    lotus_* entry points; torch.bfloat16 runs their bf16-storage twins (lotus_b16_*, include/lotus_hip_b16.h): every
+    activation tensor in HBM is bf16, parameters / parameter gradients / statistics / accumulation stay fp32 — the
+    "bf16 activations, fp32 master weights" mode of BASELINE configs[4].  The operand precision inside is 'bf16'
+    (one bf16 MFMA product, fp32 accumulate).  Like the precision, the storage type is captured per autograd node and
+    replayed in its backward, so models of both kinds coexist in one process."""
+
+    def __init__(self, dtype):
+        assert dtype in (None, torch.float32, torch.bfloat16), dtype
+        self.bf = dtype is torch.bfloat16
+
+    def __enter__(self):
+        global _PREC
+        self.prev = (_capi.BF16, _PREC)
+        _capi.BF16 = self.bf
+        if self.bf:
+            _PREC = 1
+        return self
+
+    def __exit__(self, *a):
+        global _PREC
+        _capi.BF16, _PREC = self.prev
+
+
 def set_gemm_precision(mode):
     """Default operand precision of the dense, sparse-convolution and attention products for forward passes started
     from now on: 'fp32' = fp32 MFMA, exact products (default, the 1e-4 logit parity mode); 'bf16x3' = split-bf16 products
@@ -236,7 +261,7 @@ def _end_of_backward():
 def _fwd(fn):
     """forward() decorator: the node remembers the operand precision it was computed in."""
     def wrapped(ctx, *args):
-        ctx.prec = _PREC
+        ctx.prec, ctx.bf = _PREC, _capi.BF16
         return fn(ctx, *args)
     return staticmethod(wrapped)
 
@@ -248,6 +273,7 @@ def _joined(fn):
         global _IN_NODE, _END_CB_PENDING, _PREC
         _IN_NODE += 1
         prev, _PREC = _PREC, getattr(ctx, "prec", _PREC)
+        prev_bf, _capi.BF16 = _capi.BF16, getattr(ctx, "bf", _capi.BF16)
         try:
             if _JOIN == "end" and _SIDE_ON and not _END_CB_PENDING:
                 _END_CB_PENDING = True
@@ -255,6 +281,7 @@ def _joined(fn):
             return fn(ctx, *grads)
         finally:
             _PREC = prev
+            _capi.BF16 = prev_bf
             _IN_NODE -= 1
             if _JOIN == "node":
                 sync_side_stream()
@@ -292,14 +319,14 @@ def _counters_for(dev, ptr):
 
 
 def _empty_like_rows(x, cols):
-    return torch.empty(x.shape[0], cols, dtype=torch.float32, device=x.device)
+    return torch.empty(x.shape[0], cols, dtype=x.dtype, device=x.device)
 
 
 # ------------------------------------------------------------------------------------ primitives
 def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0, seed=0, prec=None):
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    y = torch.empty(M, N, dtype=x.dtype, device=x.device)
     pre = torch.empty_like(y) if save_pre else None
     if CALL_LOG is not None:
         CALL_LOG.append(("fwd", M, N, K))
@@ -314,7 +341,7 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
 def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0, prec=None):
     M, N = dy.shape
     K = w.shape[1]
-    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
     if CALL_LOG is not None:
         CALL_LOG.append(("dgrad", M, N, K))
     nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
@@ -444,7 +471,7 @@ def _conv_ws(n, cin, cout, dev):
 def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None):
     n, cin = x.shape
     cout, T = w.shape[0], nbr.shape[0]
-    y = torch.empty(n, cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, cout, dtype=x.dtype, device=x.device)
     if T == 27:
         ws = _conv_ws(n, cin, cout, x.device)
     else:  # thin-input stem kernel: room for the transposed weights
@@ -465,7 +492,7 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
         dyr = torch.empty_like(dy)
         call("lotus_conv_dup_fold", dy, lvl.code[0], lvl.order[0], n, cout, dyr)
         dy = dyr
-    dx = torch.empty(n, cin, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(n, cin, dtype=dy.dtype, device=dy.device)
     ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
     call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _PREC if prec is None else prec, ws,
          ws.numel() if ws is not None else 0)
@@ -669,7 +696,7 @@ def set_composites(on):
 
 
 def _sizes(kind, *dims):
-    key = (kind,) + dims
+    key = (kind, _capi.BF16) + dims
     v = _SIZE_CACHE.get(key)
     if v is None:
         if kind == "ffn":
@@ -871,7 +898,7 @@ class SelfAttnFn(torch.autograd.Function):
             return y
         n, mean, rstd = ln_fwd(x, g, b)
         qkv, _ = linear_fwd(n, wqkv, bqkv)
-        att = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
         attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
                       lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, mix_seed(seed, 1))
@@ -913,8 +940,8 @@ class SelfAttnFn(torch.autograd.Function):
         datt = linear_dgrad(dz, wp)
         # every (point, q|k|v column) is written exactly once by its owner position; the k/v gradients of the
         # borrowed tail-patch copies go to a small side buffer and are added afterwards (no atomics, no memset)
-        dqkv = torch.empty(N, 3 * C, dtype=torch.float32, device=x.device)
-        extra = torch.empty(max(lvl.n_extra, 1), 2 * C, dtype=torch.float32, device=x.device)
+        dqkv = torch.empty(N, 3 * C, dtype=x.dtype, device=x.device)
+        extra = torch.empty(max(lvl.n_extra, 1), 2 * C, dtype=x.dtype, device=x.device)
         gq, bq, gk, bk = attention_bwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner,
                                        lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, (qnw, qnb), (knw, knb), att,
                                        datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, attn_p, mix_seed(seed, 1),
@@ -952,7 +979,7 @@ class CrossAttnFn(torch.autograd.Function):
         n, mean, rstd = ln_fwd(x, g, b)
         q, _ = linear_fwd(n, wq, bq)
         kv, _ = linear_fwd(context, wkv, bkv)
-        att = torch.empty(N, C, dtype=torch.float32, device=x.device)
+        att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
                       att, lse, H, d, attn_p, mix_seed(seed, 1))
@@ -1002,9 +1029,9 @@ class CrossAttnFn(torch.autograd.Function):
         dz = _masked(dy, p, seed, hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
-        dq = torch.empty(N, C, dtype=torch.float32, device=dev)
+        dq = torch.empty(N, C, dtype=x.dtype, device=dev)
         G, L = lvl.ca_groups, kv.shape[0]
-        dkv_part = torch.empty(G, L, 2 * C, dtype=torch.float32, device=dev)
+        dkv_part = torch.empty(G, L, 2 * C, dtype=x.dtype, device=dev)
         gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
                                          lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
                                          2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1))
@@ -1046,7 +1073,7 @@ class PoolFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, g, b, rmean, rvar, child, training):
         proj, _ = linear_fwd(x, w, bias)
         C = w.shape[0]
-        pooled = torch.empty(child.n, C, dtype=torch.float32, device=x.device)
+        pooled = torch.empty(child.n, C, dtype=x.dtype, device=x.device)
         arg = torch.empty(child.n, C, dtype=torch.int32, device=x.device)
         call("lotus_pool_max_fwd", proj, child.members, child.seg_start, child.n, C, pooled, arg)
         y, mean, invstd = bn_fwd(pooled, g, b, rmean, rvar, training, ACT_GELU)
@@ -1060,7 +1087,7 @@ class PoolFn(torch.autograd.Function):
         child, training = ctx.meta
         C = w.shape[0]
         dpool, dg, db = bn_bwd(dy.contiguous(), pooled, mean, invstd, g, b, training, ACT_GELU)
-        dproj = torch.empty(x.shape[0], C, dtype=torch.float32, device=x.device)
+        dproj = torch.empty(x.shape[0], C, dtype=x.dtype, device=x.device)
         call("lotus_pool_max_bwd", dpool, arg, child.cluster, x.shape[0], C, dproj)
         dw, dbias = linear_wgrad(dproj, x)
         dx = linear_dgrad(dproj, w)
@@ -1088,7 +1115,7 @@ class UnpoolFn(torch.autograd.Function):
         child, training = ctx.meta
         C = wu.shape[0]
         dx = dx.contiguous()
-        dup = torch.empty(child.n, C, dtype=torch.float32, device=dx.device)
+        dup = torch.empty(child.n, C, dtype=dx.dtype, device=dx.device)
         call("lotus_unpool_bwd", dx, child.members, child.seg_start, child.n, C, dup)
         dsk = add(dx, dskip.contiguous()) if dskip is not None else dx
         (dlu, dgu, dbetau), (dls, dgs, dbetas) = bn_bwd_pair((dup, lu, mu, iu, gu, betau), (dsk, ls, ms, is_, gs, betas),
@@ -1129,7 +1156,7 @@ class HeadLossFn(torch.autograd.Function):
         B = len(lvl.counts)
         h, hpre = linear_fwd(x, hw0, hb0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=seed)
         xt, _ = linear_fwd(h, hw3, hb3)
-        pc = torch.empty(B, C, dtype=torch.float32, device=dev)
+        pc = torch.empty(B, C, dtype=x.dtype, device=dev)
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
         ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
         call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg, ws, ws.numel())
@@ -1139,7 +1166,7 @@ class HeadLossFn(torch.autograd.Function):
         nb = xt.shape[1] // 3
         nrot = (ae.shape[1] - 1) // 3
         stats = torch.empty(query("lotus_loss_stats_floats", B), dtype=torch.float32, device=dev)
-        dae = torch.empty_like(ae)
+        dae = torch.empty(ae.shape, dtype=torch.float32, device=dev)  # saved gradient factors stay fp32
         if with_loss:
             call("lotus_loss_fwd", xt, ae, tgt, gt, lvl.off, B, nb, nrot, gt.shape[1], float(pos_w), float(rot_w),
                  losses, stats, dae)
@@ -1158,7 +1185,7 @@ class HeadLossFn(torch.autograd.Function):
         B = len(lvl.counts)
         gl = gl.contiguous()
         dxt = torch.empty_like(xt)
-        dae_o = torch.empty_like(dae)
+        dae_o = torch.empty(dae.shape, dtype=xt.dtype, device=dev)
         call("lotus_loss_bwd", xt, tgt, lvl.off, lvl.batch, stats, dae, gl, float(pos_w), float(rot_w), B, N, nb, nrot,
              dxt, dae_o)
         # action branch (B rows)
@@ -1243,7 +1270,7 @@ class PosCEFn(torch.autograd.Function):
         ctx.lvl = lvl
         return stats[:B * 12].view(B, 3, 4)[:, :, 0].clone()
 
-    @staticmethod
+    @_joined
     def backward(ctx, g):
         xt, tgt, stats = ctx.saved_tensors
         lvl = ctx.lvl
@@ -1258,23 +1285,24 @@ class TrajLossFn(torch.autograd.Function):
     cross entropy, openness / stop BCE and the masked mean of the heatmap cross entropies ce [B, T, 3].  Returns the
     vector (pos, rot, open, stop, total)."""
 
-    @staticmethod
+    @_fwd
     def forward(ctx, ae, ce, gt, stop, mask, nrot, pos_w, rot_w):
         B, T = mask.shape
-        ae, ce = ae.contiguous(), ce.contiguous()
+        ae, ce = ae.contiguous(), ce.contiguous().float()
         losses = torch.empty(5, dtype=torch.float32, device=ae.device)
-        dae = torch.empty_like(ae)
+        dae = torch.empty(ae.shape, dtype=torch.float32, device=ae.device)  # saved gradient factors stay fp32
         dce = torch.empty_like(ce)
         call("lotus_mp_loss_fwd", ae, gt, stop, mask, ce, B, T, nrot, gt.shape[-1], float(pos_w), float(rot_w), losses, dae, dce)
         ctx.save_for_backward(dae, dce)
         ctx.dims = (B, T, nrot, float(pos_w), float(rot_w))
         return losses
 
-    @staticmethod
+    @_joined
     def backward(ctx, g):
         dae, dce = ctx.saved_tensors
         B, T, nrot, pos_w, rot_w = ctx.dims
-        dae_o, dce_o = torch.empty_like(dae), torch.empty_like(dce)
+        dae_o = torch.empty(dae.shape, dtype=torch.bfloat16 if _capi.BF16 else torch.float32, device=dae.device)
+        dce_o = torch.empty_like(dce)
         call("lotus_mp_loss_bwd", dae, dce, g.contiguous().float(), pos_w, rot_w, B, T, nrot, dae_o, dce_o)
         return dae_o, dce_o, None, None, None, None, None, None
 
@@ -1286,7 +1314,7 @@ class CloudMaxFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, x, lvl):
         B, C = len(lvl.counts), x.shape[1]
-        y = torch.empty(B, C, dtype=torch.float32, device=x.device)
+        y = torch.empty(B, C, dtype=x.dtype, device=x.device)
         arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
         ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
         call("lotus_cloud_max_fwd", x, lvl.off, B, C, y, arg, ws, ws.numel())
@@ -1294,9 +1322,9 @@ class CloudMaxFn(torch.autograd.Function):
         ctx.lvl, ctx.n = lvl, x.shape[0]
         return y
 
-    @staticmethod
+    @_joined
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
-        dx = torch.empty(ctx.n, dy.shape[1], dtype=torch.float32, device=dy.device)
+        dx = torch.empty(ctx.n, dy.shape[1], dtype=dy.dtype, device=dy.device)
         call("lotus_cloud_max_bwd", dy.contiguous(), arg, ctx.lvl.batch, ctx.n, dy.shape[1], None, dx)
         return dx, None

@@ -89,10 +89,17 @@ class SimplePolicyPTV3CA(BaseModel):
     # -- reference API ---------------------------------------------------------------------
     def prepare_ptv3_batch(self, batch):
         """simple_policy_ptv3.py:403-431 (context = txt_fc(txt_embeds), one segment per cloud)."""
-        ctx = ops.LinearFn.apply(batch["txt_embeds"].contiguous(), self.txt_fc.weight, self.txt_fc.bias)
+        txt, feat = batch["txt_embeds"].contiguous(), batch["pc_fts"]
+        extra = {}
+        if self.act_storage == "bf16":
+            # bf16 activation storage: the network inputs are rounded once here (what autocast does to the first
+            # layers' inputs); the integer front end keeps reading the fp32 coordinates of pc_fts
+            txt, feat = txt.to(torch.bfloat16), feat.to(torch.bfloat16)
+            extra["coord_src"] = batch["pc_fts"]
+        ctx = ops.LinearFn.apply(txt, self.txt_fc.weight, self.txt_fc.bias)
         return {"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
-                "offset": batch["offset"], "feat": batch["pc_fts"], "context": ctx,
-                "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])}
+                "offset": batch["offset"], "feat": feat, "context": ctx,
+                "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"]), **extra}
 
     @torch.no_grad()
     def prefetch(self, batch):
@@ -114,13 +121,20 @@ class SimplePolicyPTV3CA(BaseModel):
         if not batch["pc_fts"].is_contiguous():
             batch["pc_fts"] = batch["pc_fts"].contiguous()
         self.ptv3_model.prefetch({"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
-                                  "offset": batch["offset"], "feat": batch["pc_fts"],
+                                  "offset": batch["offset"], "feat": batch["pc_fts"], "coord_src": batch["pc_fts"],
                                   "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])},
                                  wait_current=not on_host)
 
     gemm_precision = None  # 'fp32' | 'bf16x3' | 'bf16': operand precision of THIS model's products (None = ops default)
+    # None / 'fp32': activations are stored in fp32 (the parity path).  'bf16': every activation tensor in HBM is bf16,
+    # parameters, their gradients, statistics and accumulation stay fp32, products are bf16 MFMA — the configuration of
+    # BASELINE configs[4] (RLBench-18 / PerAct, bf16); runs the lotus_b16_* twins of the C-ABI (include/lotus_hip_b16.h)
+    act_storage = None
 
     def forward(self, batch, compute_loss=False, **kwargs):
+        if self.act_storage == "bf16":
+            with ops.storage(torch.bfloat16):
+                return self._forward(batch, compute_loss, **kwargs)
         with ops.precision(self.gemm_precision):
             return self._forward(batch, compute_loss, **kwargs)
 

@@ -257,7 +257,9 @@ class PointTransformerV3CA(nn.Module):
         if context is not None:
             context = context.contiguous()
         coord = data_dict["coord"]
-        src = feat if (coord.data_ptr() == feat.data_ptr() and feat.shape[1] >= 3) else coord.contiguous()
+        src = data_dict.get("coord_src")  # optional: the fp32 row-major tensor whose first three columns are `coord`
+        if src is None or src.dtype != torch.float32 or not src.is_contiguous() or src.data_ptr() != coord.data_ptr():
+            src = feat if (coord.data_ptr() == feat.data_ptr() and feat.shape[1] >= 3) else coord.contiguous()
         self.frontend.grid_size = float(np.float32(data_dict.get("grid_size", 0.01)))
         return feat, src, counts, ctx_counts, context
 

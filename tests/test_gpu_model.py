@@ -255,6 +255,57 @@ def test_peract_config_bf16_backward_with_augmented_dense_clouds():
         assert rel < gtol and cos > cos_min, (mode, rel, cos)
 
 
+def test_peract_config_bf16_storage_forward_backward():
+    """BASELINE configs[4] as SURVEY 8(d) reads it: bf16 ACTIVATION STORAGE (every [N, C] tensor in HBM is bf16: the
+    lotus_b16_* twins of the C-ABI), fp32 master weights, fp32 parameter gradients, fp32 accumulation.  PerAct preset, two
+    dense 4096-point clouds after the PerAct augmentation (duplicate voxels), train mode, against the fp32 oracle under
+    autograd.  Bounds are bf16-sized and were measured on MI355X (see profiles/r03_parity.json): logits relative to the
+    largest logit, the whole gradient in norm and direction.  The fp32 model on the same inputs stays at fp32 accuracy, and
+    a forward pass of an fp32 model after the bf16 one is bit-identical to one before it (no state leaks between the two
+    storage modes)."""
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("peract")
+    sd = seeded_state_dict(gu.state_template(cfg), 93, "init")
+    batch = synth.augment_clouds(synth.synth_batch(2, 4096, ragged=False, seed=323), seed=10, max_rot_deg=45.0)
+    perms = [[3, 1, 0, 2], [0, 2, 1, 3], [1, 0, 3, 2], [2, 3, 1, 0], [0, 1, 2, 3]]
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(cfg), training=True).forward(batch, perms)
+    out["losses"]["total"].backward()
+    ref = out["xt"].detach().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    names = [n for n, _ in _build(cfg, sd, True).named_parameters()]
+    gref = torch.cat([sdg[n].grad.flatten() for n in names])
+
+    def run(storage):
+        m = _build(cfg, sd, True)
+        m.act_storage = storage
+        m.ptv3_model.order_perms = perms
+        _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        return m, losses
+
+    m32, l32 = run(None)
+    xt32 = m32.last_pred[0].detach().clone()
+    mb, lb = run("bf16")
+    assert mb.last_pred[0].dtype == torch.bfloat16 and all(p.grad.dtype == torch.float32 for p in mb.parameters())
+    err = float(np.abs(mb.last_pred[0].detach().float().cpu().numpy() - ref).max()) / scale
+    g = torch.cat([p.grad.flatten() for p in mb.parameters()]).cpu()
+    assert torch.isfinite(g).all()
+    rel = float((g - gref).norm() / gref.norm())
+    cos = float(torch.dot(g.double(), gref.double()) / (g.double().norm() * gref.double().norm()))
+    lerr = abs(lb["total"].item() - out["losses"]["total"].item()) / max(1.0, abs(out["losses"]["total"].item()))
+    ledger.record("peract_bf16_storage/2x4096_augmented", logit_rel_err=err, loss_rel_err=lerr, grad_rel_err=rel, grad_cosine=cos,
+                  logit_max=scale)
+    assert err <= 3e-2 and lerr <= 3e-2 and rel < 0.35 and cos > 0.95, (err, lerr, rel, cos)
+    m32b, _ = run(None)
+    assert torch.equal(m32b.last_pred[0], xt32), "fp32 forward changed after a bf16-storage pass"
+    assert all(torch.equal(a.grad, b.grad) for a, b in zip(m32.parameters(), m32b.parameters()))
+    assert float(np.abs(xt32.cpu().numpy() - ref).max()) <= LOGIT_TOL * scale
+
+
 def test_full_size_train_step_properties():
     """BASELINE configs[1] size (16 x 4096, v1): forward+backward runs, everything finite, every
     parameter receives a gradient, eval-mode API returns f64[B, 8] like the reference."""
