@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
       st4q(p.y, i + step, one(xb, db));
     }
     if (i < p.total4)
-      st4q(p.y, i, one(reinterpret_cast<const float4*>(p.x)[i], p.dy ? reinterpret_cast<const float4*>(p.dy)[i] : z4));
+      st4q(p.y, i, one(ld4q(p.x, i), p.dy ? ld4q(p.dy, i) : z4));
   }
   if (p.dy && p.dgamma && blockIdx.x == 0) {
     for (int c = threadIdx.x; c < p.C; c += 256) {
