@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=16, help="key-step clouds per GPU")
     ap.add_argument("--npoints", type=int, default=4096)
+    ap.add_argument("--ragged", action="store_true",
+                    help="clouds of n ~ U(npoints / 2, npoints) points (SURVEY 8d: the ragged variant of the canonical batch; the "
+                         "headline is quoted on exactly npoints per cloud)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--with-optimizer", action="store_true",
@@ -220,6 +223,9 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus}, "
                          f"or start bench.py bare and let it spawn its ranks)")
     rccl_ranks = world if (dist.is_initialized() and dist.get_backend() == "nccl") else 0
+    if world > 1 and torch.cuda.device_count() >= world and rccl_ranks != world:
+        raise SystemExit(f"bench.py: {world} ranks on {torch.cuda.device_count()} visible devices must run over RCCL "
+                         f"(backend is {dist.get_backend() if dist.is_initialized() else None})")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     torch.manual_seed(0)
@@ -238,7 +244,7 @@ def main():
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1" or dist.is_initialized():  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
         parallel.enable_sync_batchnorm()
-    host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, seed=rank)
+    host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, ragged=args.ragged, seed=rank)
     if peract:  # aug_max_rot 45 + jitter (job_scripts/train_3dlotus_policy_peract.sh:42): 1-7 % duplicate voxels
         host_batch = synth.augment_clouds(host_batch, seed=rank, max_rot_deg=45.0)
     batch = dev_batch(host_batch, dev)
@@ -323,6 +329,39 @@ def main():
                 d2 = float(t.item())
             other[mode] = round(args.batch * world * 20 / d2, 2)
         ops.set_gemm_precision("fp32")
+
+    # side measurement: the same step followed by lr schedule + clip_grad_norm_(10) + fused AdamW (what a
+    # trainer iteration adds to the headline's forward + backward), reported next to the headline, never as `value`
+    with_opt = None
+    if opt is None and not mp and not peract and args.gemm_precision == "fp32" and not args.no_other_modes:
+        from types import SimpleNamespace
+        from robot_3dlotus_amd import optim as loptim
+        topts = SimpleNamespace(learning_rate=1e-4, weight_decay=0.05, optim="adamw", betas=[0.9, 0.98], lr_sched="cosine",
+                                warmup_steps=5000, num_train_steps=150000, grad_norm=10.0)  # simple_policy_ptv3.yaml TRAIN
+        backup = [p.detach().clone() for p in params]
+        opt, init_lrs = loptim.build_optimizer(model, topts)
+        gstep = [0]
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(15):
+            step()
+        torch.cuda.synchronize()
+        d4 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([d4], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d4 = float(t.item())
+        with_opt = {"value": round(args.batch * world * 15 / d4, 2), "unit": "keystep-samples/s", "steps": 15,
+                    "ms_per_step": round(d4 / 15 * 1e3, 3),
+                    "note": "forward + backward + lr schedule + clip_grad_norm_(10) + fused multi-tensor AdamW (csrc/optim.hip)"}
+        opt = None
+        with torch.no_grad():
+            for p_, b_ in zip(params, backup):
+                p_.copy_(b_)
 
     # end-to-end side measurement: a NEW host batch every step (pinned + packed by the collate function, as a DataLoader
     # with pin_memory would hand it over), uploaded and serialised by prefetch() under the previous step's backward, so
@@ -413,6 +452,15 @@ def main():
             out["config"].pop("model_gflop_per_sample"); out["config"].pop("model_tflops")
         if fresh is not None:
             out["fresh_batches"] = fresh
+        if with_opt is not None:
+            out["with_optimizer"] = with_opt
+        if args.ragged:
+            out["config"]["workload"] += f"; RAGGED clouds n ~ U({args.npoints // 2}, {args.npoints}) ({sum(host_batch['npoints_in_batch'])} points on rank 0)"
+        if reducer is not None:
+            sizes = [(hi_ - lo_) * 4 / 2 ** 20 for lo_, hi_ in reducer.buckets]
+            out["reducer"] = {"buckets": len(sizes), "bucket_mb": [round(x, 1) for x in sizes], "last_bucket_mb": round(sizes[-1], 1),
+                              "gradient_mb": round(sum(sizes), 1), "syncbn_messages_per_step": "18 forward + 26 backward (fp64, own communicator)",
+                              "points_rank0": int(sum(host_batch["npoints_in_batch"]))}
         if peract:
             out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"
             out["config"]["workload"] = (f"3D-LOTUS v1 network, PerAct preset (BASELINE configs[4]), {args.batch} dense clouds x {args.npoints} pts "

@@ -348,6 +348,11 @@ int lotus_step_act_bwd(const lotus_act_t* dh, const lotus_act_t* base, const flo
 int lotus_add(const lotus_act_t* a, const lotus_act_t* b, lotus_act_t* y, long n, void* stream);
 /* nn.Dropout with a stateless counter-based mask (same (seed, index) -> same mask in backward) */
 int lotus_dropout(const lotus_act_t* x, lotus_act_t* y, long n, float p, unsigned long long seed, void* stream);
+/* DropPath / stochastic depth (timm.DropPath on the attention and MLP branches of a Block, model.py:655-657,666,672): one
+ * Bernoulli draw per row, kept rows scaled by 1 / (1 - p); y = x + s_row * branch, x optional (null: y = s_row * branch, which
+ * is also the backward map).  Stateless: keep iff hash(seed, row) >= p * 2^32.  C % 4 == 0. */
+int lotus_drop_path(const lotus_act_t* branch, const lotus_act_t* x, lotus_act_t* y, int M, int C, float p, unsigned long long seed,
+                    void* stream);
 
 /* ---- soft position targets / arg-max position decode: get_disc_gt_pos_prob and
  * get_best_pos_from_disc_pos(best='max'), genrobo3d/utils/action_position_utils.py:7-46, :48-64.  pc = point rows whose

@@ -133,14 +133,16 @@ class Oracle:
         return self.lin(F.gelu(self.lin(x, name + ".fc1")), name + ".fc2")
 
     # -- blocks ----------------------------------------------------------------------------
-    def block(self, x, xs, lvl, name, H, patch_size):
+    def block(self, x, xs, lvl, name, H, patch_size, order_index=0):
         """Block.forward, PointTransformerV3/model.py:659-680.  xs = sparse_conv_feat.features
-        (== x in the encoder, == proj_skip branch only in the decoder: Trap 3)."""
+        (== x in the encoder, == proj_skip branch only for the first Block of a decoder stage: Trap 3).  order_index =
+        i % len(order) for the i-th Block of a stage (model_ca.py:285,354).  DropPath (model.py:655-657) is the identity in
+        every configuration the oracle is run in (drop_path 0, or eval mode)."""
         sd = self.sd
         c = subm_conv(xs, lvl["nbr27_t"], sd[name + ".cpe.0.weight"], sd[name + ".cpe.0.bias"])
         x = x + self.ln(self.lin(c, name + ".cpe.1"), name + ".cpe.2")
         qkv = self.lin(self.ln(x, name + ".norm1.0"), name + ".attn.qkv")
-        a = patch_attention(qkv, lvl, 0, H, sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
+        a = patch_attention(qkv, lvl, order_index, H, sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
                             sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], patch_size,
                             self.fp16_attn)
         x = x + self.lin(a, name + ".attn.proj")
@@ -164,6 +166,7 @@ class Oracle:
         """SimplePolicyPTV3AdaNorm.forward + SimplePolicyPTV3CA.prepare_ptv3_batch,
         simple_policy_ptv3.py:225-306, :403-431.  batch uses the reference schema
         (pc_fts, npoints_in_batch, txt_embeds, txt_lens, gt_actions, disc_pos_probs)."""
+        assert not (self.training and self.cfg["ptv3"].get("drop_path", 0.0) > 0), "oracle: DropPath masks are not reproducible"
         pc32 = batch["pc_fts"].float()
         pc = pc32.to(self.dt)
         counts = list(batch["npoints_in_batch"])
@@ -201,8 +204,9 @@ class Oracle:
                 x = proj.new_zeros(lvl["grid"].shape[0], proj.shape[1]).scatter_reduce(
                     0, cl, proj, reduce="amax", include_self=False)
                 x = F.gelu(self.bn(x, name + ".down.norm.0"))
-            x = self.block(x, x, lvl, name + ".block0", p3["enc_num_head"][s], p3["enc_patch_size"][s])
-            x = self.ca_block(x, lvl, ctx, ctx_counts, name + ".ca_block0", p3["enc_num_head"][s])
+            for i in range(p3["enc_depths"][s]):  # model_ca.py:270-310
+                x = self.block(x, x, lvl, name + f".block{i}", p3["enc_num_head"][s], p3["enc_patch_size"][s], i % 4)
+                x = self.ca_block(x, lvl, ctx, ctx_counts, name + f".ca_block{i}", p3["enc_num_head"][s])
             skips.append(x)
         feats.append(x)
         for s in reversed(range(n_lv - 1)):  # SerializedUnpooling, model.py:817-828
@@ -211,8 +215,10 @@ class Oracle:
             up = F.gelu(self.bn(self.lin(x, name + ".up.proj.0"), name + ".up.proj.1"))
             skip = F.gelu(self.bn(self.lin(skips[s], name + ".up.proj_skip.0"), name + ".up.proj_skip.1"))
             x = skip + up[_t(levels[s + 1]["cluster"])]
-            x = self.block(x, skip, lvl, name + ".block0", p3["dec_num_head"][s], p3["dec_patch_size"][s])
-            x = self.ca_block(x, lvl, ctx, ctx_counts, name + ".ca_block0", p3["dec_num_head"][s])
+            for i in range(p3["dec_depths"][s]):  # model_ca.py:340-380; later Blocks see the refreshed sparse_conv_feat
+                x = self.block(x, skip if i == 0 else x, lvl, name + f".block{i}", p3["dec_num_head"][s],
+                               p3["dec_patch_size"][s], i % 4)
+                x = self.ca_block(x, lvl, ctx, ctx_counts, name + f".ca_block{i}", p3["dec_num_head"][s])
             feats.append(x)
         out["feats"] = feats
         return x, out

@@ -82,6 +82,11 @@ TINY_OVERRIDES = V1_OVERRIDES + [
 ]
 
 
+# the tiny width with stages deeper than one Block (the reference YAML default is enc_depths [2, 2, 2, 6, 2]): Block i of a
+# stage attends along curve slot i % 4, so depth 5 wraps around the four curves
+TINYDEEP_OVERRIDES = TINY_OVERRIDES + ["ptv3_config.enc_depths", "[2, 5]", "ptv3_config.dec_depths", "[2]"]
+
+
 def _parse(v):
     if not isinstance(v, str):
         return v
@@ -154,7 +159,8 @@ def preset(name="v1"):
         model["model_class"] = _YAML_MP_DELTA["model_class"]
         model["action_config"].update(_YAML_MP_DELTA["action_config"])
         return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES}[name]))
-    return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES, "peract": PERACT_OVERRIDES}[name])
+    return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES, "peract": PERACT_OVERRIDES,
+                                    "tinydeep": TINYDEEP_OVERRIDES}[name])
 
 
 def plain(cfg):

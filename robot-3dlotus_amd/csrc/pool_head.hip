@@ -419,6 +419,24 @@ __global__ void dropout_mask_kernel(const act_t* __restrict__ x, act_t* __restri
     y[i] = x[i] * dropout_scale(seed, (unsigned long long)i, thresh, inv_keep);
 }
 
+// DropPath (stochastic depth, timm.DropPath as the reference's Block uses it on the attention and MLP branches,
+// PointTransformerV3/model.py:655-657,666,672): one Bernoulli draw per ROW (the tensor is [points][channels], so a "sample" is a
+// point), kept rows scaled by 1 / (1 - p).  y = x + s_row * branch (x optional: the backward pass is the same map without it).
+// Stateless like the dropout mask: keep iff hash(seed, row) >= p * 2^32.
+__global__ void drop_path_kernel(const act_t* __restrict__ branch, const act_t* __restrict__ x, act_t* __restrict__ y,
+                                 long total4, int c4n, unsigned long long seed, unsigned thresh, float inv_keep) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const float s = dropout_scale(seed, (unsigned long long)(i / c4n), thresh, inv_keep);
+    float4 v = ld4q(branch, i);
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    if (x) {
+      const float4 r = ld4q(x, i);
+      v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    st4q(y, i, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Trajectory head of the motion planner (genrobo3d/models/motion_planner_ptv3.py:88-97,113-114): the hidden layer of
 // step t is dropout(LeakyReLU(base + bias_t)) where base = x W_x^T is shared by all steps and bias_t carries the step
@@ -775,6 +793,20 @@ int lotus_dropout(const act_t* x, act_t* y, long n, float p, unsigned long long 
   LOTUS_LAUNCH(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
                      1.f / (1.f - p));
   LOTUS_LAUNCH_CHECK("lotus_dropout");
+  return LOTUS_OK;
+}
+
+// y = x + droppath(branch) (x may be null): rows [M] of C channels, C % 4 == 0
+int lotus_drop_path(const act_t* branch, const act_t* x, act_t* y, int M, int C, float p, unsigned long long seed, void* stream) {
+  LOTUS_CHECK_ARG(branch && y && M >= 0 && C > 0 && C % 4 == 0 && p >= 0.f && p < 1.f, "lotus_drop_path: bad arguments");
+  if (M == 0) return LOTUS_OK;
+  unsigned th = (unsigned)(p * 4294967296.0);
+  if (p > 0.f && th == 0) th = 1;
+  const long total4 = (long)M * (C / 4);
+  int g = cdiv(total4, 256);
+  LOTUS_LAUNCH(drop_path_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, branch, x, y, total4, C / 4, seed, th,
+               p > 0.f ? 1.f / (1.f - p) : 1.f);
+  LOTUS_LAUNCH_CHECK("lotus_drop_path");
   return LOTUS_OK;
 }
 

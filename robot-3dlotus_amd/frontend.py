@@ -20,7 +20,23 @@ class Level:
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
                  "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
-                 "coord", "parent", "n_dup")
+                 "coord", "parent", "n_dup", "patch", "_views")
+
+    def for_order(self, k):
+        """The level as the k-th block of a stage sees it: `Block(order_index = i % len(order))` attends along curve slot k
+        (model.py:480-481, model_ca.py:285,354), so only the patch gather tables differ; everything else is shared."""
+        if k == 0:
+            return self
+        v = self._views.get(k)
+        if v is None:
+            v = Level()
+            for name in Level.__slots__:
+                if name not in ("_views",) and hasattr(self, name):
+                    setattr(v, name, getattr(self, name))
+            v.gidx, v.owner, v.kext, v.ext_pos = self.patch[k]
+            v._views = {}
+            self._views[k] = v
+        return v
 
 
 def draw_order_perms(n_levels, shuffle=True):
@@ -33,8 +49,9 @@ def draw_order_perms(n_levels, shuffle=True):
 
 
 class FrontEnd:
-    def __init__(self, n_levels, patch_size=128, grid_size=0.01, orders=ORDERS):
+    def __init__(self, n_levels, patch_size=128, grid_size=0.01, orders=ORDERS, n_patch_orders=1):
         self.n_levels = n_levels
+        self.n_patch_orders = max(1, min(4, int(n_patch_orders)))  # curve slots whose patch tables are built (stage depth)
         self.K = patch_size
         self.grid_size = float(np.float32(grid_size))
         self.order_ids = [ORDERS.index(o) for o in orders]
@@ -229,6 +246,12 @@ class FrontEnd:
             lv.ext_pos = torch.empty(max(lv.n_extra, 1), **i32)
             call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner, lv.kext,
                  lv.ext_pos)
+            lv.patch, lv._views = [(lv.gidx, lv.owner, lv.kext, lv.ext_pos)], {}
+            for k in range(1, self.n_patch_orders):  # deeper stages: block i attends along curve slot i % 4
+                tabs_k = (torch.empty(lv.npad, **i32), torch.empty(lv.npad, **i32), torch.empty(lv.npad, **i32),
+                          torch.empty(max(lv.n_extra, 1), **i32))
+                call("lotus_fe_patch", r["order"][k], lv.off, view(pl["offp"]), B, K, lv.npad, *tabs_k)
+                lv.patch.append(tabs_k)
             lv.self_tiles, lv.self_blocks = view(pl["tiles"], 4), view(pl["blocks"], 6)
             lv.n_self_tiles = pl["n_tiles"]
             lv.ca_tiles, lv.ca_blocks = view(pl["ca_tiles"], 4), view(pl["ca_blocks"], 6)

@@ -553,6 +553,15 @@ def sum_slabs(part):
     return out
 
 
+def drop_path(branch, x, p, seed):
+    """x + DropPath(branch) (x may be None: the per-row mask alone, i.e. the backward map); timm.DropPath semantics, one
+    draw per point row (model.py:655-657)."""
+    M, C = branch.shape
+    y = torch.empty_like(branch)
+    call("lotus_drop_path", branch, x, y, M, C, float(p), int(seed))
+    return y
+
+
 def add(a, b):
     y = torch.empty_like(a)
     call("lotus_add", a, b, y, a.numel())
@@ -813,12 +822,17 @@ class FfnFn(torch.autograd.Function):
     """y = x + drop(fc2(drop(GELU(fc1(LN(x))))))   (MLP, model.py:577-583; pre-norm residual)."""
 
     @_fwd
-    def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed, hand_in=None, hand_out=None):
+    def forward(ctx, x, g, b, w1, b1, w2, b2, drop_p, seed, hand_in=None, hand_out=None, dpath=0.0):
+        # dpath > 0: DropPath on the branch (Block.mlp only, training only; model.py:672) — its own elementwise pass, the
+        # per-launch path, no hand-over of a pre-masked gradient (the published models train with drop_path 0)
         ctx.drop = (drop_p, seed)
+        ctx.dpath = float(dpath)
+        if dpath > 0.0:
+            hand_in = None
         ctx.hands = (hand_in, hand_out)
         if hand_in is not None:
             hand_in.arm(drop_p, mix_seed(seed, 1))
-        ctx.comp = composites_enabled() and x.shape[1] % 4 == 0
+        ctx.comp = composites_enabled() and x.shape[1] % 4 == 0 and dpath == 0.0
         if ctx.comp:
             M, C = x.shape
             Hd = w1.shape[0]
@@ -832,7 +846,11 @@ class FfnFn(torch.autograd.Function):
             return y
         n, mean, rstd = ln_fwd(x, g, b)
         a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
-        y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
+        if dpath > 0.0:
+            br, _ = linear_fwd(a, w2, b2, drop_p=drop_p, seed=mix_seed(seed, 1))
+            y = drop_path(br, x, dpath, mix_seed(seed, 5))
+        else:
+            y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
         ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         return y
 
@@ -863,29 +881,33 @@ class FfnFn(torch.autograd.Function):
             o1 = 2 * _al4(C)
             o2 = o1 + _al4(Hd * C + Hd)
             return (dx, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + Hd * C].view(Hd, C), grads[o1 + Hd * C:o1 + Hd * C + Hd],
-                    grads[o2:o2 + C * Hd].view(C, Hd), grads[o2 + C * Hd:o2 + C * Hd + C], None, None, None, None)
+                    grads[o2:o2 + C * Hd].view(C, Hd), grads[o2 + C * Hd:o2 + C * Hd + C], None, None, None, None, None)
         x, g, w1, w2, n, hpre, a, mean, rstd = ctx.saved_tensors
-        dz2 = _masked(dy, p, mix_seed(seed, 1), hand_in)
+        dyb = drop_path(dy, None, ctx.dpath, mix_seed(seed, 5)) if ctx.dpath > 0.0 else dy
+        dz2 = _masked(dyb, p, mix_seed(seed, 1), hand_in)
         dw2, db2 = linear_wgrad(dz2, a)
         dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
         dw1, db1 = linear_wgrad(dh, n)
         dn = linear_dgrad(dh, w1)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
-        return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None
+        return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None, None
 
 
 class SelfAttnFn(torch.autograd.Function):
     """y = x + drop(proj(PatchAttention(qkv(LN(x)))))   (SerializedAttention flash path)."""
 
     @_fwd
-    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0, hand_in=None):
+    def forward(ctx, x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p=0.0, hand_in=None, dpath=0.0):
         N, C = x.shape
         d = C // H
         ctx.meta = (lvl, H, d, drop_p, seed, attn_p)
+        ctx.dpath = float(dpath)  # DropPath on the branch (model.py:666), see FfnFn
+        if dpath > 0.0:
+            hand_in = None
         ctx.hand_in = hand_in
         if hand_in is not None:
             hand_in.arm(drop_p, seed)
-        ctx.comp = composites_enabled() and C % 4 == 0
+        ctx.comp = composites_enabled() and C % 4 == 0 and dpath == 0.0
         if ctx.comp:
             n_saved, _, _, ws_main, _ = _sizes("self", N, C, H, lvl.npad, lvl.n_self_tiles, lvl.n_extra)
             saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
@@ -902,7 +924,11 @@ class SelfAttnFn(torch.autograd.Function):
         lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
         attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
                       lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, mix_seed(seed, 1))
-        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        if dpath > 0.0:
+            br, _ = linear_fwd(att, wp, bp, drop_p=drop_p, seed=seed)
+            y = drop_path(br, x, dpath, mix_seed(seed, 5))
+        else:
+            y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
         return y
 
@@ -932,10 +958,11 @@ class SelfAttnFn(torch.autograd.Function):
             return (dx, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + 3 * C * C].view(3 * C, C),
                     grads[o1 + 3 * C * C:o1 + 3 * C * C + 3 * C], grads[o2:o2 + d], grads[o2 + d4:o2 + d4 + d],
                     grads[o2 + 2 * d4:o2 + 2 * d4 + d], grads[o2 + 3 * d4:o2 + 3 * d4 + d], grads[o3:o3 + C * C].view(C, C),
-                    grads[o3 + C * C:o3 + C * C + C], None, None, None, None, None, None)
+                    grads[o3 + C * C:o3 + C * C + C], None, None, None, None, None, None, None)
         x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd = ctx.saved_tensors
         N, C = x.shape
-        dz = _masked(dy, p, seed, ctx.hand_in)
+        dyb = drop_path(dy, None, ctx.dpath, mix_seed(seed, 5)) if ctx.dpath > 0.0 else dy
+        dz = _masked(dyb, p, seed, ctx.hand_in)
         dwp, dbp = linear_wgrad(dz, att)
         datt = linear_dgrad(dz, wp)
         # every (point, q|k|v column) is written exactly once by its owner position; the k/v gradients of the
@@ -949,7 +976,7 @@ class SelfAttnFn(torch.autograd.Function):
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
         dn = linear_dgrad(dqkv, wqkv)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
-        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None, None
+        return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None, None, None
 
 
 class CrossAttnFn(torch.autograd.Function):

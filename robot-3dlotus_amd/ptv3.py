@@ -73,20 +73,21 @@ class Block(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, xs, lvl, drop_p, seed, attn_p=0.0, wt=None):
+    def run(self, x, xs, lvl, drop_p, seed, attn_p=0.0, wt=None, dpath=0.0):
         """-> (x, hand): `hand` lets the next sub-block's backward pre-mask the gradient this block's MLP needs
-        (ops.Handoff; the blocks of a stage form a chain with a single consumer each)."""
+        (ops.Handoff; the blocks of a stage form a chain with a single consumer each).  `lvl` carries the patch tables of
+        this block's curve slot (Level.for_order); dpath = DropPath rate of the attention and MLP branches (training)."""
         c0, c1, c2 = self.cpe[0], self.cpe[1], self.cpe[2]
         x = ops.CpeFn.apply(x, xs, c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias, lvl, wt)
         a, n1 = self.attn, self.norm1[0]
         h_attn, h_mlp = ops.Handoff(), ops.Handoff()
         x = ops.SelfAttnFn.apply(x, n1.weight, n1.bias, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.q_norm.bias,
                                  a.k_norm.weight, a.k_norm.bias, a.proj.weight, a.proj.bias, lvl, self.num_heads,
-                                 drop_p, seed, attn_p, h_attn)
+                                 drop_p, seed, attn_p, h_attn, dpath)
         m, n2 = self.mlp[0], self.norm2[0]
         x = ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
-                            ops.mix_seed(seed, 2), h_mlp, h_attn)
-        return x, h_mlp
+                            ops.mix_seed(seed, 2), h_mlp, h_attn, dpath)
+        return x, (h_mlp if dpath == 0.0 else None)
 
 
 class CABlock(nn.Module):
@@ -163,8 +164,8 @@ class PointTransformerV3CA(nn.Module):
         unsupported = dict(pdnorm_bn=pdnorm_bn, pdnorm_ln=pdnorm_ln, enable_rpe=enable_rpe, cls_mode=cls_mode,
                            scaled_cosine_attn=scaled_cosine_attn, not_flash=not enable_flash, not_qk_norm=not qk_norm,
                            not_pre_norm=not pre_norm, no_qkv_bias=not qkv_bias, qk_scale=qk_scale is not None,
-                           add_coords=add_coords_in_attn not in (False, "none", None), drop_path=drop_path > 0,
-                           depth_gt_1=any(d != 1 for d in list(enc_depths) + list(dec_depths)),
+                           add_coords=add_coords_in_attn not in (False, "none", None),
+                           depth_lt_1=any(d < 1 for d in list(enc_depths) + list(dec_depths)),
                            stride_ne_2=any(s != 2 for s in stride),
                            patch_ne_128=any(p > 128 for p in list(enc_patch_size) + list(dec_patch_size)))
         bad = [k for k, v in unsupported.items() if v]
@@ -177,7 +178,16 @@ class PointTransformerV3CA(nn.Module):
         self.shuffle_orders = shuffle_orders
         self.proj_drop, self.attn_drop = float(proj_drop), float(attn_drop)
         self.enc_channels, self.dec_channels = list(enc_channels), list(dec_channels) + [enc_channels[-1]]
-        self.frontend = FrontEnd(self.num_stages, patch_size=enc_patch_size[0], orders=self.order)
+        self.enc_depths, self.dec_depths = [int(d) for d in enc_depths], [int(d) for d in dec_depths]
+        self.frontend = FrontEnd(self.num_stages, patch_size=enc_patch_size[0], orders=self.order,
+                                 n_patch_orders=max(self.enc_depths + self.dec_depths))
+        # stochastic-depth schedule, model_ca.py:250-252,316-325: linear in the block index over the whole encoder /
+        # decoder; the decoder's per-stage slice is reversed
+        ed = torch.linspace(0, drop_path, sum(self.enc_depths)).tolist()
+        dd = torch.linspace(0, drop_path, sum(self.dec_depths)).tolist() if self.dec_depths else []
+        self.enc_drop_path = [ed[sum(self.enc_depths[:s]):sum(self.enc_depths[:s + 1])] for s in range(self.num_stages)]
+        self.dec_drop_path = [list(reversed(dd[sum(self.dec_depths[:s]):sum(self.dec_depths[:s + 1])]))
+                              for s in range(self.num_stages - 1)]
 
         self.embedding = _Embedding(in_channels, enc_channels[0])
         self.enc = nn.Sequential()
@@ -185,16 +195,18 @@ class PointTransformerV3CA(nn.Module):
             enc = nn.Sequential()
             if s > 0:
                 enc.add_module("down", _Down(enc_channels[s - 1], enc_channels[s]))
-            enc.add_module("block0", Block(enc_channels[s], enc_num_head[s], mlp_ratio))
-            enc.add_module("ca_block0", CABlock(enc_channels[s], enc_num_head[s], ctx_channels, mlp_ratio))
+            for i in range(self.enc_depths[s]):  # model_ca.py:270-310: Block i, then CABlock i
+                enc.add_module(f"block{i}", Block(enc_channels[s], enc_num_head[s], mlp_ratio))
+                enc.add_module(f"ca_block{i}", CABlock(enc_channels[s], enc_num_head[s], ctx_channels, mlp_ratio))
             self.enc.add_module(f"enc{s}", enc)
         self.dec = nn.Sequential()
         dc = self.dec_channels
         for s in reversed(range(self.num_stages - 1)):
             dec = nn.Sequential()
             dec.add_module("up", _Up(dc[s + 1], enc_channels[s], dc[s]))
-            dec.add_module("block0", Block(dc[s], dec_num_head[s], mlp_ratio))
-            dec.add_module("ca_block0", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
+            for i in range(self.dec_depths[s]):  # model_ca.py:340-380
+                dec.add_module(f"block{i}", Block(dc[s], dec_num_head[s], mlp_ratio))
+                dec.add_module(f"ca_block{i}", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
             self.dec.add_module(f"dec{s}", dec)
         self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
         self._seed_base = None
@@ -310,8 +322,9 @@ class PointTransformerV3CA(nn.Module):
         site = 0
 
         st = self.embedding.stem
-        blocks = [e.block0 for e in self.enc] + [d.block0 for d in self.dec]
+        blocks = [m for m in self.modules() if isinstance(m, Block)]
         packs = dict(zip(blocks, ops.prepack_conv_weights([b.cpe[0].weight for b in blocks])))
+        n_ord = len(self.order)
         # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input
         # features are a linear code of something smaller, e.g. the motion planner's label embedding
         x = ops.StemFn.apply(feat, data_dict.get("stem_weight", st.conv.weight), st.norm.weight, st.norm.bias, st.norm.running_mean,
@@ -326,8 +339,12 @@ class PointTransformerV3CA(nn.Module):
                 d, bn = enc.down, enc.down.norm[0]
                 x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                      lvl, training)
-            x, hand = enc.block0.run(x, x, lvl, p, seed, pa, packs[enc.block0])
-            x = enc.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa, hand)
+            for i in range(self.enc_depths[s]):
+                blk, cab = getattr(enc, f"block{i}"), getattr(enc, f"ca_block{i}")
+                si = seed if i == 0 else ops.mix_seed(seed, 16 + i)
+                x, hand = blk.run(x, x, lvl.for_order(i % n_ord), p, si, pa, packs[blk],
+                                  self.enc_drop_path[s][i] if training else 0.0)
+                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand)
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
@@ -338,7 +355,13 @@ class PointTransformerV3CA(nn.Module):
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
                                          us[1].running_mean, us[1].running_var, child, training)
-            x, hand = dec.block0.run(x, skip, lvl, p, seed, pa, packs[dec.block0])
-            x = dec.ca_block0.run(x, context, lvl, p, ops.mix_seed(seed, 8), pa, hand)
+            for i in range(self.dec_depths[s]):
+                blk, cab = getattr(dec, f"block{i}"), getattr(dec, f"ca_block{i}")
+                si = seed if i == 0 else ops.mix_seed(seed, 16 + i)
+                # only the first Block of a decoder stage sees the stale skip branch in its CPE convolution (Trap 3):
+                # every Block / CABlock ends with sparse_conv_feat.replace_feature(feat) (model.py:678, model_ca.py:151)
+                x, hand = blk.run(x, skip if i == 0 else x, lvl.for_order(i % n_ord), p, si, pa, packs[blk],
+                                  self.dec_drop_path[s][i] if training else 0.0)
+                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand)
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]

@@ -17,6 +17,7 @@ does, model.py:544 / model_ca.py:63) is stored next to each fp32-ideal output to
 """
 import copy
 import os
+import re
 import sys
 
 import numpy as np
@@ -38,6 +39,10 @@ CASES = {
     "v1_init_train": ("v1", 2, 1024, True, 13, 2, "init", True),
     "v1_scaled_train": ("v1", 2, 1024, True, 14, 3, "scaled", True),
     "v1_scaled_eval": ("v1", 2, 1024, True, 15, 3, "scaled", False),
+    # stages deeper than one Block (enc_depths [2, 5], dec_depths [2] on the tiny width: order_index = i % 4 wraps); the eval
+    # case carries the YAML's drop_path 0.1 (DropPath is the identity in eval mode, model.py:655-657)
+    "tinydeep_scaled_train": ("tinydeep", 2, 700, True, 16, 4, "scaled", True),
+    "tinydeep_scaled_eval": ("tinydeep", 2, 700, True, 17, 4, "scaled", False, 0.1),
 }
 GRAD_KEYS_SAMPLE = 48  # leading entries of every gradient kept besides its norm
 
@@ -51,9 +56,10 @@ def zero_dropouts(model):
 
 
 def run_case(name, spec):
-    variant, B, n, ragged, dseed, wseed, wvar, train = spec
+    variant, B, n, ragged, dseed, wseed, wvar, train = spec[:8]
+    drop_path = spec[8] if len(spec) > 8 else 0.0
     torch.manual_seed(0)
-    ref, cfg = rh.build_reference_policy(variant)
+    ref, cfg = rh.build_reference_policy(variant, drop_path=drop_path)
     sd = seeded_state_dict(ref.state_dict(), wseed, wvar)
     ref.load_state_dict(sd, strict=True)
     zero_dropouts(ref)
@@ -78,7 +84,7 @@ def run_case(name, spec):
              if nme.endswith("block0") and "ca_" not in nme]
     feats = []
     fhooks = [m.register_forward_hook(lambda mod, i, o: feats.append(o.feat.detach().clone()))
-              for nme, m in ref.ptv3_model.named_modules() if nme.endswith("ca_block0")]
+              for nme, m in ref.ptv3_model.named_modules() if re.search(r"ca_block\d+$", nme)]
     head = {}
     hh = ref.act_proj_head.register_forward_hook(lambda mod, i, o: head.update(xt=o[0], xr=o[1], xo=o[2]))
 
@@ -90,7 +96,7 @@ def run_case(name, spec):
         p.grad = None
     losses["total"].backward()
     out = {"meta_variant": variant, "meta_B": B, "meta_n": n, "meta_ragged": ragged, "meta_dseed": dseed,
-           "meta_wseed": wseed, "meta_wvar": wvar, "meta_train": train,
+           "meta_wseed": wseed, "meta_wvar": wvar, "meta_train": train, "meta_drop_path": np.float64(drop_path),
            "perms": torch.stack(perms).numpy().astype(np.int64),
            "npoints_in_batch": np.array(batch["npoints_in_batch"]),
            "input_checksum": np.float64(batch["pc_fts"].double().sum().item()),

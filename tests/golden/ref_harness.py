@@ -270,20 +270,23 @@ def reference_model_config(variant="v1"):
              pos_heatmap_temp=0.1, max_steps=30, use_step_id=False, use_ee_pose=False,
              pos_pred_type="heatmap_disc", pos_bins=15)
     cfg["loss_config"].update(pos_weight=1, rot_weight=1)
-    if variant == "tiny":
+    if variant in ("tiny", "tinydeep"):
         p.update(enc_depths=[1, 1], enc_channels=[64, 64], enc_num_head=[2, 2], enc_patch_size=[128, 128],
                  stride=[2], dec_depths=[1], dec_channels=[64], dec_num_head=[2], dec_patch_size=[128])
+    if variant == "tinydeep":  # stages deeper than one Block (order_index = i % 4 wraps at depth 5)
+        p.update(enc_depths=[2, 5], dec_depths=[2])
     # PointTransformerV3CA.__init__ does not accept these two keys of the YAML
     for k in ("pdnorm_only_decoder",):
         pass
     return to_cfg(cfg)
 
 
-def build_reference_policy(variant="v1"):
+def build_reference_policy(variant="v1", drop_path=0.0):
     install_shims()
     from genrobo3d.models.simple_policy_ptv3 import SimplePolicyPTV3CA
 
     cfg = reference_model_config(variant)
+    cfg["ptv3_config"]["drop_path"] = drop_path
     return SimplePolicyPTV3CA(cfg), cfg
 
 

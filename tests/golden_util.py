@@ -9,7 +9,8 @@ from robot_3dlotus_amd import config as lcfg, synth
 from weights_util import seeded_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["tiny_init_eval", "tiny_scaled_train", "v1_init_train", "v1_scaled_train", "v1_scaled_eval"]
+CASES = ["tiny_init_eval", "tiny_scaled_train", "v1_init_train", "v1_scaled_train", "v1_scaled_eval",
+         "tinydeep_scaled_train", "tinydeep_scaled_eval"]
 
 
 def load_case(name, state_template):
@@ -18,10 +19,14 @@ def load_case(name, state_template):
     fx = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
     variant = str(fx["meta_variant"])
     cfg = lcfg.preset(variant)
+    if "meta_drop_path" in fx:
+        cfg.ptv3_config.drop_path = float(fx["meta_drop_path"])
     batch = synth.synth_batch(int(fx["meta_B"]), int(fx["meta_n"]), ragged=bool(fx["meta_ragged"]),
                               seed=int(fx["meta_dseed"]))
     assert batch["npoints_in_batch"] == fx["npoints_in_batch"].tolist()
     assert abs(batch["pc_fts"].double().sum().item() - float(fx["input_checksum"])) < 1e-9
+    if callable(state_template):
+        state_template = state_template(cfg)
     sd = seeded_state_dict(state_template, int(fx["meta_wseed"]), str(fx["meta_wvar"]))
     ck = sum(v.double().sum().item() for v in sd.values())
     assert abs(ck - float(fx["weight_checksum"])) < 1e-6 * max(1.0, abs(ck)), "weight rebuild mismatch"
@@ -66,12 +71,14 @@ def state_template(cfg):
         n = f"ptv3_model.enc.enc{s}"
         if s > 0:
             lin(n + ".down.proj", ec[s], ec[s - 1]); norm(n + ".down.norm.0", ec[s], True)
-        block(n + ".block0", ec[s], eh[s]); ca(n + ".ca_block0", ec[s], eh[s], ctx)
+        for i in range(p3["enc_depths"][s]):
+            block(n + f".block{i}", ec[s], eh[s]); ca(n + f".ca_block{i}", ec[s], eh[s], ctx)
     for s in reversed(range(len(ec) - 1)):
         n = f"ptv3_model.dec.dec{s}"
         lin(n + ".up.proj.0", dc[s], dc[s + 1]); norm(n + ".up.proj.1", dc[s], True)
         lin(n + ".up.proj_skip.0", dc[s], ec[s]); norm(n + ".up.proj_skip.1", dc[s], True)
-        block(n + ".block0", dc[s], dh[s]); ca(n + ".ca_block0", dc[s], dh[s], ctx)
+        for i in range(p3["dec_depths"][s]):
+            block(n + f".block{i}", dc[s], dh[s]); ca(n + f".ca_block{i}", dc[s], dh[s], ctx)
     lin("txt_fc", act["context_channels"], act["txt_ft_size"])
     hs = dc[0]
     if mp:  # motion_planner_ptv3.py:165-185, :41-73

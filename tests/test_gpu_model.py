@@ -42,8 +42,7 @@ def _dev_batch(batch):
 def test_golden_fixture_parity(case):
     from robot_3dlotus_amd import config as lcfg
 
-    cfg0 = lcfg.preset("tiny" if case.startswith("tiny") else "v1")
-    fx, cfg, batch, sd = gu.load_case(case, gu.state_template(cfg0))
+    fx, cfg, batch, sd = gu.load_case(case, gu.state_template)
     train = bool(fx["meta_train"])
     m = _build(cfg, sd, train)
     m.ptv3_model.order_perms = [p.tolist() for p in fx["perms"]]
@@ -304,6 +303,54 @@ def test_peract_config_bf16_storage_forward_backward():
     assert torch.equal(m32b.last_pred[0], xt32), "fp32 forward changed after a bf16-storage pass"
     assert all(torch.equal(a.grad, b.grad) for a, b in zip(m32.parameters(), m32b.parameters()))
     assert float(np.abs(xt32.cpu().numpy() - ref).max()) <= LOGIT_TOL * scale
+
+
+def test_drop_path_rows_and_backward():
+    """DropPath (timm semantics, model.py:655-657): a stage of depth 2 with drop_path > 0 in train mode.  (1) the op: every row
+    of x + DropPath(branch) is either x (dropped) or x + branch / (1 - p), the keep rate is 1 - p, the backward map uses the
+    same rows; (2) the model: train-mode forward / backward run, differ from the drop_path = 0 run, repeat bit-identically for
+    the same step seed, and eval mode ignores drop_path (bit-identical to a drop_path = 0 model)."""
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from weights_util import seeded_state_dict
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x, br = torch.randn(20000, 64, device="cuda", generator=g), torch.randn(20000, 64, device="cuda", generator=g)
+    p = 0.3
+    y = ops.drop_path(br, x, p, 1234)
+    kept = (y - x).abs().sum(1) > 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.02
+    assert torch.allclose(y[kept], x[kept] + br[kept] / (1 - p), rtol=1e-6, atol=1e-6) and torch.equal(y[~kept], x[~kept])
+    dy = ops.drop_path(br, None, p, 1234)
+    assert torch.equal(dy[~kept], torch.zeros_like(dy[~kept])) and torch.allclose(dy[kept], br[kept] / (1 - p), rtol=1e-6, atol=1e-6)
+
+    cfg = lcfg.preset("tinydeep")
+    sd = seeded_state_dict(gu.state_template(cfg), 3, "scaled")
+    batch = _dev_batch(synth.synth_batch(2, 600, ragged=True, seed=8))
+    perms = [[1, 3, 0, 2], [2, 0, 3, 1]]
+
+    def run(dp, train, seed_step=None):
+        c = lcfg.preset("tinydeep")
+        c.ptv3_config.drop_path = dp
+        m = _build(c, sd, train)
+        m.ptv3_model.order_perms = perms
+        out = m(batch, compute_loss=True, compute_final_action=False)
+        losses = out[1]
+        if train:
+            losses["total"].backward()
+        return m, losses["total"].detach().clone()
+
+    torch.manual_seed(5)
+    m0, l0 = run(0.0, True)
+    torch.manual_seed(5)
+    m1, l1 = run(0.4, True)
+    torch.manual_seed(5)
+    m1b, l1b = run(0.4, True)
+    assert torch.isfinite(l1) and float((l1 - l0).abs()) > 1e-4, "drop_path had no effect in train mode"
+    assert torch.equal(l1, l1b) and all(torch.equal(a.grad, b.grad) for a, b in zip(m1.parameters(), m1b.parameters()))
+    assert all(p_.grad is not None and torch.isfinite(p_.grad).all() for p_ in m1.parameters())
+    _, e0 = run(0.0, False)
+    _, e1 = run(0.4, False)
+    assert torch.equal(e0, e1), "drop_path must be the identity in eval mode"
 
 
 def test_full_size_train_step_properties():

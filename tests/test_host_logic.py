@@ -45,6 +45,25 @@ def test_module_state_dict_layout(variant, nparams, nentries):
     assert all(n.endswith("bias") for n in nodecay)
 
 
+def test_yaml_default_depths_and_drop_path_construct():
+    """The reference YAML's stage depths (enc [2, 2, 2, 6, 2], dec [2, 2, 2, 2]) and drop_path 0.1 on the v1 widths: block{i} /
+    ca_block{i} containers with the reference's state_dict keys, the stochastic-depth schedule of model_ca.py:250-252,316-325
+    (linear over the encoder / decoder, decoder slices reversed), patch tables for min(depth, 4) curve slots."""
+    c = lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["ptv3_config.enc_depths", "[2, 2, 2, 6, 2]", "ptv3_config.dec_depths",
+                                                          "[2, 2, 2, 2]", "ptv3_config.drop_path", "0.1"])
+    m = SimplePolicyPTV3CA(c)
+    sd, t = m.state_dict(), gu.state_template(c)
+    assert set(sd) == set(t) and all(tuple(sd[k].shape) == tuple(t[k].shape) for k in t)
+    assert "ptv3_model.enc.enc3.block5.attn.qkv.weight" in sd and "ptv3_model.dec.dec0.ca_block1.attn.kv.weight" in sd
+    p = m.ptv3_model
+    flat = [x for r in p.enc_drop_path for x in r]
+    assert len(flat) == 14 and flat[0] == 0.0 and abs(flat[-1] - 0.1) < 1e-7 and flat == sorted(flat)
+    assert abs(p.dec_drop_path[3][0] - 0.1) < 1e-7 and p.dec_drop_path[0][1] == 0.0 and p.dec_drop_path[0][0] > 0
+    assert p.frontend.n_patch_orders == 4
+    m2 = SimplePolicyPTV3CA(lcfg.preset("tinydeep"))
+    assert len(m2.state_dict()) == 397 and m2.ptv3_model.frontend.n_patch_orders == 4
+
+
 def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         SimplePolicyPTV3CA(lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["ptv3_config.enable_flash", "False"]))

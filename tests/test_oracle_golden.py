@@ -11,8 +11,7 @@ from robot_3dlotus_amd import config as lcfg
 
 @pytest.mark.parametrize("case", gu.CASES)
 def test_oracle_matches_reference_fixture(case):
-    cfg0 = lcfg.preset("tiny" if case.startswith("tiny") else "v1")
-    fx, cfg, batch, sd = gu.load_case(case, gu.state_template(cfg0))
+    fx, cfg, batch, sd = gu.load_case(case, gu.state_template)
     train = bool(fx["meta_train"])
     sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
     orc = Oracle(sdg, lcfg.plain(cfg), training=train)
