@@ -707,6 +707,16 @@ static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweep
     }                                                                                                                            \
   } while (0)
 
+static int bf16_slab_depth(int klen) {
+  static int forced = -1;
+  if (forced < 0) forced = tune_env("LOTUS_GEMM_BK_BF16");
+  if (forced == 32 || forced == 64 || forced == 128) return forced;
+  // measured (PerAct preset, 16 x 4096, bf16 storage): slab depth 32 / 64 / 128 -> 1134 / 1124 / 1020 samples/s: deeper slabs cost
+  // occupancy (LDS, staging registers) and the step is host-bound at this size anyway; 32 stays the default
+  (void)klen;
+  return 32;
+}
+
 template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   const long blocks64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
@@ -719,8 +729,16 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
     dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if constexpr (SUM_A && !A_KC && !B_KC && FAST) {
-      if (g_prec == 1) GEMM_GO(64, 64, 32, 1, g64);
-      else if constexpr (!LOTUS_ACT_IS_BF16) GEMM_GO(64, 64, 32, 3, g64);
+      if (g_prec == 1) {
+        if constexpr (LOTUS_ACT_IS_BF16) {  // bf16 storage: deep slabs, see below
+          const int bk = bf16_slab_depth(p.klen);
+          if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
+          else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
+          else GEMM_GO(64, 64, 32, 1, g64);
+        } else {
+          GEMM_GO(64, 64, 32, 1, g64);
+        }
+      } else if constexpr (!LOTUS_ACT_IS_BF16) GEMM_GO(64, 64, 32, 3, g64);
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
     return LOTUS_OK;
@@ -731,7 +749,15 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     if constexpr (!SUM_A && FAST) {
       if (g_prec == 1) {
         if (tile == 1) GEMM_GO(128, 128, 16, 1, g128);  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
-        else GEMM_GO(64, 64, 32, 1, g64);
+        else if constexpr (LOTUS_ACT_IS_BF16) {
+          // bf16 storage: one bf16 MFMA covers 16 k, so a 32-deep slab is two MFMAs per wave between barriers and the block
+          // pays one global-load round trip per slab — K / 32 serialised latencies.  Deep slabs (the whole reduction for
+          // K <= 128) put all of a block's loads in flight at once.
+          const int bk = bf16_slab_depth(min(p.klen, p.K));
+          if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
+          else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
+          else GEMM_GO(64, 64, 32, 1, g64);
+        } else GEMM_GO(64, 64, 32, 1, g64);
       } else if constexpr (!LOTUS_ACT_IS_BF16) {
         if (tile == 1) GEMM_GO(128, 128, 16, 3, g128);
         else GEMM_GO(64, 64, 32, 3, g64);
@@ -748,6 +774,16 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   // weight-gradient stream sharing the CUs — 64x64 tiles are better or equal at every batch size measured
   // (16 clouds: 820 vs 806 samples/s; 32: 945 vs 920; 64: 1051 vs 1032; 128: equal), so 128x128 is opt-in only
   if (tile == 0) tile = 3;
+  // forward products (both operands k-contiguous) run while the weight-gradient stream is idle: LOTUS_GEMM_TILE_FWD = 1 / 2
+  // selects 128x128 / 128x64 tiles for them alone when the grid still fills the GPU (tuning knob)
+  static int tile_fwd = -1;
+  if (tile_fwd < 0) tile_fwd = tune_env("LOTUS_GEMM_TILE_FWD");
+  if (A_KC && B_KC && !SUM_A && tile_fwd && g_force_tile == 0) {
+    static int min_blocks = 0;
+    if (!min_blocks) { min_blocks = tune_env("LOTUS_GEMM_TILE_FWD_MINBLOCKS"); if (min_blocks <= 0) min_blocks = 1024; }
+    const long nb = tile_fwd == 1 ? (long)cdiv(p.M, 128) * cdiv(p.N, 128) : (long)cdiv(p.M, 128) * cdiv(p.N, 64);
+    if (nb * nz >= min_blocks) tile = tile_fwd;
+  }
   if constexpr (LOTUS_ACT_IS_BF16) {
     // bf16-storage build: the exact-fp32 product path only serves the shapes the vectorised bf16 path cannot take
     // (odd widths such as the 90- and 217-wide head layers)
