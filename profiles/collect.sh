@@ -3,7 +3,7 @@
 # 1. the three counter passes (profiles/pmc_passes.sh)  2. a kernel trace of 30 steps  3. the bench lines quoted in
 # profiles/<tag>_bench.json.  Everything lands under gpurun_out/; profiles/assemble.py turns it into the committed files.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof gpurun_out/bench_$TAG
 bash profiles/pmc_passes.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1

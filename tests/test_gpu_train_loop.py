@@ -124,3 +124,22 @@ def test_episode_reader_to_training_step(tmp_path):
             opt.step()
             losses.append(l["total"].item())
     assert all(np.isfinite(losses)) and np.mean(losses[-2:]) < np.mean(losses[:2]), losses
+
+
+def test_checkpoint_validator_self_test():
+    """tools/validate_checkpoint.py --self-test: strict load of a (synthetic) checkpoint, eval-mode inference on stored key
+    steps through the episode reader, action errors under the assumed spconv weight layout and the two alternatives."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "validate_checkpoint.py"), "--self-test"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rep = json.loads(r.stdout[r.stdout.index("{"):])
+    assert set(rep["interpretations"]) == {"as_assumed", "taps_z_major", "cin_cout_swapped"}
+    for v in rep["interpretations"].values():
+        assert v["n"] > 0 and all(k in v for k in ("pos_err_m", "rot_err_deg", "open_acc"))
+    assert any(len(s) == 5 for s in rep["conv_weight_shapes"].values())
