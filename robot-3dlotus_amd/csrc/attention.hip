@@ -9,8 +9,10 @@
 // the softmax core in fp16 (model.py:544); here it is fp32 end-to-end, which is what the 1e-4
 // logit parity against the fp32-ideal oracle requires (SURVEY.md Trap 2).
 //
-// LDS plan (floats): Q[128][33] K[128][33] V[128][33] (dO[128][33]) S[128][129]; everything a
-// (tile, head) needs stays on chip between the QK^T, softmax and PV stages.
+// LDS plan (floats): row images Q[128][33] K[128][33] V[128][33] (+ dO[128][33] in backward) — 51 / 68 KB.  There is NO
+// score image: scores are computed transposed (S^T = K Q^T) so that a lane owns one query and its accumulator registers
+// run over the keys; softmax, dropout and the P / dS operands of the following products live in registers (see the
+// comments at the kernels).  Everything a (tile, head) needs stays on chip between the QK^T, softmax and PV stages.
 #include "common.h"
 #include <stdlib.h>
 

@@ -52,6 +52,16 @@ struct GemmP {
 // agent-scope fence would write back / invalidate the whole L2 of the issuing XCD (measured: ~100 us per launch), so
 // the partials themselves are moved with agent-scope relaxed atomics — write-through stores, L2-bypassing loads — and
 // only workgroup-scope fences (s_waitcnt) order them against the arrival counter.
+//
+// HARDWARE CONTRACT (gfx942 / gfx950 only): this is the "sc1 stores AND sc1 loads on both sides" hand-off of
+// MI355X_MICROARCH.md (Workgroup dispatch ... valid forms): a relaxed agent-scope atomic store lowers to `global_store ...
+// sc1` (write-through: the bytes have left the XCD's L2 once vmcnt drains), a relaxed agent-scope atomic load to
+// `global_load ... sc1` (served by memory, never by a stale L1 / remote-L2 line); `fence(release, "workgroup")` +
+// `__syncthreads()` make every thread's vmcnt drain before lane 0 bumps the counter.  It is NOT the HSA memory model's
+// agent-scope release / acquire and is not portable to other targets or guaranteed against compiler changes.  Guards:
+// the library is built for gfx950 only; LOTUS_SPLITK_FUSED=0 switches every split-K product to the two-launch path
+// (partials, then a reduction kernel — ordinary kernel-boundary visibility); tests/test_gpu_ops.py compares the two paths
+// and tests/test_gpu_fullsize_properties.py runs the fused one at the bench size against the two-launch result.
 __device__ __forceinline__ void st_agent4(float* p, float4 v) {
   unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
   const unsigned long long lo = (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32);
@@ -904,8 +914,15 @@ static int fwd_splits(int M, int N, int K, bool fused = false) {
 
 #define LOTUS_SPLITK_MAX_TILES 4096  // per-tile arrival counters of the fused split-K path (one unsigned each)
 
+static bool splitk_fused_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("LOTUS_SPLITK_FUSED"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+
 template <bool A_KC, bool B_KC>
 static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, unsigned* counters, hipStream_t st) {
+  if (!splitk_fused_enabled()) counters = nullptr;
   const int nz = (p.N % 4 == 0 && p.ldc == p.N) ? fwd_splits(p.M, p.N, p.K, counters != nullptr) : 1;
   const size_t need = (size_t)nz * p.M * p.N * sizeof(float);
   if (nz == 1 || !workspace || workspace_bytes < need || ((uintptr_t)workspace) % 16) return launch_gemm<A_KC, B_KC, false>(p, 1, st);
@@ -1025,7 +1042,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
   static int fuse_max = -1;
   if (fuse_max < 0) { fuse_max = tune_env("LOTUS_WGRAD_FUSE_MAX"); if (fuse_max <= 0) fuse_max = 4; }  // measured: nz 4 fused 46 -> 41 us, nz 16 fused 42 -> 51 us
   const long wtiles = (long)cdiv(N, 64) * cdiv(K, 64);
-  if (!direct && counters && nz <= fuse_max && wtiles <= LOTUS_SPLITK_MAX_TILES && g_force_tile != 1) {
+  if (!direct && counters && splitk_fused_enabled() && nz <= fuse_max && wtiles <= LOTUS_SPLITK_MAX_TILES && g_force_tile != 1) {
     // few splits: the last block of every output tile sums the partials (and the bias partials) itself
     GemmP q = p;
     q.C = dw; q.part = part; q.part_stride = (long)slab; q.cnt = (unsigned*)counters;

@@ -578,3 +578,38 @@ def test_cloud_max_first_index_ties_and_ragged_clouds():
     for b, (i, o) in enumerate(zip(ref_i, off[:-1].tolist())):
         want[i + o, torch.arange(C, device="cuda")] += g[b]
     assert torch.equal(xr.grad, want)
+
+
+@pytest.mark.parametrize("M,N,K", [(361, 768, 3072), (1450, 512, 2048), (441, 3072, 768), (1727, 512, 512)])
+def test_fused_splitk_handoff_equals_two_launch_path(M, N, K):
+    """The fused split-K hand-off (partials through sc1 stores / loads + an arrival counter, csrc/gemm.hip "HARDWARE CONTRACT")
+    against the two-launch path (partials, kernel boundary, reduction kernel) on the deep-level shapes that split: forward and
+    input-gradient products sum their partials in the same z order -> bit-identical; repeated 20 times under load from a
+    second stream (the hand-off must not depend on timing).  LOTUS_SPLITK_FUSED=0 selects the two-launch path globally."""
+    from robot_3dlotus_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M, N, device="cuda", generator=g)
+    nb = ops.query("lotus_linear_workspace", M, N, K)
+    assert nb > 0, "shape was meant to take the split-K path"
+    ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(ops.query("lotus_splitk_counters_bytes"), dtype=torch.uint8, device="cuda")
+
+    def fwd(counters):
+        y = torch.empty(M, N, device="cuda")
+        ops.call("lotus_linear_fwd", x, w, b, res, y, None, M, N, K, ops.ACT_GELU, 0.0, 0, 0, ws, nb, counters)
+        return y
+
+    ref = fwd(None)
+    side = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda")
+    for it in range(20):
+        with torch.cuda.stream(side):   # uneven load on the CUs while the hand-off runs
+            big = big @ big * 1e-3
+        y = fwd(cnt)
+        assert torch.equal(y, ref), f"fused split-K differs from the two-launch path (iteration {it})"
+    assert int(cnt.view(torch.int32).abs().sum()) == 0, "arrival counters must be left at zero"
+    torch.cuda.synchronize()
