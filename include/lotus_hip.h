@@ -185,12 +185,15 @@ int lotus_batchnorm_bwd_apply(const lotus_act_t* dy, const lotus_act_t* x, const
  * (model_ca.py:62-66) with the preceding q_norm/k_norm LayerNorm(d, eps) (model.py:532-533,
  * model_ca.py:52-53), in fp32.  tiles: int32 [ntiles][4] = q_start, q_len, k_start, k_len (<= 128).
  * Row r of q lives at q + r*q_ld + q_off + h*d; k/v rows at kv + r*kv_ld + {k_off, v_off} + h*d.
- * drop_p / drop_seed: dropout on the probabilities (flash-attn dropout_p), regenerated in backward. */
+ * drop_p / drop_seed: dropout on the probabilities (flash-attn dropout_p), regenerated in backward.
+ * k_max: the caller's upper bound of k_len over all tiles (0 = unknown).  With identity-indexed rows (qidx = kidx = owner =
+ * null) and 0 < k_max <= 32 — the point <-> instruction cross attention, whose key side is a cloud's 6-19 tokens — the call
+ * takes the short-key kernels (one lane per query, keys / values as LDS broadcast rows, exact fp32 whatever `precision`). */
 int lotus_attention_fwd(const lotus_act_t* q, long q_ld, int q_off, const lotus_act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, lotus_act_t* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
-                        unsigned long long drop_seed, int precision, void* stream);
+                        unsigned long long drop_seed, int precision, int k_max, void* stream);
 size_t lotus_attention_bwd_workspace(int nblocks, int H);
 /* blocks: int32 [nblocks][6] = first_tile, n_tiles, tile_step, part_slot, k_start, k_len.  kext / ext_pos /
  * dkv_extra (optional, from lotus_fe_patch): k/v gradients of the borrowed tail-patch copies go to a side
@@ -202,7 +205,7 @@ int lotus_attention_bwd(const lotus_act_t* q, long q_ld, int q_off, const lotus_
                         int dq_off, lotus_act_t* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, const int* kext, const int* ext_pos, int n_extra, lotus_act_t* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
-                        int precision, void* workspace, size_t workspace_bytes, void* stream);
+                        int precision, int k_max, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- composite entry points (csrc/blocks.cpp): ONE call enqueues the whole forward / backward of a sub-block by chaining
  * the entry points above in the order the per-launch host path uses (bit-identical results).  The caller passes three flat
@@ -266,13 +269,13 @@ int lotus_crossattn_fwd(const lotus_act_t* x, const lotus_act_t* context, const 
                         const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
                         const float* wp, const float* bp, lotus_act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
                         int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
-                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream);
+                        int precision, int k_max, void* ws, size_t ws_bytes, void* counters, void* stream);
 int lotus_crossattn_bwd(const lotus_act_t* dy, const lotus_act_t* dz_in, const lotus_act_t* x, const lotus_act_t* context, const float* g, const float* wq,
                         const float* wkv, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
                         const float* saved, lotus_act_t* dx, lotus_act_t* dctx, lotus_act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed,
                         float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
                         int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
-                        int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                        int precision, int k_max, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
                         void* counters_side, unsigned long long link, int join, void* stream, void* side);
 /* Conditional positional encoding, y = x + LN(Linear(SubMConv3d_3(xs))), model.py:615-625,660-662 (xs == x in the encoder,
  * the stale skip branch in the decoder).  cw_packed: lotus_conv_weight_transpose output for `precision`.

@@ -853,6 +853,341 @@ __global__ void attn_extra_fixup_kernel(const act_t* __restrict__ extra, long ex
   st4(o, v);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Short-key attention: every key range has at most 32 rows and rows are identity-indexed — the point <-> instruction
+// cross attention of CABlock (model_ca.py:46-101): a cloud's 4096 points attend to its 6-19 language tokens.  The tile
+// kernels above spend a 128 x 128 machinery (row images, per-phase barriers, one busy wave in the key orientation) on a
+// problem whose whole key side fits in 8 KB, and ran at 27-44 us forward / 75-145 us backward per launch for ~1 GFLOP.
+// Here ONE LANE OWNS ONE QUERY: its q row, LayerNorm, scores, softmax and output stay in registers, the normalised keys
+// and values are LDS rows read as broadcasts, and the forward pass has no barrier after the key set-up.  The backward pass
+// keeps the per-query part in registers the same way (dS, dq, LayerNorm backward) and reduces over the queries — dV = P^T dO
+// and T = dS^T qhat, from which d k and the q-norm parameter gradients follow (see below) — with two MFMA chains per wave
+// over wave-private LDS images.  Exact fp32 (VALU + fp32 MFMA) whatever `precision` says.  Dropout masks use the same
+// (tile, head, query, key) hash index as the tile kernels.
+template <int D>
+__device__ __forceinline__ void xattn_load_keys(const AttnP& p, int h, int k_start, int k_len, float* __restrict__ kraw,
+                                                float* __restrict__ v_s) {
+  // rows j < k_len of K and V (D floats each) -> [32][32] images, zero elsewhere; 8 lanes per row
+  for (int i = threadIdx.x; i < 32 * 8; i += blockDim.x) {
+    const int j = i >> 3, c4 = i & 7;
+    float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
+    if (j < k_len && c4 * 4 < D) {
+      const act_t* row = p.kv + (long)(k_start + j) * p.kv_ld + h * D + c4 * 4;
+      kv4 = ld4(row + p.k_off);
+      vv4 = ld4(row + p.v_off);
+    }
+    *reinterpret_cast<float4*>(kraw + j * 32 + c4 * 4) = kv4;
+    *reinterpret_cast<float4*>(v_s + j * 32 + c4 * 4) = vv4;
+  }
+}
+
+// LayerNorm(d, eps) of the 32 key rows in place, 8 lanes per row (two passes of 128 threads): khat -> kraw, rstd -> krstd
+template <int D>
+__device__ __forceinline__ void xattn_norm_keys(float eps, int k_len, float* __restrict__ kraw, float* __restrict__ krstd) {
+  for (int i = threadIdx.x; i < 32 * 8; i += blockDim.x) {
+    const int j = i >> 3, c4 = i & 7;
+    float4 v = *reinterpret_cast<const float4*>(kraw + j * 32 + c4 * 4);
+    float sum = (c4 * 4 < D) ? (v.x + v.y) + (v.z + v.w) : 0.f;
+    sum += __shfl_xor(sum, 1, 8); sum += __shfl_xor(sum, 2, 8); sum += __shfl_xor(sum, 4, 8);
+    const float m = sum / D;
+    const float cx = v.x - m, cy = v.y - m, cz = v.z - m, cw = v.w - m;
+    float var = (c4 * 4 < D) ? (cx * cx + cy * cy) + (cz * cz + cw * cw) : 0.f;
+    var += __shfl_xor(var, 1, 8); var += __shfl_xor(var, 2, 8); var += __shfl_xor(var, 4, 8);
+    const float rs = (j < k_len) ? rsqrtf(var / D + eps) : 0.f;
+    if (c4 * 4 < D) *reinterpret_cast<float4*>(kraw + j * 32 + c4 * 4) = make_float4(cx * rs, cy * rs, cz * rs, cw * rs);
+    if (c4 == 0) krstd[j] = rs;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(128) void xattn_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) float kn_s[32 * 32], v_s[32 * 32], krstd_s[32];
+  const int tid = threadIdx.x, h = blockIdx.y;
+  const int q_start = p.tiles[blockIdx.x * 4 + 0], q_len = p.tiles[blockIdx.x * 4 + 1];
+  const int k_start = p.tiles[blockIdx.x * 4 + 2], k_len = p.tiles[blockIdx.x * 4 + 3];
+  xattn_load_keys<D>(p, h, k_start, k_len, kn_s, v_s);
+  __syncthreads();
+  xattn_norm_keys<D>(p.eps, k_len, kn_s, krstd_s);
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 128) {  // affine part of k_norm
+    const int c = i & 31;
+    if (c < D) kn_s[i] = kn_s[i] * p.kn_w[c] + p.kn_b[c];
+  }
+  __syncthreads();
+  const int qi = tid;
+  if (qi >= q_len) return;
+  const long row = q_start + qi;
+  float q[D];
+  {
+    const act_t* qp = p.q + row * p.q_ld + p.q_off + h * D;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const float4 v = ld4(qp + c4 * 4);
+      q[4 * c4] = v.x; q[4 * c4 + 1] = v.y; q[4 * c4 + 2] = v.z; q[4 * c4 + 3] = v.w;
+    }
+  }
+  {  // q_norm (LayerNorm(d, eps) with affine), model_ca.py:56-58
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) m += q[c];
+    m /= D;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      const float t = q[c] - m;
+      var += t * t;
+    }
+    const float rs = rsqrtf(var / D + p.eps);
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = (q[c] - m) * rs * p.qn_w[c] + p.qn_b[c];
+  }
+  const unsigned long long rb = (((unsigned long long)blockIdx.x * p.H + h) * AT + qi) * AT;
+  const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+  const unsigned s0 = (unsigned)p.drop_seed;
+  float mx = -INFINITY, l = 0.f, o[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) o[c] = 0.f;
+  for (int j = 0; j < k_len; ++j) {  // streaming softmax over the (few) keys: everything stays in registers
+    const float4* kr = reinterpret_cast<const float4*>(kn_s + j * 32);
+    float sc = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const float4 k4 = kr[c4];
+      sc = fmaf(q[4 * c4], k4.x, sc); sc = fmaf(q[4 * c4 + 1], k4.y, sc);
+      sc = fmaf(q[4 * c4 + 2], k4.z, sc); sc = fmaf(q[4 * c4 + 3], k4.w, sc);
+    }
+    sc *= p.scale;
+    const float mn = fmaxf(mx, sc);
+    const float corr = __expf(mx - mn), pj = __expf(sc - mn);
+    l = l * corr + pj;
+    mx = mn;
+    float w = pj;
+    if (p.drop_thresh) w = keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh) ? pj * p.drop_inv_keep : 0.f;
+    const float4* vr = reinterpret_cast<const float4*>(v_s + j * 32);
+#pragma unroll
+    for (int c4 = 0; c4 < D / 4; ++c4) {
+      const float4 v4 = vr[c4];
+      o[4 * c4] = fmaf(o[4 * c4], corr, w * v4.x); o[4 * c4 + 1] = fmaf(o[4 * c4 + 1], corr, w * v4.y);
+      o[4 * c4 + 2] = fmaf(o[4 * c4 + 2], corr, w * v4.z); o[4 * c4 + 3] = fmaf(o[4 * c4 + 3], corr, w * v4.w);
+    }
+  }
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (p.lse) p.lse[row * p.H + h] = mx + logf(l);
+  act_t* op = p.out + row * p.out_ld + h * D;
+#pragma unroll
+  for (int c4 = 0; c4 < D / 4; ++c4)
+    st4(op + c4 * 4, make_float4(o[4 * c4] * inv, o[4 * c4 + 1] * inv, o[4 * c4 + 2] * inv, o[4 * c4 + 3] * inv));
+}
+
+// Backward.  With kn = khat gk + bk (k_norm output), qn = qhat gq + bq (q_norm output) and dS the score gradient:
+//   s_ij = scale (qhat_i . kg_j + kb_j),  kg_j = gq * kn_j,  kb_j = bq . kn_j          (the q affine folded into the keys)
+//   d qhat_i = sum_j dS_ij kg_j                                                          (registers, per query)
+//   T = dS^T qhat  [keys x d],  cs_j = sum_i dS_ij                                       (MFMA / column sums over queries)
+//   d kn_j = gq * T_j + bq cs_j,   d gq = sum_j kn_j * T_j,   d bq = sum_j kn_j cs_j
+//   d V = (P * mask)^T dO                                                                (MFMA)
+// so the only reductions over queries are two [32 x 128] x [128 x 32] products per tile, done by each wave on its own 64
+// rows of the LDS images (no block barrier between the per-query phase and the products).
+template <int D>
+__global__ __launch_bounds__(128) void xattn_bwd_kernel(AttnP p) {
+  constexpr int ILD = 33;
+  __shared__ __attribute__((aligned(16))) float khat_s[32 * 32], kg_s[32 * 32], v_s[32 * 32], krstd_s[32], kb_s[32], cs_s[2][32];
+  __shared__ float ds_s[128 * ILD], pm_s[128 * ILD], qh_s[128 * ILD], do_s[128 * ILD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1, h = blockIdx.y;
+  const int* bd = p.blocks + blockIdx.x * 6;
+  const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3], k_start = bd[4], k_len = bd[5];
+  xattn_load_keys<D>(p, h, k_start, k_len, khat_s, v_s);
+  for (int i = tid; i < 128 * ILD; i += 128) { qh_s[i] = 0.f; do_s[i] = 0.f; }  // columns >= D stay zero for the MFMA operands
+  __syncthreads();
+  xattn_norm_keys<D>(p.eps, k_len, khat_s, krstd_s);
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += 128) {
+    const int c = i & 31;
+    kg_s[i] = (c < D) ? (khat_s[i] * p.kn_w[c] + p.kn_b[c]) * p.qn_w[c] : 0.f;
+  }
+  if (tid < 32) {
+    float a = 0.f;
+    for (int c = 0; c < D; ++c) a += (khat_s[tid * 32 + c] * p.kn_w[c] + p.kn_b[c]) * p.qn_b[c];
+    kb_s[tid] = a;
+  }
+  __syncthreads();
+  f32x16 accT = zero16(), accV = zero16();
+  float cs_acc = 0.f;  // lanes 0..31 of each wave: column sums of dS over the wave's queries
+  const unsigned s0 = (unsigned)p.drop_seed;
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int tile = first_tile + ti * tile_step;
+    const int q_start = p.tiles[tile * 4 + 0], q_len = p.tiles[tile * 4 + 1];
+    const int qi = tid;
+    float* dsr = ds_s + qi * ILD;
+    float* pmr = pm_s + qi * ILD;
+    if (qi < q_len) {
+      const long row = q_start + qi;
+      float qh[D], go[D], dx[D];
+      float Di = 0.f;
+      {
+        const act_t* qp = p.q + row * p.q_ld + p.q_off + h * D;
+        const act_t* gp = p.dout + row * p.out_ld + h * D;
+        const act_t* op = p.out + row * p.out_ld + h * D;
+        float4 qv[D / 4], gv[D / 4], ov[D / 4];
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; ++c4) { qv[c4] = ld4(qp + c4 * 4); gv[c4] = ld4(gp + c4 * 4); ov[c4] = ld4(op + c4 * 4); }
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; ++c4) {
+          qh[4 * c4] = qv[c4].x; qh[4 * c4 + 1] = qv[c4].y; qh[4 * c4 + 2] = qv[c4].z; qh[4 * c4 + 3] = qv[c4].w;
+          go[4 * c4] = gv[c4].x; go[4 * c4 + 1] = gv[c4].y; go[4 * c4 + 2] = gv[c4].z; go[4 * c4 + 3] = gv[c4].w;
+          Di += (gv[c4].x * ov[c4].x + gv[c4].y * ov[c4].y) + (gv[c4].z * ov[c4].z + gv[c4].w * ov[c4].w);
+        }
+      }
+      float m = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) m += qh[c];
+      m /= D;
+      float var = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        const float t = qh[c] - m;
+        var += t * t;
+      }
+      const float rs = rsqrtf(var / D + p.eps);
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        qh[c] = (qh[c] - m) * rs;
+        dx[c] = 0.f;
+      }
+      const float lse = p.lse[row * p.H + h];
+      const unsigned long long rb = (((unsigned long long)tile * p.H + h) * AT + qi) * AT;
+      const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+      for (int j = 0; j < k_len; ++j) {
+        const float4* kr = reinterpret_cast<const float4*>(kg_s + j * 32);
+        const float4* vr = reinterpret_cast<const float4*>(v_s + j * 32);
+        float sc = kb_s[j], dp = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; ++c4) {
+          const float4 k4 = kr[c4], v4 = vr[c4];
+          sc = fmaf(qh[4 * c4], k4.x, sc); sc = fmaf(qh[4 * c4 + 1], k4.y, sc);
+          sc = fmaf(qh[4 * c4 + 2], k4.z, sc); sc = fmaf(qh[4 * c4 + 3], k4.w, sc);
+          dp = fmaf(go[4 * c4], v4.x, dp); dp = fmaf(go[4 * c4 + 1], v4.y, dp);
+          dp = fmaf(go[4 * c4 + 2], v4.z, dp); dp = fmaf(go[4 * c4 + 3], v4.w, dp);
+        }
+        const float pj = __expf(sc * p.scale - lse);
+        const bool keep = !p.drop_thresh || keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh);
+        const float pmj = keep ? pj * p.drop_inv_keep : 0.f;
+        const float ds = p.scale * pj * ((keep ? dp * p.drop_inv_keep : 0.f) - Di);
+        dsr[j] = ds;
+        pmr[j] = pmj;
+#pragma unroll
+        for (int c4 = 0; c4 < D / 4; ++c4) {
+          const float4 k4 = kr[c4];
+          dx[4 * c4] = fmaf(ds, k4.x, dx[4 * c4]); dx[4 * c4 + 1] = fmaf(ds, k4.y, dx[4 * c4 + 1]);
+          dx[4 * c4 + 2] = fmaf(ds, k4.z, dx[4 * c4 + 2]); dx[4 * c4 + 3] = fmaf(ds, k4.w, dx[4 * c4 + 3]);
+        }
+      }
+      for (int j = k_len; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
+      // q_norm backward (dx = d qhat): dq = rs (dx - mean(dx) - qhat mean(dx qhat))
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) { a += dx[c]; b = fmaf(dx[c], qh[c], b); }
+      a /= D; b /= D;
+      act_t* dqp = p.dq + row * p.dq_ld + p.dq_off + h * D;
+#pragma unroll
+      for (int c4 = 0; c4 < D / 4; ++c4)
+        st4(dqp + c4 * 4, make_float4(rs * (dx[4 * c4] - a - qh[4 * c4] * b), rs * (dx[4 * c4 + 1] - a - qh[4 * c4 + 1] * b),
+                                      rs * (dx[4 * c4 + 2] - a - qh[4 * c4 + 2] * b), rs * (dx[4 * c4 + 3] - a - qh[4 * c4 + 3] * b)));
+#pragma unroll
+      for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = qh[c]; do_s[qi * ILD + c] = go[c]; }
+    } else {
+      for (int j = 0; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
+#pragma unroll
+      for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = 0.f; do_s[qi * ILD + c] = 0.f; }
+    }
+    __syncthreads();
+    {  // this wave's 64 queries: T += dS^T qhat, dV += (P mask)^T dO; lane = (key | channel) l31, k-half hh = query parity
+      const int base = wave * 64;
+      if (lane < 32) {
+        float a = 0.f;
+        for (int i = 0; i < 64; ++i) a += ds_s[(base + i) * ILD + lane];
+        cs_acc += a;
+      }
+#pragma unroll 8
+      for (int kk = 0; kk < 64; kk += 2) {
+        const int r = (base + kk + hh) * ILD + l31;
+        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_s[r], qh_s[r], accT, 0, 0, 0);
+        accV = __builtin_amdgcn_mfma_f32_32x32x2f32(pm_s[r], do_s[r], accV, 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- combine the two waves, finish d k / d v and the four LayerNorm parameter gradients
+  float* T_s = ds_s;            // [2][32][ILD]
+  float* V_s = pm_s;            // [2][32][ILD]
+  if (lane < 32) cs_s[wave][lane] = cs_acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    T_s[(wave * 32 + key) * ILD + l31] = accT[r];
+    V_s[(wave * 32 + key) * ILD + l31] = accV[r];
+  }
+  __syncthreads();
+  float* dkn_s = qh_s;          // [32][ILD]: d kn, then its LayerNorm backward in place
+  float* gq_s = do_s;           // [32][ILD]: kn * T  (column sums -> d gq), then kn * cs at + 32 * ILD
+  for (int i = tid; i < 32 * 32; i += 128) {
+    const int j = i >> 5, c = i & 31;
+    const float T = T_s[j * ILD + c] + T_s[(32 + j) * ILD + c];
+    const float cs = cs_s[0][j] + cs_s[1][j];
+    const float kn = (c < D) ? khat_s[j * 32 + c] * p.kn_w[c] + p.kn_b[c] : 0.f;
+    dkn_s[j * ILD + c] = (c < D && j < k_len) ? p.qn_w[c] * T + p.qn_b[c] * cs : 0.f;
+    gq_s[j * ILD + c] = (j < k_len) ? kn * T : 0.f;
+    gq_s[(32 + j) * ILD + c] = (j < k_len) ? kn * cs : 0.f;
+  }
+  __syncthreads();
+  float* lnp = p.ln_part + ((long)(blockIdx.x * p.H + h) * 4) * 32;
+  if (tid < 32) {  // column sums over the keys
+    float dgq = 0.f, dbq = 0.f, dgk = 0.f, dbk = 0.f;
+    for (int j = 0; j < 32; ++j) {
+      dgq += gq_s[j * ILD + tid];
+      dbq += gq_s[(32 + j) * ILD + tid];
+      const float g = dkn_s[j * ILD + tid];
+      dgk += g * khat_s[j * 32 + tid];
+      dbk += g;
+    }
+    lnp[tid] = dgq; lnp[32 + tid] = dbq; lnp[64 + tid] = dgk; lnp[96 + tid] = dbk;
+  }
+  __syncthreads();
+  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+  for (int i = tid; i < 32 * 8; i += 128) {  // k_norm backward per key row (8 lanes per row) + the dV rows
+    const int j = i >> 3, c4 = i & 7;
+    float g[4], kh[4];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c4 * 4 + e;
+      kh[e] = khat_s[j * 32 + c];
+      g[e] = (c < D) ? dkn_s[j * ILD + c] * p.kn_w[c] : 0.f;
+      a += g[e];
+      b = fmaf(g[e], kh[e], b);
+    }
+    a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
+    b += __shfl_xor(b, 1, 8); b += __shfl_xor(b, 2, 8); b += __shfl_xor(b, 4, 8);
+    a /= D; b /= D;
+    if (j < k_len && c4 * 4 < D) {
+      const float rs = krstd_s[j];
+      act_t* kp = dkv + (long)(k_start + j) * p.dkv_ld + h * D + c4 * 4;
+      st4(kp + p.dk_off, make_float4(rs * (g[0] - a - kh[0] * b), rs * (g[1] - a - kh[1] * b), rs * (g[2] - a - kh[2] * b),
+                                     rs * (g[3] - a - kh[3] * b)));
+      const int c = c4 * 4;
+      st4(kp + p.dv_off, make_float4(V_s[j * ILD + c] + V_s[(32 + j) * ILD + c], V_s[j * ILD + c + 1] + V_s[(32 + j) * ILD + c + 1],
+                                     V_s[j * ILD + c + 2] + V_s[(32 + j) * ILD + c + 2], V_s[j * ILD + c + 3] + V_s[(32 + j) * ILD + c + 3]));
+    }
+  }
+}
+
+// the short-key kernels take identity-indexed rows, key ranges of at most 32 rows (k_max = the caller's upper bound, 0 =
+// unknown) and head widths 32 / 24 / 16; LOTUS_XATTN=0 keeps everything on the tile kernels (A/B switch)
+static bool short_keys_ok(int k_max, const int* qidx, const int* kidx, const int* owner, const int* kext, int atomic_out, int d) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("LOTUS_XATTN"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && k_max > 0 && k_max <= 32 && !qidx && !kidx && !owner && !kext && !atomic_out && (d == 32 || d == 24 || d == 16);
+}
+
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
 
 extern "C" {
@@ -863,7 +1198,7 @@ int lotus_attention_fwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, act_t* out,
                         long out_ld, float* lse, int H, int d, float scale, float eps, float drop_p,
-                        unsigned long long drop_seed, int precision, void* stream) {
+                        unsigned long long drop_seed, int precision, int k_max, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && out && check_geom(H, d) == 0, "lotus_attention_fwd: bad arguments (H=%d d=%d)", H, d);
   if (ntiles == 0) return LOTUS_OK;
   AttnP p;
@@ -873,6 +1208,13 @@ int lotus_attention_fwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
+  if (short_keys_ok(k_max, qidx, kidx, owner, nullptr, 0, d)) {  // one lane per query, keys in LDS (cross attention)
+    if (d == 32) LOTUS_LAUNCH(xattn_fwd_kernel<32>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    else if (d == 24) LOTUS_LAUNCH(xattn_fwd_kernel<24>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    else LOTUS_LAUNCH(xattn_fwd_kernel<16>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    LOTUS_LAUNCH_CHECK("lotus_attention_fwd(short keys)");
+    return LOTUS_OK;
+  }
   const size_t sm = attn_smem_bytes(false);
   const int prec = precision;
   if (prec == 3) {
@@ -901,7 +1243,7 @@ int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
                         int dq_off, act_t* dkv, long dkv_ld, int dk_off, int dv_off, long dkv_part_stride,
                         int atomic_out, const int* kext, const int* ext_pos, int n_extra, act_t* dkv_extra, float* dqn_w, float* dqn_b, float* dkn_w, float* dkn_b, int accumulate,
                         int H, int d, float scale, float eps, float drop_p, unsigned long long drop_seed,
-                        int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                        int precision, int k_max, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(q && kv && tiles && blocks && out && dout && lse && dq && dkv && check_geom(H, d) == 0,
                   "lotus_attention_bwd: bad arguments");
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= lotus_attention_bwd_workspace(nblocks, H),
@@ -925,7 +1267,11 @@ int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   const size_t sm = attn_smem_bytes(true);
   const int prec = precision;
   StopEventOnLast stop_ev;
-  if (prec == 3) {
+  if (short_keys_ok(k_max, qidx, kidx, owner, kext, atomic_out, d)) {
+    if (d == 32) LOTUS_LAUNCH(xattn_bwd_kernel<32>, dim3(nblocks, H), dim3(128), 0, st, p);
+    else if (d == 24) LOTUS_LAUNCH(xattn_bwd_kernel<24>, dim3(nblocks, H), dim3(128), 0, st, p);
+    else LOTUS_LAUNCH(xattn_bwd_kernel<16>, dim3(nblocks, H), dim3(128), 0, st, p);
+  } else if (prec == 3) {
     { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a4 = true; } }
     LOTUS_LAUNCH(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else if (prec == 1) {

@@ -213,7 +213,7 @@ int lotus_selfattn_fwd(const act_t* x, const float* g, const float* b, const flo
   CHECK(lotus_linear_fwd(n, wqkv, bqkv, nullptr, qkv, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws,
                          big ? 0 : ws_bytes, big ? nullptr : counters, stream));
   CHECK(lotus_attention_fwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse,
-                            H, d, scale, 1e-6f, attn_p, attn_seed, precision, stream));
+                            H, d, scale, 1e-6f, attn_p, attn_seed, precision, 0, stream));
   return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
@@ -273,7 +273,7 @@ int lotus_selfattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, cons
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   PRODUCE_THEN_FORK(lotus_attention_bwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, blocks, nblocks, qnw, qnb, knw, knb,
                                         att, datt, (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra,
-                                        gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
+                                        gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, 0, ws_main, ws_main_bytes, stream));
   CHECK(lotus_linear_wgrad(dqkv, n, dwqkv, dbqkv, M, 3 * C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dqkv, wqkv, dn, nullptr, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
@@ -315,7 +315,7 @@ int lotus_crossattn_fwd(const act_t* x, const act_t* context, const float* g, co
                         const float* wkv, const float* bkv, const float* qnw, const float* qnb, const float* knw, const float* knb,
                         const float* wp, const float* bp, act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H,
                         int L, int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
-                        int precision, void* ws, size_t ws_bytes, void* counters, void* stream) {
+                        int precision, int k_max, void* ws, size_t ws_bytes, void* counters, void* stream) {
   const int d = C / H;
   Carve sv(saved);
   act_t* n = sv.act((size_t)M * C);
@@ -332,7 +332,7 @@ int lotus_crossattn_fwd(const act_t* x, const act_t* context, const float* g, co
   CHECK(lotus_linear_fwd(context, wkv, bkv, nullptr, kv, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws,
                          bigL ? 0 : ws_bytes, bigL ? nullptr : counters, stream));
   CHECK(lotus_attention_fwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse, H,
-                            d, scale, 1e-6f, attn_p, attn_seed, precision, stream));
+                            d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, stream));
   return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
@@ -343,7 +343,7 @@ int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, con
                         const float* saved, act_t* dx, act_t* dctx, act_t* dz_out, float dz_out_p, unsigned long long dz_out_seed,
                         float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks, int G, int M, int C, int H, int L,
                         int Cc, float scale, float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed,
-                        int precision, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
+                        int precision, int k_max, void* ws_main, size_t ws_main_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main,
                         void* counters_side, unsigned long long link, int join, void* stream, void* side) {
   const int d = C / H;
   Carve sv(saved);
@@ -401,7 +401,7 @@ int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, con
     if (G > 1) lotus_tls_stop_event = nullptr;
     CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att,
                               datt, (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq,
-                              bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, ws_main, ws_main_bytes, stream));
+                              bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, ws_main, ws_main_bytes, stream));
     if (G > 1) {  // fixed-order sum of the key-side partial slots
       lotus_tls_stop_event = fa.ev;
       CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));

@@ -20,7 +20,7 @@ class Level:
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
                  "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
-                 "coord", "parent", "n_dup", "patch", "_views")
+                 "coord", "parent", "n_dup", "patch", "_views", "ca_kmax")
 
     def for_order(self, k):
         """The level as the k-th block of a stage sees it: `Block(order_index = i % len(order))` attends along curve slot k
@@ -256,6 +256,7 @@ class FrontEnd:
             lv.n_self_tiles = pl["n_tiles"]
             lv.ca_tiles, lv.ca_blocks = view(pl["ca_tiles"], 4), view(pl["ca_blocks"], 6)
             lv.n_ca_tiles, lv.n_ca_blocks, lv.ca_groups = pl["n_ca_tiles"], pl["n_ca_blocks"], pl["G"]
+            lv.ca_kmax = int(max(ctx_counts)) if len(ctx_counts) else 0  # longest instruction: selects the short-key kernels
             lv.cluster = lv.seg_start = lv.members = lv.coord = lv.parent = None
             if s > 0:
                 pr = raw[s - 1]

@@ -667,22 +667,22 @@ def bn_bwd_pair(a, bb, training, act):
 
 
 def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles, qn, kn, out, lse, H, d,
-                  drop_p=0.0, seed=0, prec=None):
+                  drop_p=0.0, seed=0, prec=None, k_max=0):
     call("lotus_attention_fwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles,
          qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6, float(drop_p), int(seed),
-         _PREC if prec is None else prec)
+         _PREC if prec is None else prec, int(k_max))
 
 
 def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
                   dout, lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off, part_stride, atomic, H, d, drop_p=0.0, seed=0,
-                  kext=None, ext_pos=None, n_extra=0, dkv_extra=None, prec=None):
+                  kext=None, ext_pos=None, n_extra=0, dkv_extra=None, prec=None, k_max=0):
     dev = q.device
     grads = [torch.empty(d, dtype=torch.float32, device=dev) for _ in range(4)]
     ws = _ws(query("lotus_attention_bwd_workspace", nblocks, H), dev)
     call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
          qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
          part_stride, atomic, kext, ext_pos, n_extra, dkv_extra, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
-         int(seed), _PREC if prec is None else prec, ws, ws.numel())
+         int(seed), _PREC if prec is None else prec, int(k_max), ws, ws.numel())
     return grads
 
 
@@ -735,11 +735,15 @@ def _al4(n):
     return (n + 3) & ~3
 
 
-def _side_ctx(dev, ws_side_bytes, reads):
+_SIDE_MAX_ROWS = int(os.environ.get("LOTUS_SIDE_MAX_ROWS", "0"))  # tuning: weight gradients of layers with more rows stay on
+#                                                                   the critical stream (0 = every weight gradient forks)
+
+
+def _side_ctx(dev, ws_side_bytes, reads, rows=0):
     """(side stream pointer or 0, its workspace, its counters) for a composite backward; in the deferred-join mode the
     tensors the side stream reads are announced to the allocator (as _OnSide does)."""
     global _CUR
-    if _side() is None:
+    if _side() is None or (_SIDE_MAX_ROWS and rows > _SIDE_MAX_ROWS):
         return 0, None, None
     _CUR = 0
     st, ptr = _SIDES[0]
@@ -792,7 +796,7 @@ class CpeFn(torch.autograd.Function):
             grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dxc = torch.empty_like(xs)
-            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27))
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27), n_)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             wc = WS.get(ws_conv, dev, slot=2)
             _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, lw, g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
@@ -873,7 +877,7 @@ class FfnFn(torch.autograd.Function):
                 po, so = hand_out.drop
                 dz_out = torch.empty_like(x)
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
-            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), M)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_ffn_bwd", dy, dz_in, x, g, w1, w2, saved, dx, dz_out, po, so, grads, tmp, M, C, Hd, float(p),
                            int(seed), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss, wss.numel() if wss is not None else 0,
@@ -945,7 +949,7 @@ class SelfAttnFn(torch.autograd.Function):
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dx = torch.empty_like(x)
             dz_in = ctx.hand_in.take(dy) if ctx.hand_in is not None else None
-            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in))
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), N)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_selfattn_bwd", dy, dz_in, x, g, wqkv, qnw, qnb, knw, knb, wp, saved, dx, grads, tmp, lvl.gidx,
                            lvl.owner, lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, lvl.kext, lvl.ext_pos, lvl.n_extra, lvl.npad,
@@ -1000,7 +1004,7 @@ class CrossAttnFn(torch.autograd.Function):
             ws = _ws(ws_main, x.device)
             _capi.call_raw("lotus_crossattn_fwd", x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, y, saved,
                            lvl.ca_tiles, lvl.n_ca_tiles, N, C, H, L, Cc, float(d ** -0.5), float(drop_p), int(seed), float(attn_p),
-                           mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+                           mix_seed(seed, 1), _PREC, lvl.ca_kmax, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved)
             return y
         n, mean, rstd = ln_fwd(x, g, b)
@@ -1009,7 +1013,7 @@ class CrossAttnFn(torch.autograd.Function):
         att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
-                      att, lse, H, d, attn_p, mix_seed(seed, 1))
+                      att, lse, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
         y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
         return y
@@ -1035,11 +1039,11 @@ class CrossAttnFn(torch.autograd.Function):
                 po, so = hand_out.drop
                 dz_out = torch.empty_like(x)
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
-            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in, context))
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in, context), N)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             _capi.call_raw("lotus_crossattn_bwd", dy, dz_in, x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved, dx, dctx, dz_out,
                            po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L, Cc, float(d ** -0.5),
-                           float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss,
+                           float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, lvl.ca_kmax, wsm, wsm.numel(), wss,
                            wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             d4 = _al4(d)
             o1 = 2 * _al4(C)
@@ -1061,7 +1065,7 @@ class CrossAttnFn(torch.autograd.Function):
         dkv_part = torch.empty(G, L, 2 * C, dtype=x.dtype, device=dev)
         gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
                                          lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, dkv_part,
-                                         2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1))
+                                         2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
         dkv = sum_slabs(dkv_part)
         dwkv, dbkv = linear_wgrad(dkv, context)
         dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None

@@ -239,17 +239,37 @@ class GradReducer:
             torch.cuda.current_stream().wait_stream(self._comm)
         self._keep = []
         if self.world > 1:
-            # parameters NO rank used keep .grad None, as under DistributedDataParallel(find_unused_parameters=True) and
-            # as on one GPU: the optimiser skips them (no decoupled weight decay, no moment update for e.g. a head
-            # that never ran).  One tiny MAX all-reduce of the usage bitmap per step.
-            # (issued unconditionally: a rank-local "everything was used here" shortcut would mismatch the collective)
-            u = self._used.to(self.flat.device)
-            dist.all_reduce(u, op=dist.ReduceOp.MAX, group=self.group)
-            if int(u.min().item()) == 0:
-                for p, flag in zip(self.params, u.tolist()):
-                    if not flag:
-                        p.grad = None
+            self._sync_usage()
         self._used.zero_()
+
+    def _sync_usage(self):
+        """Parameters NO rank used keep .grad None, as under DistributedDataParallel(find_unused_parameters=True) and as on
+        one GPU: the optimiser skips them (no decoupled weight decay, no moment update for e.g. a head that never ran).
+        The per-parameter usage flags are MAX-reduced on the device every step (issued unconditionally: a rank-local
+        shortcut would mismatch the collective) but read by the host ONE STEP LATER through a pinned copy, so the step never
+        waits for the GPU; only the very first step blocks once.  Usage patterns are static in practice (a module either
+        takes part in the model's forward or it does not); a parameter whose global usage changes is handled one step late
+        (one update with a zero gradient, or one skipped update)."""
+        dev = self.flat.device
+        u = self._used.to(dev, non_blocking=True)
+        dist.all_reduce(u, op=dist.ReduceOp.MAX, group=self.group)      # stream-ordered on RCCL, blocking on gloo
+        if self._unused is None or not u.is_cuda:                          # first step (one blocking read) / host tensors
+            self._unused = {i for i, f in enumerate(u.tolist()) if not f}
+        else:
+            if self._usage_pending is not None:                           # last step's flags (long finished)
+                host, ev = self._usage_pending
+                if ev is not None:
+                    ev.synchronize()
+                self._unused = {i for i, f in enumerate(host.tolist()) if not f}
+            host = torch.empty(u.shape, dtype=u.dtype, pin_memory=True)
+            host.copy_(u, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._usage_pending = (host, ev)
+        for i in self._unused:
+            self.params[i].grad = None
+
+    _unused, _usage_pending = None, None
 
 
 _BN_GROUP = None

@@ -400,39 +400,78 @@ def test_patch_attention_bf16_operand_paths(prec, tol, C, H):
         _close(a, b.grad, 10 * tol, f"{name} prec {prec}")
 
 
-@pytest.mark.parametrize("C,H", [(64, 2), (768, 32)])
-def test_cross_attention_fwd_bwd(C, H):
+@pytest.mark.parametrize("path", ["tile", "short_keys"])
+@pytest.mark.parametrize("C,H,drop", [(64, 2, 0.0), (768, 32, 0.0), (128, 4, 0.0), (128, 4, 0.25)])
+def test_cross_attention_fwd_bwd(C, H, drop, path):
+    """Both kernel families of the cross attention against the fp64 formulation: the 128 x 128 tile kernels (k_max = 0) and
+    the short-key kernels (one lane per query; k_max = longest instruction <= 32).  With dropout on the probabilities the
+    reference cannot be evaluated (hash masks), so the two families — which share the mask index — are compared with each
+    other, and backward is checked against central differences of the forward along a random direction."""
     ops = _ops()
     batch, ref, got = _cloud_levels(3, 700, seed=C + 1)
     lv = got[0]
     n, d = lv.n, C // H
     counts, ctx_counts = batch["npoints_in_batch"], batch["txt_lens"]
+    assert 0 < lv.ca_kmax <= 32 and lv.ca_kmax == max(ctx_counts)
+    k_max = lv.ca_kmax if path == "short_keys" else 0
     L = sum(ctx_counts)
     g = torch.Generator().manual_seed(C + 5)
     q, kv = torch.randn(n, C, generator=g) * 1.5, torch.randn(L, 2 * C, generator=g) * 1.5
     qn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
     kn = (torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2)
     dout = torch.randn(n, C, generator=g)
-    qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
-    pr = [t.double().requires_grad_(True) for t in (*qn, *kn)]
-    oref = om.cross_attention(qd, kvd, counts, ctx_counts, H, pr[0], pr[1], pr[2], pr[3])
-    oref.backward(dout.double())
     qc, kvc = q.cuda(), kv.cuda()
     qnc, knc = tuple(t.cuda() for t in qn), tuple(t.cuda() for t in kn)
-    att = torch.empty(n, C, device="cuda")
-    lse = torch.empty(n, H, device="cuda")
-    ops.attention_fwd(qc, C, 0, kvc, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.n_ca_tiles, qnc, knc, att, lse, H, d)
-    _close(att, oref, 5e-6, "xattn fwd")
-    dq = torch.empty(n, C, device="cuda")
     G = lv.ca_groups
-    dkvp = torch.empty(G, L, 2 * C, device="cuda")
-    gr = ops.attention_bwd(qc, C, 0, kvc, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.ca_blocks, lv.n_ca_blocks, qnc,
-                           knc, att, dout.cuda(), lse, dq, C, 0, dkvp, 2 * C, 0, C, L * 2 * C, 0, H, d)
-    _close(dq, qd.grad, 2e-5, "xattn dq")
-    _close(dkvp.sum(0), kvd.grad, 2e-5, "xattn dkv")
-    for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
-        # dkn_b is mathematically zero (softmax is shift-invariant per query): pure fp32 cancellation noise
-        _close(a, b.grad, 5e-4 if name == "dkn_b" else 5e-5, name)
+
+    def run(km, qq=qc, kk=kvc):
+        att = torch.empty(n, C, device="cuda")
+        lse = torch.empty(n, H, device="cuda")
+        ops.attention_fwd(qq, C, 0, kk, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.n_ca_tiles, qnc, knc, att, lse, H, d,
+                          drop_p=drop, seed=77, k_max=km)
+        return att, lse
+
+    def back(km, att, lse):
+        dq = torch.empty(n, C, device="cuda")
+        dkvp = torch.empty(G, L, 2 * C, device="cuda")
+        gr = ops.attention_bwd(qc, C, 0, kvc, 2 * C, 0, C, None, None, None, lv.ca_tiles, lv.ca_blocks, lv.n_ca_blocks, qnc,
+                               knc, att, dout.cuda(), lse, dq, C, 0, dkvp, 2 * C, 0, C, L * 2 * C, 0, H, d, drop_p=drop, seed=77,
+                               k_max=km)
+        return dq, dkvp.sum(0), gr
+
+    att, lse = run(k_max)
+    dq, dkv, gr = back(k_max, att, lse)
+    if drop == 0.0:
+        qd, kvd = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+        pr = [t.double().requires_grad_(True) for t in (*qn, *kn)]
+        oref = om.cross_attention(qd, kvd, counts, ctx_counts, H, pr[0], pr[1], pr[2], pr[3])
+        oref.backward(dout.double())
+        _close(att, oref, 5e-6, "xattn fwd")
+        _close(dq, qd.grad, 2e-5, "xattn dq")
+        _close(dkv, kvd.grad, 2e-5, "xattn dkv")
+        for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
+            # dkn_b is mathematically zero (softmax is shift-invariant per query): pure fp32 cancellation noise
+            _close(a, b.grad, 5e-4 if name == "dkn_b" else 5e-5, name)
+    else:
+        att0, lse0 = run(0)
+        dq0, dkv0, gr0 = back(0, att0, lse0)
+        _close(att, att0, 5e-6, "xattn fwd (dropout) vs tile kernels")
+        _close(lse, lse0, 5e-6, "xattn lse")
+        _close(dq, dq0, 2e-5, "xattn dq (dropout)")
+        _close(dkv, dkv0, 2e-5, "xattn dkv (dropout)")
+        for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, gr0):
+            _close(a, b, 5e-4 if name == "dkn_b" else 5e-5, name + " (dropout)")
+        keep = float((att != 0).float().mean())
+        assert keep > 0.99  # outputs are sums over the kept keys: essentially never all dropped
+        # directional derivative of <out, dout> along a random direction of (q, kv)
+        gdir = torch.Generator(device="cuda").manual_seed(1)
+        vq, vk = torch.randn(n, C, device="cuda", generator=gdir), torch.randn(L, 2 * C, device="cuda", generator=gdir)
+        want = float((dq.double() * vq.double()).sum() + (dkv.double() * vk.double()).sum())
+        eps = 1e-2
+        fp = float((run(k_max, qc + eps * vq, kvc + eps * vk)[0].double() * dout.cuda().double()).sum())
+        fm = float((run(k_max, qc - eps * vq, kvc - eps * vk)[0].double() * dout.cuda().double()).sum())
+        fd = (fp - fm) / (2 * eps)
+        assert abs(fd - want) <= 2e-3 * max(abs(want), abs(fd)) + 1e-2, (fd, want)
 
 
 # ------------------------------------------------------------------------------------ pool / head / loss
@@ -580,7 +619,7 @@ def test_cloud_max_first_index_ties_and_ragged_clouds():
     assert torch.equal(xr.grad, want)
 
 
-@pytest.mark.parametrize("M,N,K", [(361, 768, 3072), (1450, 512, 2048), (441, 3072, 768), (1727, 512, 512)])
+@pytest.mark.parametrize("M,N,K", [(361, 768, 3072), (1450, 512, 2048), (441, 3072, 768), (1727, 512, 2048)])
 def test_fused_splitk_handoff_equals_two_launch_path(M, N, K):
     """The fused split-K hand-off (partials through sc1 stores / loads + an arrival counter, csrc/gemm.hip "HARDWARE CONTRACT")
     against the two-launch path (partials, kernel boundary, reduction kernel) on the deep-level shapes that split: forward and
