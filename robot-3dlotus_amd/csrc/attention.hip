@@ -854,25 +854,29 @@ __global__ void attn_extra_fixup_kernel(const act_t* __restrict__ extra, long ex
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Short-key attention: every key range has at most 32 rows and rows are identity-indexed — the point <-> instruction
-// cross attention of CABlock (model_ca.py:46-101): a cloud's 4096 points attend to its 6-19 language tokens.  The tile
-// kernels above spend a 128 x 128 machinery (row images, per-phase barriers, one busy wave in the key orientation) on a
-// problem whose whole key side fits in 8 KB, and ran at 27-44 us forward / 75-145 us backward per launch for ~1 GFLOP.
-// Here ONE LANE OWNS ONE QUERY: its q row, LayerNorm, scores, softmax and output stay in registers, the normalised keys
-// and values are LDS rows read as broadcasts, and the forward pass has no barrier after the key set-up.  The backward pass
-// keeps the per-query part in registers the same way (dS, dq, LayerNorm backward) and reduces over the queries — dV = P^T dO
-// and T = dS^T qhat, from which d k and the q-norm parameter gradients follow (see below) — with two MFMA chains per wave
-// over wave-private LDS images.  Exact fp32 (VALU + fp32 MFMA) whatever `precision` says.  Dropout masks use the same
-// (tile, head, query, key) hash index as the tile kernels.
+// Query-per-lane attention.  fp32 MFMA runs at the fp32 VECTOR rate on gfx950 (64 FLOP / clk / SIMD either way), so for the
+// exact-fp32 mode the matrix cores buy nothing in QK^T and PV — but the 128 x 128 tile kernels above pay for them with row
+// images, per-phase barriers, transposed-accumulator bookkeeping and, in backward, two recomputed products (MFMA
+// utilisation 0.15 forward / 0.21 backward).  Here ONE LANE OWNS ONE QUERY: its q row, q_norm, scores, softmax and output
+// stay in registers; the normalised keys and the values are LDS rows that every lane reads at the same address
+// (broadcast); the forward pass has no barrier after the key set-up.  The backward pass keeps the per-query part in
+// registers the same way (dS, dq, q_norm backward) and does the only reductions over queries — dV = (P mask)^T dO and
+// T = dS^T qhat, from which d k and the q_norm parameter gradients follow (see xq_bwd_kernel) — with two MFMA chains per
+// wave over wave-private LDS images, 32 keys at a time.
+// Serves both call sites: the point <-> instruction cross attention (identity rows, 6-19 keys per cloud: one key chunk,
+// several query tiles per block) and the patch self attention (gathered rows, 128 keys = four chunks, one tile per block;
+// owner flags and the borrowed tail-patch copies as in the tile kernels).  Exact fp32 whatever `precision` says.
+// Dropout masks use the same (tile, head, query, key) hash index as the tile kernels.
+
+// rows j < n of K and V (D floats each, row ids from rows_s) -> [.][32] images, zero beyond n / D; 8 lanes per row
 template <int D>
-__device__ __forceinline__ void xattn_load_keys(const AttnP& p, int h, int k_start, int k_len, float* __restrict__ kraw,
-                                                float* __restrict__ v_s) {
-  // rows j < k_len of K and V (D floats each) -> [32][32] images, zero elsewhere; 8 lanes per row
-  for (int i = threadIdx.x; i < 32 * 8; i += blockDim.x) {
+__device__ __forceinline__ void xq_load_keys(const AttnP& p, int h, const int* __restrict__ rows_s, int n, int npad,
+                                             float* __restrict__ kraw, float* __restrict__ v_s) {
+  for (int i = threadIdx.x; i < npad * 8; i += blockDim.x) {
     const int j = i >> 3, c4 = i & 7;
     float4 kv4 = make_float4(0.f, 0.f, 0.f, 0.f), vv4 = kv4;
-    if (j < k_len && c4 * 4 < D) {
-      const act_t* row = p.kv + (long)(k_start + j) * p.kv_ld + h * D + c4 * 4;
+    if (j < n && c4 * 4 < D) {
+      const act_t* row = p.kv + (long)rows_s[j] * p.kv_ld + h * D + c4 * 4;
       kv4 = ld4(row + p.k_off);
       vv4 = ld4(row + p.v_off);
     }
@@ -881,42 +885,48 @@ __device__ __forceinline__ void xattn_load_keys(const AttnP& p, int h, int k_sta
   }
 }
 
-// LayerNorm(d, eps) of the 32 key rows in place, 8 lanes per row (two passes of 128 threads): khat -> kraw, rstd -> krstd
+// LayerNorm(d, eps) of npad key rows in place, 8 lanes per row: khat -> kraw, rstd -> krstd (0 for rows >= n)
 template <int D>
-__device__ __forceinline__ void xattn_norm_keys(float eps, int k_len, float* __restrict__ kraw, float* __restrict__ krstd) {
-  for (int i = threadIdx.x; i < 32 * 8; i += blockDim.x) {
+__device__ __forceinline__ void xq_norm_keys(float eps, int n, int npad, float* __restrict__ kraw, float* __restrict__ krstd) {
+  for (int i = threadIdx.x; i < npad * 8; i += blockDim.x) {
     const int j = i >> 3, c4 = i & 7;
-    float4 v = *reinterpret_cast<const float4*>(kraw + j * 32 + c4 * 4);
+    const float4 v = *reinterpret_cast<const float4*>(kraw + j * 32 + c4 * 4);
     float sum = (c4 * 4 < D) ? (v.x + v.y) + (v.z + v.w) : 0.f;
     sum += __shfl_xor(sum, 1, 8); sum += __shfl_xor(sum, 2, 8); sum += __shfl_xor(sum, 4, 8);
     const float m = sum / D;
     const float cx = v.x - m, cy = v.y - m, cz = v.z - m, cw = v.w - m;
     float var = (c4 * 4 < D) ? (cx * cx + cy * cy) + (cz * cz + cw * cw) : 0.f;
     var += __shfl_xor(var, 1, 8); var += __shfl_xor(var, 2, 8); var += __shfl_xor(var, 4, 8);
-    const float rs = (j < k_len) ? rsqrtf(var / D + eps) : 0.f;
+    const float rs = (j < n) ? rsqrtf(var / D + eps) : 0.f;
     if (c4 * 4 < D) *reinterpret_cast<float4*>(kraw + j * 32 + c4 * 4) = make_float4(cx * rs, cy * rs, cz * rs, cw * rs);
     if (c4 == 0) krstd[j] = rs;
   }
 }
 
 template <int D>
-__global__ __launch_bounds__(128) void xattn_fwd_kernel(AttnP p) {
-  __shared__ __attribute__((aligned(16))) float kn_s[32 * 32], v_s[32 * 32], krstd_s[32];
+__global__ __launch_bounds__(128) void xq_fwd_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) float kn_s[AT * 32], v_s[AT * 32], krstd_s[AT];
+  __shared__ int krow_s[AT];
   const int tid = threadIdx.x, h = blockIdx.y;
   const int q_start = p.tiles[blockIdx.x * 4 + 0], q_len = p.tiles[blockIdx.x * 4 + 1];
   const int k_start = p.tiles[blockIdx.x * 4 + 2], k_len = p.tiles[blockIdx.x * 4 + 3];
-  xattn_load_keys<D>(p, h, k_start, k_len, kn_s, v_s);
+  const int kpad = (k_len + 3) & ~3;  // keys are consumed four at a time
+  if (tid < AT) krow_s[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
   __syncthreads();
-  xattn_norm_keys<D>(p.eps, k_len, kn_s, krstd_s);
+  xq_load_keys<D>(p, h, krow_s, k_len, kpad, kn_s, v_s);
   __syncthreads();
-  for (int i = tid; i < 32 * 32; i += 128) {  // affine part of k_norm
+  xq_norm_keys<D>(p.eps, k_len, kpad, kn_s, krstd_s);
+  __syncthreads();
+  for (int i = tid; i < kpad * 32; i += 128) {  // affine part of k_norm
     const int c = i & 31;
     if (c < D) kn_s[i] = kn_s[i] * p.kn_w[c] + p.kn_b[c];
   }
   __syncthreads();
   const int qi = tid;
   if (qi >= q_len) return;
-  const long row = q_start + qi;
+  const int pos = q_start + qi;
+  if (p.owner && !p.owner[pos]) return;  // borrowed copy of a tail patch: its output row is never used
+  const long row = p.qidx ? p.qidx[pos] : pos;
   float q[D];
   {
     const act_t* qp = p.q + row * p.q_ld + p.q_off + h * D;
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(128) void xattn_fwd_kernel(AttnP p) {
       q[4 * c4] = v.x; q[4 * c4 + 1] = v.y; q[4 * c4 + 2] = v.z; q[4 * c4 + 3] = v.w;
     }
   }
-  {  // q_norm (LayerNorm(d, eps) with affine), model_ca.py:56-58
+  {  // q_norm (LayerNorm(d, eps) with affine), model.py:532 / model_ca.py:52; the softmax scale is folded in
     float m = 0.f;
 #pragma unroll
     for (int c = 0; c < D; ++c) m += q[c];
@@ -947,32 +957,43 @@ __global__ __launch_bounds__(128) void xattn_fwd_kernel(AttnP p) {
   float mx = -INFINITY, l = 0.f, o[D];
 #pragma unroll
   for (int c = 0; c < D; ++c) o[c] = 0.f;
-  for (int j = 0; j < k_len; ++j) {  // streaming softmax over the (few) keys: everything stays in registers
-    const float4* kr = reinterpret_cast<const float4*>(kn_s + j * 32);
-    float sc = 0.f;
+  for (int j0 = 0; j0 < k_len; j0 += 4) {  // streaming softmax, four keys per rescale
+    float sc[4];
 #pragma unroll
-    for (int c4 = 0; c4 < D / 4; ++c4) {
-      const float4 k4 = kr[c4];
-      sc = fmaf(q[4 * c4], k4.x, sc); sc = fmaf(q[4 * c4 + 1], k4.y, sc);
-      sc = fmaf(q[4 * c4 + 2], k4.z, sc); sc = fmaf(q[4 * c4 + 3], k4.w, sc);
+    for (int e = 0; e < 4; ++e) {
+      const float4* kr = reinterpret_cast<const float4*>(kn_s + (j0 + e) * 32);
+      float a = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < D / 4; ++c4) {
+        const float4 k4 = kr[c4];
+        a = fmaf(q[4 * c4], k4.x, a); a = fmaf(q[4 * c4 + 1], k4.y, a);
+        a = fmaf(q[4 * c4 + 2], k4.z, a); a = fmaf(q[4 * c4 + 3], k4.w, a);
+      }
+      sc[e] = (j0 + e < k_len) ? a * p.scale : -INFINITY;
     }
-    sc *= p.scale;
-    const float mn = fmaxf(mx, sc);
-    const float corr = __expf(mx - mn), pj = __expf(sc - mn);
-    l = l * corr + pj;
+    const float mn = fmaxf(fmaxf(mx, fmaxf(sc[0], sc[1])), fmaxf(sc[2], sc[3]));
+    const float corr = __expf(mx - mn);
     mx = mn;
-    float w = pj;
-    if (p.drop_thresh) w = keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh) ? pj * p.drop_inv_keep : 0.f;
-    const float4* vr = reinterpret_cast<const float4*>(v_s + j * 32);
+    l *= corr;
 #pragma unroll
-    for (int c4 = 0; c4 < D / 4; ++c4) {
-      const float4 v4 = vr[c4];
-      o[4 * c4] = fmaf(o[4 * c4], corr, w * v4.x); o[4 * c4 + 1] = fmaf(o[4 * c4 + 1], corr, w * v4.y);
-      o[4 * c4 + 2] = fmaf(o[4 * c4 + 2], corr, w * v4.z); o[4 * c4 + 3] = fmaf(o[4 * c4 + 3], corr, w * v4.w);
+    for (int c = 0; c < D; ++c) o[c] *= corr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pj = __expf(sc[e] - mn);
+      l += pj;
+      float w = pj;
+      if (p.drop_thresh) w = keep_lo(lo0 + (unsigned)(j0 + e), s0, c2, p.drop_thresh) ? pj * p.drop_inv_keep : 0.f;
+      const float4* vr = reinterpret_cast<const float4*>(v_s + (j0 + e) * 32);
+#pragma unroll
+      for (int c4 = 0; c4 < D / 4; ++c4) {
+        const float4 v4 = vr[c4];
+        o[4 * c4] = fmaf(w, v4.x, o[4 * c4]); o[4 * c4 + 1] = fmaf(w, v4.y, o[4 * c4 + 1]);
+        o[4 * c4 + 2] = fmaf(w, v4.z, o[4 * c4 + 2]); o[4 * c4 + 3] = fmaf(w, v4.w, o[4 * c4 + 3]);
+      }
     }
   }
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  if (p.lse) p.lse[row * p.H + h] = mx + logf(l);
+  if (p.lse) p.lse[(long)pos * p.H + h] = mx + logf(l);
   act_t* op = p.out + row * p.out_ld + h * D;
 #pragma unroll
   for (int c4 = 0; c4 < D / 4; ++c4)
@@ -980,212 +1001,307 @@ __global__ __launch_bounds__(128) void xattn_fwd_kernel(AttnP p) {
 }
 
 // Backward.  With kn = khat gk + bk (k_norm output), qn = qhat gq + bq (q_norm output) and dS the score gradient:
-//   s_ij = scale (qhat_i . kg_j + kb_j),  kg_j = gq * kn_j,  kb_j = bq . kn_j          (the q affine folded into the keys)
-//   d qhat_i = sum_j dS_ij kg_j                                                          (registers, per query)
+//   s_ij = scale (qgk_i . khat_j + qb_i + kb_j),  qgk = qhat gq gk,  qb_i = (qhat_i gq) . bk,  kb_j = bq . kn_j
+//   d qhat_i = gq (gk sum_j dS_ij khat_j + bk sum_j dS_ij)                               (registers, per query)
 //   T = dS^T qhat  [keys x d],  cs_j = sum_i dS_ij                                       (MFMA / column sums over queries)
 //   d kn_j = gq * T_j + bq cs_j,   d gq = sum_j kn_j * T_j,   d bq = sum_j kn_j cs_j
 //   d V = (P * mask)^T dO                                                                (MFMA)
-// so the only reductions over queries are two [32 x 128] x [128 x 32] products per tile, done by each wave on its own 64
-// rows of the LDS images (no block barrier between the per-query phase and the products).
+// Keys are taken 32 at a time (chunk kc); a block either has one chunk and several query tiles (cross attention: T / dV
+// accumulate over the tiles) or one tile and several chunks (patch attention: the query state stays in registers across the
+// chunks, every chunk is finished and stored on its own) — the host routes nothing else here.  Each wave reduces its own
+// 64 rows of the LDS images, so there is no block barrier between the per-query phase and the products beyond the one
+// that publishes the images.
 template <int D>
-__global__ __launch_bounds__(128) void xattn_bwd_kernel(AttnP p) {
+__global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
   constexpr int ILD = 33;
-  __shared__ __attribute__((aligned(16))) float khat_s[32 * 32], kg_s[32 * 32], v_s[32 * 32], krstd_s[32], kb_s[32], cs_s[2][32];
+  __shared__ __attribute__((aligned(16))) float khat_s[32 * 32], v_s[32 * 32], krstd_s[32], kb_s[32], cs_s[2][32];
+  __shared__ int krow_s[32], kext_s[32];
   __shared__ float ds_s[128 * ILD], pm_s[128 * ILD], qh_s[128 * ILD], do_s[128 * ILD];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1, h = blockIdx.y;
   const int* bd = p.blocks + blockIdx.x * 6;
   const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3], k_start = bd[4], k_len = bd[5];
-  xattn_load_keys<D>(p, h, k_start, k_len, khat_s, v_s);
+  const int n_chunks = (k_len + 31) >> 5;
   for (int i = tid; i < 128 * ILD; i += 128) { qh_s[i] = 0.f; do_s[i] = 0.f; }  // columns >= D stay zero for the MFMA operands
-  __syncthreads();
-  xattn_norm_keys<D>(p.eps, k_len, khat_s, krstd_s);
-  __syncthreads();
-  for (int i = tid; i < 32 * 32; i += 128) {
-    const int c = i & 31;
-    kg_s[i] = (c < D) ? (khat_s[i] * p.kn_w[c] + p.kn_b[c]) * p.qn_w[c] : 0.f;
-  }
-  if (tid < 32) {
-    float a = 0.f;
-    for (int c = 0; c < D; ++c) a += (khat_s[tid * 32 + c] * p.kn_w[c] + p.kn_b[c]) * p.qn_b[c];
-    kb_s[tid] = a;
-  }
-  __syncthreads();
-  f32x16 accT = zero16(), accV = zero16();
-  float cs_acc = 0.f;  // lanes 0..31 of each wave: column sums of dS over the wave's queries
   const unsigned s0 = (unsigned)p.drop_seed;
-  for (int ti = 0; ti < n_tiles; ++ti) {
-    const int tile = first_tile + ti * tile_step;
-    const int q_start = p.tiles[tile * 4 + 0], q_len = p.tiles[tile * 4 + 1];
-    const int qi = tid;
-    float* dsr = ds_s + qi * ILD;
-    float* pmr = pm_s + qi * ILD;
-    if (qi < q_len) {
-      const long row = q_start + qi;
-      float qh[D], go[D], dx[D];
-      float Di = 0.f;
-      {
-        const act_t* qp = p.q + row * p.q_ld + p.q_off + h * D;
-        const act_t* gp = p.dout + row * p.out_ld + h * D;
-        const act_t* op = p.out + row * p.out_ld + h * D;
-        float4 qv[D / 4], gv[D / 4], ov[D / 4];
+  const int qi = tid;
+  // per-query state (lives across the key chunks when the block has a single tile)
+  float qh[D], go[D], dx[D], qgk[D];  // qgk = qhat gq gk: s_ij = qgk_i . khat_j + qb_i + kb_j (both affines folded in)
+  float Di = 0.f, lse = 0.f, rs = 0.f, qb = 0.f, dsum = 0.f;
+  long qrow = 0;
+  int tile = first_tile;
+  bool act = false;  // this lane holds an owner query of the current tile
+  float lnq[4] = {0.f, 0.f, 0.f, 0.f};  // tid < 32: d gq, d bq, d gk, d bk of channel tid, summed over the chunks
+  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+
+  for (int kc = 0; kc < n_chunks; ++kc) {
+    const int kl = min(32, k_len - kc * 32);
+    __syncthreads();  // the previous chunk's epilogue is done with the key arrays and the images
+    if (tid < 32) {
+      const int pos = k_start + kc * 32 + tid;
+      krow_s[tid] = tid < kl ? (p.kidx ? p.kidx[pos] : pos) : -1;
+      kext_s[tid] = (tid < kl && p.kext && p.dkv_extra) ? p.kext[pos] : -1;
+    }
+    __syncthreads();
+    xq_load_keys<D>(p, h, krow_s, kl, 32, khat_s, v_s);
+    __syncthreads();
+    xq_norm_keys<D>(p.eps, kl, 32, khat_s, krstd_s);
+    __syncthreads();
+    if (tid < 32) {  // kb_j = bq . kn_j
+      float a = 0.f;
+      for (int c = 0; c < D; ++c) a += (khat_s[tid * 32 + c] * p.kn_w[c] + p.kn_b[c]) * p.qn_b[c];
+      kb_s[tid] = a;
+    }
+    __syncthreads();
+    f32x16 accT = zero16(), accV = zero16();
+    float cs_acc = 0.f;  // lanes 0..31 of each wave: column sums of dS over the wave's queries
+    // The q / dO / O rows of tile ti + 1 are requested before the products of tile ti (a block runs one wave per SIMD:
+    // nothing else would hide the round trip) and consumed at the top of the next iteration.
+    float4 qv[D / 4], gv[D / 4], ov[D / 4];
+    bool nact = false;
+    long nrow = 0;
+    int npos = 0;
+    auto fetch = [&](int ti_) {
+      const int t_ = first_tile + ti_ * tile_step;
+      const int q_start = p.tiles[t_ * 4 + 0], q_len = p.tiles[t_ * 4 + 1];
+      npos = q_start + qi;
+      nact = qi < q_len && (!p.owner || p.owner[npos]);
+      if (nact) {
+        nrow = p.qidx ? p.qidx[npos] : npos;
+        const act_t* qp = p.q + nrow * p.q_ld + p.q_off + h * D;
+        const act_t* gp = p.dout + nrow * p.out_ld + h * D;
+        const act_t* op = p.out + nrow * p.out_ld + h * D;
 #pragma unroll
         for (int c4 = 0; c4 < D / 4; ++c4) { qv[c4] = ld4(qp + c4 * 4); gv[c4] = ld4(gp + c4 * 4); ov[c4] = ld4(op + c4 * 4); }
+      }
+    };
+    if (kc == 0 || n_tiles > 1) fetch(0);
+    for (int ti = 0; ti < n_tiles; ++ti) {
+      float* dsr = ds_s + qi * ILD;
+      float* pmr = pm_s + qi * ILD;
+      if (kc == 0 || n_tiles > 1) {  // take over the query side of this tile
+        tile = first_tile + ti * tile_step;
+        const int pos = npos;
+        act = nact;
+        if (act) {
+          qrow = nrow;
+          Di = 0.f;
 #pragma unroll
-        for (int c4 = 0; c4 < D / 4; ++c4) {
-          qh[4 * c4] = qv[c4].x; qh[4 * c4 + 1] = qv[c4].y; qh[4 * c4 + 2] = qv[c4].z; qh[4 * c4 + 3] = qv[c4].w;
-          go[4 * c4] = gv[c4].x; go[4 * c4 + 1] = gv[c4].y; go[4 * c4 + 2] = gv[c4].z; go[4 * c4 + 3] = gv[c4].w;
-          Di += (gv[c4].x * ov[c4].x + gv[c4].y * ov[c4].y) + (gv[c4].z * ov[c4].z + gv[c4].w * ov[c4].w);
+          for (int c4 = 0; c4 < D / 4; ++c4) {
+            qh[4 * c4] = qv[c4].x; qh[4 * c4 + 1] = qv[c4].y; qh[4 * c4 + 2] = qv[c4].z; qh[4 * c4 + 3] = qv[c4].w;
+            go[4 * c4] = gv[c4].x; go[4 * c4 + 1] = gv[c4].y; go[4 * c4 + 2] = gv[c4].z; go[4 * c4 + 3] = gv[c4].w;
+            Di += (gv[c4].x * ov[c4].x + gv[c4].y * ov[c4].y) + (gv[c4].z * ov[c4].z + gv[c4].w * ov[c4].w);
+          }
+          float m = 0.f;
+#pragma unroll
+          for (int c = 0; c < D; ++c) m += qh[c];
+          m /= D;
+          float var = 0.f;
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            const float t = qh[c] - m;
+            var += t * t;
+          }
+          rs = rsqrtf(var / D + p.eps);
+          qb = 0.f;
+          dsum = 0.f;
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            qh[c] = (qh[c] - m) * rs;
+            dx[c] = 0.f;  // accumulates sum_j dS_ij khat_j[c]
+            const float qg = qh[c] * p.qn_w[c];
+            qgk[c] = qg * p.kn_w[c];
+            qb = fmaf(qg, p.kn_b[c], qb);
+          }
+          lse = p.lse[(long)pos * p.H + h];
+#pragma unroll
+          for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = qh[c]; do_s[qi * ILD + c] = go[c]; }
+        } else {
+#pragma unroll
+          for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = 0.f; do_s[qi * ILD + c] = 0.f; }
         }
       }
-      float m = 0.f;
+      if (act) {
+        const unsigned long long rb = (((unsigned long long)tile * p.H + h) * AT + qi) * AT + kc * 32;
+        const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+        // two keys per iteration: eight independent dot-product chains and their LDS reads in flight together (a block
+        // runs one wave per SIMD, so nothing else hides an LDS round trip or a dependent FMA chain)
+        for (int j0 = 0; j0 < kl; j0 += 2) {
+          float4 k4[2][D / 4];
+          float sc[2], dp[2];
 #pragma unroll
-      for (int c = 0; c < D; ++c) m += qh[c];
-      m /= D;
-      float var = 0.f;
+          for (int e = 0; e < 2; ++e) {
+            const float4* kr = reinterpret_cast<const float4*>(khat_s + (j0 + e) * 32);
+            const float4* vr = reinterpret_cast<const float4*>(v_s + (j0 + e) * 32);
+            float a0 = kb_s[j0 + e] + qb, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
-      for (int c = 0; c < D; ++c) {
-        const float t = qh[c] - m;
-        var += t * t;
-      }
-      const float rs = rsqrtf(var / D + p.eps);
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+              const float4 kk = kr[c4], v4 = vr[c4];
+              k4[e][c4] = kk;
+              a0 = fmaf(qgk[4 * c4], kk.x, a0); a1 = fmaf(qgk[4 * c4 + 1], kk.y, a1);
+              a0 = fmaf(qgk[4 * c4 + 2], kk.z, a0); a1 = fmaf(qgk[4 * c4 + 3], kk.w, a1);
+              b0 = fmaf(go[4 * c4], v4.x, b0); b1 = fmaf(go[4 * c4 + 1], v4.y, b1);
+              b0 = fmaf(go[4 * c4 + 2], v4.z, b0); b1 = fmaf(go[4 * c4 + 3], v4.w, b1);
+            }
+            sc[e] = a0 + a1;
+            dp[e] = b0 + b1;
+          }
 #pragma unroll
-      for (int c = 0; c < D; ++c) {
-        qh[c] = (qh[c] - m) * rs;
-        dx[c] = 0.f;
-      }
-      const float lse = p.lse[row * p.H + h];
-      const unsigned long long rb = (((unsigned long long)tile * p.H + h) * AT + qi) * AT;
-      const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
-      for (int j = 0; j < k_len; ++j) {
-        const float4* kr = reinterpret_cast<const float4*>(kg_s + j * 32);
-        const float4* vr = reinterpret_cast<const float4*>(v_s + j * 32);
-        float sc = kb_s[j], dp = 0.f;
+          for (int e = 0; e < 2; ++e) {
+            const int j = j0 + e;
+            const bool in = j < kl;  // (rows kl .. 31 of the chunk are zero rows)
+            const float pj = in ? __expf(sc[e] * p.scale - lse) : 0.f;
+            const bool keep = !p.drop_thresh || keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh);
+            const float pmj = keep ? pj * p.drop_inv_keep : 0.f;
+            const float ds = p.scale * pj * ((keep ? dp[e] * p.drop_inv_keep : 0.f) - Di);
+            dsr[j] = ds;
+            pmr[j] = pmj;
+            dsum += ds;
 #pragma unroll
-        for (int c4 = 0; c4 < D / 4; ++c4) {
-          const float4 k4 = kr[c4], v4 = vr[c4];
-          sc = fmaf(qh[4 * c4], k4.x, sc); sc = fmaf(qh[4 * c4 + 1], k4.y, sc);
-          sc = fmaf(qh[4 * c4 + 2], k4.z, sc); sc = fmaf(qh[4 * c4 + 3], k4.w, sc);
-          dp = fmaf(go[4 * c4], v4.x, dp); dp = fmaf(go[4 * c4 + 1], v4.y, dp);
-          dp = fmaf(go[4 * c4 + 2], v4.z, dp); dp = fmaf(go[4 * c4 + 3], v4.w, dp);
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+              dx[4 * c4] = fmaf(ds, k4[e][c4].x, dx[4 * c4]); dx[4 * c4 + 1] = fmaf(ds, k4[e][c4].y, dx[4 * c4 + 1]);
+              dx[4 * c4 + 2] = fmaf(ds, k4[e][c4].z, dx[4 * c4 + 2]); dx[4 * c4 + 3] = fmaf(ds, k4[e][c4].w, dx[4 * c4 + 3]);
+            }
+          }
         }
-        const float pj = __expf(sc * p.scale - lse);
-        const bool keep = !p.drop_thresh || keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh);
-        const float pmj = keep ? pj * p.drop_inv_keep : 0.f;
-        const float ds = p.scale * pj * ((keep ? dp * p.drop_inv_keep : 0.f) - Di);
-        dsr[j] = ds;
-        pmr[j] = pmj;
+        for (int j = (kl + 1) & ~1; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
+        if (kc == n_chunks - 1) {
+          // d qhat[c] = gq[c] (gk[c] sum_j dS_ij khat_j[c] + bk[c] sum_j dS_ij), complete after the last chunk; then the
+          // q_norm backward: dq = rs (dx - mean(dx) - qhat mean(dx qhat))
+          float a = 0.f, b = 0.f;
 #pragma unroll
-        for (int c4 = 0; c4 < D / 4; ++c4) {
-          const float4 k4 = kr[c4];
-          dx[4 * c4] = fmaf(ds, k4.x, dx[4 * c4]); dx[4 * c4 + 1] = fmaf(ds, k4.y, dx[4 * c4 + 1]);
-          dx[4 * c4 + 2] = fmaf(ds, k4.z, dx[4 * c4 + 2]); dx[4 * c4 + 3] = fmaf(ds, k4.w, dx[4 * c4 + 3]);
+          for (int c = 0; c < D; ++c) {
+            dx[c] = p.qn_w[c] * fmaf(p.kn_w[c], dx[c], p.kn_b[c] * dsum);
+            a += dx[c];
+            b = fmaf(dx[c], qh[c], b);
+          }
+          a /= D; b /= D;
+          act_t* dqp = p.dq + qrow * p.dq_ld + p.dq_off + h * D;
+#pragma unroll
+          for (int c4 = 0; c4 < D / 4; ++c4)
+            st4(dqp + c4 * 4, make_float4(rs * (dx[4 * c4] - a - qh[4 * c4] * b), rs * (dx[4 * c4 + 1] - a - qh[4 * c4 + 1] * b),
+                                          rs * (dx[4 * c4 + 2] - a - qh[4 * c4 + 2] * b), rs * (dx[4 * c4 + 3] - a - qh[4 * c4 + 3] * b)));
+        }
+      } else {
+        for (int j = 0; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
+      }
+      if (n_tiles > 1 && ti + 1 < n_tiles) fetch(ti + 1);
+      __syncthreads();
+      {  // this wave's 64 queries: T += dS^T qhat, dV += (P mask)^T dO; lane = (key | channel) l31, k-half hh = query parity
+        const int base = wave * 64;
+        if (lane < 32) {  // four independent partial sums: the loads of a dependent chain would be exposed one by one
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+          for (int i = 0; i < 64; i += 4) {
+            a0 += ds_s[(base + i) * ILD + lane];
+            a1 += ds_s[(base + i + 1) * ILD + lane];
+            a2 += ds_s[(base + i + 2) * ILD + lane];
+            a3 += ds_s[(base + i + 3) * ILD + lane];
+          }
+          cs_acc += (a0 + a1) + (a2 + a3);
+        }
+#pragma unroll 8
+        for (int kk = 0; kk < 64; kk += 2) {
+          const int r = (base + kk + hh) * ILD + l31;
+          accT = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_s[r], qh_s[r], accT, 0, 0, 0);
+          accV = __builtin_amdgcn_mfma_f32_32x32x2f32(pm_s[r], do_s[r], accV, 0, 0, 0);
         }
       }
-      for (int j = k_len; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
-      // q_norm backward (dx = d qhat): dq = rs (dx - mean(dx) - qhat mean(dx qhat))
+      __syncthreads();
+    }
+    // ---- this chunk's keys: combine the two waves, finish d k / d v, accumulate the LayerNorm parameter gradients.
+    // Scratch: T / dV of the two waves in rows 0..63 of the dS / P images, d kn and the q_norm products in rows 64..127
+    // (the query images qh_s / do_s must survive: a single-tile block re-uses them for the next chunk)
+    float* T_s = ds_s;              // [2][32][ILD]
+    float* V_s = pm_s;              // [2][32][ILD]
+    float* dkn_s = ds_s + 64 * ILD;  // [32][ILD]
+    float* gq_s = pm_s + 64 * ILD;   // [64][ILD]: kn * T, then kn * cs
+    if (lane < 32) cs_s[wave][lane] = cs_acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      T_s[(wave * 32 + key) * ILD + l31] = accT[r];
+      V_s[(wave * 32 + key) * ILD + l31] = accV[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 32 * 32; i += 128) {
+      const int j = i >> 5, c = i & 31;
+      const float T = T_s[j * ILD + c] + T_s[(32 + j) * ILD + c];
+      const float cs = cs_s[0][j] + cs_s[1][j];
+      const float kn = (c < D) ? khat_s[j * 32 + c] * p.kn_w[c] + p.kn_b[c] : 0.f;
+      dkn_s[j * ILD + c] = (c < D && j < kl) ? p.qn_w[c] * T + p.qn_b[c] * cs : 0.f;
+      gq_s[j * ILD + c] = (j < kl) ? kn * T : 0.f;
+      gq_s[(32 + j) * ILD + c] = (j < kl) ? kn * cs : 0.f;
+    }
+    __syncthreads();
+    if (tid < 32) {  // column sums over the keys
+#pragma unroll 8
+      for (int j = 0; j < 32; ++j) {
+        lnq[0] += gq_s[j * ILD + tid];
+        lnq[1] += gq_s[(32 + j) * ILD + tid];
+        const float g = dkn_s[j * ILD + tid];
+        lnq[2] += g * khat_s[j * 32 + tid];
+        lnq[3] += g;
+      }
+    }
+    for (int i = tid; i < 32 * 8; i += 128) {  // k_norm backward per key row (8 lanes per row) + the dV rows
+      const int j = i >> 3, c4 = i & 7;
+      float g[4], kh[4];
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int c = 0; c < D; ++c) { a += dx[c]; b = fmaf(dx[c], qh[c], b); }
+      for (int e = 0; e < 4; ++e) {
+        const int c = c4 * 4 + e;
+        kh[e] = khat_s[j * 32 + c];
+        g[e] = (c < D) ? dkn_s[j * ILD + c] * p.kn_w[c] : 0.f;
+        a += g[e];
+        b = fmaf(g[e], kh[e], b);
+      }
+      a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
+      b += __shfl_xor(b, 1, 8); b += __shfl_xor(b, 2, 8); b += __shfl_xor(b, 4, 8);
       a /= D; b /= D;
-      act_t* dqp = p.dq + row * p.dq_ld + p.dq_off + h * D;
-#pragma unroll
-      for (int c4 = 0; c4 < D / 4; ++c4)
-        st4(dqp + c4 * 4, make_float4(rs * (dx[4 * c4] - a - qh[4 * c4] * b), rs * (dx[4 * c4 + 1] - a - qh[4 * c4 + 1] * b),
-                                      rs * (dx[4 * c4 + 2] - a - qh[4 * c4 + 2] * b), rs * (dx[4 * c4 + 3] - a - qh[4 * c4 + 3] * b)));
-#pragma unroll
-      for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = qh[c]; do_s[qi * ILD + c] = go[c]; }
-    } else {
-      for (int j = 0; j < 32; ++j) { dsr[j] = 0.f; pmr[j] = 0.f; }
-#pragma unroll
-      for (int c = 0; c < D; ++c) { qh_s[qi * ILD + c] = 0.f; do_s[qi * ILD + c] = 0.f; }
-    }
-    __syncthreads();
-    {  // this wave's 64 queries: T += dS^T qhat, dV += (P mask)^T dO; lane = (key | channel) l31, k-half hh = query parity
-      const int base = wave * 64;
-      if (lane < 32) {
-        float a = 0.f;
-        for (int i = 0; i < 64; ++i) a += ds_s[(base + i) * ILD + lane];
-        cs_acc += a;
-      }
-#pragma unroll 8
-      for (int kk = 0; kk < 64; kk += 2) {
-        const int r = (base + kk + hh) * ILD + l31;
-        accT = __builtin_amdgcn_mfma_f32_32x32x2f32(ds_s[r], qh_s[r], accT, 0, 0, 0);
-        accV = __builtin_amdgcn_mfma_f32_32x32x2f32(pm_s[r], do_s[r], accV, 0, 0, 0);
+      if (j < kl && c4 * 4 < D) {
+        const float krs = krstd_s[j];
+        const int c = c4 * 4;
+        const float4 dk4 = make_float4(krs * (g[0] - a - kh[0] * b), krs * (g[1] - a - kh[1] * b), krs * (g[2] - a - kh[2] * b),
+                                       krs * (g[3] - a - kh[3] * b));
+        const float4 dv4 = make_float4(V_s[j * ILD + c] + V_s[(32 + j) * ILD + c], V_s[j * ILD + c + 1] + V_s[(32 + j) * ILD + c + 1],
+                                       V_s[j * ILD + c + 2] + V_s[(32 + j) * ILD + c + 2], V_s[j * ILD + c + 3] + V_s[(32 + j) * ILD + c + 3]);
+        if (kext_s[j] >= 0) {  // borrowed copy of a tail patch: its k | v gradient goes to the side buffer
+          act_t* ep = p.dkv_extra + (long)kext_s[j] * p.dkv_extra_ld + h * D + c;
+          st4(ep, dk4);
+          st4(ep + (p.dv_off - p.dk_off), dv4);
+        } else {
+          act_t* kp = dkv + (long)krow_s[j] * p.dkv_ld + h * D + c;
+          st4(kp + p.dk_off, dk4);
+          st4(kp + p.dv_off, dv4);
+        }
       }
     }
-    __syncthreads();
   }
-  // ---- combine the two waves, finish d k / d v and the four LayerNorm parameter gradients
-  float* T_s = ds_s;            // [2][32][ILD]
-  float* V_s = pm_s;            // [2][32][ILD]
-  if (lane < 32) cs_s[wave][lane] = cs_acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
-    T_s[(wave * 32 + key) * ILD + l31] = accT[r];
-    V_s[(wave * 32 + key) * ILD + l31] = accV[r];
-  }
-  __syncthreads();
-  float* dkn_s = qh_s;          // [32][ILD]: d kn, then its LayerNorm backward in place
-  float* gq_s = do_s;           // [32][ILD]: kn * T  (column sums -> d gq), then kn * cs at + 32 * ILD
-  for (int i = tid; i < 32 * 32; i += 128) {
-    const int j = i >> 5, c = i & 31;
-    const float T = T_s[j * ILD + c] + T_s[(32 + j) * ILD + c];
-    const float cs = cs_s[0][j] + cs_s[1][j];
-    const float kn = (c < D) ? khat_s[j * 32 + c] * p.kn_w[c] + p.kn_b[c] : 0.f;
-    dkn_s[j * ILD + c] = (c < D && j < k_len) ? p.qn_w[c] * T + p.qn_b[c] * cs : 0.f;
-    gq_s[j * ILD + c] = (j < k_len) ? kn * T : 0.f;
-    gq_s[(32 + j) * ILD + c] = (j < k_len) ? kn * cs : 0.f;
-  }
-  __syncthreads();
-  float* lnp = p.ln_part + ((long)(blockIdx.x * p.H + h) * 4) * 32;
-  if (tid < 32) {  // column sums over the keys
-    float dgq = 0.f, dbq = 0.f, dgk = 0.f, dbk = 0.f;
-    for (int j = 0; j < 32; ++j) {
-      dgq += gq_s[j * ILD + tid];
-      dbq += gq_s[(32 + j) * ILD + tid];
-      const float g = dkn_s[j * ILD + tid];
-      dgk += g * khat_s[j * 32 + tid];
-      dbk += g;
-    }
-    lnp[tid] = dgq; lnp[32 + tid] = dbq; lnp[64 + tid] = dgk; lnp[96 + tid] = dbk;
-  }
-  __syncthreads();
-  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
-  for (int i = tid; i < 32 * 8; i += 128) {  // k_norm backward per key row (8 lanes per row) + the dV rows
-    const int j = i >> 3, c4 = i & 7;
-    float g[4], kh[4];
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = c4 * 4 + e;
-      kh[e] = khat_s[j * 32 + c];
-      g[e] = (c < D) ? dkn_s[j * ILD + c] * p.kn_w[c] : 0.f;
-      a += g[e];
-      b = fmaf(g[e], kh[e], b);
-    }
-    a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
-    b += __shfl_xor(b, 1, 8); b += __shfl_xor(b, 2, 8); b += __shfl_xor(b, 4, 8);
-    a /= D; b /= D;
-    if (j < k_len && c4 * 4 < D) {
-      const float rs = krstd_s[j];
-      act_t* kp = dkv + (long)(k_start + j) * p.dkv_ld + h * D + c4 * 4;
-      st4(kp + p.dk_off, make_float4(rs * (g[0] - a - kh[0] * b), rs * (g[1] - a - kh[1] * b), rs * (g[2] - a - kh[2] * b),
-                                     rs * (g[3] - a - kh[3] * b)));
-      const int c = c4 * 4;
-      st4(kp + p.dv_off, make_float4(V_s[j * ILD + c] + V_s[(32 + j) * ILD + c], V_s[j * ILD + c + 1] + V_s[(32 + j) * ILD + c + 1],
-                                     V_s[j * ILD + c + 2] + V_s[(32 + j) * ILD + c + 2], V_s[j * ILD + c + 3] + V_s[(32 + j) * ILD + c + 3]));
-    }
+  if (tid < 32) {
+    float* lnp = p.ln_part + ((long)(blockIdx.x * p.H + h) * 4) * 32;
+    lnp[tid] = lnq[0]; lnp[32 + tid] = lnq[1]; lnp[64 + tid] = lnq[2]; lnp[96 + tid] = lnq[3];
   }
 }
 
-// the short-key kernels take identity-indexed rows, key ranges of at most 32 rows (k_max = the caller's upper bound, 0 =
-// unknown) and head widths 32 / 24 / 16; LOTUS_XATTN=0 keeps everything on the tile kernels (A/B switch)
-static bool short_keys_ok(int k_max, const int* qidx, const int* kidx, const int* owner, const int* kext, int atomic_out, int d) {
+// Query-per-lane kernels: fp32 operand mode (or a caller-declared short key side, k_max <= 32: cross attention in every
+// mode), head widths 32 / 24 / 16, no atomic accumulation; backward needs blocks that are "one key chunk, many tiles" or
+// "one tile, many chunks" — k_max (the caller's upper bound of k_len, 0 = unknown: a patch, up to 128) tells which.
+// LOTUS_XQ: 0 = tile kernels everywhere, 1 (default) = short key sides only, 2 = also the patch attention in fp32 mode.
+// Measured stand-alone at the bench size (tools/attn_ab.py, us per launch, tile -> query per lane): cross attention forward
+// 22 / 36 / 21 / 12.5 -> 15 / 24 / 13 / 11.6, backward 79 / 94 / 73 / 57 -> 66 / 73 / 52 / 40 (levels 0 (C 64), 0 (C 128), 1,
+// 2); in the training step 0.95 -> 0.63 ms and +1.2 % throughput.  The 128-key patch attention LOSES on this path (forward
+// 68 -> 143, backward 237 -> 396 at level 0, C 128): every lane re-reads each key / value row from LDS (one dword per FMA,
+// ~3x what the LDS delivers beside the VALU), where the tile kernels feed 32 x 32 MFMA tiles from one fragment read — so
+// mode 2 is a switch for experiments, not the default.
+static int xq_mode() {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("LOTUS_XATTN"); on = (e && e[0] == '0') ? 0 : 1; }
-  return on && k_max > 0 && k_max <= 32 && !qidx && !kidx && !owner && !kext && !atomic_out && (d == 32 || d == 24 || d == 16);
+  if (on < 0) { const char* e = getenv("LOTUS_XQ"); on = e ? atoi(e) : 1; }
+  return on;
+}
+static bool xq_ok(int k_max, int precision, int atomic_out, int d) {
+  const bool geom = !atomic_out && (d == 32 || d == 24 || d == 16);
+  const bool short_keys = k_max > 0 && k_max <= 32;
+  return geom && ((short_keys && xq_mode() >= 1) || (!short_keys && precision == 0 && !LOTUS_ACT_IS_BF16 && xq_mode() >= 2));
 }
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
@@ -1208,11 +1324,11 @@ int lotus_attention_fwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   p.qn_w = qn_w; p.qn_b = qn_b; p.kn_w = kn_w; p.kn_b = kn_b;
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
-  if (short_keys_ok(k_max, qidx, kidx, owner, nullptr, 0, d)) {  // one lane per query, keys in LDS (cross attention)
-    if (d == 32) LOTUS_LAUNCH(xattn_fwd_kernel<32>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
-    else if (d == 24) LOTUS_LAUNCH(xattn_fwd_kernel<24>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
-    else LOTUS_LAUNCH(xattn_fwd_kernel<16>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
-    LOTUS_LAUNCH_CHECK("lotus_attention_fwd(short keys)");
+  if (xq_ok(k_max, precision, 0, d)) {  // one lane per query, keys as LDS broadcast rows
+    if (d == 32) LOTUS_LAUNCH(xq_fwd_kernel<32>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    else if (d == 24) LOTUS_LAUNCH(xq_fwd_kernel<24>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    else LOTUS_LAUNCH(xq_fwd_kernel<16>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    LOTUS_LAUNCH_CHECK("lotus_attention_fwd(query per lane)");
     return LOTUS_OK;
   }
   const size_t sm = attn_smem_bytes(false);
@@ -1267,10 +1383,10 @@ int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   const size_t sm = attn_smem_bytes(true);
   const int prec = precision;
   StopEventOnLast stop_ev;
-  if (short_keys_ok(k_max, qidx, kidx, owner, kext, atomic_out, d)) {
-    if (d == 32) LOTUS_LAUNCH(xattn_bwd_kernel<32>, dim3(nblocks, H), dim3(128), 0, st, p);
-    else if (d == 24) LOTUS_LAUNCH(xattn_bwd_kernel<24>, dim3(nblocks, H), dim3(128), 0, st, p);
-    else LOTUS_LAUNCH(xattn_bwd_kernel<16>, dim3(nblocks, H), dim3(128), 0, st, p);
+  if (xq_ok(k_max, precision, atomic_out, d)) {
+    if (d == 32) LOTUS_LAUNCH(xq_bwd_kernel<32>, dim3(nblocks, H), dim3(128), 0, st, p);
+    else if (d == 24) LOTUS_LAUNCH(xq_bwd_kernel<24>, dim3(nblocks, H), dim3(128), 0, st, p);
+    else LOTUS_LAUNCH(xq_bwd_kernel<16>, dim3(nblocks, H), dim3(128), 0, st, p);
   } else if (prec == 3) {
     { static bool a4 = false; if (!a4) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a4 = true; } }
     LOTUS_LAUNCH(attn_bwd_kernel<3>, dim3(nblocks, H), dim3(256), sm, st, p);

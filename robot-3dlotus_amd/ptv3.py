@@ -208,6 +208,7 @@ class PointTransformerV3CA(nn.Module):
                 dec.add_module(f"block{i}", Block(dc[s], dec_num_head[s], mlp_ratio))
                 dec.add_module(f"ca_block{i}", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
             self.dec.add_module(f"dec{s}", dec)
+        self._blocks = [m for m in self.modules() if isinstance(m, Block)]
         self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
         self._seed_base = None
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
@@ -322,7 +323,7 @@ class PointTransformerV3CA(nn.Module):
         site = 0
 
         st = self.embedding.stem
-        blocks = [m for m in self.modules() if isinstance(m, Block)]
+        blocks = self._blocks  # every Block of the model, in module order (cached: a tree walk per forward costs 0.4 ms)
         packs = dict(zip(blocks, ops.prepack_conv_weights([b.cpe[0].weight for b in blocks])))
         n_ord = len(self.order)
         # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input

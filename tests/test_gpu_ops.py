@@ -356,7 +356,23 @@ def test_patch_attention_fwd_bwd(C, H):
                            lv.kext, lv.ext_pos, lv.n_extra, extra)
     _close(dqkv, qd.grad, 2e-5, "attn dqkv")
     for name, a, b in zip(("dqn_w", "dqn_b", "dkn_w", "dkn_b"), gr, pr):
-        _close(a, b.grad, 5e-5, name)
+        # dkn_b is mathematically zero (softmax is shift-invariant per query): pure fp32 cancellation noise
+        _close(a, b.grad, 5e-4 if name == "dkn_b" else 5e-5, name)
+
+
+def test_patch_attention_query_per_lane_path():
+    """The query-per-lane kernels on the 128-key patch attention (LOTUS_XQ=2; slower than the tile kernels there, hence not
+    the default — csrc/attention.hip): gathered rows, owner flags, borrowed tail-patch copies and four key chunks per tile,
+    against the same fp64 formulation.  The switch is read once per process, so the cases run in a child interpreter."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_patch_attention_fwd_bwd or test_cross_attention_fwd_bwd"], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, LOTUS_XQ="2"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 @pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 4e-2)])
