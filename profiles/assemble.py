@@ -18,6 +18,10 @@ open(os.path.join(ROOT, "profiles", f"{tag}_timeline.txt"), "w").write(
     subprocess.run([py, os.path.join(ROOT, "profiles", "timeline.py"), db], check=True, capture_output=True, text=True).stdout)
 bdir = f"{g}/bench_{tag}"
 flags = {"headline": "--steps 30 --warmup 10", "with_optimizer": "--with-optimizer", "mp": "--workload mp", "peract": "--workload peract",
+         "peract_fp32_storage": "--workload peract --act-storage fp32", "peract_batch_64": "--workload peract --batch 64",
+         "peract_fp32_storage_batch_64": "--workload peract --act-storage fp32 --batch 64", "peract_batch_128": "--workload peract --batch 128",
+         "peract_fp32_storage_batch_128": "--workload peract --act-storage fp32 --batch 128",
+         "ragged": "--ragged (clouds of U(2048, 4096) points)", "batch_38": "--batch 38 (the batch of the published A100 run, BASELINE.md 2)",
          "batch_32": "--batch 32", "batch_64": "--batch 64", "batch_128": "--batch 128",
          "one_rank_rccl": "LOTUS_FORCE_COLLECTIVES=1 (one-rank RCCL rehearsal of the DP step)",
          "two_ranks_one_gpu_gloo": "--gpus 2 on ONE device (gloo; functional check, both ranks share the GPU)"}
@@ -32,7 +36,7 @@ for key, fl in flags.items():
         continue
     if key == "headline":
         rec = {"flags": fl}
-        for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks", "opt_in_modes", "fresh_batches", "cpu_baseline", "roofline", "counters"):
+        for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks", "opt_in_modes", "with_optimizer", "fresh_batches", "cpu_baseline", "roofline", "counters"):
             if k in d:
                 rec[k] = d[k]
     else:

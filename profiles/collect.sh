@@ -15,6 +15,13 @@ Q="--no-cpu-baseline --no-roofline --no-fresh-batches"
 python bench.py --with-optimizer $Q --no-other-modes 2>/dev/null | tail -1 > $O/with_optimizer.json
 python bench.py --workload mp $Q --no-other-modes 2>/dev/null | tail -1 > $O/mp.json
 python bench.py --workload peract $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract.json
+python bench.py --workload peract --act-storage fp32 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_fp32_storage.json
+for b in 64 128; do
+  python bench.py --workload peract --batch $b --steps 12 --warmup 4 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_batch_$b.json
+  python bench.py --workload peract --act-storage fp32 --batch $b --steps 12 --warmup 4 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_fp32_storage_batch_$b.json
+done
+python bench.py --ragged $Q --no-other-modes 2>/dev/null | tail -1 > $O/ragged.json
+python bench.py --batch 38 $Q --no-other-modes 2>/dev/null | tail -1 > $O/batch_38.json
 for b in 32 64 128; do python bench.py --batch $b --steps 12 --warmup 4 $Q 2>/dev/null | tail -1 > $O/batch_$b.json; done
 LOTUS_FORCE_COLLECTIVES=1 python bench.py $Q --no-other-modes 2>/dev/null | tail -1 > $O/one_rank_rccl.json
 LOTUS_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 $Q --no-other-modes 2>/dev/null | tail -1 > $O/two_ranks_one_gpu_gloo.json
