@@ -143,8 +143,10 @@ int lotus_conv_dup_fold(const lotus_act_t* dy, const long long* code0, const int
                         void* stream);
 int lotus_conv_dup_mask(lotus_act_t* dx, const lotus_act_t* add, const int* rep, int n, int C, void* stream);
 size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout);
+/* precision (0 fp32 | 1 bf16 | 3 bf16x3): operand mode of the products, as lotus_linear_wgrad; accumulation, the split
+ * partials and the bias gradient (summed from the fp32 rows) stay fp32. */
 int lotus_subm_conv_wgrad(const lotus_act_t* dy, const lotus_act_t* x, float* dw, float* db, const int* nbr, int n, int T,
-                          int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
+                          int cin, int cout, int accumulate, int precision, void* workspace, size_t workspace_bytes,
                           void* stream);
 
 /* ---- normalisation ------------------------------------------------------------------------ */

@@ -497,7 +497,7 @@ int lotus_cpe_bwd(const act_t* dy, const act_t* xs, const float* cw, const float
   CHECK(lotus_linear_wgrad(dl, c, dlw, dlb, n, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   PRODUCE_THEN_FORK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                                        big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, wws, wws_bytes, sw));
+  CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, precision, wws, wws_bytes, sw));
   const act_t* dsrc = dc;
   if (n_dup != 0) {
     CHECK(lotus_conv_dup_fold(dc, code0, order0, n, C, dyr, stream));

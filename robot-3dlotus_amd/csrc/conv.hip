@@ -300,6 +300,148 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
   }
 }
 
+// bf16 operand variants of the weight gradient (precision 1: bf16 operands; 3: bf16x3 split — the operand modes of the
+// dense layers, gemm.hip): same decomposition and pair compaction, 32 pairs per slab; the gathered dy / x rows are
+// converted (and split) while they are staged into k-contiguous bf16 images (mma.h BTile, pair index = k), the products
+// are v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The bias gradient is summed from the fp32 staging registers.
+template <int PREC>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvWgP p) {
+  constexpr int BM = 64, BN = 64, BK = 32;
+  using TA = BTile<BM, BK, PREC>;
+  using TB = BTile<BN, BK, PREC>;
+  __shared__ __attribute__((aligned(16))) unsigned Aw[TA::kWords];
+  __shared__ __attribute__((aligned(16))) unsigned Bw[TB::kWords];
+  __shared__ int pair_p[WG_MAX_PAIRS + BK];
+  __shared__ int pair_q[WG_MAX_PAIRS + BK];
+  static_assert(TA::kWords * 4 >= 256 * 16, "bias reduction reuses the A image");
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tiles_ci = (p.cin + BN - 1) / BN;
+  const int co0 = (blockIdx.x / tiles_ci) * BM, ci0 = (blockIdx.x % tiles_ci) * BN;
+  const int t = blockIdx.y;
+  const int p0 = blockIdx.z * p.chunk, p1 = min(p.n, p0 + p.chunk);
+  const int wr0 = (wave >> 1) * 32, wc0 = (wave & 1) * 32;
+
+  constexpr int NW = WG_MAX_PAIRS / 256;
+  __shared__ int wcnt[NW][4];
+  int total = 0;
+  {  // ordered compaction of the active pairs of this split (as conv_wgrad_kernel)
+    int qv[NW];
+    unsigned long long bv[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const int pp = p0 + w * 256 + tid;
+      qv[w] = pp < p1 ? p.nbr[(long)t * p.n + pp] : -1;
+    }
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      bv[w] = __ballot(qv[w] >= 0);
+      if (lane == 0) wcnt[w][wave] = __popcll(bv[w]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      int off = total;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < wave) off += wcnt[w][k];
+        total += wcnt[w][k];
+      }
+      if (qv[w] >= 0) {
+        const int rank = __popcll(bv[w] & ((1ull << lane) - 1ull));
+        pair_p[off + rank] = p0 + w * 256 + tid;
+        pair_q[off + rank] = qv[w];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = total + tid; i < total + BK; i += 256) {
+    pair_p[i] = -1;
+    pair_q[i] = -1;
+  }
+  __syncthreads();
+
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  const bool a_vec = (p.cout % 4 == 0) && (((uintptr_t)p.dy) % 16 == 0);
+  const bool b_vec = (p.cin % 4 == 0) && (((uintptr_t)p.x) % 16 == 0);
+  const int kr2 = tid / 16, iq = tid % 16;  // pairs 2 kr2, 2 kr2 + 1 of the slab; channels 4 iq .. 4 iq + 3 of the tile
+  const bool want_bias = p.bias_part && t == p.T / 2 && ci0 == 0;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  float4 ra[2], rb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int pp = pair_p[k0 + 2 * kr2 + e], qq = pair_q[k0 + 2 * kr2 + e];
+      ra[e] = pp >= 0 ? load4_guard(p.dy, p.cout, pp, co0 + iq * 4, p.n, p.cout, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[e] = qq >= 0 ? load4_guard(p.x, p.cin, qq, ci0 + iq * 4, p.n, p.cin, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage = [&](unsigned* W, int plane, const float4& v0, const float4& v1, bool sum) {
+    const float va[4] = {v0.x, v0.y, v0.z, v0.w}, vb[4] = {v1.x, v1.y, v1.z, v1.w};
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_bf16(va[e], vb[e], hw[e], lw[e]);
+    if (sum) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bsum[e] += va[e] + vb[e];
+    }
+    const int rot = (iq >> 2) & 3;  // rotated row order: the 64 lanes of a store hit distinct banks (gemm.hip)
+    rot4(hw, rot);
+    if (PREC == 3) rot4(lw, rot);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int row = iq * 4 + ((e + rot) & 3);
+      W[row * TA::kLdW + kr2] = hw[e];
+      if (PREC == 3) W[plane + row * TA::kLdW + kr2] = lw[e];
+    }
+  };
+  auto lstore = [&]() {
+    stage(Aw, TA::kPlaneW, ra[0], ra[1], want_bias);
+    stage(Bw, TB::kPlaneW, rb[0], rb[1], false);
+  };
+  if (total > 0) {
+    gload(0);
+    lstore();
+    __syncthreads();
+    for (int k0 = 0; k0 < total; k0 += BK) {
+      const bool more = k0 + BK < total;
+      if (more) gload(k0 + BK);
+      gemm_slab_bf16<BM, BN, BK, PREC>(Aw, Bw, wr0, wc0, acc);
+      __syncthreads();
+      if (more) {
+        lstore();
+        __syncthreads();
+      }
+    }
+  }
+  float* part = p.part + (long)blockIdx.z * p.part_stride;
+  const int col = ci0 + acc_col(wc0, 0);
+  if (col < p.cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = co0 + acc_row(wr0, 0, r);
+      if (row < p.cout) part[((long)row * p.T + t) * p.cin + col] = acc[0][0][r];
+    }
+  }
+  if (want_bias) {  // fixed-order sum of the 16 thread groups that staged the same channel quad
+    float4* red = reinterpret_cast<float4*>(Aw);
+    red[tid] = make_float4(bsum[0], bsum[1], bsum[2], bsum[3]);
+    __syncthreads();
+    if (tid < BM) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float4 v = red[g * 16 + (tid >> 2)];
+        s += (tid & 3) == 0 ? v.x : (tid & 3) == 1 ? v.y : (tid & 3) == 2 ? v.z : v.w;
+      }
+      if (co0 + tid < p.cout) p.bias_part[(long)blockIdx.z * p.part_stride + co0 + tid] = s;
+    }
+  }
+}
+
 static size_t conv_dyn_lds(int T, int BM) { return (size_t)(T * BM + 2 * T) * sizeof(int); }
 
 extern "C" {
@@ -646,9 +788,10 @@ size_t lotus_subm_conv_wgrad_workspace(int n, int T, int cin, int cout) {
 
 // dw [cout][T][cin] (+)= sum_p dy[p] (x) x[nbr[t][p]] ;  db [cout] (+)= colsum(dy)
 int lotus_subm_conv_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, const int* nbr, int n, int T,
-                          int cin, int cout, int accumulate, void* workspace, size_t workspace_bytes,
+                          int cin, int cout, int accumulate, int precision, void* workspace, size_t workspace_bytes,
                           void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && nbr && n >= 0, "lotus_subm_conv_wgrad: bad arguments");
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_subm_conv_wgrad: precision must be 0, 1 or 3");
   hipStream_t st = (hipStream_t)stream;
   const int nsplit = cdiv(n > 0 ? n : 1, WG_MAX_PAIRS);
   const size_t wsz = (size_t)cout * T * cin;
@@ -669,7 +812,9 @@ int lotus_subm_conv_wgrad(const act_t* dy, const act_t* x, float* dw, float* db,
     LOTUS_LAUNCH(conv_smallcin_wgrad_kernel, dim3(cout / 64, T, nsplit), dim3(256), 0, st, p);
   } else {
     dim3 grid(cdiv(cout, 64) * cdiv(cin, 64), T, nsplit);
-    LOTUS_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
+    if (precision == 1) LOTUS_LAUNCH(conv_wgrad_bf16_kernel<1>, grid, dim3(256), 0, st, p);
+    else if (precision == 3) LOTUS_LAUNCH(conv_wgrad_bf16_kernel<3>, grid, dim3(256), 0, st, p);
+    else LOTUS_LAUNCH(conv_wgrad_kernel, grid, dim3(256), 0, st, p);
   }
   LOTUS_LAUNCH_CHECK("lotus_subm_conv_wgrad");
   if (direct) return LOTUS_OK;

@@ -73,3 +73,71 @@ __device__ __forceinline__ int acc_row(int wr0, int tm, int r) {
   return wr0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * ((threadIdx.x >> 5) & 1);
 }
 __device__ __forceinline__ int acc_col(int wc0, int tn) { return wc0 + tn * 32 + (threadIdx.x & 31); }
+
+// ---- bf16 operand path (PREC 1: plain bf16 operands, fp32 accumulate — the bf16 compute mode of BASELINE configs[4];
+// PREC 3: "bf16x3" split, a = hi + lo with hi = bf16(a), lo = bf16(a - hi), products hi*hi + hi*lo + lo*hi accumulated
+// in fp32: ~2^-17 relative error per product at 3/16 of the fp32-MFMA issue time).  v_mfma_f32_32x32x16_bf16: lane
+// l holds 8 consecutive k (k = 8 * (l >> 5) + 0..7) of row / column l & 31; C/D layout as the fp32 32x32 form.
+// LDS images are k-contiguous bf16 rows for BOTH global layouts: [R][BK] bf16, row stride BK * 2 + 16 bytes (the 16
+// lanes of a ds_read_b128 group land on distinct 16-byte slots), PREC 3 keeps a second plane with the lo parts.
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+
+template <int R, int BK, int PREC>
+struct BTile {
+  static constexpr int kLdW = BK / 2 + 4;   // row stride in 32-bit words
+  static constexpr int kPlaneW = R * kLdW;  // words per plane
+  static constexpr int kWords = (PREC == 3 ? 2 : 1) * kPlaneW;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const bf16x2 v = {(__bf16)a, (__bf16)b};
+  return __builtin_bit_cast(unsigned, v);
+}
+// (hi, lo) words of the value pair (a, b); lo = bf16(x - float(hi))
+__device__ __forceinline__ void split_bf16(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
+}
+
+// w[e] <- w[(e + rot) & 3] with value selects (a dynamically indexed register array would go through scratch)
+__device__ __forceinline__ void rot4(unsigned (&w)[4], int rot) {
+  const bool r1 = rot & 1, r2 = rot & 2;
+  const unsigned a0 = r1 ? w[1] : w[0], a1 = r1 ? w[2] : w[1], a2 = r1 ? w[3] : w[2], a3 = r1 ? w[0] : w[3];
+  w[0] = r2 ? a2 : a0; w[1] = r2 ? a3 : a1; w[2] = r2 ? a0 : a2; w[3] = r2 ? a1 : a3;
+}
+
+template <int BM, int BN, int BK, int PREC>
+__device__ __forceinline__ void gemm_slab_bf16(const unsigned* __restrict__ Aw, const unsigned* __restrict__ Bw, int wr0,
+                                               int wc0, f32x16 (&acc)[BM / 64][BN / 64]) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using TA = BTile<BM, BK, PREC>;
+  using TB = BTile<BN, BK, PREC>;
+  const int l31 = threadIdx.x & 31, h = (threadIdx.x >> 5) & 1;
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    uint4 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const unsigned* q = Aw + (wr0 + tm * 32 + l31) * TA::kLdW + ks * 8 + h * 4;
+      ah[tm] = *reinterpret_cast<const uint4*>(q);
+      if (PREC == 3) al[tm] = *reinterpret_cast<const uint4*>(q + TA::kPlaneW);
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const unsigned* q = Bw + (wc0 + tn * 32 + l31) * TB::kLdW + ks * 8 + h * 4;
+      bh[tn] = *reinterpret_cast<const uint4*>(q);
+      if (PREC == 3) bl[tn] = *reinterpret_cast<const uint4*>(q + TB::kPlaneW);
+    }
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        if (PREC == 3) {  // small terms first
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[tm]), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, bl[tn]), acc[tm][tn], 0, 0, 0);
+        }
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[tm]), __builtin_bit_cast(bf16x8, bh[tn]), acc[tm][tn], 0, 0, 0);
+      }
+  }
+}

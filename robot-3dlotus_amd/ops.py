@@ -501,7 +501,7 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
     return dx
 
 
-def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
+def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None):
     n, cout = dy.shape
     cin, T = x.shape[1], nbr.shape[0]
     nw = cout * T * cin
@@ -511,7 +511,8 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True):
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
     with _OnSide(dy, x, nbr):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
-        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, ws, ws.numel())
+        # thin-input stem (cin <= 8): one VALU kernel in every mode, exact fp32
+        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, _PREC if prec is None else prec, ws, ws.numel())
     return dw, db
 
 

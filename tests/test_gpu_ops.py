@@ -307,12 +307,13 @@ def test_subm_conv_bf16_operand_paths(prec, cin, cout):
         wt = ops.conv_weight_t(w.cuda())
         y = ops.conv_fwd(x.cuda(), w.cuda(), None, got[0].nbr27, got[0].order[0], w_t=wt)
         dx = ops.conv_dgrad(dy.cuda(), w.cuda(), got[0].nbr27, got[0].order[0], w_t=wt)
+        dw, db = ops.conv_wgrad(dy.cuda(), x.cuda(), w.shape, got[0].nbr27)
     finally:
         ops.set_gemm_precision("fp32")
     rnd = (lambda t: t.bfloat16().double()) if prec == 1 else (lambda t: t.double())
-    xd, wd = rnd(x).requires_grad_(True), rnd(w)
+    xd, wd = rnd(x).requires_grad_(True), rnd(w).requires_grad_(True)
     yref = om.subm_conv(xd, nbr_ref, wd, None)
-    (dxref,) = torch.autograd.grad(yref, xd, rnd(dy))
+    dxref, dwref = torch.autograd.grad(yref, (xd, wd), rnd(dy))
     sy = om.subm_conv(x.abs().double(), nbr_ref, w.abs().double(), None).clamp_min(1.0)
     tol = 2e-6 if prec == 1 else 2.0 ** -16
     ey = ((y.cpu().double() - yref.detach()).abs() / sy).max().item()
@@ -321,6 +322,14 @@ def test_subm_conv_bf16_operand_paths(prec, cin, cout):
     (sx,) = torch.autograd.grad(om.subm_conv(xa, nbr_ref, w.abs().double(), None), xa, dy.abs().double())
     ex = ((dx.cpu().double() - dxref).abs() / sx.clamp_min(1.0)).max().item()
     assert ex <= tol, (prec, "dgrad", ex)
+    # weight gradient (same operand modes; ~n / 3 active pairs per tap are summed in fp32) and the bias gradient, which is
+    # the column sum of the UNROUNDED dy rows in every mode
+    wa = w.abs().double().requires_grad_(True)
+    (sw,) = torch.autograd.grad(om.subm_conv(x.abs().double(), nbr_ref, wa, None), wa, dy.abs().double())
+    ew = ((dw.cpu().double() - dwref).abs() / sw.clamp_min(1.0)).max().item()
+    assert ew <= tol, (prec, "wgrad", ew)
+    eb = ((db.cpu().double() - dy.double().sum(0)).abs() / dy.abs().double().sum(0)).max().item()
+    assert eb <= 2e-6, (prec, "bgrad", eb)
 
 
 # ------------------------------------------------------------------------------------ attention
