@@ -293,6 +293,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    bn_msgs0 = parallel.BN_MESSAGES
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step()
@@ -301,6 +302,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    bn_msgs = parallel.BN_MESSAGES - bn_msgs0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,7 +461,7 @@ def main():
         if reducer is not None:
             sizes = [(hi_ - lo_) * 4 / 2 ** 20 for lo_, hi_ in reducer.buckets]
             out["reducer"] = {"buckets": len(sizes), "bucket_mb": [round(x, 1) for x in sizes], "last_bucket_mb": round(sizes[-1], 1),
-                              "gradient_mb": round(sum(sizes), 1), "syncbn_messages_per_step": "18 forward + 26 backward (fp64, own communicator)",
+                              "gradient_mb": round(sum(sizes), 1), "syncbn_messages_per_step": f"{bn_msgs / max(1, args.steps):.0f} (counted; one fp64 message per BN layer or merged pair and direction, own communicator)",
                               "points_rank0": int(sum(host_batch["npoints_in_batch"]))}
         if peract:
             out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"

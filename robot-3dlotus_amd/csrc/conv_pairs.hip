@@ -27,6 +27,7 @@ struct ConvP2 {
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] or null
   int n, T, KD, ND, mirror;
+  int dbg;           // tuning probes (LOTUS_CONV_DBG): 1 = stop after the pair / slot tables are built
   int tpz;           // taps per blockIdx.z
   long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
 };
@@ -38,17 +39,21 @@ struct ConvP2 {
 // per-pair slot index — no per-tap gather, no per-tap barrier.  (v1 re-gathered rows per
 // (tap, chunk) and spent ~80 % of its time waiting for those loads.)  If a pathological tile
 // overflows the table, its tap range is halved and processed in phases.
-template <int NCS>
+template <int NCS, int PREC = 0, bool WIDE = false>
 struct PairsCfg {
   // BM = 64 keeps the block at ~74 KB of LDS so that TWO blocks share a CU (8 waves): the hashing, image
   // fills and fold latencies of one block hide under the MFMAs of the other (BM = 128 / one block per CU
   // measured 43 % MFMA utilisation inside the tap loop)
-  static constexpr int BM = 64, NRT = 4 / NCS, KC = NCS == 4 ? 32 : 16, NW = 32 * NCS, MAXT = 27;
+  // reduction chunk: 32 (16 for the two-row-tile shape) channels of fp32 rows; plain bf16 operands (PREC 1) keep no lo
+  // plane, so the same image holds TWICE the channels — half as many chunks, barriers and output-tile folds per tile
+  // (with 16x cheaper MFMAs the fold's LDS traffic, not the products, bounds a step)
+  static constexpr int BM = 64, NRT = 4 / NCS, KC = (NCS == 4 ? 32 : 16) * (WIDE ? 2 : 1), NW = 32 * NCS, MAXT = 27;
+  static constexpr int XW = WIDE ? KC / 2 : KC;  // 32-bit words of one image row
   static constexpr int HT = 256;  // hash slots (= resident rows) per row tile
   // image row stride: 16-byte rows read with ds_read_b128 where the LDS budget allows (NCS = 2 sits exactly at
   // two blocks per CU with the odd stride)
   static constexpr bool AVEC = NCS == 4;
-  static constexpr int XLD = AVEC ? KC + 4 : KC + 1;
+  static constexpr int XLD = AVEC ? XW + 4 : XW + 1;
   // output tile row stride: +4 floats so that the 16-byte fold accesses of lanes on consecutive rows land on
   // distinct 16-byte LDS slots
   static constexpr int OLD = NW + 4;
@@ -71,11 +76,13 @@ __device__ __forceinline__ void csplit_bf16(float a, float b, unsigned& hi, unsi
 }
 
 // PREC != 0: the row image keeps, per row and chunk, KC/2 words of bf16 hi pairs followed by KC/2 words of lo pairs
-// (same XLD as the fp32 image), the packed weights hold 8 words per (tap, 16-k block, k half, column): 4 hi + 4 lo;
+// (same XLD as the fp32 image; PREC 1: hi words only, 2 x the channels per chunk), the packed weights hold 8 words per (tap,
+// 16-k block, k half, column): 4 hi + 4 lo (PREC 1: the 4 hi words only);
 // a step issues KC/16 x (1 | 3) v_mfma_f32_32x32x16_bf16 instead of KC/2 fp32 MFMAs.
-template <int NCS, int PREC>
+template <int NCS, int PREC, bool WIDE = false>
 __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
-  using Cfg = PairsCfg<NCS>;
+  static_assert(!WIDE || PREC == 1, "double-width chunks need the hi-only image");
+  using Cfg = PairsCfg<NCS, PREC, WIDE>;
   constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT, XLD = Cfg::XLD;
   constexpr int OLD = Cfg::OLD;
   constexpr int TG = BM / 32;   // max pair groups per tap
@@ -188,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
     if constexpr (PREC != 0) {  // per 16-k block: [hi x4 | lo x4] words of (k half hh, column j) -> float4 index 2 * (...)
 #pragma unroll
       for (int q2 = 0; q2 < KC / 16; ++q2) {
-        const unsigned base = (unsigned)((((tw * (p.KD / 16) + kc * (KC / 16) + q2) * 2 + hh) * p.ND + n0 + cs * 32 + l31) * 2);
+        const unsigned tup = (unsigned)(((tw * (p.KD / 16) + kc * (KC / 16) + q2) * 2 + hh) * p.ND + n0 + cs * 32 + l31);
+        const unsigned base = PREC == 3 ? tup * 2 : tup;  // PREC 1: hi words only (packed without the lo halves)
         dst[2 * q2] = wp4[base];
         if (PREC == 3) dst[2 * q2 + 1] = wp4[base + 1];
       }
@@ -280,6 +288,7 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         }
       }
     };
+    if (p.dbg == 1) return;
     issue_fill(0);
     store_fill();
     // fold base of this lane: its wave's 32-column slice, the 4-column run 4 * hh of every 8-column group
@@ -515,9 +524,10 @@ __global__ __launch_bounds__(256) void conv_wpack_kernel(const float* __restrict
 
 // bf16 packing of the same weights (PREC 1 / 3): per direction, 8 words per (tap, 16-k block kb, k half h, column j)
 // at ((((t * (KD/16) + kb) * 2 + h) * ND + j) * 8: words 0..3 = bf16 hi pairs of k = kb*16 + h*8 + (0,1)(2,3)(4,5)(6,7),
-// words 4..7 = the lo pairs (w - float(hi)).  Same buffer size as the fp32 packing.
+// words 4..7 = the lo pairs (w - float(hi)).  Same buffer size as the fp32 packing.  with_lo == 0 (plain bf16 operands):
+// 4 words per tuple at (...) * 4, the dgrad half still starts at cout * T * cin words.
 __global__ __launch_bounds__(256) void conv_wpack_bf16_kernel(const float* __restrict__ w, unsigned* __restrict__ wp, int cout,
-                                                              int T, int cin) {
+                                                              int T, int cin, int with_lo) {
   const long half = (long)cout * T * cin;
   const long per_dir = half / 8;  // (t, kb, h, j) tuples per direction
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < 2 * per_dir; i += (long)gridDim.x * blockDim.x) {
@@ -537,9 +547,13 @@ __global__ __launch_bounds__(256) void conv_wpack_bf16_kernel(const float* __res
     unsigned hi[4], lo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) csplit_bf16(v[2 * q], v[2 * q + 1], hi[q], lo[q]);
-    uint4* o = reinterpret_cast<uint4*>(wp + dir * half + (i - dir * per_dir) * 8);
-    o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    o[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (with_lo) {
+      uint4* o = reinterpret_cast<uint4*>(wp + dir * half + (i - dir * per_dir) * 8);
+      o[0] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+      o[1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    } else {  // plain bf16 operands: 4 words per tuple, the direction halves stay where they are
+      *reinterpret_cast<uint4*>(wp + dir * half + (i - dir * per_dir) * 4) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    }
   }
 }
 
@@ -550,16 +564,16 @@ static int tap_splits(int n, int ND) {
   return nz;
 }
 
-template <int NCS, int PREC>
+template <int NCS, int PREC, bool WIDE = false>
 static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
-  using Cfg = PairsCfg<NCS>;
+  using Cfg = PairsCfg<NCS, PREC, WIDE>;
   static int pad = -1;
   if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
   const size_t sm = Cfg::bytes() + (size_t)pad;
   static bool attr_set = false;  // per instantiation; the attribute call costs host time on every launch otherwise
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
-  LOTUS_LAUNCH((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
+  LOTUS_LAUNCH((conv_pairs_kernel<NCS, PREC, WIDE>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
@@ -568,7 +582,12 @@ static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
 template <int NCS>
 static int launch_pairs(ConvP2& p, int nz, int prec, hipStream_t st) {
   if (prec == 3) return launch_pairs_p<NCS, 3>(p, nz, st);
-  if (prec == 1) return launch_pairs_p<NCS, 1>(p, nz, st);
+  if (prec == 1) {
+    static int wide = -1;
+    if (wide < 0) { const char* e = getenv("LOTUS_CONV_WIDE"); wide = e ? atoi(e) : 1; }
+    if (wide && p.KD % (2 * PairsCfg<NCS, 1>::KC) == 0) return launch_pairs_p<NCS, 1, true>(p, nz, st);
+    return launch_pairs_p<NCS, 1>(p, nz, st);
+  }
   return launch_pairs_p<NCS, 0>(p, nz, st);
 }
 
@@ -585,7 +604,7 @@ int lotus_conv_weight_transpose_impl(const float* w, float* wp, int cout, int T,
   if (prec != 0) {
     const long tuples = 2L * cout * T * cin / 8;
     const int g = (int)((tuples + 255) / 256);
-    LOTUS_LAUNCH(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin);
+    LOTUS_LAUNCH(conv_wpack_bf16_kernel, dim3(g > 8192 ? 8192 : g), dim3(256), 0, st, w, (unsigned*)wp, cout, T, cin, prec == 3 ? 1 : 0);
   } else {
     LOTUS_LAUNCH(conv_wpack_kernel, dim3(cin / 32, cout / 32, 2 * T), dim3(256), 0, st, w, wp, cout, T, cin);
   }
@@ -609,6 +628,7 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
   p.w = w_t + (mode == 0 ? 0 : (long)cout * T * cin);
   p.tpz = cdiv(T, nz);
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LOTUS_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   p.y = y; p.ypart = nz > 1 ? (float*)workspace : nullptr;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
   *rc = ND == 64 ? launch_pairs<2>(p, nz, prec, st) : launch_pairs<4>(p, nz, prec, st);

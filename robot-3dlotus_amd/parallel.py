@@ -292,9 +292,14 @@ def enable_sync_batchnorm(group=None):
         group = _BN_GROUP
 
     def reduce(sums):
+        global BN_MESSAGES
+        BN_MESSAGES += 1
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # in place, no host sync
 
     ops.BnState.reduce = reduce
+
+
+BN_MESSAGES = 0  # SyncBN all-reduces issued by this process (bench.py reports the count per step)
 
 
 def shard_clouds(counts, world):

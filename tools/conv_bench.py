@@ -1,0 +1,38 @@
+"""Diagnostic: the 3^3 submanifold convolution (pair-compacted kernel) at every level of one synthetic v1 batch (16 clouds x
+4096 points), forward mode, encoder and decoder widths, fp32 / bf16 operands.   python tools/conv_bench.py
+LOTUS_CONV_DBG=1 stops the kernel after its table-building prologue (how much of a launch is not rows x weights)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch  # noqa: E402
+import robot_3dlotus_amd  # noqa: E402,F401
+from robot_3dlotus_amd import ops, synth  # noqa: E402
+from robot_3dlotus_amd.frontend import FrontEnd  # noqa: E402
+
+dev = torch.device("cuda", 0)
+b = synth.synth_batch(int(os.environ.get("CLOUDS", "16")), 4096, seed=0)
+levels = FrontEnd(5).build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * 5)
+ENC, DEC = (64, 128, 256, 512, 768), (64, 64, 128, 256)   # v1 widths
+for li, L in enumerate(levels):
+    for C in sorted({ENC[li]} | ({DEC[li]} if li < 4 else set())):
+        x = torch.randn(L.n, C, device=dev)
+        w = torch.randn(C, 3, 3, 3, C, device=dev) / (C * 9) ** 0.5
+        row = [f"level {li} n={L.n:6d} C={C:4d}"]
+        for mode in ("fp32", "bf16"):
+            ops.set_gemm_precision(mode)
+            wt = ops.conv_weight_t(w)
+            for _ in range(3):
+                ops.conv_fwd(x, w, None, L.nbr27, L.order[0], w_t=wt)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.conv_fwd(x, w, None, L.nbr27, L.order[0], w_t=wt)
+            e1.record(); e1.synchronize()
+            row.append(f"{mode} {e0.elapsed_time(e1) * 100:7.1f} us")
+        ops.set_gemm_precision("fp32")
+        pairs = int((L.nbr27 >= 0).sum())
+        row.append(f"pairs/row {pairs / L.n:.1f}  useful GFLOP {2 * pairs * C * C / 1e9:.2f}")
+        print("  ".join(row), flush=True)
