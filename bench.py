@@ -516,12 +516,15 @@ def main():
             try:
                 import hashlib
                 from robot_3dlotus_amd import _capi as _lc
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
+                import glob
+                pmc_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))[-1]  # the latest round's passes
+                pmc_name = "profiles/" + os.path.basename(pmc_path)
+                pmc = json.load(open(pmc_path))
                 sha = hashlib.sha256(open(_lc.LIB_PATH, "rb").read()).hexdigest()[:16]
                 if pmc.get("library_sha256_16") == sha:
                     k = pmc["kernels"]
                     traffic = k["gemm_kernel"]["hbm_bytes_per_launch"]
-                    evidence = {"source": "profiles/r02_pmc.json, profiles/r02_sq.md (rocprofv3 --pmc, kernels serialised, this library build)",
+                    evidence = {"source": f"{pmc_name}, {pmc_name.replace('_pmc.json', '_sq.md')} (rocprofv3 --pmc, kernels serialised, this library build)",
                                 "attention_mfma_util": {"attn_fwd_kernel": k["attn_fwd_kernel"]["mfma_util"],
                                                         "attn_bwd_kernel": k["attn_bwd_kernel"]["mfma_util"]},
                                 "gemm_mfma_util": k["gemm_kernel"]["mfma_util"],
@@ -530,9 +533,9 @@ def main():
                                 "conv_pairs_fetch_bytes_per_launch": k["conv_pairs_kernel"]["fetch_bytes_per_launch"],
                                 "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300}
                 else:
-                    evidence = {"note": f"profiles/r02_pmc.json was collected on library {pmc.get('library_sha256_16')}, this run loaded {sha}: "
+                    evidence = {"note": f"{pmc_name} was collected on library {pmc.get('library_sha256_16')}, this run loaded {sha}: "
                                         "counter figures withheld (re-run profiles/pmc_passes.sh)"}
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, IndexError):
                 pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
