@@ -15,6 +15,7 @@ dev = torch.device("cuda", 0)
 b = synth.synth_batch(int(os.environ.get("CLOUDS", "16")), 4096, seed=0)
 levels = FrontEnd(5).build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * 5)
 ENC, DEC = (64, 128, 256, 512, 768), (64, 64, 128, 256)   # v1 widths
+NATURAL = os.environ.get("ROWIDX") == "0"  # row tiles in index order instead of curve order (diagnostic)
 for li, L in enumerate(levels):
     for C in sorted({ENC[li]} | ({DEC[li]} if li < 4 else set())):
         x = torch.randn(L.n, C, device=dev)
@@ -24,12 +25,12 @@ for li, L in enumerate(levels):
             ops.set_gemm_precision(mode)
             wt = ops.conv_weight_t(w)
             for _ in range(3):
-                ops.conv_fwd(x, w, None, L.nbr27, L.order[0], w_t=wt)
+                ops.conv_fwd(x, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.conv_fwd(x, w, None, L.nbr27, L.order[0], w_t=wt)
+                ops.conv_fwd(x, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
             e1.record(); e1.synchronize()
             row.append(f"{mode} {e0.elapsed_time(e1) * 100:7.1f} us")
         ops.set_gemm_precision("fp32")
