@@ -270,8 +270,7 @@ def main():
             for p in params:  # model.zero_grad(set_to_none=True) without the module-tree walk (2 ms of host time)
                 p.grad = None
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
-        if not mp:
-            model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
+        model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
         losses["total"].backward()
         if reducer is not None:
             reducer.finish()

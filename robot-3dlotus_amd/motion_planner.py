@@ -76,11 +76,25 @@ class MotionPlannerPTV3CA(BaseModel):
         W, E = self.ptv3_model.embedding.stem.conv.weight, self.pc_label_embedding.weight
         c_pc = batch["pc_fts"].shape[1]
         w_eff = torch.cat([W[..., :c_pc], torch.matmul(W[..., c_pc:], E.t())], -1)                  # [64,5,5,5,c_pc+4]
-        feat = torch.cat([batch["pc_fts"].float(), F.one_hot(labels, 4).float()], -1)
+        pre, self._pre = getattr(self, "_pre", None), None
+        if pre is not None and pre[0] is batch["pc_fts"] and pre[1] is batch["pc_labels"]:
+            feat = pre[2]   # prefetch() built it (and started the front-end on exactly this tensor)
+        else:
+            feat = torch.cat([batch["pc_fts"].float(), F.one_hot(labels, 4).float()], -1)
         ctx = ops.LinearFn.apply(batch["txt_embeds"].contiguous(), self.txt_fc.weight, self.txt_fc.bias)
         return {"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
                 "feat": feat, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
                 "context_counts": list(batch["txt_lens"])}
+
+    @torch.no_grad()
+    def prefetch(self, batch):
+        """Input-pipeline hook, as SimplePolicyPTV3CA.prefetch: build the network input of `batch` ([pc | one-hot label]) and
+        start its integer front-end on the side stream; the following forward(batch) must get the same (device) batch."""
+        batch = self.prepare_batch(batch)
+        feat = torch.cat([batch["pc_fts"].float(), F.one_hot(batch["pc_labels"].long(), 4).float()], -1)
+        self._pre = (batch["pc_fts"], batch["pc_labels"], feat)
+        self.ptv3_model.prefetch({"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
+                                  "feat": feat, "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
 
     gemm_precision = None  # as SimplePolicyPTV3CA.gemm_precision
 

@@ -130,6 +130,43 @@ def test_mp_train_step_is_deterministic():
         assert torch.equal(grads[0][n], grads[1][n]), n
 
 
+def test_mp_prefetch_is_bit_identical():
+    """MotionPlannerPTV3CA.prefetch() (network input + integer front-end of the next batch on the side stream) only moves
+    work in time: losses and gradients equal the synchronous path bit for bit over pipelined steps, and the prefetched
+    front-end is actually consumed (no second build)."""
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("mp_tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 44, "scaled")
+    batches = [_dev_batch(synth.synth_batch_mp(2, 512, ragged=True, seed=s)) for s in (81, 82, 83)]
+
+    def run(prefetch):
+        m = _build(cfg, sd, True)
+        m.ptv3_model.order_perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
+        out, consumed = [], 0
+        if prefetch:
+            m.prefetch(batches[0])
+        for i, b in enumerate(batches):
+            m.zero_grad(set_to_none=True)
+            consumed += m.ptv3_model._pending is not None
+            _, losses = m(b, compute_loss=True, compute_final_action=False)
+            assert m.ptv3_model._pending is None
+            if prefetch and i + 1 < len(batches):
+                m.prefetch(batches[i + 1])
+            losses["total"].backward()
+            out.append((losses["total"].detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+        torch.cuda.synchronize()
+        return out, consumed
+
+    (a, ca), (b, cb) = run(False), run(True)
+    assert ca == 0 and cb == len(batches)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.equal(la, lb) and ga.keys() == gb.keys()
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), n
+
+
 def test_traj_loss_fn_matches_torch_expression():
     """ops.TrajLossFn (one launch) against the reference's expression on the [B, T]-sized tensors
     (motion_planner_ptv3.py:327-397): the five losses and the gradients w.r.t. the logits and the heatmap cross
