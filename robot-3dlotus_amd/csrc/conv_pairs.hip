@@ -39,16 +39,13 @@ struct ConvP2 {
 // per-pair slot index — no per-tap gather, no per-tap barrier.  (v1 re-gathered rows per
 // (tap, chunk) and spent ~80 % of its time waiting for those loads.)  If a pathological tile
 // overflows the table, its tap range is halved and processed in phases.
-template <int NCS, int PREC = 0, bool WIDE = false>
+template <int NCS, int PREC = 0>
 struct PairsCfg {
   // BM = 64 keeps the block at ~74 KB of LDS so that TWO blocks share a CU (8 waves): the hashing, image
   // fills and fold latencies of one block hide under the MFMAs of the other (BM = 128 / one block per CU
   // measured 43 % MFMA utilisation inside the tap loop)
-  // reduction chunk: 32 (16 for the two-row-tile shape) channels of fp32 rows; plain bf16 operands (PREC 1) keep no lo
-  // plane, so the same image holds TWICE the channels — half as many chunks, barriers and output-tile folds per tile
-  // (with 16x cheaper MFMAs the fold's LDS traffic, not the products, bounds a step)
-  static constexpr int BM = 64, NRT = 4 / NCS, KC = (NCS == 4 ? 32 : 16) * (WIDE ? 2 : 1), NW = 32 * NCS, MAXT = 27;
-  static constexpr int XW = WIDE ? KC / 2 : KC;  // 32-bit words of one image row
+  static constexpr int BM = 64, NRT = 4 / NCS, KC = NCS == 4 ? 32 : 16, NW = 32 * NCS, MAXT = 27;
+  static constexpr int XW = KC;  // 32-bit words of one image row
   static constexpr int HT = 256;  // hash slots (= resident rows) per row tile
   // image row stride: 16-byte rows read with ds_read_b128 where the LDS budget allows (NCS = 2 sits exactly at
   // two blocks per CU with the odd stride)
@@ -76,13 +73,12 @@ __device__ __forceinline__ void csplit_bf16(float a, float b, unsigned& hi, unsi
 }
 
 // PREC != 0: the row image keeps, per row and chunk, KC/2 words of bf16 hi pairs followed by KC/2 words of lo pairs
-// (same XLD as the fp32 image; PREC 1: hi words only, 2 x the channels per chunk), the packed weights hold 8 words per (tap,
+// (same XLD as the fp32 image; PREC 1 fills the hi run only), the packed weights hold 8 words per (tap,
 // 16-k block, k half, column): 4 hi + 4 lo (PREC 1: the 4 hi words only);
 // a step issues KC/16 x (1 | 3) v_mfma_f32_32x32x16_bf16 instead of KC/2 fp32 MFMAs.
-template <int NCS, int PREC, bool WIDE = false>
+template <int NCS, int PREC>
 __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
-  static_assert(!WIDE || PREC == 1, "double-width chunks need the hi-only image");
-  using Cfg = PairsCfg<NCS, PREC, WIDE>;
+  using Cfg = PairsCfg<NCS, PREC>;
   constexpr int BM = Cfg::BM, NRT = Cfg::NRT, KC = Cfg::KC, NW = Cfg::NW, MAXT = Cfg::MAXT, HT = Cfg::HT, XLD = Cfg::XLD;
   constexpr int OLD = Cfg::OLD;
   constexpr int TG = BM / 32;   // max pair groups per tap
@@ -468,6 +464,239 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
   }
 }
 
+// ------------------------------------------------------------------------------------ bf16 operands: output-stationary
+// With v_mfma_f32_32x32x16_bf16 a product costs 1/16 of the fp32 form (3/16 as a bf16x3 split), and what bounds the
+// pair-compacted kernel above is everything around the products: compaction, hashing rows into the LDS image, one LDS
+// fold of the accumulators per 32-pair group (tools/conv_bench.py: bf16 launches only 1.5-2x faster than fp32 ones).  For
+// the bf16 operand modes the zeros of an output-stationary formulation are cheaper than all of that:
+//   * a wave owns 32 OUTPUT rows x NS*32 columns; its accumulators stay in registers over all taps and chunks (no fold,
+//     no pair tables, no row image);
+//   * per tap the lane of row r loads its neighbour row nbr[t][r] straight from global memory as MFMA B fragments — the
+//     8 consecutive k of a bf16 MFMA operand are 16 contiguous bytes of a bf16 row (32 of an fp32 row, converted in
+//     registers); an absent neighbour is a zero fragment (27-48 % of the fragments are real: 2-3.7x the products of
+//     the compacted form, still several times below its cost);
+//   * the packed weights of (tap, k chunk) — already in fragment order, conv_wpack_bf16_kernel — are staged through a
+//     double-buffered LDS image shared by the block's four waves (128 rows per weight fetch), one barrier per stage;
+//   * the product is transposed like above (weights = A operand): a lane owns one output row, the epilogue goes through
+//     an LDS tile for coalesced row stores.
+template <int PREC, int NS, int KCH>
+struct OsCfg {
+  static constexpr int BR = 128, NW = 32 * NS, NB = KCH / 16, MAXT = 27;
+  static constexpr int U4T = PREC == 3 ? 2 : 1;                 // uint4 per packed (tap, 16-k block, k half, column) tuple
+  static constexpr int STAGE_U4 = NB * 2 * NW * U4T;            // uint4 per weight stage
+  static constexpr int OLD = NW + 4;                            // epilogue tile row stride (floats)
+  // [2 weight stages | neighbour ids of the block's rows, all taps] during the tap loop; the epilogue tile reuses both
+  static constexpr size_t loop_bytes() { return 2 * (size_t)STAGE_U4 * 16 + (size_t)MAXT * BR * sizeof(int); }
+  static constexpr size_t tile_bytes() { return (size_t)BR * OLD * 4; }
+  static constexpr size_t bytes() { return (loop_bytes() > tile_bytes() ? loop_bytes() : tile_bytes()) + BR * sizeof(int); }
+};
+
+template <int PREC, int NS, int KCH>
+__global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
+  static_assert(PREC == 1 || PREC == 3, "bf16 operand modes only");
+  using Cfg = OsCfg<PREC, NS, KCH>;
+  constexpr int BR = Cfg::BR, NW = Cfg::NW, NB = Cfg::NB, U4T = Cfg::U4T, STAGE_U4 = Cfg::STAGE_U4, OLD = Cfg::OLD;
+  constexpr int WPT = STAGE_U4 / 256;  // weight uint4 per thread and stage
+  static_assert(STAGE_U4 % 256 == 0, "stage copy shape");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* wst = reinterpret_cast<uint4*>(smem);                                  // [2][STAGE_U4]
+  int* nbr_s = reinterpret_cast<int*>(wst + 2 * STAGE_U4);                      // [taps of this block][BR]
+  int* prow_s = reinterpret_cast<int*>(reinterpret_cast<char*>(smem) + (Cfg::bytes() - BR * sizeof(int)));
+
+  const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1;
+  // XCD-aware order as above: an XCD walks a contiguous run of row blocks of one column block
+  int bx = blockIdx.x, by = blockIdx.y;
+  {
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const int lin = by * gx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    bx = t / gy;
+    by = t - bx * gy;
+  }
+  const int n0 = bx * NW, m0 = by * BR;
+  const int z_beg = blockIdx.z * p.tpz, z_end = min(p.T, z_beg + p.tpz);
+  const int nkc = p.KD / KCH, nst = (z_end - z_beg) * nkc;
+
+  if (tid < BR) {
+    const int m = m0 + tid;
+    prow_s[tid] = m < p.n ? (p.rowidx ? p.rowidx[m] : m) : -1;
+  }
+  __syncthreads();
+  {  // neighbour ids of the block's rows for all its taps, one batch of independent loads: inside the tap loop a row
+     // fetch must not sit behind the id fetch it depends on (two memory latencies per stage otherwise)
+    constexpr int NL = (Cfg::MAXT * BR + 255) / 256;
+    const int total = (z_end - z_beg) * BR;
+    int vals[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = tid + j * 256;
+      vals[j] = -1;
+      if (i < total) {
+        const int prr = prow_s[i % BR];
+        if (prr >= 0) vals[j] = p.nbr[(long)(z_beg + i / BR) * p.n + prr];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int i = tid + j * 256;
+      if (i < total) nbr_s[i] = vals[j];
+    }
+  }
+  const int lrow = wave * 32 + l31;  // this lane's output row within the block (both k halves of a row share it)
+
+  f32x16 acc[NS];
+#pragma unroll
+  for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[s2][r] = 0.f;
+
+  // raw neighbour-row fragments of one stage: NB x 8 consecutive k of row q (this lane's k half).  bf16 storage: the 16
+  // row bytes ARE the MFMA operand and two stages are kept in flight; fp32 storage: 32 bytes, converted in registers
+  constexpr int RAWV = LOTUS_ACT_IS_BF16 ? 1 : 2;  // 16-byte loads per fragment
+  constexpr int DEPTH = LOTUS_ACT_IS_BF16 ? 2 : 1; // row stages in flight
+  uint4 braw[DEPTH][NB][RAWV];
+  auto load_rows = [&](uint4 (&dst)[NB][RAWV], int st) __attribute__((always_inline)) -> bool {  // rows of stage st (taps outer, chunks inner)
+    const int tl = st / nkc, kc = st - tl * nkc;
+    const int q = nbr_s[tl * BR + lrow];
+    // every load is issued unconditionally (an absent neighbour reads row 0 and is zeroed by value selects): a branch
+    // around each load makes the compiler wait for it before the next one — NB dependent round trips per stage
+    const act_t* src = p.x + (long)max(q, 0) * p.KD + kc * KCH + hh * 8;
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+      for (int v = 0; v < RAWV; ++v) dst[kb][v] = reinterpret_cast<const uint4*>(src + kb * 16)[v];
+    return q >= 0;  // applied when the fragments are converted (selecting here would wait for the loads)
+  };
+  uint4 bhi[NB], blo[NB];
+  auto convert_rows = [&](const uint4 (&src)[NB][RAWV], bool ok) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      if constexpr (LOTUS_ACT_IS_BF16) {
+        bhi[kb] = make_uint4(ok ? src[kb][0].x : 0u, ok ? src[kb][0].y : 0u, ok ? src[kb][0].z : 0u, ok ? src[kb][0].w : 0u);
+        blo[kb] = make_uint4(0u, 0u, 0u, 0u);
+      } else {
+        const float f[8] = {__builtin_bit_cast(float, src[kb][0].x), __builtin_bit_cast(float, src[kb][0].y),
+                            __builtin_bit_cast(float, src[kb][0].z), __builtin_bit_cast(float, src[kb][0].w),
+                            __builtin_bit_cast(float, src[kb][1].x), __builtin_bit_cast(float, src[kb][1].y),
+                            __builtin_bit_cast(float, src[kb][1].z), __builtin_bit_cast(float, src[kb][1].w)};
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (PREC == 3) csplit_bf16(f[2 * e], f[2 * e + 1], h[e], l[e]);
+          else { h[e] = cpack_bf16(f[2 * e], f[2 * e + 1]); l[e] = 0u; }
+        }
+        bhi[kb] = make_uint4(ok ? h[0] : 0u, ok ? h[1] : 0u, ok ? h[2] : 0u, ok ? h[3] : 0u);
+        blo[kb] = make_uint4(ok ? l[0] : 0u, ok ? l[1] : 0u, ok ? l[2] : 0u, ok ? l[3] : 0u);
+      }
+    }
+  };
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // native vectors: the array stays in registers
+  u32x4_t wreg[WPT];
+  const u32x4_t* wp4 = reinterpret_cast<const u32x4_t*>(p.w);
+  auto load_w = [&](int st) __attribute__((always_inline)) {
+    const int tl = st / nkc, kc = st - tl * nkc, t = z_beg + tl;
+    const int tw = p.mirror ? (p.T - 1 - t) : t;
+    constexpr int L = NW * U4T;  // contiguous uint4 of one (16-k block, k half) run of this column block
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+      const int i = tid + j * 256, run = i / L, off = i - run * L;
+      const long tup = ((long)(tw * (p.KD / 16) + kc * NB + (run >> 1)) * 2 + (run & 1)) * p.ND + n0;
+      wreg[j] = wp4[tup * U4T + off];
+    }
+  };
+  auto store_w = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) reinterpret_cast<u32x4_t*>(wst)[buf * STAGE_U4 + tid + j * 256] = wreg[j];
+  };
+  auto products = [&](int st) __attribute__((always_inline)) {
+    const uint4* wb = wst + (st & 1) * STAGE_U4;
+    const int tl = st / nkc;
+    if (!__ballot(nbr_s[tl * BR + lrow] >= 0)) return;  // a tap none of the wave's rows has: nothing to add
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+      for (int s2 = 0; s2 < NS; ++s2) {
+        const uint4* a = wb + ((kb * 2 + hh) * NW + s2 * 32 + l31) * U4T;
+        const uint4 ah = a[0];
+        if constexpr (PREC == 3) {
+          const uint4 al = a[1];
+          acc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, al), __builtin_bit_cast(cbf16x8, bhi[kb]), acc[s2], 0, 0, 0);
+          acc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, ah), __builtin_bit_cast(cbf16x8, blo[kb]), acc[s2], 0, 0, 0);
+        }
+        acc[s2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cbf16x8, ah), __builtin_bit_cast(cbf16x8, bhi[kb]), acc[s2], 0, 0, 0);
+      }
+    }
+  };
+
+  __syncthreads();  // nbr_s
+  bool bok[DEPTH];
+  load_w(0);
+  bok[0] = load_rows(braw[0], 0);
+  if (DEPTH == 2) bok[DEPTH - 1] = load_rows(braw[DEPTH - 1], min(1, nst - 1));
+  store_w(0);
+  convert_rows(braw[0], bok[0]);
+  __syncthreads();
+  // (every lambda of this kernel is always_inline: `stage` has several call sites, and an out-of-line closure keeps the
+  // register arrays it captures — wreg, braw — in scratch memory: each weight load was waited for and spilled at once)
+  // stage st: weights of st + 1 and rows of st + DEPTH go into registers, the products of st run from LDS / bhi, then the
+  // rows of st + 1 become the operand registers and the weights of st + 1 the other LDS stage; one barrier per stage
+  auto stage = [&](int st, uint4 (&fetch)[NB][RAWV], bool& fetch_ok, const uint4 (&next)[NB][RAWV], const bool& next_ok) __attribute__((always_inline)) {
+    // every load of the stage is unconditional (the last stages re-fetch stage nst - 1): a load under a branch is a
+    // "register or load" merge, for which the compiler waits right behind the load instead of where the value is used
+    load_w(min(st + 1, nst - 1));
+    fetch_ok = load_rows(fetch, min(st + DEPTH, nst - 1));
+    products(st);
+    store_w((st + 1) & 1);
+    convert_rows(next, next_ok);
+    __syncthreads();
+  };
+  if constexpr (DEPTH == 2) {
+    for (int st = 0; st < nst; st += 2) {  // rows of st live in braw[0] (already converted), st + 1 in braw[1]
+      stage(st, braw[0], bok[0], braw[1], bok[1]);
+      if (st + 1 < nst) stage(st + 1, braw[1], bok[1], braw[0], bok[0]);
+    }
+  } else {
+    for (int st = 0; st < nst; ++st) stage(st, braw[0], bok[0], braw[0], bok[0]);
+  }
+
+  // epilogue: accumulators (channel runs of one row per lane) -> LDS tile -> coalesced row stores
+  float* out_s = smem;  // [BR][OLD], reuses the weight stages (every wave passed the loop's last barrier)
+  {
+    float* orow = out_s + (wave * 32 + l31) * OLD + 4 * hh;
+#pragma unroll
+    for (int s2 = 0; s2 < NS; ++s2)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)
+        *reinterpret_cast<float4*>(orow + s2 * 32 + 8 * q4) =
+            make_float4(acc[s2][4 * q4], acc[s2][4 * q4 + 1], acc[s2][4 * q4 + 2], acc[s2][4 * q4 + 3]);
+  }
+  __syncthreads();
+  const bool final_out = p.part_stride == 0;
+  float* yo = p.ypart + (long)blockIdx.z * p.part_stride;
+  for (int i = tid; i < BR * (NW / 4); i += 256) {
+    const int r = i / (NW / 4), c4 = i % (NW / 4);
+    const int prr = prow_s[r];
+    if (prr < 0) continue;
+    float4 v = ld4(out_s + r * OLD + c4 * 4);
+    const int col = n0 + c4 * 4;
+    const long o = (long)prr * p.ND + col;
+    if (final_out) {
+      if (p.bias) {
+        const float4 b = ld4(p.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+      }
+      if (p.add) {
+        const float4 a = ld4(p.add + o);
+        v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+      }
+      st4(p.y + o, v);
+    } else {
+      st4(yo + o, v);
+    }
+  }
+}
+
 // y = sum_z part[z] + bias + add   (fixed order -> deterministic)
 __global__ void conv_part_reduce_kernel(const float* __restrict__ part, long stride, int nz, const float* __restrict__ bias,
                                         const act_t* __restrict__ add, act_t* __restrict__ y, long total4, int nd4) {
@@ -564,16 +793,16 @@ static int tap_splits(int n, int ND) {
   return nz;
 }
 
-template <int NCS, int PREC, bool WIDE = false>
+template <int NCS, int PREC>
 static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
-  using Cfg = PairsCfg<NCS, PREC, WIDE>;
+  using Cfg = PairsCfg<NCS, PREC>;
   static int pad = -1;
   if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
   const size_t sm = Cfg::bytes() + (size_t)pad;
   static bool attr_set = false;  // per instantiation; the attribute call costs host time on every launch otherwise
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC, WIDE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
-  LOTUS_LAUNCH((conv_pairs_kernel<NCS, PREC, WIDE>), grid, dim3(256), sm, st, p);
+  LOTUS_LAUNCH((conv_pairs_kernel<NCS, PREC>), grid, dim3(256), sm, st, p);
   LOTUS_LAUNCH_CHECK("lotus_subm_conv(pairs)");
   return LOTUS_OK;
 }
@@ -582,17 +811,45 @@ static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
 template <int NCS>
 static int launch_pairs(ConvP2& p, int nz, int prec, hipStream_t st) {
   if (prec == 3) return launch_pairs_p<NCS, 3>(p, nz, st);
-  if (prec == 1) {
-    static int wide = -1;
-    if (wide < 0) { const char* e = getenv("LOTUS_CONV_WIDE"); wide = e ? atoi(e) : 1; }
-    if (wide && p.KD % (2 * PairsCfg<NCS, 1>::KC) == 0) return launch_pairs_p<NCS, 1, true>(p, nz, st);
-    return launch_pairs_p<NCS, 1>(p, nz, st);
-  }
+  if (prec == 1) return launch_pairs_p<NCS, 1>(p, nz, st);
   return launch_pairs_p<NCS, 0>(p, nz, st);
 }
 
+// output-stationary bf16 kernel: 128-row blocks; taps split 1 / 3 / 9 ways until the grid covers the CUs
+static int os_splits(int n, int ND) {
+  const long base = (long)cdiv(n, 128) * (ND == 64 ? 1 : ND / 128);
+  int nz = 1;
+  while (nz < 9 && base * nz < 256) nz = nz == 1 ? 3 : 9;
+  return nz;
+}
+static int os_mode() {  // LOTUS_CONV_OS=0: the bf16 operand modes use the pair-compacted kernel as well
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("LOTUS_CONV_OS"); on = e ? atoi(e) : 1; }
+  return on;
+}
+
+template <int PREC, int NS, int KCH>
+static int launch_os_t(ConvP2& p, int nz, hipStream_t st) {
+  using Cfg = OsCfg<PREC, NS, KCH>;
+  const size_t sm = Cfg::bytes();
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_os_kernel<PREC, NS, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
+  dim3 grid(p.ND / Cfg::NW, cdiv(p.n, Cfg::BR), nz);
+  LOTUS_LAUNCH((conv_os_kernel<PREC, NS, KCH>), grid, dim3(256), sm, st, p);
+  LOTUS_LAUNCH_CHECK("lotus_subm_conv(output-stationary bf16)");
+  return LOTUS_OK;
+}
+static int launch_os(ConvP2& p, int nz, int prec, hipStream_t st) {
+  const bool wide = p.ND != 64;
+  if (prec == 3) return wide ? launch_os_t<3, 4, 64>(p, nz, st) : launch_os_t<3, 2, 64>(p, nz, st);
+  static int kch = -1;
+  if (kch < 0) { const char* e = getenv("LOTUS_CONV_OS_KCH"); kch = e ? atoi(e) : 128; }
+  if (p.KD % 128 == 0 && kch == 128) return wide ? launch_os_t<1, 4, 128>(p, nz, st) : launch_os_t<1, 2, 128>(p, nz, st);
+  return wide ? launch_os_t<1, 4, 64>(p, nz, st) : launch_os_t<1, 2, 64>(p, nz, st);
+}
+
 size_t lotus_conv_pairs_workspace(int n, int ND) {
-  const int nz = tap_splits(n, ND);
+  const int a = tap_splits(n, ND), b = os_splits(n, ND), nz = a > b ? a : b;  // either kernel may serve the call
   return nz > 1 ? (size_t)nz * n * ND * sizeof(float) : 0;
 }
 
@@ -621,7 +878,8 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
   if (!w_t || ((uintptr_t)w_t) % 16) return 0;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16) return 0;
-  const int nz = tap_splits(n, ND);
+  const bool os = prec != 0 && os_mode() && KD % 64 == 0;
+  const int nz = os ? os_splits(n, ND) : tap_splits(n, ND);
   if (nz > 1 && (!workspace || workspace_bytes < (size_t)nz * n * ND * sizeof(float))) return 0;
   ConvP2 p;
   p.x = x; p.bias = bias; p.add = add; p.nbr = nbr; p.rowidx = rowidx;
@@ -631,7 +889,8 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LOTUS_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   p.y = y; p.ypart = nz > 1 ? (float*)workspace : nullptr;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
-  *rc = ND == 64 ? launch_pairs<2>(p, nz, prec, st) : launch_pairs<4>(p, nz, prec, st);
+  if (os) *rc = launch_os(p, nz, prec, st);
+  else *rc = ND == 64 ? launch_pairs<2>(p, nz, prec, st) : launch_pairs<4>(p, nz, prec, st);
   if (*rc == 0 && nz > 1) {
     const long total4 = (long)n * ND / 4;
     int g = cdiv(total4, 256);

@@ -21,17 +21,19 @@ for li, L in enumerate(levels):
         x = torch.randn(L.n, C, device=dev)
         w = torch.randn(C, 3, 3, 3, C, device=dev) / (C * 9) ** 0.5
         row = [f"level {li} n={L.n:6d} C={C:4d}"]
-        for mode in ("fp32", "bf16"):
-            ops.set_gemm_precision(mode)
-            wt = ops.conv_weight_t(w)
-            for _ in range(3):
-                ops.conv_fwd(x, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                ops.conv_fwd(x, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
-            e1.record(); e1.synchronize()
+        for mode in ("fp32", "bf16", "bf16 storage"):
+            ops.set_gemm_precision("bf16" if mode != "fp32" else "fp32")
+            with ops.storage(torch.bfloat16 if mode == "bf16 storage" else None):
+                xx = x.bfloat16() if mode == "bf16 storage" else x
+                wt = ops.conv_weight_t(w)
+                for _ in range(3):
+                    ops.conv_fwd(xx, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    ops.conv_fwd(xx, w, None, L.nbr27, None if NATURAL else L.order[0], w_t=wt)
+                e1.record(); e1.synchronize()
             row.append(f"{mode} {e0.elapsed_time(e1) * 100:7.1f} us")
         ops.set_gemm_precision("fp32")
         pairs = int((L.nbr27 >= 0).sum())
