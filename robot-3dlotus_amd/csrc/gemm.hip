@@ -172,6 +172,28 @@ __device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const fl
 
 // (the bf16 operand tiles — BTile, split_bf16, rot4, gemm_slab_bf16 — live in mma.h: the sparse-conv weight gradient shares them)
 
+// Four consecutive operand elements AS LOADED.  The staging registers of the next slab must not be touched between the
+// load and the LDS store behind the MFMAs: converting at the load site (what ld4 does for bf16 storage: two shifts and
+// two ands per 8 bytes) makes the compiler wait for the load right there, and the global latency of every slab lands in
+// front of its products (seen in the ISA of the bf16-storage build: s_waitcnt vmcnt directly behind the loads).
+template <typename T> struct Raw4 { float4 v; };
+template <> struct Raw4<__bf16> { uint2 v; };
+__device__ __forceinline__ Raw4<float> ldraw(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
+__device__ __forceinline__ Raw4<__bf16> ldraw(const __bf16* p) { return {*reinterpret_cast<const uint2*>(p)}; }
+__device__ __forceinline__ float4 unraw(const Raw4<float>& r) { return r.v; }
+__device__ __forceinline__ float4 unraw(const Raw4<__bf16>& r) {
+  return make_float4(__builtin_bit_cast(float, r.v.x << 16), __builtin_bit_cast(float, r.v.x & 0xffff0000u),
+                     __builtin_bit_cast(float, r.v.y << 16), __builtin_bit_cast(float, r.v.y & 0xffff0000u));
+}
+__device__ __forceinline__ Raw4<float> toraw(float4 v, const float*) { return {v}; }
+__device__ __forceinline__ Raw4<__bf16> toraw(float4 v, const __bf16*) {  // (guarded loads of odd shapes: values are exact bf16)
+  return {make_uint2(lotus_pack_bf16(v.x, v.y), lotus_pack_bf16(v.z, v.w))};
+}
+__device__ __forceinline__ Raw4<float> rsel(bool ok, Raw4<float> r) {
+  return {make_float4(ok ? r.v.x : 0.f, ok ? r.v.y : 0.f, ok ? r.v.z : 0.f, ok ? r.v.w : 0.f)};
+}
+__device__ __forceinline__ Raw4<__bf16> rsel(bool ok, Raw4<__bf16> r) { return {make_uint2(ok ? r.v.x : 0u, ok ? r.v.y : 0u)}; }
+
 // value-wise select (a pointer select between the loaded vector and a zero constant goes through scratch)
 __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -237,7 +259,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // bf16 path, SUM_A: this thread's partial row sums of A (exact fp32 inputs)
-  float4 ra[A4], rb[B4];
+  Raw4<EA> rra[A4];
+  Raw4<EB> rrb[B4];
   auto gload = [&](int k0) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
@@ -246,20 +269,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
-          const float4 v = ld4(pA + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4));
-          ra[t] = zsel(k < kend, v);
+          rra[t] = rsel(k < kend, ldraw(pA + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4)));
         } else {
-          ra[t] = load4_guard(pA, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec);
+          rra[t] = toraw(load4_guard(pA, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec), pA);
         }
       } else {
         const int f2 = PREC ? tid + (t >> 1) * 256 : f;  // bf16 path: registers 2p, 2p+1 hold k, k+1 of one row quad
         const int kr = PREC ? (f2 / (BM / 4)) * 2 + (t & 1) : f / (BM / 4), iq = f2 % (BM / 4);
         if (FAST) {
           const int k = k0 + kr;
-          const float4 v = ld4(pA + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4));
-          ra[t] = zsel(k < kend, v);
+          rra[t] = rsel(k < kend, ldraw(pA + (long)min(k, p.K - 1) * p.lda + min(m0 + iq * 4, p.M - 4)));
         } else {
-          ra[t] = load4_guard(pA, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec);
+          rra[t] = toraw(load4_guard(pA, p.lda, k0 + kr, m0 + iq * 4, kend, p.M, p.a_vec), pA);
         }
       }
     }
@@ -270,25 +291,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
-          const float4 v = ld4(pB + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4));
-          rb[t] = zsel(k < kend, v);
+          rrb[t] = rsel(k < kend, ldraw(pB + (long)min(n0 + row, p.N - 1) * p.ldb + min(k, p.K - 4)));
         } else {
-          rb[t] = load4_guard(pB, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec);
+          rrb[t] = toraw(load4_guard(pB, p.ldb, n0 + row, k0 + kq * 4, p.N, kend, p.b_vec), pB);
         }
       } else {
         const int f2 = PREC ? tid + (t >> 1) * 256 : f;
         const int kr = PREC ? (f2 / (BN / 4)) * 2 + (t & 1) : f / (BN / 4), jq = f2 % (BN / 4);
         if (FAST) {
           const int k = k0 + kr;
-          const float4 v = ld4(pB + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4));
-          rb[t] = zsel(k < kend, v);
+          rrb[t] = rsel(k < kend, ldraw(pB + (long)min(k, p.K - 1) * p.ldb + min(n0 + jq * 4, p.N - 4)));
         } else {
-          rb[t] = load4_guard(pB, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec);
+          rrb[t] = toraw(load4_guard(pB, p.ldb, k0 + kr, n0 + jq * 4, kend, p.N, p.b_vec), pB);
         }
       }
     }
   };
   auto lstore = [&](float* Ad, float* Bd) {
+    float4 ra[A4], rb[B4];  // the staged elements as fp32, converted HERE (behind the products of the running slab)
+#pragma unroll
+    for (int t = 0; t < A4; ++t) ra[t] = unraw(rra[t]);
+#pragma unroll
+    for (int t = 0; t < B4; ++t) rb[t] = unraw(rrb[t]);
     if (PREC) {  // convert (and split) while staging: bf16 rows, k-contiguous for both layouts
       unsigned* Aw = reinterpret_cast<unsigned*>(Ad);
       unsigned* Bw = reinterpret_cast<unsigned*>(Bd);
@@ -410,9 +434,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   }
   auto gload_full = [&](int k0) {
 #pragma unroll
-    for (int t = 0; t < A4; ++t) ra[t] = ld4(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
+    for (int t = 0; t < A4; ++t) rra[t] = ldraw(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
 #pragma unroll
-    for (int t = 0; t < B4; ++t) rb[t] = ld4(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
+    for (int t = 0; t < B4; ++t) rrb[t] = ldraw(pb[t] + (B_KC ? (long)k0 : (long)k0 * p.ldb));
   };
 
   // double-buffered LDS, one barrier per slab; the next slab's global loads fly under the MFMAs.  (Measured and rejected:
