@@ -17,8 +17,8 @@ python bench.py --workload mp $Q --no-other-modes 2>/dev/null | tail -1 > $O/mp.
 python bench.py --workload peract $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract.json
 python bench.py --workload peract --act-storage fp32 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_fp32_storage.json
 for b in 64 128; do
-  python bench.py --workload peract --batch $b --steps 12 --warmup 4 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_batch_$b.json
-  python bench.py --workload peract --act-storage fp32 --batch $b --steps 12 --warmup 4 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_fp32_storage_batch_$b.json
+  python bench.py --workload peract --batch $b --steps 20 --warmup 8 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_batch_$b.json
+  python bench.py --workload peract --act-storage fp32 --batch $b --steps 20 --warmup 8 $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract_fp32_storage_batch_$b.json
 done
 python bench.py --ragged $Q --no-other-modes 2>/dev/null | tail -1 > $O/ragged.json
 python bench.py --batch 38 $Q --no-other-modes 2>/dev/null | tail -1 > $O/batch_38.json
