@@ -332,6 +332,21 @@ def test_subm_conv_bf16_operand_paths(prec, cin, cout):
     assert eb <= 2e-6, (prec, "bgrad", eb)
 
 
+def test_subm_conv_bf16_operands_pair_compacted_path():
+    """The bf16 operand modes on the PAIR-COMPACTED kernel (LOTUS_CONV_OS=0; the default for them is the output-stationary
+    kernel): same cases, same fp64 references, so the hi-only / hi + lo weight packings stay covered on both kernels.  The
+    switch is read once per process, so the cases run in a child interpreter."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_subm_conv_bf16_operand_paths"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, LOTUS_CONV_OS="0"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("C,H", [(64, 2), (128, 4), (768, 32)])
 def test_patch_attention_fwd_bwd(C, H):
