@@ -6,7 +6,7 @@
 set -u
 TAG=${1:-r03}
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-modes --no-fresh-batches"
+ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-modes --no-fresh-batches ${BENCH_ARGS:-}"  # e.g. BENCH_ARGS="--workload peract" with tag r03p
 mkdir -p gpurun_out
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_fetch -o f -- python bench.py $ARGS > gpurun_out/pmc_${TAG}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_${TAG}_write -o w -- python bench.py $ARGS > gpurun_out/pmc_${TAG}_write.log 2>&1

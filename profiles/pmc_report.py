@@ -19,7 +19,9 @@ import json
 import os
 import sys
 
-FAMILIES = [("gemm_kernel", "gemm_kernel"), ("conv_pairs_kernel", "conv_pairs_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"),
+FAMILIES = [("gemm_kernel", "gemm_kernel"), ("conv_pairs_kernel", "conv_pairs_kernel"), ("conv_os_kernel", "conv_os_kernel (bf16 modes)"),
+            ("conv_wgrad_bf16_kernel", "conv_wgrad_bf16_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"),
+            ("xq_fwd_kernel", "xq_fwd_kernel (cross attention)"), ("xq_bwd_kernel", "xq_bwd_kernel (cross attention)"),
             ("conv_smallcin", "conv_smallcin (stem)"), ("attn_fwd_kernel", "attn_fwd_kernel"), ("attn_bwd_kernel", "attn_bwd_kernel"),
             ("fe_neighbour_kernel", "fe_neighbour_kernel"), ("fe_hash_build_kernel", "fe_hash_build_kernel"), ("ln_bwd_kernel", "ln_bwd_kernel"),
             ("ln_fwd_kernel", "ln_fwd_kernel"), ("bn_stat_kernel", "bn_stat_kernel"), ("bn_apply_kernel", "bn_apply_kernel"),

@@ -304,6 +304,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(ConvWgP p) {
 // dense layers, gemm.hip): same decomposition and pair compaction, 32 pairs per slab; the gathered dy / x rows are
 // converted (and split) while they are staged into k-contiguous bf16 images (mma.h BTile, pair index = k), the products
 // are v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The bias gradient is summed from the fp32 staging registers.
+__device__ __forceinline__ float4 zsel4(bool ok, float4 v) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 template <int PREC>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvWgP p) {
   constexpr int BM = 64, BN = 64, BK = 32;
@@ -370,16 +374,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvWgP p) {
   const bool want_bias = p.bias_part && t == p.T / 2 && ci0 == 0;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
-  float4 ra[2], rb[2];
-  auto gload = [&](int k0) {
+  // staging registers hold the rows AS LOADED, every load is issued unconditionally (padding pairs read row 0 and are
+  // zeroed by a select when staged): a conversion or a branch at the load site makes the compiler wait for the load
+  // there, in front of the products it should fly under (gemm.hip, conv_os_kernel)
+  Raw4<act_t> rra[2], rrb[2];
+  bool oka[2], okb[2];
+  const bool a_fast = a_vec && co0 + iq * 4 + 3 < p.cout, b_fast = b_vec && ci0 + iq * 4 + 3 < p.cin;
+  auto gload = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int pp = pair_p[k0 + 2 * kr2 + e], qq = pair_q[k0 + 2 * kr2 + e];
-      ra[e] = pp >= 0 ? load4_guard(p.dy, p.cout, pp, co0 + iq * 4, p.n, p.cout, a_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[e] = qq >= 0 ? load4_guard(p.x, p.cin, qq, ci0 + iq * 4, p.n, p.cin, b_vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+      oka[e] = pp >= 0;
+      okb[e] = qq >= 0;
+      if (a_fast) rra[e] = ldraw(p.dy + (long)max(pp, 0) * p.cout + co0 + iq * 4);
+      else rra[e] = toraw(load4_guard(p.dy, p.cout, max(pp, 0), co0 + iq * 4, p.n, p.cout, a_vec), p.dy);
+      if (b_fast) rrb[e] = ldraw(p.x + (long)max(qq, 0) * p.cin + ci0 + iq * 4);
+      else rrb[e] = toraw(load4_guard(p.x, p.cin, max(qq, 0), ci0 + iq * 4, p.n, p.cin, b_vec), p.x);
     }
   };
-  auto stage = [&](unsigned* W, int plane, const float4& v0, const float4& v1, bool sum) {
+  auto stage = [&](unsigned* W, int plane, const float4& v0, const float4& v1, bool sum) __attribute__((always_inline)) {
     const float va[4] = {v0.x, v0.y, v0.z, v0.w}, vb[4] = {v1.x, v1.y, v1.z, v1.w};
     unsigned hw[4], lw[4];
 #pragma unroll
@@ -398,9 +411,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(ConvWgP p) {
       if (PREC == 3) W[plane + row * TA::kLdW + kr2] = lw[e];
     }
   };
-  auto lstore = [&]() {
-    stage(Aw, TA::kPlaneW, ra[0], ra[1], want_bias);
-    stage(Bw, TB::kPlaneW, rb[0], rb[1], false);
+  auto lstore = [&]() __attribute__((always_inline)) {
+    stage(Aw, TA::kPlaneW, zsel4(oka[0], unraw(rra[0])), zsel4(oka[1], unraw(rra[1])), want_bias);
+    stage(Bw, TB::kPlaneW, zsel4(okb[0], unraw(rrb[0])), zsel4(okb[1], unraw(rrb[1])), false);
   };
   if (total > 0) {
     gload(0);

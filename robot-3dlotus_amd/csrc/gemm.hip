@@ -172,28 +172,7 @@ __device__ __forceinline__ void gemm_slab(const float* __restrict__ As, const fl
 
 // (the bf16 operand tiles — BTile, split_bf16, rot4, gemm_slab_bf16 — live in mma.h: the sparse-conv weight gradient shares them)
 
-// Four consecutive operand elements AS LOADED.  The staging registers of the next slab must not be touched between the
-// load and the LDS store behind the MFMAs: converting at the load site (what ld4 does for bf16 storage: two shifts and
-// two ands per 8 bytes) makes the compiler wait for the load right there, and the global latency of every slab lands in
-// front of its products (seen in the ISA of the bf16-storage build: s_waitcnt vmcnt directly behind the loads).
-template <typename T> struct Raw4 { float4 v; };
-template <> struct Raw4<__bf16> { uint2 v; };
-__device__ __forceinline__ Raw4<float> ldraw(const float* p) { return {*reinterpret_cast<const float4*>(p)}; }
-__device__ __forceinline__ Raw4<__bf16> ldraw(const __bf16* p) { return {*reinterpret_cast<const uint2*>(p)}; }
-__device__ __forceinline__ float4 unraw(const Raw4<float>& r) { return r.v; }
-__device__ __forceinline__ float4 unraw(const Raw4<__bf16>& r) {
-  return make_float4(__builtin_bit_cast(float, r.v.x << 16), __builtin_bit_cast(float, r.v.x & 0xffff0000u),
-                     __builtin_bit_cast(float, r.v.y << 16), __builtin_bit_cast(float, r.v.y & 0xffff0000u));
-}
-__device__ __forceinline__ Raw4<float> toraw(float4 v, const float*) { return {v}; }
-__device__ __forceinline__ Raw4<__bf16> toraw(float4 v, const __bf16*) {  // (guarded loads of odd shapes: values are exact bf16)
-  return {make_uint2(lotus_pack_bf16(v.x, v.y), lotus_pack_bf16(v.z, v.w))};
-}
-__device__ __forceinline__ Raw4<float> rsel(bool ok, Raw4<float> r) {
-  return {make_float4(ok ? r.v.x : 0.f, ok ? r.v.y : 0.f, ok ? r.v.z : 0.f, ok ? r.v.w : 0.f)};
-}
-__device__ __forceinline__ Raw4<__bf16> rsel(bool ok, Raw4<__bf16> r) { return {make_uint2(ok ? r.v.x : 0u, ok ? r.v.y : 0u)}; }
-
+// (Raw4 / ldraw / unraw / toraw / rsel — operand elements as loaded — live in mma.h)
 // value-wise select (a pointer select between the loaded vector and a zero constant goes through scratch)
 __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
