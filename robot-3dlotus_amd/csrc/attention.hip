@@ -13,7 +13,7 @@
 // score image: scores are computed transposed (S^T = K Q^T) so that a lane owns one query and its accumulator registers
 // run over the keys; softmax, dropout and the P / dS operands of the following products live in registers (see the
 // comments at the kernels).  Everything a (tile, head) needs stays on chip between the QK^T, softmax and PV stages.
-#include "common.h"
+#include "mma.h"
 #include <stdlib.h>
 
 namespace LOTUS_NS {
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
     float cs_acc = 0.f;  // lanes 0..31 of each wave: column sums of dS over the wave's queries
     // The q / dO / O rows of tile ti + 1 are requested before the products of tile ti (a block runs one wave per SIMD:
     // nothing else would hide the round trip) and consumed at the top of the next iteration.
-    float4 qv[D / 4], gv[D / 4], ov[D / 4];
+    Raw4<act_t> rq[D / 4], rg[D / 4], ro[D / 4];  // next tile's rows as loaded (converted when taken over: mma.h Raw4)
     bool nact = false;
     long nrow = 0;
     int npos = 0;
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
         const act_t* gp = p.dout + nrow * p.out_ld + h * D;
         const act_t* op = p.out + nrow * p.out_ld + h * D;
 #pragma unroll
-        for (int c4 = 0; c4 < D / 4; ++c4) { qv[c4] = ld4(qp + c4 * 4); gv[c4] = ld4(gp + c4 * 4); ov[c4] = ld4(op + c4 * 4); }
+        for (int c4 = 0; c4 < D / 4; ++c4) { rq[c4] = ldraw(qp + c4 * 4); rg[c4] = ldraw(gp + c4 * 4); ro[c4] = ldraw(op + c4 * 4); }
       }
     };
     if (kc == 0 || n_tiles > 1) fetch(0);
@@ -1087,9 +1087,10 @@ __global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
           Di = 0.f;
 #pragma unroll
           for (int c4 = 0; c4 < D / 4; ++c4) {
-            qh[4 * c4] = qv[c4].x; qh[4 * c4 + 1] = qv[c4].y; qh[4 * c4 + 2] = qv[c4].z; qh[4 * c4 + 3] = qv[c4].w;
-            go[4 * c4] = gv[c4].x; go[4 * c4 + 1] = gv[c4].y; go[4 * c4 + 2] = gv[c4].z; go[4 * c4 + 3] = gv[c4].w;
-            Di += (gv[c4].x * ov[c4].x + gv[c4].y * ov[c4].y) + (gv[c4].z * ov[c4].z + gv[c4].w * ov[c4].w);
+            const float4 qv_ = unraw(rq[c4]), gv_ = unraw(rg[c4]), ov_ = unraw(ro[c4]);
+            qh[4 * c4] = qv_.x; qh[4 * c4 + 1] = qv_.y; qh[4 * c4 + 2] = qv_.z; qh[4 * c4 + 3] = qv_.w;
+            go[4 * c4] = gv_.x; go[4 * c4 + 1] = gv_.y; go[4 * c4 + 2] = gv_.z; go[4 * c4 + 3] = gv_.w;
+            Di += (gv_.x * ov_.x + gv_.y * ov_.y) + (gv_.z * ov_.z + gv_.w * ov_.w);
           }
           float m = 0.f;
 #pragma unroll
