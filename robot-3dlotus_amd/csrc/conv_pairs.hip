@@ -481,9 +481,11 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
 //     an LDS tile for coalesced row stores.
 template <int PREC, int NS, int KCH>
 struct OsCfg {
-  static constexpr int BR = 128, NW = 32 * NS, NB = KCH / 16, MAXT = 27;
+  // NB = row fragments (16 bytes per lane) of a stage: bf16 modes 8 k of a 16-k block, fp32 (PREC 0) 4 k of an 8-k block —
+  // lane half h of a block takes k = 4 h + j for the four fp32 MFMAs j, which is the k-quad layout of the packed weights
+  static constexpr int BR = 128, NW = 32 * NS, NB = PREC == 0 ? KCH / 8 : KCH / 16, MAXT = 27;
   static constexpr int U4T = PREC == 3 ? 2 : 1;                 // uint4 per packed (tap, 16-k block, k half, column) tuple
-  static constexpr int STAGE_U4 = NB * 2 * NW * U4T;            // uint4 per weight stage
+  static constexpr int STAGE_U4 = NB * 2 * NW * U4T;            // uint4 per weight stage (fp32: one float4 per k quad and column)
   static constexpr int OLD = NW + 4;                            // epilogue tile row stride (floats)
   // [2 weight stages | neighbour ids of the block's rows, all taps] during the tap loop; the epilogue tile reuses both
   static constexpr size_t loop_bytes() { return 2 * (size_t)STAGE_U4 * 16 + (size_t)MAXT * BR * sizeof(int); }
@@ -493,7 +495,8 @@ struct OsCfg {
 
 template <int PREC, int NS, int KCH>
 __global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
-  static_assert(PREC == 1 || PREC == 3, "bf16 operand modes only");
+  static_assert(PREC == 0 || PREC == 1 || PREC == 3, "operand mode");
+  static_assert(PREC != 0 || !LOTUS_ACT_IS_BF16, "the fp32 products read fp32 rows");
   using Cfg = OsCfg<PREC, NS, KCH>;
   constexpr int BR = Cfg::BR, NW = Cfg::NW, NB = Cfg::NB, U4T = Cfg::U4T, STAGE_U4 = Cfg::STAGE_U4, OLD = Cfg::OLD;
   constexpr int WPT = STAGE_U4 / 256;  // weight uint4 per thread and stage
@@ -553,7 +556,8 @@ __global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
 
   // raw neighbour-row fragments of one stage: NB x 8 consecutive k of row q (this lane's k half).  bf16 storage: the 16
   // row bytes ARE the MFMA operand and two stages are kept in flight; fp32 storage: 32 bytes, converted in registers
-  constexpr int RAWV = LOTUS_ACT_IS_BF16 ? 1 : 2;  // 16-byte loads per fragment
+  constexpr int RAWV = (LOTUS_ACT_IS_BF16 || PREC == 0) ? 1 : 2;  // 16-byte loads per fragment
+  constexpr int KFR = PREC == 0 ? 4 : 8;                          // k per lane and fragment
   constexpr int DEPTH = LOTUS_ACT_IS_BF16 ? 2 : 1; // row stages in flight
   uint4 braw[DEPTH][NB][RAWV];
   auto load_rows = [&](uint4 (&dst)[NB][RAWV], int st) __attribute__((always_inline)) -> bool {  // rows of stage st (taps outer, chunks inner)
@@ -561,18 +565,18 @@ __global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
     const int q = nbr_s[tl * BR + lrow];
     // every load is issued unconditionally (an absent neighbour reads row 0 and is zeroed by value selects): a branch
     // around each load makes the compiler wait for it before the next one — NB dependent round trips per stage
-    const act_t* src = p.x + (long)max(q, 0) * p.KD + kc * KCH + hh * 8;
+    const act_t* src = p.x + (long)max(q, 0) * p.KD + kc * KCH + hh * KFR;
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-      for (int v = 0; v < RAWV; ++v) dst[kb][v] = reinterpret_cast<const uint4*>(src + kb * 16)[v];
+      for (int v = 0; v < RAWV; ++v) dst[kb][v] = reinterpret_cast<const uint4*>(src + kb * 2 * KFR)[v];
     return q >= 0;  // applied when the fragments are converted (selecting here would wait for the loads)
   };
   uint4 bhi[NB], blo[NB];
   auto convert_rows = [&](const uint4 (&src)[NB][RAWV], bool ok) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-      if constexpr (LOTUS_ACT_IS_BF16) {
+      if constexpr (LOTUS_ACT_IS_BF16 || PREC == 0) {  // the loaded bytes ARE the operand (bf16 rows / four fp32 k)
         bhi[kb] = make_uint4(ok ? src[kb][0].x : 0u, ok ? src[kb][0].y : 0u, ok ? src[kb][0].z : 0u, ok ? src[kb][0].w : 0u);
         blo[kb] = make_uint4(0u, 0u, 0u, 0u);
       } else {
@@ -601,8 +605,12 @@ __global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
       const int i = tid + j * 256, run = i / L, off = i - run * L;
-      const long tup = ((long)(tw * (p.KD / 16) + kc * NB + (run >> 1)) * 2 + (run & 1)) * p.ND + n0;
-      wreg[j] = wp4[tup * U4T + off];
+      if constexpr (PREC == 0) {  // fp32 fragments: float4 (k quad, column) at (tap * KD/4 + quad) * ND + column
+        wreg[j] = wp4[((long)tw * (p.KD / 4) + kc * (KCH / 4) + run) * p.ND + n0 + off];
+      } else {
+        const long tup = ((long)(tw * (p.KD / 16) + kc * NB + (run >> 1)) * 2 + (run & 1)) * p.ND + n0;
+        wreg[j] = wp4[tup * U4T + off];
+      }
     }
   };
   auto store_w = [&](int buf) __attribute__((always_inline)) {
@@ -613,6 +621,27 @@ __global__ __launch_bounds__(256, 2) void conv_os_kernel(ConvP2 p) {
     const uint4* wb = wst + (st & 1) * STAGE_U4;
     const int tl = st / nkc;
     if (!__ballot(nbr_s[tl * BR + lrow] >= 0)) return;  // a tap none of the wave's rows has: nothing to add
+    if constexpr (PREC == 0) {
+      // exact fp32: four products (k = 8 kb + 4 hh + j on both operands) per 16-byte weight fragment; the fragment of
+      // step i + 1 is requested before the MFMAs of step i (one LDS round trip per 256 MFMA cycles would otherwise be
+      // exposed in front of every group of four)
+      constexpr int N = NB * NS;
+      uint4 a_cur = wb[(hh * NW) + l31];  // step 0: kb = 0, slice 0
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int kb = i / NS, s2 = i % NS;
+        uint4 a_nxt = a_cur;
+        if (i + 1 < N) a_nxt = wb[(((i + 1) / NS) * 2 + hh) * NW + ((i + 1) % NS) * 32 + l31];
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise sinks the read below the products it should fly under)
+        acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a_cur.x), __builtin_bit_cast(float, bhi[kb].x), acc[s2], 0, 0, 0);
+        acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a_cur.y), __builtin_bit_cast(float, bhi[kb].y), acc[s2], 0, 0, 0);
+        acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a_cur.z), __builtin_bit_cast(float, bhi[kb].z), acc[s2], 0, 0, 0);
+        acc[s2] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, a_cur.w), __builtin_bit_cast(float, bhi[kb].w), acc[s2], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_cur = a_nxt;
+      }
+      return;
+    }
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
 #pragma unroll
@@ -818,6 +847,9 @@ static int launch_pairs(ConvP2& p, int nz, int prec, hipStream_t st) {
 // output-stationary bf16 kernel: 128-row blocks; taps split 1 / 3 / 9 ways until the grid covers the CUs
 static int os_splits(int n, int ND) {
   const long base = (long)cdiv(n, 128) * (ND == 64 ? 1 : ND / 128);
+  static int force = -1;
+  if (force < 0) { const char* e = getenv("LOTUS_CONV_OS_NZ"); force = e ? atoi(e) : 0; }
+  if (force == 1 || force == 3 || force == 9) return force;
   int nz = 1;
   while (nz < 9 && base * nz < 256) nz = nz == 1 ? 3 : 9;
   return nz;
@@ -841,6 +873,10 @@ static int launch_os_t(ConvP2& p, int nz, hipStream_t st) {
 }
 static int launch_os(ConvP2& p, int nz, int prec, hipStream_t st) {
   const bool wide = p.ND != 64;
+  if (prec == 0) {
+    if constexpr (!LOTUS_ACT_IS_BF16) return wide ? launch_os_t<0, 4, 64>(p, nz, st) : launch_os_t<0, 2, 64>(p, nz, st);
+    else return LOTUS_E_UNSUPPORTED;
+  }
   if (prec == 3) return wide ? launch_os_t<3, 4, 64>(p, nz, st) : launch_os_t<3, 2, 64>(p, nz, st);
   static int kch = -1;
   if (kch < 0) { const char* e = getenv("LOTUS_CONV_OS_KCH"); kch = e ? atoi(e) : 128; }
@@ -878,7 +914,16 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   if (T != 27 || KD % 32 || ND % 64 || (ND > 64 && ND % 128)) return 0;
   if (!w_t || ((uintptr_t)w_t) % 16) return 0;
   if ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16) return 0;
-  const bool os = prec != 0 && os_mode() && KD % 64 == 0;
+  // exact fp32 products on the output-stationary kernel too (LOTUS_CONV_OS_F32 = 1 all eligible shapes | 2 the 64-wide
+  // layers | 3 also small levels; fp32 storage only; OPT-IN): 2-3.7x the MFMAs of the compacted form but none of its folds,
+  // tables and fills.  Measured (tools/conv_bench.py, us, pair-compacted -> output-stationary): level 0 C 64 189 -> 145,
+  // level 1 C 64 111 -> 77, level 2 C 128 80 -> 69, but level 1 C 128 220 -> 231 (9 tap groups; 264 with 3), level 2
+  // C 256 227 -> 226, level 4 135 -> 175; in the step 867 -> 872 samples/s with the 64-wide layers only, 839 with all —
+  // the compacted kernel stays the fp32 default
+  static int os_f32 = -1;
+  if (os_f32 < 0) { const char* e = getenv("LOTUS_CONV_OS_F32"); os_f32 = e ? atoi(e) : 0; }
+  const bool f32_fit = os_f32 == 1 || (os_f32 >= 2 && ND == 64) || (os_f32 == 3 && n <= 8192 && ND <= 256);
+  const bool os = KD % 64 == 0 && (prec != 0 ? os_mode() != 0 : (f32_fit && !LOTUS_ACT_IS_BF16));
   const int nz = os ? os_splits(n, ND) : tap_splits(n, ND);
   if (nz > 1 && (!workspace || workspace_bytes < (size_t)nz * n * ND * sizeof(float))) return 0;
   ConvP2 p;

@@ -345,6 +345,12 @@ def test_subm_conv_bf16_operands_pair_compacted_path():
                         "-k", "test_subm_conv_bf16_operand_paths"], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, LOTUS_CONV_OS="0"), cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    # and the converse: exact fp32 products on the output-stationary kernel (LOTUS_CONV_OS_F32=1; opt-in — it only wins
+    # on the 64-wide layers and is worth +0.5 % of the step, csrc/conv_pairs.hip) against the same fp64 references
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_subm_conv_fwd_dgrad_wgrad or duplicate"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, LOTUS_CONV_OS_F32="1"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
 # ------------------------------------------------------------------------------------ attention
