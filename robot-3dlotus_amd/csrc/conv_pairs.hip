@@ -919,7 +919,9 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   // tables and fills.  Measured (tools/conv_bench.py, us, pair-compacted -> output-stationary): level 0 C 64 189 -> 145,
   // level 1 C 64 111 -> 77, level 2 C 128 80 -> 69, but level 1 C 128 220 -> 231 (9 tap groups; 264 with 3), level 2
   // C 256 227 -> 226, level 4 135 -> 175; in the step 867 -> 872 samples/s with the 64-wide layers only, 839 with all —
-  // the compacted kernel stays the fp32 default
+  // the compacted kernel stays the fp32 default.  (Its different summation order is enough to flip max-pool arg-max ties
+  // on the v1_init fixture: whole-gradient error 1.5e-3 against the 1e-4 bar the default path meets there — the re-routing
+  // sensitivity tests/test_gpu_fullsize_oracle.py measures; per-op it is within 3e-6 of fp64 like the default.)
   static int os_f32 = -1;
   if (os_f32 < 0) { const char* e = getenv("LOTUS_CONV_OS_F32"); os_f32 = e ? atoi(e) : 0; }
   const bool f32_fit = os_f32 == 1 || (os_f32 >= 2 && ND == 64) || (os_f32 == 3 && n <= 8192 && ND <= 256);
