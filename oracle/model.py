@@ -97,6 +97,19 @@ def cross_attention(q, kv, counts, ctx_counts, H, qn_w, qn_b, kn_w, kn_b, fp16_a
     return _round_fp16(torch.cat(outs, 0), fp16_attn)
 
 
+class _RoundBF16(torch.autograd.Function):
+    """y = bf16(x) in the forward pass, dx = bf16(dy) in the backward pass, both kept in x's dtype: what storing an
+    activation (and its gradient) as bf16 in memory does to it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
 class Oracle:
     """sd: dict name -> tensor (reference key grammar).  cfg: dict(ptv3=..., action=..., loss=...)."""
 
@@ -109,13 +122,27 @@ class Oracle:
         self.fp16_attn = fp16_attn
         self.bn_momentum = bn_momentum
         self.new_running = {}
+        self.record_arg = False  # True: record the max-pool / cloud-max arg-max tables in the output dict (tests)
+        # True: simulate bf16 ACTIVATION STORAGE (BASELINE configs[4]): every tensor an implementation would keep in
+        # memory between two operators — and its gradient — is rounded to bf16, and the operands of the products
+        # (weights included) are bf16; accumulation, statistics, master weights and parameter gradients keep `dtype`.
+        # Not the reference's arithmetic (torch autocast keeps fp32 residuals): a model of the rounding noise such a mode
+        # cannot avoid, which the full-size bf16 parity test states its bars from.
+        self.bf16_storage = False
+
+    def q(self, x):
+        return _RoundBF16.apply(x) if self.bf16_storage else x
+
+    def qw(self, w):
+        """Weight as a product operand (no gradient rounding: parameter gradients stay in `dtype`)."""
+        return (w.to(torch.bfloat16).to(w.dtype) - w).detach() + w if self.bf16_storage and w is not None else w
 
     # -- small helpers ---------------------------------------------------------------------
     def lin(self, x, name):
-        return F.linear(x, self.sd[name + ".weight"], self.sd.get(name + ".bias"))
+        return self.q(F.linear(x, self.qw(self.sd[name + ".weight"]), self.sd.get(name + ".bias")))
 
     def ln(self, x, name, eps=1e-5):
-        return F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], eps)
+        return self.q(F.layer_norm(x, (x.shape[-1],), self.sd[name + ".weight"], self.sd[name + ".bias"], eps))
 
     def bn(self, x, name):
         """nn.BatchNorm1d(eps=1e-3, momentum=0.01), PointTransformerV3/model_ca.py:226."""
@@ -130,7 +157,7 @@ class Oracle:
 
     def mlp(self, x, name):
         """MLP, PointTransformerV3/model.py:577-583 (dropouts are identity in every fixture)."""
-        return self.lin(F.gelu(self.lin(x, name + ".fc1")), name + ".fc2")
+        return self.lin(self.q(F.gelu(self.lin(x, name + ".fc1"))), name + ".fc2")
 
     # -- blocks ----------------------------------------------------------------------------
     def block(self, x, xs, lvl, name, H, patch_size, order_index=0):
@@ -139,14 +166,15 @@ class Oracle:
         i % len(order) for the i-th Block of a stage (model_ca.py:285,354).  DropPath (model.py:655-657) is the identity in
         every configuration the oracle is run in (drop_path 0, or eval mode)."""
         sd = self.sd
-        c = subm_conv(xs, lvl["nbr27_t"], sd[name + ".cpe.0.weight"], sd[name + ".cpe.0.bias"])
-        x = x + self.ln(self.lin(c, name + ".cpe.1"), name + ".cpe.2")
+        q_ = self.q
+        c = q_(subm_conv(xs, lvl["nbr27_t"], self.qw(sd[name + ".cpe.0.weight"]), sd[name + ".cpe.0.bias"]))
+        x = q_(x + self.ln(self.lin(c, name + ".cpe.1"), name + ".cpe.2"))
         qkv = self.lin(self.ln(x, name + ".norm1.0"), name + ".attn.qkv")
-        a = patch_attention(qkv, lvl, order_index, H, sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
-                            sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], patch_size,
-                            self.fp16_attn)
-        x = x + self.lin(a, name + ".attn.proj")
-        x = x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0")
+        a = q_(patch_attention(qkv, lvl, order_index, H, sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
+                               sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], patch_size,
+                               self.fp16_attn))
+        x = q_(x + self.lin(a, name + ".attn.proj"))
+        x = q_(x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0"))
         return x
 
     def ca_block(self, x, lvl, ctx, ctx_counts, name, H):
@@ -154,11 +182,11 @@ class Oracle:
         sd = self.sd
         q = self.lin(self.ln(x, name + ".norm1.0"), name + ".attn.q")
         kv = self.lin(ctx, name + ".attn.kv")
-        a = cross_attention(q, kv, lvl["counts"].tolist(), ctx_counts, H,
-                            sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
-                            sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], self.fp16_attn)
-        x = x + self.lin(a, name + ".attn.proj")
-        x = x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0")
+        a = self.q(cross_attention(q, kv, lvl["counts"].tolist(), ctx_counts, H,
+                                   sd[name + ".attn.q_norm.weight"], sd[name + ".attn.q_norm.bias"],
+                                   sd[name + ".attn.k_norm.weight"], sd[name + ".attn.k_norm.bias"], self.fp16_attn))
+        x = self.q(x + self.lin(a, name + ".attn.proj"))
+        x = self.q(x + self.mlp(self.ln(x, name + ".norm2.0"), name + ".mlp.0"))
         return x
 
     # -- whole model -----------------------------------------------------------------------
@@ -168,9 +196,9 @@ class Oracle:
         (pc_fts, npoints_in_batch, txt_embeds, txt_lens, gt_actions, disc_pos_probs)."""
         assert not (self.training and self.cfg["ptv3"].get("drop_path", 0.0) > 0), "oracle: DropPath masks are not reproducible"
         pc32 = batch["pc_fts"].float()
-        pc = pc32.to(self.dt)
+        pc = self.q(pc32.to(self.dt))
         counts = list(batch["npoints_in_batch"])
-        ctx = self.lin(batch["txt_embeds"].to(self.dt), "txt_fc")  # simple_policy_ptv3.py:414
+        ctx = self.lin(self.q(batch["txt_embeds"].to(self.dt)), "txt_fc")  # simple_policy_ptv3.py:414
         x, out = self.backbone(pc, pc32[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
         return self.head(x, counts, batch, out, compute_loss)
 
@@ -192,8 +220,8 @@ class Oracle:
         out = {"levels": levels}
 
         # Embedding, PointTransformerV3/model.py:844-861
-        x = subm_conv(pc, _t(levels[0]["nbr125"]), sd["ptv3_model.embedding.stem.conv.weight"], None)
-        x = F.gelu(self.bn(x, "ptv3_model.embedding.stem.norm"))
+        x = self.q(subm_conv(pc, _t(levels[0]["nbr125"]), sd["ptv3_model.embedding.stem.conv.weight"], None))
+        x = self.q(F.gelu(self.bn(x, "ptv3_model.embedding.stem.norm")))
         feats, skips = [], []
         for s in range(n_lv):
             name = f"ptv3_model.enc.enc{s}"
@@ -203,7 +231,18 @@ class Oracle:
                 cl = _t(lvl["cluster"]).view(-1, 1).expand(-1, proj.shape[1])
                 x = proj.new_zeros(lvl["grid"].shape[0], proj.shape[1]).scatter_reduce(
                     0, cl, proj, reduce="amax", include_self=False)
-                x = F.gelu(self.bn(x, name + ".down.norm.0"))
+                if self.record_arg:
+                    # arg-max table of the segment max (the FIRST parent row attaining it, as torch_scatter's CPU reduction
+                    # and the HIP kernel pick it) and, so that the gradient is routed to exactly that row (amax's autograd
+                    # would split it evenly among exact ties), the pooled value re-read through the table
+                    with torch.no_grad():
+                        rows = torch.arange(proj.shape[0]).view(-1, 1).expand_as(proj)
+                        cand = torch.where(proj == x[cl[:, 0]], rows, torch.full_like(rows, proj.shape[0]))
+                        arg = torch.full((x.shape[0], x.shape[1]), proj.shape[0], dtype=torch.long).scatter_reduce(
+                            0, cl, cand, reduce="amin", include_self=True)
+                    out.setdefault("pool_arg", []).append(arg)
+                    x = torch.gather(proj, 0, arg)
+                x = self.q(F.gelu(self.bn(x, name + ".down.norm.0")))
             for i in range(p3["enc_depths"][s]):  # model_ca.py:270-310
                 x = self.block(x, x, lvl, name + f".block{i}", p3["enc_num_head"][s], p3["enc_patch_size"][s], i % 4)
                 x = self.ca_block(x, lvl, ctx, ctx_counts, name + f".ca_block{i}", p3["enc_num_head"][s])
@@ -212,9 +251,9 @@ class Oracle:
         for s in reversed(range(n_lv - 1)):  # SerializedUnpooling, model.py:817-828
             name = f"ptv3_model.dec.dec{s}"
             lvl = levels[s]
-            up = F.gelu(self.bn(self.lin(x, name + ".up.proj.0"), name + ".up.proj.1"))
-            skip = F.gelu(self.bn(self.lin(skips[s], name + ".up.proj_skip.0"), name + ".up.proj_skip.1"))
-            x = skip + up[_t(levels[s + 1]["cluster"])]
+            up = self.q(F.gelu(self.bn(self.lin(x, name + ".up.proj.0"), name + ".up.proj.1")))
+            skip = self.q(F.gelu(self.bn(self.lin(skips[s], name + ".up.proj_skip.0"), name + ".up.proj_skip.1")))
+            x = self.q(skip + up[_t(levels[s + 1]["cluster"])])
             for i in range(p3["dec_depths"][s]):  # model_ca.py:340-380; later Blocks see the refreshed sparse_conv_feat
                 x = self.block(x, skip if i == 0 else x, lvl, name + f".block{i}", p3["dec_num_head"][s],
                                p3["dec_patch_size"][s], i % 4)
@@ -226,12 +265,16 @@ class Oracle:
     def head(self, x, counts, batch, out, compute_loss):
         """ActionHead.forward (heatmap_disc / max / euler_disc), simple_policy_ptv3.py:113-157, and
         compute_loss, :308-373."""
-        h = F.leaky_relu(self.lin(x, "act_proj_head.heatmap_mlp.0"), 0.02)
+        h = self.q(F.leaky_relu(self.lin(x, "act_proj_head.heatmap_mlp.0"), 0.02))
         xt = self.lin(h, "act_proj_head.heatmap_mlp.3")  # (N, 3*2*pos_bins)
         nb = xt.shape[1] // 3
         xt = xt.view(-1, 3, nb).permute(1, 0, 2)  # 'n (c b) -> c n b'
-        pcs = torch.stack([t_.max(0)[0] for t_ in torch.split(x, counts)], 0)
-        ae = self.lin(F.leaky_relu(self.lin(pcs, "act_proj_head.action_mlp.0"), 0.02), "act_proj_head.action_mlp.3")
+        mx = [t_.max(0) for t_ in torch.split(x, counts)]
+        pcs = torch.stack([m_[0] for m_ in mx], 0)
+        if self.record_arg:  # global row of every (cloud, channel) maximum (torch.max routes the gradient to this row)
+            base = np.concatenate([[0], np.cumsum(counts)])
+            out["cloud_arg"] = torch.stack([m_[1] + int(base[i]) for i, m_ in enumerate(mx)], 0)
+        ae = self.lin(self.q(F.leaky_relu(self.lin(pcs, "act_proj_head.action_mlp.0"), 0.02)), "act_proj_head.action_mlp.3")
         ebins = 360 // 5
         xr = ae[..., : ebins * 3].reshape(-1, ebins, 3)
         xo = ae[..., -1]
@@ -256,11 +299,12 @@ class Oracle:
         pc_labels, txt_embeds, txt_lens, npoints_in_batch, gt_trajs [B,T,7], gt_trajs_stop, traj_masks,
         gt_trajs_disc_pos_probs (list of [T,3,n*nb])."""
         sd, act = self.sd, self.cfg["action"]
-        pc = batch["pc_fts"].float()
+        pc32 = batch["pc_fts"].float()   # the integer front end always sees the float32 coordinates
+        pc = pc32.to(self.dt)
         counts = list(batch["npoints_in_batch"])
         feat = torch.cat([pc, sd["pc_label_embedding.weight"][batch["pc_labels"].long()]], -1)   # :441-442
-        ctx = self.lin(batch["txt_embeds"].float(), "txt_fc")                                      # :447
-        x, out = self.backbone(feat, pc[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        ctx = self.lin(batch["txt_embeds"].to(self.dt), "txt_fc")                                  # :447
+        x, out = self.backbone(feat, pc32[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
         T, B = act["max_traj_len"], len(counts)
         te = sd["act_proj_head.traj_embedding.weight"]
         pe = torch.cat([x.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(x.shape[0], -1, -1)], -1)  # :90-97
@@ -268,16 +312,25 @@ class Oracle:
         nb = xt.shape[-1] // 3
         xt = xt.view(-1, T, 3, nb).permute(1, 2, 0, 3)                       # 'n t (c b) -> t c n b', :113-114
         pcs = torch.stack([t_.max(0)[0] for t_ in torch.split(pe, counts)], 0)                   # :116-120
+        if self.record_arg:
+            # the per-cloud maximum of [x | traj_embedding] over the points: the embedding half is constant over the points, so
+            # only the feature half has an arg-max (the same row for every step); re-read through it so that the gradient is
+            # routed to exactly that row
+            mx = [t_.max(0) for t_ in torch.split(x, counts)]
+            base = np.concatenate([[0], np.cumsum(counts)])
+            out["cloud_arg"] = torch.stack([m_[1] + int(base[i]) for i, m_ in enumerate(mx)], 0)
+            px = torch.stack([m_[0] for m_ in mx], 0)
+            pcs = torch.cat([px.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(B, -1, -1)], -1)
         ae = self.lin(F.leaky_relu(self.lin(pcs, "act_proj_head.action_mlp.0"), 0.02), "act_proj_head.action_mlp.3")
         ebins = 360 // 5
         xr = ae[..., : ebins * 3].reshape(B, T, ebins, 3)                    # :139-142
         xo, xs = ae[..., -2], ae[..., -1]                                     # :145-146
         out.update(xt=xt, xr=xr, xo=xo, xstop=xs)
         if compute_loss:
-            gt, m = batch["gt_trajs"].float(), batch["traj_masks"].float()
+            gt, m = batch["gt_trajs"].to(self.dt), batch["traj_masks"].to(self.dt)
             pos = 0
             for i, lg in enumerate(torch.split(xt, counts, dim=2)):          # :324-336
-                ce = F.cross_entropy(lg.reshape(T * 3, -1), batch["gt_trajs_disc_pos_probs"][i].float().reshape(T * 3, -1),
+                ce = F.cross_entropy(lg.reshape(T * 3, -1), batch["gt_trajs_disc_pos_probs"][i].to(self.dt).reshape(T * 3, -1),
                                      reduction="none")
                 mk = m[i].unsqueeze(1).expand(-1, 3).reshape(-1)
                 pos = pos + (ce * mk).sum() / mk.sum()
@@ -286,7 +339,7 @@ class Oracle:
                                  reduction="none").view(B, T, 3)             # :365-372
             rot = (rl * m.unsqueeze(-1)).sum() / m.sum() / 3
             opn = (F.binary_cross_entropy_with_logits(xo, gt[..., -1], reduction="none") * m).sum() / m.sum()
-            stp = (F.binary_cross_entropy_with_logits(xs, batch["gt_trajs_stop"].float(), reduction="none") * m).sum() / m.sum()
+            stp = (F.binary_cross_entropy_with_logits(xs, batch["gt_trajs_stop"].to(self.dt), reduction="none") * m).sum() / m.sum()
             lc = self.cfg["loss"]
             out["losses"] = dict(pos=pos, rot=rot, open=opn, stop=stp,
                                  total=lc["pos_weight"] * pos + lc["rot_weight"] * rot + opn + stp)

@@ -903,6 +903,7 @@ int lotus_linear_fwd(const act_t* x, const float* w, const float* bias, const ac
                      int precision, void* workspace, size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_fwd: precision must be 0, 1 or 3");
+  LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_fwd: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   if (M == 0) return LOTUS_OK;
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -923,6 +924,7 @@ int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* 
                        size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_dgrad: precision must be 0, 1 or 3");
+  LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_dgrad: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   if (M == 0) return LOTUS_OK;
   GemmP p;
   memset(&p, 0, sizeof(p));
@@ -962,6 +964,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
                        void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_wgrad: precision must be 0, 1 or 3");
+  LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_wgrad: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   hipStream_t st = (hipStream_t)stream;
   const int nz = wgrad_splits(M, N, K);
   const size_t slab = (size_t)N * K + N;

@@ -569,6 +569,26 @@ def add(a, b):
     return y
 
 
+# Test-only taps of the two arg-max tables of the model (SerializedPooling's segment max, model.py:760-765, and the head's
+# per-cloud max, simple_policy_ptv3.py:117-119).  ARG_TAP: a list that receives (kind, int32 table) in forward order.
+# ARG_INJECT: a list of int32 tables consumed in the same order — the backward pass then routes the gradient of every
+# (segment, channel) to the row the INJECTED table names while the forward values stay the kernel's own.  This is how
+# tests/test_gpu_fullsize_oracle.py separates "a near-tie was broken the other way" (a discrete re-routing both fp32
+# implementations are entitled to) from a defect: with the oracle's table injected every gradient must meet 1e-4.
+ARG_TAP = None
+ARG_INJECT = None
+
+
+def _arg_hook(kind, arg):
+    if ARG_TAP is not None:
+        ARG_TAP.append((kind, arg))
+    if ARG_INJECT:
+        k2, inj = ARG_INJECT.pop(0)
+        assert k2 == kind and tuple(inj.shape) == tuple(arg.shape), (k2, kind, tuple(inj.shape), tuple(arg.shape))
+        return inj.to(device=arg.device, dtype=torch.int32).contiguous()
+    return arg
+
+
 class BnState:
     """Batch statistics hook: `reduce(sums)` all-reduces the fp64 vector (sum, sumsq, count) across
     ranks when SyncBatchNorm semantics are wanted (train_simple_policy.py:116-117); None = local."""
@@ -1108,6 +1128,8 @@ class PoolFn(torch.autograd.Function):
         pooled = torch.empty(child.n, C, dtype=x.dtype, device=x.device)
         arg = torch.empty(child.n, C, dtype=torch.int32, device=x.device)
         call("lotus_pool_max_fwd", proj, child.members, child.seg_start, child.n, C, pooled, arg)
+        if ARG_TAP is not None or ARG_INJECT:
+            arg = _arg_hook("pool", arg)
         y, mean, invstd = bn_fwd(pooled, g, b, rmean, rvar, training, ACT_GELU)
         ctx.save_for_backward(x, w, g, b, pooled, arg, mean, invstd)
         ctx.meta = (child, training)
@@ -1192,6 +1214,8 @@ class HeadLossFn(torch.autograd.Function):
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
         ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
         call("lotus_cloud_max_fwd", x, lvl.off, B, C, pc, arg, ws, ws.numel())
+        if ARG_TAP is not None or ARG_INJECT:
+            arg = _arg_hook("cloud", arg)
         a, apre = linear_fwd(pc, aw0, ab0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=mix_seed(seed, 1))
         ae, _ = linear_fwd(a, aw3, ab3)
         losses = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -1350,6 +1374,8 @@ class CloudMaxFn(torch.autograd.Function):
         arg = torch.empty(B, C, dtype=torch.int32, device=x.device)
         ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)
         call("lotus_cloud_max_fwd", x, lvl.off, B, C, y, arg, ws, ws.numel())
+        if ARG_TAP is not None or ARG_INJECT:
+            arg = _arg_hook("cloud", arg)
         ctx.save_for_backward(arg)
         ctx.lvl, ctx.n = lvl, x.shape[0]
         return y

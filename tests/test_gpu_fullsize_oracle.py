@@ -61,12 +61,13 @@ def _run(variant, augment, seed, tag):
         batch = synth.augment_clouds(batch, seed=seed + 1)
     torch.set_num_threads(min(32, torch.get_num_threads() if torch.get_num_threads() > 1 else 16))
 
-    def oracle(dt, tie_noise=0.0):
+    def oracle(dt, tie_noise=0.0, record_arg=False):
         sdg_ = {k: (v.clone().to(dt) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         for k, v in sdg_.items():
             if v.is_floating_point() and "running" not in k:
                 v.requires_grad_(True)
         o = Oracle(sdg_, lcfg.plain(cfg), training=True, dtype=dt)
+        o.record_arg = record_arg
         if tie_noise:  # perturb what the max-pool compares by a float32-rounding-sized relative amount
             gen, lin0 = torch.Generator().manual_seed(5), o.lin
 
@@ -81,7 +82,7 @@ def _run(variant, augment, seed, tag):
 
     # the yardstick is the oracle evaluated in float64; the same oracle in float32 (the reference's arithmetic) is
     # measured against it too, which shows how much of a difference is fp32 summation order rather than a defect
-    out, sdg = oracle(torch.float64)
+    out, sdg = oracle(torch.float64, record_arg=True)
     out32, sdg32 = oracle(torch.float32)
     _, sdg_tie = oracle(torch.float64, tie_noise=1e-7)
 
@@ -91,10 +92,23 @@ def _run(variant, augment, seed, tag):
     m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0
     m.act_proj_head.dropout = 0.0
     m.ptv3_model.order_perms = PERMS
-    _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    from robot_3dlotus_amd import ops
+    ops.ARG_TAP = []
+    try:
+        _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+    finally:
+        tap, ops.ARG_TAP = ops.ARG_TAP, None
+    # the arg-max tables: the four SerializedPooling levels (model.py:760-765) in encoder order, then the head's cloud max
+    ref_args = [("pool", a) for a in out["pool_arg"]] + [("cloud", out["cloud_arg"])]
+    assert [k for k, _ in tap] == [k for k, _ in ref_args]
+    argdiff = []
+    for (kind, a), (_, r) in zip(tap, ref_args):
+        a = a.cpu().long()
+        argdiff.append(dict(kind=kind, pairs=int(a.numel()), differ=int((a != r).sum())))
     if augment:
         assert m.ptv3_model.last_n_dup > 0, "the augmented clouds were meant to contain duplicate voxels"
-    rec = {"n_dup": int(m.ptv3_model.last_n_dup), "points": int(sum(batch["npoints_in_batch"])), "weights": variant, "augmented": bool(augment)}
+    rec = {"n_dup": int(m.ptv3_model.last_n_dup), "points": int(sum(batch["npoints_in_batch"])), "weights": variant, "augmented": bool(augment),
+           "argmax_tables_vs_f64_oracle": argdiff}
     fails = []
     for name, got, ref in (("xt", m.last_pred[0], out["xt"]), ("xr", m.last_pred[1], out["xr"]), ("xo", m.last_pred[2], out["xo"])):
         o32 = float((out32[name].detach().double() - ref.detach()).abs().max())
@@ -138,6 +152,28 @@ def _run(variant, augment, seed, tag):
     rec.update(n_gradients=n, grad_rel_err_max=worst[0], grad_rel_err_argmax=worst[1], grad_rel_err_median=float(np.median(rels)),
                oracle32_grad_rel_err_max=worst32[0], oracle32_grad_rel_err_argmax=worst32[1], grad_norm_max=gmax,
                grad_tol=GRAD_TOL, grad_floor=GRAD_FLOOR, grad_max_tol=GRAD_MAX_TOL, yardstick="oracle/model.py evaluated in float64")
+    # ---- the proof: the same model, the float64 oracle's arg-max tables injected into backward (forward values stay the
+    # kernels' own).  Every discrete routing decision is now the yardstick's, so what is left is summation noise and EVERY
+    # gradient has to meet the 1e-4 bar — at the shapes only this test reaches (65 536 rows, split-K, tap-split).
+    for p_ in m.parameters():
+        p_.grad = None
+    ops.ARG_INJECT = [(k, r.to(torch.int32)) for k, r in ref_args]
+    try:
+        _, losses2 = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+        assert not ops.ARG_INJECT, "not every injected table was consumed"
+    finally:
+        ops.ARG_INJECT = None
+    losses2["total"].backward()
+    inj = []
+    for name, p_ in m.named_parameters():
+        r = sdg[name].grad
+        inj.append((float((p_.grad.cpu().double() - r).norm()) / (float(r.norm()) + GRAD_FLOOR * gmax), name))
+    inj.sort(reverse=True)
+    rec["injected_argmax"] = dict(grad_rel_err_max=inj[0][0], grad_rel_err_argmax=inj[0][1], grad_rel_err_median=float(np.median([t[0] for t in inj])),
+                                  n_gradients_above_1e_4=sum(1 for t in inj if t[0] > GRAD_TOL), worst5=[dict(name=t[1], rel=float("%.3g" % t[0])) for t in inj[:5]])
+    for rel, name in inj:
+        if rel > GRAD_TOL:
+            fails.append(f"grad {name} with the oracle's arg-max injected: rel {rel:.2e} > {GRAD_TOL}")
     ledger.record("fullsize_oracle/" + tag, **rec)
     assert not fails, "; ".join(fails[:8])
 
