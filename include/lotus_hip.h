@@ -171,6 +171,18 @@ int lotus_batchnorm_stats(const lotus_act_t* x, double* sums, int M, int C, void
                           void* stream);
 int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, float* running_mean,
                              float* running_var, int C, float eps, float momentum, void* stream);
+/* One-launch statistics (round 4): the last block to arrive reduces the per-block partials in a fixed order (two levels of
+ * 16) and, forward, finishes mean / invstd / running averages — lotus_batchnorm_stats + _finalize, or _bwd_stats, without
+ * their second and third launch.  `counter`: 64 zeroed unsigned of the launching stream, left at zero (the tail of the
+ * lotus_splitk_counters_bytes() buffer, at byte offset lotus_bn_counters_offset()).  Not for SyncBatchNorm, which needs the
+ * sums between the two halves. */
+size_t lotus_bn_counters_offset(void);
+int lotus_batchnorm_stats_fused(const lotus_act_t* x, double* sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                                int M, int C, float eps, float momentum, void* workspace, size_t workspace_bytes, void* counter,
+                                void* stream);
+int lotus_batchnorm_bwd_stats_fused(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, double* sums, int M, int C, int act, void* workspace, size_t workspace_bytes,
+                                    void* counter, void* stream);
 int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                                float eps, void* stream);
 int lotus_batchnorm_apply(const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,
@@ -299,6 +311,32 @@ int lotus_cpe_bwd(const lotus_act_t* dy, const lotus_act_t* xs, const float* cw,
                   unsigned long long link, int join, void* stream, void* side);
 /* out[e] = sum_z part[z * stride + e] in fixed order (e.g. the key-side partial slots of the cross-attention backward) */
 int lotus_sum_slabs(const lotus_act_t* part, lotus_act_t* out, long n, long stride, int nz, void* stream);
+/* out[r][c] (row stride out_ld) = sum_z part[z * stride + r * cols + c]: the same sum written into a column slice of a wider slab */
+int lotus_sum_slabs_ld(const lotus_act_t* part, lotus_act_t* out, int rows, int cols, long out_ld, long stride, int nz, void* stream);
+/* Cross-attention sub-block with PRECOMPUTED keys / values (round 4).  Every CABlock projects the same context
+ * (model_ca.py:46-67), so the model computes kv for all of them with one product [L, Cc] x [Cc, sum 2C] and each block reads
+ * its column slice `kv` (row stride kv_ld); backward writes d kv into the block's slice `dkv` (row stride dkv_ld) of the
+ * shared gradient slab.  Otherwise identical to lotus_crossattn_fwd / _bwd.
+ *   saved [n M*C | q M*C | att M*C | lse M*H | mean M | rstd M]
+ *   grads [dg C | db C | dwq C*C + dbq C | gq d | bq d | gk d | bk d | dwp C*C + dbp C] */
+size_t lotus_crossattn_kv_saved_floats(int M, int C, int H);
+size_t lotus_crossattn_kv_grads_floats(int C, int H);
+size_t lotus_crossattn_kv_tmp_floats(int M, int C, int L, int G);
+size_t lotus_crossattn_kv_ws_main_bytes(int M, int C, int H, int nblocks);
+size_t lotus_crossattn_kv_ws_side_bytes(int M, int C);
+int lotus_crossattn_kv_fwd(const lotus_act_t* x, const lotus_act_t* kv, long kv_ld, const float* g, const float* b, const float* wq,
+                           const float* bq, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
+                           const float* bp, lotus_act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H, float scale,
+                           float drop_p, unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, int k_max,
+                           void* ws, size_t ws_bytes, void* counters, void* stream);
+int lotus_crossattn_kv_bwd(const lotus_act_t* dy, const lotus_act_t* dz_in, const lotus_act_t* x, const lotus_act_t* kv, long kv_ld,
+                           const float* g, const float* wq, const float* qnw, const float* qnb, const float* knw, const float* knb,
+                           const float* wp, const float* saved, lotus_act_t* dx, lotus_act_t* dkv, long dkv_ld, lotus_act_t* dz_out,
+                           float dz_out_p, unsigned long long dz_out_seed, float* grads, float* tmp, const int* tiles, const int* blocks,
+                           int nblocks, int G, int M, int C, int H, int L, float scale, float drop_p, unsigned long long seed,
+                           float attn_p, unsigned long long attn_seed, int precision, int k_max, void* ws_main, size_t ws_main_bytes,
+                           void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side, unsigned long long link,
+                           int join, void* stream, void* side);
 
 /* ---- pooling, head, losses ---------------------------------------------------------------- */
 /* torch_scatter.segment_csr(reduce="max") and its arg-max backward, model.py:760-762 */

@@ -429,6 +429,123 @@ int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Cross-attention sub-block with PRECOMPUTED keys / values.  The context is the same for every CABlock of a forward pass
+// (model_ca.py:46-67: kv = Linear(256 -> 2C)(context)), so the model projects it once for all blocks — one product
+// [L, 256] x [256, sum 2C] — and each block reads its column slice `kv` (row stride kv_ld) of that slab; backward writes
+// d kv into the block's slice `dkv` (row stride dkv_ld) of the shared gradient slab, from which ONE input-gradient and ONE
+// weight-gradient product follow (ops.KvAllFn).  Everything else is lotus_crossattn_fwd / _bwd.
+//   saved [n M*C | q M*C | att M*C | lse M*H | mean M | rstd M]
+//   grads [dg C | db C | dwq C*C + dbq C | gq d | bq d | gk d | bk d | dwp C*C + dbp C]
+//   tmp   [dz M*C | datt M*C | dq M*C | dkv_part (G > 1 ? G : 0)*L*2C | dn M*C | ln partials]
+size_t lotus_crossattn_kv_saved_floats(int M, int C, int H) { return 3 * actf((size_t)M * C) + al4((size_t)M * H) + 2 * al4((size_t)M); }
+size_t lotus_crossattn_kv_grads_floats(int C, int H) { return 2 * al4(C) + 2 * al4((size_t)C * C + C) + 4 * al4(C / H); }
+size_t lotus_crossattn_kv_tmp_floats(int M, int C, int L, int G) {
+  return 4 * actf((size_t)M * C) + (G > 1 ? actf((size_t)G * L * 2 * C) : 0) + lotus_layernorm_bwd_workspace(M, C) / sizeof(float);
+}
+size_t lotus_crossattn_kv_ws_main_bytes(int M, int C, int H, int nblocks) {
+  const size_t a = lotus_linear_workspace(M, C, C), c = lotus_attention_bwd_workspace(nblocks, H);
+  return c > a ? c : a;
+}
+size_t lotus_crossattn_kv_ws_side_bytes(int M, int C) { return lotus_linear_wgrad_workspace(M, C, C); }
+
+int lotus_crossattn_kv_fwd(const act_t* x, const act_t* kv, long kv_ld, const float* g, const float* b, const float* wq, const float* bq,
+                           const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp, const float* bp,
+                           act_t* y, float* saved, const int* tiles, int ntiles, int M, int C, int H, float scale, float drop_p,
+                           unsigned long long seed, float attn_p, unsigned long long attn_seed, int precision, int k_max, void* ws,
+                           size_t ws_bytes, void* counters, void* stream) {
+  const int d = C / H;
+  Carve sv(saved);
+  act_t* n = sv.act((size_t)M * C);
+  act_t* q = sv.act((size_t)M * C);
+  act_t* att = sv.act((size_t)M * C);
+  float* lse = sv.f32((size_t)M * H);
+  float* mean = sv.f32(M);
+  float* rstd = sv.f32(M);
+  const bool big = M > 8192;
+  CHECK(lotus_layernorm_fwd(x, nullptr, g, b, n, mean, rstd, M, C, 1e-5f, stream));
+  CHECK(lotus_linear_fwd(n, wq, bq, nullptr, q, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
+                         big ? nullptr : counters, stream));
+  CHECK(lotus_attention_fwd(q, (long)C, 0, kv, kv_ld, 0, C, nullptr, nullptr, nullptr, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse, H,
+                            d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, stream));
+  return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
+                          big ? 0 : ws_bytes, big ? nullptr : counters, stream);
+}
+
+int lotus_crossattn_kv_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, const act_t* kv, long kv_ld, const float* g,
+                           const float* wq, const float* qnw, const float* qnb, const float* knw, const float* knb, const float* wp,
+                           const float* saved, act_t* dx, act_t* dkv, long dkv_ld, act_t* dz_out, float dz_out_p,
+                           unsigned long long dz_out_seed, float* grads, float* tmp, const int* tiles, const int* blocks, int nblocks,
+                           int G, int M, int C, int H, int L, float scale, float drop_p, unsigned long long seed, float attn_p,
+                           unsigned long long attn_seed, int precision, int k_max, void* ws_main, size_t ws_main_bytes, void* ws_side,
+                           size_t ws_side_bytes, void* counters_main, void* counters_side, unsigned long long link, int join,
+                           void* stream, void* side) {
+  const int d = C / H;
+  Carve sv(saved);
+  const act_t* n = sv.act((size_t)M * C);
+  const act_t* q = sv.act((size_t)M * C);
+  const act_t* att = sv.act((size_t)M * C);
+  const float* lse = sv.f32((size_t)M * H);
+  const float* mean = sv.f32(M);
+  const float* rstd = sv.f32(M);
+  float* dg = grads;
+  float* db = dg + al4(C);
+  float* dwq = db + al4(C);
+  float* dbq = dwq + (size_t)C * C;
+  float* gq = dwq + al4((size_t)C * C + C);
+  float* bq_ = gq + al4(d);
+  float* gk = bq_ + al4(d);
+  float* bk_ = gk + al4(d);
+  float* dwp = bk_ + al4(d);
+  float* dbp = dwp + (size_t)C * C;
+  Carve tp(tmp);
+  act_t* dzb = tp.act((size_t)M * C);
+  act_t* datt = tp.act((size_t)M * C);
+  act_t* dq = tp.act((size_t)M * C);
+  act_t* dkv_part = G > 1 ? tp.act((size_t)G * L * 2 * C) : nullptr;
+  act_t* dn = tp.act((size_t)M * C);
+  float* lnp = tp.f32(0);
+  const size_t lnp_bytes = lotus_layernorm_bwd_workspace(M, C);
+  void* sw = side ? side : stream;
+  void* wws = side ? ws_side : ws_main;
+  const size_t wws_bytes = side ? ws_side_bytes : ws_main_bytes;
+  void* wcnt = side ? counters_side : counters_main;
+  const bool big = M > 8192;
+  const act_t* dz = dz_in;
+  if (!dz) {
+    if (drop_p > 0.f) {
+      PRODUCE_THEN_FORK(lotus_dropout(dy, dzb, (long)M * C, drop_p, seed, stream));
+      dz = dzb;
+    } else {
+      dz = dy;
+      CHECK(fork_side(link, stream, side));
+    }
+  }
+  CHECK(lotus_linear_wgrad(dz, att, dwp, dbp, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dz, wp, datt, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  // d q (-> the weight gradient of the q projection on the side stream) and d kv: with one key-side slot the attention
+  // backward writes the block's slice of the shared gradient slab directly, else the slots are summed into it
+  PRODUCE_THEN_FORK(lotus_attention_bwd(q, (long)C, 0, kv, kv_ld, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb,
+                                        att, datt, (long)C, lse, dq, (long)C, 0, G > 1 ? dkv_part : dkv, G > 1 ? 2L * C : dkv_ld, 0, C,
+                                        G > 1 ? (long)L * 2 * C : 0, 0, nullptr, nullptr, 0, nullptr, gq, bq_, gk, bk_, 0, H, d, scale,
+                                        1e-6f, attn_p, attn_seed, precision, k_max, ws_main, ws_main_bytes, stream));
+  if (G > 1) CHECK(lotus_sum_slabs_ld(dkv_part, dkv, L, 2 * C, dkv_ld, (long)L * 2 * C, G, stream));
+  CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
+  CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
+                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
+  if (side) {
+    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
+                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
+    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
+    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
+  } else {
+    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
+                              lnp, lnp_bytes, stream));
+  }
+  return LOTUS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Conditional positional encoding: y = x + LN(Linear(SubMConv3d_3(xs)))   (model.py:615-625, :660-662); xs == x in the
 // encoder, the stale skip branch in the decoder (SURVEY.md Trap 3).
 //   saved [c n*C | l n*C | mean n | rstd n]

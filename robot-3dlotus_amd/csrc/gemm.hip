@@ -631,6 +631,40 @@ extern "C" int lotus_sum_slabs(const act_t* part, act_t* out, long n, long strid
   return LOTUS_OK;
 }
 
+// out[r][c] (row stride out_ld) = sum_z part[z * stride + r * cols + c], z ascending: the key-side partial slots of one
+// cross-attention backward summed straight into that block's column slice of the shared [L][sum 2C] gradient slab
+__global__ __launch_bounds__(256) void sum_slabs_ld_kernel(const act_t* __restrict__ part, act_t* __restrict__ out, int rows, int cols,
+                                                           long out_ld, long stride, int nz) {
+  const int c4 = cols / 4;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows * c4) return;
+  const int r = (int)(i / c4), q = (int)(i % c4);
+  const act_t* src = part + (long)r * cols + 4 * q;
+  float4 s = ld4(src);
+  int z = 1;
+  for (; z + 3 < nz; z += 4) {
+    const float4 v0 = ld4(src + (long)z * stride), v1 = ld4(src + (long)(z + 1) * stride);
+    const float4 v2 = ld4(src + (long)(z + 2) * stride), v3 = ld4(src + (long)(z + 3) * stride);
+    s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x; s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+    s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z; s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+  }
+  for (; z < nz; ++z) {
+    const float4 v = ld4(src + (long)z * stride);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  st4(out + (long)r * out_ld + 4 * q, s);
+}
+
+extern "C" int lotus_sum_slabs_ld(const act_t* part, act_t* out, int rows, int cols, long out_ld, long stride, int nz, void* stream) {
+  LOTUS_CHECK_ARG(part && out && rows >= 0 && cols > 0 && cols % 4 == 0 && out_ld % 4 == 0 && stride % 4 == 0 && nz >= 1,
+                  "lotus_sum_slabs_ld: bad arguments (cols, out_ld and stride must be multiples of 4)");
+  if (rows == 0) return LOTUS_OK;
+  LOTUS_LAUNCH(sum_slabs_ld_kernel, dim3(cdiv((long)rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, part, out, rows, cols,
+               out_ld, stride, nz);
+  LOTUS_LAUNCH_CHECK("lotus_sum_slabs_ld");
+  return LOTUS_OK;
+}
+
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }  // (bf16 rows: 8-byte accesses, same rule)
 
 static int tune_env(const char* name) {
@@ -890,7 +924,10 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
 extern "C" {
 
 // y = dropout(act(x w^T + bias)) + residual ; pre (optional) receives x w^T + bias.
-size_t lotus_splitk_counters_bytes(void) { return (size_t)LOTUS_SPLITK_MAX_TILES * sizeof(unsigned); }
+// the zeroed per-stream counter buffer: one arrival counter per output tile of a fused split-K product, followed by the
+// 64 counters of the fused BatchNorm statistics (norm.hip; lotus_bn_counters_offset() = their byte offset)
+size_t lotus_splitk_counters_bytes(void) { return (size_t)(LOTUS_SPLITK_MAX_TILES + 64) * sizeof(unsigned); }
+size_t lotus_bn_counters_offset(void) { return (size_t)LOTUS_SPLITK_MAX_TILES * sizeof(unsigned); }
 
 size_t lotus_linear_workspace(int M, int N, int K) {
   const int a = fwd_splits(M, N, K, true), b = fwd_splits(M, K, N, true);

@@ -227,6 +227,9 @@ static int ln_geometry_bwd(int C, int* LPR, int* NV) {
 }
 
 // --------------------------------------------------------------------------------- BatchNorm
+#define BN_GS 16         // blocks per group of the fused (last-arrival) statistics reduction
+#define BN_FUSED_MAX_GRID 256
+#define BN_COUNTERS (1 + BN_FUSED_MAX_GRID / BN_GS)
 // Column statistics in double: per-block partial (sum, sumsq) -> fixed-order reduction.
 struct BnStatP {
   const act_t* x;     // [M][C]
@@ -237,6 +240,16 @@ struct BnStatP {
   const float* beta;
   double* part;  // [gridDim.x][2][C]
   int M, C, act;
+  // fused reduction (round 4): with `cnt` the LAST block to arrive sums the per-block partials in block order (fixed order:
+  // deterministic) into sums[2C + 1] = (.., .., M) and — forward, `mean` given — finishes the statistics: mean, 1/std, running
+  // averages.  One launch instead of three (statistics, partial reduction, finalisation).  cnt is left at zero.
+  unsigned* cnt;
+  double* sums;
+  float* out_mean;
+  float* out_invstd;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
 };
 
 __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
@@ -262,12 +275,12 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
       if (!p.dy) {
         // forward statistics: four independent row loads in flight per thread (one load per iteration left the
         // kernel latency-bound at 0.24 TB/s); the accumulation order per thread is unchanged
-        for (; row + 3 * stride < p.M; row += 4 * stride) {
-          float4 xv[4];
+        for (; row + 7 * stride < p.M; row += 8 * stride) {
+          float4 xv[8];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xv[u] = ld4q(p.x + (long)(row + u * stride) * p.C, q);
+          for (int u = 0; u < 8; ++u) xv[u] = ld4q(p.x + (long)(row + u * stride) * p.C, q);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 8; ++u) {
             const float xs[4] = {xv[u].x, xv[u].y, xv[u].z, xv[u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -337,7 +350,77 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
     const int which = c / p.C, col = c % p.C;
     double s = 0;
     for (int r = 0; r < rslots; ++r) s += dred[(long)(r * 2 + which) * p.C + col];
-    p.part[((long)blockIdx.x * 2 + which) * p.C + col] = s;
+    double* dst = p.part + ((long)blockIdx.x * 2 + which) * p.C + col;
+    if (p.cnt) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through: read by another CU below
+    else *dst = s;
+  }
+  if (!p.cnt) return;
+  // ---- two-level last-arrival reduction (hand-off contract: see gemm.hip st_agent4 — write-through stores, L1-bypassing
+  // loads, workgroup fences around device-scope counters).  Blocks form groups of BN_GS consecutive ids: the last block of
+  // a group to arrive sums the group's partial rows in row order into a group row, the last GROUP to finish sums the group
+  // rows in group order — every sum has a fixed order, and no block ever re-reads more than BN_GS rows (one block alone
+  // streams a hand-off at only ~65 GB/s: MI355X_MICROARCH.md, handoff-payload).  cnt[0] counts groups, cnt[1 + g] group g.
+  __shared__ int s_last;
+  const int ncol = 2 * p.C, nb = gridDim.x;
+  const int group = blockIdx.x / BN_GS, ngroups = (nb + BN_GS - 1) / BN_GS;
+  const int gsize = min(BN_GS, nb - group * BN_GS);
+  double* gpart = p.part + (long)nb * ncol;  // [ngroups][2C]
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(p.cnt + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsize - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int c = threadIdx.x; c < ncol; c += 256) {
+    const double* src = p.part + (long)group * BN_GS * ncol + c;
+    double v[BN_GS];
+#pragma unroll
+    for (int u = 0; u < BN_GS; ++u)  // all rows in flight at once (rows past the group re-read its first row, unused)
+      v[u] = __hip_atomic_load(src + (long)(u < gsize ? u : 0) * ncol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    double acc = 0;
+#pragma unroll
+    for (int u = 0; u < BN_GS; ++u) acc += u < gsize ? v[u] : 0.0;
+    __hip_atomic_store(gpart + (long)group * ncol + c, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x == 0) p.cnt[1 + group] = 0;  // ready for the next launch on this stream
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(p.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int c = threadIdx.x; c < ncol; c += 256) {
+    double acc = 0;
+    int g0 = 0;
+    for (; g0 + BN_GS <= ngroups; g0 += BN_GS) {
+      double v[BN_GS];
+#pragma unroll
+      for (int u = 0; u < BN_GS; ++u) v[u] = __hip_atomic_load(gpart + (long)(g0 + u) * ncol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < BN_GS; ++u) acc += v[u];
+    }
+    for (; g0 < ngroups; ++g0) acc += __hip_atomic_load(gpart + (long)g0 * ncol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p.sums[c] = acc;
+  }
+  if (threadIdx.x == 0) {
+    p.sums[ncol] = (double)p.M;
+    *p.cnt = 0;
+  }
+  if (p.out_mean) {  // forward: finish the statistics here (what bn_finalize_kernel does)
+    __syncthreads();  // sums[] written by this block's threads above
+    const double count = (double)p.M;
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+      const double m = p.sums[c] / count;
+      double var = p.sums[p.C + c] / count - m * m;
+      if (var < 0) var = 0;
+      p.out_mean[c] = (float)m;
+      p.out_invstd[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+      if (p.running_mean) {
+        const double unbiased = count > 1 ? var * count / (count - 1) : var;
+        p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)m;
+        p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+      }
+    }
   }
 }
 
@@ -490,7 +573,15 @@ static int bn_grid(int M, int C) {
 static size_t bn_dyn_lds(int C) {
   const int c4 = C / 4;
   const int tpr = c4 < 256 ? c4 : 256;
-  return (size_t)(256 / tpr) * 2 * C * sizeof(double);
+  size_t n = (size_t)(256 / tpr) * 2 * C;
+  if (n < 256) n = 256;  // the fused reduction stages 256 partial sums
+  return n * sizeof(double);
+}
+// grid of the fused statistics kernels: at most BN_FUSED_MAX_GRID blocks (16 groups of 16) — 256 blocks with eight row loads
+// per thread in flight stream a level-0 tensor at HBM rate, and the partial slab + group rows fit the BN workspace
+static int bn_grid_fused(int M, int C) {
+  const int g = bn_grid(M, C);
+  return g > BN_FUSED_MAX_GRID ? BN_FUSED_MAX_GRID : g;
 }
 
 extern "C" {
@@ -577,6 +668,42 @@ int lotus_batchnorm_stats(const act_t* x, double* sums, int M, int C, void* work
   LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), st, p);
   LOTUS_LAUNCH(bn_part_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(256), 0, st, p.part, sums, grid, C, M);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_stats");
+  return LOTUS_OK;
+}
+
+// One-launch forward statistics (no SyncBatchNorm message in between): sums[2C + 1], mean, invstd and the running averages
+// from a single pass over x; `counter` = one zeroed unsigned of the launching stream (left at zero).  Replaces
+// lotus_batchnorm_stats + lotus_batchnorm_finalize (3 launches).
+int lotus_batchnorm_stats_fused(const act_t* x, double* sums, float* mean, float* invstd, float* running_mean, float* running_var,
+                                int M, int C, float eps, float momentum, void* workspace, size_t workspace_bytes, void* counter,
+                                void* stream) {
+  LOTUS_CHECK_ARG(x && sums && mean && invstd && counter && C % 4 == 0 && M > 0, "lotus_batchnorm_stats_fused: bad arguments (C=%d)", C);
+  const int grid = bn_grid_fused(M, C);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)(grid + BN_COUNTERS) * 2 * C * sizeof(double), "lotus_batchnorm_stats_fused: workspace too small");
+  BnStatP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.part = (double*)workspace; p.M = M; p.C = C;
+  p.cnt = (unsigned*)counter; p.sums = sums; p.out_mean = mean; p.out_invstd = invstd;
+  p.running_mean = running_mean; p.running_var = running_var; p.eps = eps; p.momentum = momentum;
+  LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_stats_fused");
+  return LOTUS_OK;
+}
+
+// One-launch backward statistics: sums = (sum dz, sum dz * xhat, M) — lotus_batchnorm_bwd_stats without the second launch.
+int lotus_batchnorm_bwd_stats_fused(const act_t* dy, const act_t* x, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, double* sums, int M, int C, int act, void* workspace, size_t workspace_bytes,
+                                    void* counter, void* stream) {
+  LOTUS_CHECK_ARG(dy && x && sums && counter && C % 4 == 0 && M > 0, "lotus_batchnorm_bwd_stats_fused: bad arguments");
+  const int grid = bn_grid_fused(M, C);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)(grid + BN_COUNTERS) * 2 * C * sizeof(double), "lotus_batchnorm_bwd_stats_fused: workspace too small");
+  BnStatP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.part = (double*)workspace; p.M = M; p.C = C; p.act = act;
+  p.cnt = (unsigned*)counter; p.sums = sums;
+  LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats_fused");
   return LOTUS_OK;
 }
 

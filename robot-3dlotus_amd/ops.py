@@ -614,8 +614,32 @@ def _bn_finish(x, sums, g, b, rmean, rvar, training, act, momentum, eps):
     return y, mean, invstd
 
 
+_BN_FUSED = os.environ.get("LOTUS_BN_FUSED", "1") != "0"
+_BN_CNT_OFF = None
+
+
+def _bn_counter(dev):
+    """The BatchNorm arrival counters of the stream being launched on (tail of the zeroed split-K counter buffer)."""
+    global _BN_CNT_OFF
+    if _BN_CNT_OFF is None:
+        _BN_CNT_OFF = query("lotus_bn_counters_offset")
+    return _counters(dev).data_ptr() + _BN_CNT_OFF
+
+
 def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS):
     sums = None
+    if training and _BN_FUSED and BnState.reduce is None and x.shape[0] > 0:
+        # local batch statistics: statistics, their reduction, mean / invstd and the running averages in ONE launch
+        M, C = x.shape
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        mean = torch.empty(C, dtype=torch.float32, device=x.device)
+        invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+        ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
+        call("lotus_batchnorm_stats_fused", x, sums, mean, invstd, rmean, rvar, M, C, float(eps), float(momentum), ws, ws.numel(),
+             _bn_counter(x.device))
+        y = torch.empty_like(x)
+        call("lotus_batchnorm_apply", x, mean, invstd, g, b, y, M, C, act)
+        return y, mean, invstd
     if training:
         sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
         _bn_stats(x, sums)
@@ -641,7 +665,10 @@ def bn_fwd_pair(xa, pa, xb, pb, training, act, momentum=BN_MOMENTUM, eps=BN_EPS)
 def _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums):
     M, C = x.shape
     ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
-    call("lotus_batchnorm_bwd_stats", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel())
+    if _BN_FUSED and M > 0:
+        call("lotus_batchnorm_bwd_stats_fused", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel(), _bn_counter(x.device))
+    else:
+        call("lotus_batchnorm_bwd_stats", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel())
 
 
 def _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced):
@@ -744,6 +771,11 @@ def _sizes(kind, *dims):
             v = (query("lotus_crossattn_saved_floats", M, C, H, L), query("lotus_crossattn_grads_floats", C, H, Cc),
                  query("lotus_crossattn_tmp_floats", M, C, L, G), query("lotus_crossattn_ws_main_bytes", M, C, H, L, Cc, nblocks),
                  query("lotus_crossattn_ws_side_bytes", M, C, L, Cc))
+        elif kind == "crosskv":
+            M, C, H, L, nblocks, G = dims
+            v = (query("lotus_crossattn_kv_saved_floats", M, C, H), query("lotus_crossattn_kv_grads_floats", C, H),
+                 query("lotus_crossattn_kv_tmp_floats", M, C, L, G), query("lotus_crossattn_kv_ws_main_bytes", M, C, H, nblocks),
+                 query("lotus_crossattn_kv_ws_side_bytes", M, C))
         elif kind == "cpe":
             n, C = dims
             v = (query("lotus_cpe_saved_floats", n, C), query("lotus_cpe_grads_floats", C), query("lotus_cpe_tmp_floats", n, C),
@@ -1094,6 +1126,157 @@ class CrossAttnFn(torch.autograd.Function):
         dn = linear_dgrad(dq, wq)
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
         return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None, None, None, None
+
+
+class KvBank:
+    """The keys / values of every CABlock of one forward pass, projected together.  `kv` [L, sum 2C] holds
+    Linear(ctx -> 2C_b)(context) of block b in columns offs[b] : offs[b] + 2C_b; `dkv` (same shape, allocated by the first
+    backward that needs it) collects d kv of every block, each CrossAttnKvFn.backward writing its own column slice."""
+    __slots__ = ("kv", "dkv", "offs", "widths", "slices")
+
+    def slice(self, b):
+        return self.slices[b]
+
+    def grad_slice(self, b):
+        if self.dkv is None:
+            self.dkv = torch.empty_like(self.kv)
+        return self.dkv[:, self.offs[b]:self.offs[b] + self.widths[b]]
+
+
+class KvAllFn(torch.autograd.Function):
+    """kv_b = Linear(context; W_b, bias_b) for every CABlock b in ONE product (model_ca.py:46-67 evaluates the nine
+    [L, 256] x [256, 2C_b] products one by one, each 3 row tiles tall): context [L, Cc] x cat(W_b) [sum 2C_b, Cc].  The weights
+    stay the modules' own parameters (state_dict layout unchanged); their concatenation is one copy launch per step.
+    Returns the column slices (views of one slab).  Backward: one input-gradient and one weight-gradient product over the
+    shared d kv slab that the CrossAttnKvFn backward passes filled."""
+
+    @_fwd
+    def forward(ctx, context, bank, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        W = torch.cat(ws, 0)
+        bias = torch.cat(bs, 0)
+        kv, _ = linear_fwd(context, W, bias)
+        bank.kv, bank.dkv = kv, None
+        bank.widths = [w.shape[0] for w in ws]
+        bank.offs = [0]
+        for w_ in bank.widths[:-1]:
+            bank.offs.append(bank.offs[-1] + w_)
+        bank.slices = tuple(kv[:, o:o + w_] for o, w_ in zip(bank.offs, bank.widths))
+        ctx.bank = bank
+        ctx.save_for_backward(context, W)
+        return bank.slices
+
+    @_joined
+    def backward(ctx, *gs):
+        context, W = ctx.saved_tensors
+        bank = ctx.bank
+        if bank.dkv is None:
+            bank.dkv = torch.empty_like(bank.kv)
+        dkv = bank.dkv
+        for b, g in enumerate(gs):  # normally every g IS its slice of the slab (written in place by the block's backward)
+            sl = dkv[:, bank.offs[b]:bank.offs[b] + bank.widths[b]]
+            if g is None:
+                sl.zero_()
+            elif g.data_ptr() != sl.data_ptr() or g.stride() != sl.stride():
+                sl.copy_(g)
+        dW, db = linear_wgrad(dkv, context)
+        dctx = linear_dgrad(dkv, W) if ctx.needs_input_grad[0] else None
+        out = [dctx, None]
+        for o, w_ in zip(bank.offs, bank.widths):
+            out += [dW[o:o + w_], db[o:o + w_]]
+        bank.dkv = None
+        return tuple(out)
+
+
+class CrossAttnKvFn(torch.autograd.Function):
+    """CrossAttnFn with the keys / values taken from a KvBank slice (projected once for all blocks by KvAllFn):
+    y = x + drop(proj(CrossAttention(q(LN(x)), kv)))   (model_ca.py:46-101, :135-140)."""
+
+    @_fwd
+    def forward(ctx, x, kv, g, b, wq, bq, qnw, qnb, knw, knb, wp, bp, lvl, H, drop_p, seed, attn_p, hand_in, hand_out, bank, bidx):
+        N, C = x.shape
+        d = C // H
+        ctx.meta = (lvl, H, d, drop_p, seed, attn_p, bank, bidx)
+        ctx.hands = (hand_in, hand_out)
+        if hand_in is not None:
+            hand_in.arm(drop_p, seed)
+        L, kv_ld = kv.shape[0], kv.stride(0)
+        ctx.comp = composites_enabled() and C % 4 == 0
+        if ctx.comp:
+            n_saved, _, _, ws_main, _ = _sizes("crosskv", N, C, H, L, lvl.n_ca_blocks, lvl.ca_groups)
+            saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
+            y = torch.empty_like(x)
+            ws = _ws(ws_main, x.device)
+            _capi.call_raw("lotus_crossattn_kv_fwd", x, kv, kv_ld, g, b, wq, bq, qnw, qnb, knw, knb, wp, bp, y, saved, lvl.ca_tiles,
+                           lvl.n_ca_tiles, N, C, H, float(d ** -0.5), float(drop_p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC,
+                           lvl.ca_kmax, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+            ctx.save_for_backward(x, kv, g, wq, qnw, qnb, knw, knb, wp, saved)
+            return y
+        n, mean, rstd = ln_fwd(x, g, b)
+        q, _ = linear_fwd(n, wq, bq)
+        att = torch.empty(N, C, dtype=x.dtype, device=x.device)
+        lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
+        attention_fwd(q, C, 0, kv, kv_ld, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
+                      att, lse, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
+        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x, kv, g, wq, qnw, qnb, knw, knb, wp, n, q, att, lse, mean, rstd)
+        return y
+
+    @_joined
+    def backward(ctx, dy):
+        lvl, H, d, p, seed, attn_p, bank, bidx = ctx.meta
+        hand_in, hand_out = ctx.hands
+        dy = dy.contiguous()
+        dkv = bank.grad_slice(bidx)
+        if ctx.comp:
+            x, kv, g, wq, qnw, qnb, knw, knb, wp, saved = ctx.saved_tensors
+            N, C = x.shape
+            L, dev, G = kv.shape[0], x.device, lvl.ca_groups
+            _, n_grads, n_tmp, ws_main, ws_side = _sizes("crosskv", N, C, H, L, lvl.n_ca_blocks, G)
+            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x)
+            dz_in = hand_in.take(dy) if hand_in is not None else None
+            dz_out, po, so = None, 0.0, 0
+            if hand_out is not None and hand_out.drop is not None:
+                po, so = hand_out.drop
+                dz_out = torch.empty_like(x)
+                hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
+            side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), N)
+            wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)
+            _capi.call_raw("lotus_crossattn_kv_bwd", dy, dz_in, x, kv, kv.stride(0), g, wq, qnw, qnb, knw, knb, wp, saved, dx, dkv,
+                           dkv.stride(0), dz_out, po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L,
+                           float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, lvl.ca_kmax, wsm, wsm.numel(),
+                           wss, wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
+            d4 = _al4(d)
+            o1 = 2 * _al4(C)
+            o2 = o1 + _al4(C * C + C)
+            o3 = o2 + 4 * d4
+            return (dx, dkv, grads[:C], grads[_al4(C):_al4(C) + C], grads[o1:o1 + C * C].view(C, C), grads[o1 + C * C:o1 + C * C + C],
+                    grads[o2:o2 + d], grads[o2 + d4:o2 + d4 + d], grads[o2 + 2 * d4:o2 + 2 * d4 + d], grads[o2 + 3 * d4:o2 + 3 * d4 + d],
+                    grads[o3:o3 + C * C].view(C, C), grads[o3 + C * C:o3 + C * C + C]) + (None,) * 9
+        x, kv, g, wq, qnw, qnb, knw, knb, wp, n, q, att, lse, mean, rstd = ctx.saved_tensors
+        N, C = x.shape
+        dev = x.device
+        dz = _masked(dy, p, seed, hand_in)
+        dwp, dbp = linear_wgrad(dz, att)
+        datt = linear_dgrad(dz, wp)
+        dq = torch.empty(N, C, dtype=x.dtype, device=dev)
+        G, L = lvl.ca_groups, kv.shape[0]
+        if G > 1:
+            dkv_part = torch.empty(G, L, 2 * C, dtype=x.dtype, device=dev)
+            tgt, tld, tps = dkv_part, 2 * C, L * 2 * C
+        else:
+            tgt, tld, tps = dkv, dkv.stride(0), 0
+        gq, bq_, gk, bk_ = attention_bwd(q, C, 0, kv, kv.stride(0), 0, C, None, None, None, lvl.ca_tiles, lvl.ca_blocks,
+                                         lvl.n_ca_blocks, (qnw, qnb), (knw, knb), att, datt, lse, dq, C, 0, tgt, tld, 0, C, tps, 0, H, d,
+                                         attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
+        if G > 1:
+            call("lotus_sum_slabs_ld", dkv_part, dkv, L, 2 * C, dkv.stride(0), L * 2 * C, G)
+        dwq, dbq = linear_wgrad(dq, n)
+        dn = linear_dgrad(dq, wq)
+        dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
+        return (dx, dkv, dg, db, dwq, dbq, gq, bq_, gk, bk_, dwp, dbp) + (None,) * 9
 
 
 class StemFn(torch.autograd.Function):

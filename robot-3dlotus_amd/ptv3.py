@@ -9,6 +9,8 @@ usual structure — while every forward/backward computation goes through robot_
 Only the configuration family of the published models is built (flash path, qk_norm, no RPE / PDNorm /
 cls_mode); other options raise NotImplementedError rather than silently computing something else.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -101,12 +103,19 @@ class CABlock(nn.Module):
         self.norm2 = nn.Sequential(nn.LayerNorm(c))
         self.mlp = nn.Sequential(_MLP(c, int(c * mlp_ratio)))
 
-    def run(self, x, context, lvl, drop_p, seed, attn_p=0.0, prev_hand=None):
+    def run(self, x, context, lvl, drop_p, seed, attn_p=0.0, prev_hand=None, bank=None, bidx=0):
+        """bank / bidx: the keys / values of this block come from slice `bidx` of an ops.KvBank (all CABlocks projected
+        together at the top of the forward pass) instead of this block's own product over the context."""
         a, n1 = self.attn, self.norm1[0]
         h_attn = ops.Handoff()
-        x = ops.CrossAttnFn.apply(x, context, n1.weight, n1.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
-                                  a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight,
-                                  a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p, h_attn, prev_hand)
+        if bank is not None:
+            x = ops.CrossAttnKvFn.apply(x, bank.slice(bidx), n1.weight, n1.bias, a.q.weight, a.q.bias, a.q_norm.weight,
+                                        a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight, a.proj.bias, lvl,
+                                        self.num_heads, drop_p, seed, attn_p, h_attn, prev_hand, bank, bidx)
+        else:
+            x = ops.CrossAttnFn.apply(x, context, n1.weight, n1.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
+                                      a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias, a.proj.weight,
+                                      a.proj.bias, lvl, self.num_heads, drop_p, seed, attn_p, h_attn, prev_hand)
         m, n2 = self.mlp[0], self.norm2[0]
         # the stage's last MLP: its output may feed several consumers (pooling + decoder skip), no hand-over to it
         return ops.FfnFn.apply(x, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, drop_p,
@@ -209,6 +218,11 @@ class PointTransformerV3CA(nn.Module):
                 dec.add_module(f"ca_block{i}", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
             self.dec.add_module(f"dec{s}", dec)
         self._blocks = [m for m in self.modules() if isinstance(m, Block)]
+        # every CABlock in execution order (module order = encoder stages, then decoder stages as they run): their kv
+        # projections of the shared context are evaluated as one product at the top of forward (ops.KvAllFn)
+        self._cablocks = [m for m in self.modules() if isinstance(m, CABlock)]
+        self._cab_index = {id(m): i for i, m in enumerate(self._cablocks)}
+        self.kv_group = os.environ.get("LOTUS_KV_GROUP", "1") != "0"
         self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
         self._seed_base = None
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
@@ -331,6 +345,13 @@ class PointTransformerV3CA(nn.Module):
         x = ops.StemFn.apply(feat, data_dict.get("stem_weight", st.conv.weight), st.norm.weight, st.norm.bias, st.norm.running_mean,
                              st.norm.running_var, levels[0], training)
         ops.sync_side_stream()  # the packed convolution weights (they overlapped the stem)
+        bank, cidx = None, self._cab_index
+        if self.kv_group and context is not None and len(self._cablocks) > 1:
+            bank = ops.KvBank()
+            wb = []
+            for c in self._cablocks:
+                wb += [c.attn.kv.weight, c.attn.kv.bias]
+            ops.KvAllFn.apply(context, bank, *wb)
         skips = []
         for s in range(self.num_stages):
             enc, lvl = self.enc[s], levels[s]
@@ -345,7 +366,7 @@ class PointTransformerV3CA(nn.Module):
                 si = seed if i == 0 else ops.mix_seed(seed, 16 + i)
                 x, hand = blk.run(x, x, lvl.for_order(i % n_ord), p, si, pa, packs[blk],
                                   self.enc_drop_path[s][i] if training else 0.0)
-                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand)
+                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand, bank, cidx[id(cab)])
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
@@ -356,13 +377,13 @@ class PointTransformerV3CA(nn.Module):
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
                                          us[1].running_mean, us[1].running_var, child, training)
-            for i in range(self.dec_depths[s]):
-                blk, cab = getattr(dec, f"block{i}"), getattr(dec, f"ca_block{i}")
-                si = seed if i == 0 else ops.mix_seed(seed, 16 + i)
+            for j in range(self.dec_depths[s]):
+                blk, cab = getattr(dec, f"block{j}"), getattr(dec, f"ca_block{j}")
+                si = seed if j == 0 else ops.mix_seed(seed, 16 + j)
                 # only the first Block of a decoder stage sees the stale skip branch in its CPE convolution (Trap 3):
                 # every Block / CABlock ends with sparse_conv_feat.replace_feature(feat) (model.py:678, model_ca.py:151)
-                x, hand = blk.run(x, skip if i == 0 else x, lvl.for_order(i % n_ord), p, si, pa, packs[blk],
-                                  self.dec_drop_path[s][i] if training else 0.0)
-                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand)
+                x, hand = blk.run(x, skip if j == 0 else x, lvl.for_order(j % n_ord), p, si, pa, packs[blk],
+                                  self.dec_drop_path[s][j] if training else 0.0)
+                x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand, bank, cidx[id(cab)])
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]

@@ -1,0 +1,165 @@
+"""Round-4 restructuring of the step, each piece against the path it replaces:
+
+* ops.KvAllFn / CrossAttnKvFn — the kv projections of all CABlocks as ONE product over the shared context
+  (/root/reference/genrobo3d/models/PointTransformerV3/model_ca.py:46-67 evaluates one small product per block): composite
+  entry point vs per-launch host path bit-identical, whole model vs the per-block projection path to fp32 summation noise;
+* the one-launch BatchNorm statistics (last-arrival reduction, csrc/norm.hip) vs the three-launch path and vs float64."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import golden_util as gu  # noqa: E402
+
+
+def _ops():
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("M,C", [(65536, 64), (65536, 128), (23894, 128), (6077, 256), (1450, 512), (361, 768), (37, 768), (5, 64)])
+def test_batchnorm_fused_statistics_match_three_launch_path_and_float64(M, C):
+    ops = _ops()
+    F = torch.nn.functional
+    g = torch.Generator(device="cuda").manual_seed(M + C)
+    x = torch.randn(M, C, device="cuda", generator=g) * 1.3 + 0.4
+    dy = torch.randn(M, C, device="cuda", generator=g)
+    gam, bet = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g)
+
+    def run(fused):
+        prev, ops._BN_FUSED = ops._BN_FUSED, fused
+        try:
+            rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+            y, mu, istd = ops.bn_fwd(x, gam, bet, rm, rv, True, ops.ACT_GELU)
+            dx, dg, db = ops.bn_bwd(dy, x, mu, istd, gam, bet, True, ops.ACT_GELU)
+            torch.cuda.synchronize()
+            return [y, mu, istd, rm, rv, dx, dg, db]
+        finally:
+            ops._BN_FUSED = prev
+
+    a, b, b2 = run(False), run(True), run(True)
+    for i, (u, v, w) in enumerate(zip(a, b, b2)):
+        assert torch.equal(v, w), f"fused path not reproducible (output {i})"   # counters reset, fixed summation order
+        scale = float(u.abs().max()) + 1e-12
+        assert float((u - v).abs().max()) <= 2e-6 * scale, (i, float((u - v).abs().max()), scale)
+    if M > 1:
+        xd = x.double().requires_grad_(True)
+        gd, bd = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+        ref = F.gelu(F.batch_norm(xd, None, None, gd, bd, True, 0.0, 1e-3))
+        ref.backward(dy.double())
+        for name, got, want, tol in (("y", b[0], ref.detach(), 5e-6), ("dx", b[5], xd.grad, 3e-5), ("dgamma", b[6], gd.grad, 3e-5),
+                                     ("dbeta", b[7], bd.grad, 3e-5)):
+            err = float((got.double() - want).abs().max()) / (float(want.abs().max()) + 1e-12)
+            assert err <= tol, (name, err)
+        assert float((b[3].double() - 0.01 * x.double().mean(0)).abs().max()) <= 1e-6   # running mean, momentum 0.01
+
+
+def _levels():
+    from robot_3dlotus_amd import synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    batch = synth.synth_batch(3, 1500, ragged=True, seed=11)
+    lv = FrontEnd(2).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], [[0, 1, 2, 3]] * 2)
+    return batch, lv
+
+
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("C,H", [(64, 2), (256, 8)])
+def test_crossattn_kv_composite_is_bit_identical_and_matches_own_projection(C, H, join):
+    """CrossAttnKvFn (kv from a KvBank of three differently sized 'blocks') — composite C call vs per-launch host path bit for
+    bit, both weight-gradient join modes, dropout and hand-overs on; and the same numbers as CrossAttnFn computing its own
+    projection of the context (identical kernels, the kv product only tiled over a wider output)."""
+    ops = _ops()
+    batch, lv = _levels()
+    lvl, d, Cc = lv[0], C // H, 256
+    L = sum(batch["txt_lens"])
+    widths = [2 * 128, 2 * C, 2 * 64]   # the middle slice belongs to the block under test
+
+    def tensors():
+        g = torch.Generator().manual_seed(C + 1)
+        x = torch.randn(lvl.n, C, generator=g).cuda().requires_grad_(True)
+        ctxt = torch.randn(L, Cc, generator=g).cuda().requires_grad_(True)
+        mk = lambda *s: (torch.randn(*s, generator=g) * (0.1 if len(s) == 1 else 1.0 / s[-1] ** 0.5)).cuda().requires_grad_(True)  # noqa: E731
+        ps = [mk(C), mk(C), mk(C, C), mk(C), mk(d), mk(d), mk(d), mk(d), mk(C, C), mk(C)]
+        kvw = [(mk(w, Cc), mk(w)) for w in widths]
+        dy = torch.randn(lvl.n, C, generator=g).cuda()
+        return x, ctxt, ps, kvw, dy
+
+    def run_bank(composite):
+        ops.set_composites(composite)
+        x, ctxt, ps, kvw, dy = tensors()
+        bank = ops.KvBank()
+        sl = ops.KvAllFn.apply(ctxt, bank, *[t for pair in kvw for t in pair])
+        h_in, h_out = ops.Handoff(), ops.Handoff()
+        h_out.arm(0.1, 99)
+        y = ops.CrossAttnKvFn.apply(x, sl[1], *ps, lvl, H, 0.1, 777, 0.1, h_in, h_out, bank, 1)
+        # the other two slices get a gradient too (as the other blocks' backward passes would write them)
+        loss = (y * dy).sum() + (sl[0] * 0.5).sum() + (sl[2] * -0.25).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), x.grad.clone(), ctxt.grad.clone()] + [p.grad.clone() for p in ps] + \
+               [t.grad.clone() for pair in kvw for t in pair] + [h_out.dz.clone()]
+
+    def run_own():
+        ops.set_composites(True)
+        x, ctxt, ps, kvw, dy = tensors()
+        h_in, h_out = ops.Handoff(), ops.Handoff()
+        h_out.arm(0.1, 99)
+        wkv, bkv = kvw[1]
+        y = ops.CrossAttnFn.apply(x, ctxt, ps[0], ps[1], ps[2], ps[3], wkv, bkv, *ps[4:], lvl, H, 0.1, 777, 0.1, h_in, h_out)
+        (y * dy).sum().backward()
+        torch.cuda.synchronize()
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in ps] + [wkv.grad.clone(), bkv.grad.clone()]
+
+    try:
+        ops.set_wgrad_join(join)
+        ref, got, own = run_bank(False), run_bank(True), run_own()
+    finally:
+        ops.set_composites(True)
+        ops.set_wgrad_join("node")
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+    # vs the block's own projection: forward output and d x, the block's parameters, and the kv weight / bias of slice 1
+    mine = [got[0], got[1]] + got[3:13] + [got[13 + 2], got[13 + 3]]
+    for i, (a, b) in enumerate(zip(mine, own)):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-6 * scale, (i, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("preset,n", [("tiny", 700), ("v1", 900)])
+def test_model_with_grouped_kv_matches_per_block_projections(preset, n):
+    """The whole policy, train mode with dropout ON (same seeds on both paths): kv projected once for all CABlocks vs every
+    block projecting the context itself — logits, losses and every gradient agree to fp32 summation noise (the context
+    gradient is one sum over all blocks' columns instead of a sum of per-block results)."""
+    from robot_3dlotus_amd import config as lcfg, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset(preset)
+    sd = seeded_state_dict(gu.state_template(cfg), 7, "scaled")
+    batch = synth.synth_batch(3, n, ragged=True, seed=5)
+    perms = [[1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 0, 2, 3]][:len(cfg.ptv3_config.enc_channels)]
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v))
+           for k, v in batch.items()}
+    res = []
+    for group in (False, True):
+        torch.manual_seed(3)
+        m = SimplePolicyPTV3CA(cfg)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        m.ptv3_model.kv_group = group
+        m.ptv3_model.order_perms = perms
+        _, losses = m(dict(dev), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        torch.cuda.synchronize()
+        res.append((m.last_pred[0].detach().clone(), {k: v.detach().clone() for k, v in losses.items()},
+                    {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (xa, la, ga), (xb, lb, gb) = res
+    assert float((xa - xb).abs().max()) <= 2e-6 * max(1.0, float(xa.abs().max()))
+    for k in la:
+        assert abs(la[k].item() - lb[k].item()) <= 2e-6 * max(1.0, abs(la[k].item())), k
+    gmax = max(float(v.norm()) for v in ga.values())
+    worst = max((float((ga[k] - gb[k]).norm()) / (float(ga[k].norm()) + 1e-3 * gmax), k) for k in ga)
+    assert worst[0] <= 1e-5, worst
