@@ -31,6 +31,29 @@ import torch.distributed as dist  # noqa: E402
 
 GFLOP_PER_SAMPLE = 60.5  # fwd+bwd algorithmic work per key-step sample, v1 @ 4096 pts
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (AMD's 5 PF headline includes 2:1 sparsity)
+HBM_PEAK_GBPS = 8000.0
+
+
+def side_workload(extra, timeout_s=300):
+    """Run this script again for another workload of BASELINE.json (configs[3] motion planner, configs[4] PerAct bf16) and
+    return the essentials of its JSON line: side measurements printed next to the headline, never as `value`."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "6", "--no-cpu-baseline", "--no-fresh-batches",
+           "--no-other-modes", "--no-side-workloads"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        o = json.loads(line)
+        keep = {"value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "dtype": o["dtype"], "workload": o["config"]["workload"]}
+        if "roofline" in o:
+            keep["roofline"] = {k: o["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "launches_per_step", "ms_per_step")
+                                if k in o["roofline"]}
+        return keep
+    except Exception as e:  # noqa: BLE001  (a side measurement must never take the headline down)
+        return {"value": None, "error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
 def dev_batch(batch, dev):
@@ -197,6 +220,8 @@ def main():
                     help="operand precision of the dense fwd/dgrad products: fp32 = exact fp32 MFMA (default, the parity mode "
                          "the headline is quoted in); bf16x3 / bf16 are the opt-in faster modes (DESIGN.md 4)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the bf16x3 / bf16 side measurement")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="skip the side measurements of the other BASELINE workloads (PerAct bf16 at 16 / 64 clouds, motion planner)")
     ap.add_argument("--gemm-report", default=None, help="write per-shape GEMM timings (diagnostic) to this file")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -244,6 +269,8 @@ def main():
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1" or dist.is_initialized():  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
         parallel.enable_sync_batchnorm()
+    if reducer is not None:
+        reducer.time_exposed = True
     host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, ragged=args.ragged, seed=rank)
     if peract:  # aug_max_rot 45 + jitter (job_scripts/train_3dlotus_policy_peract.sh:42): 1-7 % duplicate voxels
         host_batch = synth.augment_clouds(host_batch, seed=rank, max_rot_deg=45.0)
@@ -293,6 +320,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     bn_msgs0 = parallel.BN_MESSAGES
+    if reducer is not None:
+        reducer.exposed_comm_ms()  # drop the warm-up samples
     t0 = time.perf_counter()
     for _ in range(args.steps):
         losses = step()
@@ -302,6 +331,28 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     bn_msgs = parallel.BN_MESSAGES - bn_msgs0
+    # per-rank communication figures (outside the timed region): GPU time the backward stream waited in finish() per step,
+    # GPU time of the SyncBN statistics messages of one extra step, and the point counts the ranks hold
+    comm_stats = None
+    if reducer is not None:
+        exposed = reducer.exposed_comm_ms()
+        parallel.BN_TIMING = []
+        step()
+        torch.cuda.synchronize()
+        bn_ms = sum(a.elapsed_time(b) for a, b in parallel.BN_TIMING)
+        parallel.BN_TIMING = None
+        mine = torch.tensor([exposed or 0.0, bn_ms, float(sum(host_batch["npoints_in_batch"]))], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        pts = [float(t[2]) for t in allr]
+        comm_stats = {"exposed_comm_ms_per_rank": [round(float(t[0]), 3) for t in allr],
+                      "syncbn_ms_per_rank": [round(float(t[1]), 3) for t in allr],
+                      "points_per_rank": [int(x) for x in pts], "point_imbalance_max_over_mean": round(max(pts) / (sum(pts) / len(pts)), 4),
+                      "note": "exposed = GPU time per step between the end of backward and the last bucket's all-reduce "
+                              "(HIP events in GradReducer.finish); syncbn = summed GPU time of the fp64 statistics messages of one step"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -459,6 +510,7 @@ def main():
             out["config"]["workload"] += f"; RAGGED clouds n ~ U({args.npoints // 2}, {args.npoints}) ({sum(host_batch['npoints_in_batch'])} points on rank 0)"
         if reducer is not None:
             sizes = [(hi_ - lo_) * 4 / 2 ** 20 for lo_, hi_ in reducer.buckets]
+            out["comm"] = comm_stats
             out["reducer"] = {"buckets": len(sizes), "bucket_mb": [round(x, 1) for x in sizes], "last_bucket_mb": round(sizes[-1], 1),
                               "gradient_mb": round(sum(sizes), 1), "syncbn_messages_per_step": f"{bn_msgs / max(1, args.steps):.0f} (counted; one fp64 message per BN layer or merged pair and direction, own communicator)",
                               "points_rank0": int(sum(host_batch["npoints_in_batch"]))}
@@ -481,7 +533,31 @@ def main():
             out["dtype"] = f"f32 storage/accumulate, {args.gemm_precision} GEMM + conv operands"
         if opt is not None:
             out["config"]["workload"] += " + lr schedule + clip_grad_norm_(10) + fused AdamW step"
-        if not args.no_roofline:
+        if not args.no_roofline and peract:
+            # BASELINE configs[4]: the dense family in bf16.  Algorithmic bytes of a launch = its operands once in their
+            # storage types (activations 2 B with bf16 storage; weights 2 B when the layers read bf16 shadows, else the
+            # 4-byte masters; weight gradients 4 B); bound = whichever of sum(bytes / 8 TB/s), sum(flops / 2.5 PF) is larger
+            ab = 2.0 if args.act_storage == "bf16" else 4.0
+            wb = 2.0 if (args.act_storage == "bf16" and getattr(model, "weight_shadows", False)) else 4.0
+            in_ms = sum(e0.elapsed_time(e1) for *_, e0, e1 in events)
+            in_flop = sum(2.0 * M * N * K for _, M, N, K, _, _ in events)
+            in_bytes = sum((ab * (M * K + M * N) + 4.0 * N * K) if kind == "wgrad" else (ab * (M * K + M * N) + wb * N * K)
+                           for kind, M, N, K, _, _ in events)
+            t_hbm, t_mfma = in_bytes / (HBM_PEAK_GBPS * 1e9), in_flop / (MFMA_BF16_PEAK_TFLOPS * 1e12)
+            if t_hbm >= t_mfma:
+                ach = in_bytes / (in_ms * 1e-3) / 1e9
+                out["roofline"] = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                   "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None}
+            else:
+                ach = in_flop / (in_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None}
+            out["roofline"].update(kernel="gemm_kernel (dense bf16-MFMA linear fwd/dgrad/wgrad, bf16 storage)", launches_per_step=len(events),
+                                   ms_per_step=round(in_ms, 3), gflop_per_step=round(in_flop / 1e9, 1),
+                                   algorithmic_mb_per_step=round(in_bytes / 1e6, 1), tflops=round(in_flop / (in_ms * 1e-3) / 1e12, 2),
+                                   hbm_bound_ms=round(t_hbm * 1e3, 3), mfma_bound_ms=round(t_mfma * 1e3, 3),
+                                   measured="HIP events around every dense launch of one training step, on the stream it runs on")
+        elif not args.no_roofline:
             rep = [] if args.gemm_report else None
             flop, gms, nl = gemm_roofline(ops, calls, dev, report=rep)
             if rep is not None:
@@ -551,8 +627,23 @@ def main():
                                "isolated": {"achieved": round(ach_iso, 2), "frac": round(ach_iso / MFMA_F32_PEAK_TFLOPS, 4),
                                             "ms_per_step": round(gms, 3),
                                             "note": "same launches replayed one shape at a time on an otherwise idle GPU"}}
-        if not args.no_roofline and evidence is not None:
+        if not args.no_roofline and not peract and evidence is not None:
             out["counters"] = evidence
+        try:
+            import hashlib
+            from robot_3dlotus_amd import _capi as _lc2
+            out["library_sha256_16"] = hashlib.sha256(open(_lc2.LIB_PATH, "rb").read()).hexdigest()[:16]
+        except OSError:
+            pass
+        if world == 1 and not (mp or peract) and not args.no_side_workloads and not args.no_other_modes and args.gemm_precision == "fp32":
+            # the other workloads BASELINE.json names, each in a fresh process after the headline: configs[4] (PerAct: bf16
+            # activation + weight storage, fp32 masters) at 16 and 64 clouds per GPU, configs[3] (3D-LOTUS++ motion planner)
+            torch.cuda.synchronize()
+            out["other_workloads"] = {
+                "peract_bf16_16_clouds": side_workload(["--workload", "peract"]),
+                "peract_bf16_64_clouds": side_workload(["--workload", "peract", "--batch", "64", "--steps", "12", "--warmup", "5"]),
+                "motion_planner_16_clouds": side_workload(["--workload", "mp", "--no-roofline"]),
+                "note": "side measurements (same step structure, same script, own process): never the headline value"}
         if not args.no_cpu_baseline and world == 1:  # a reported baseline of the N = 1 line only (the other ranks would idle in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         final_line = json.dumps(out)

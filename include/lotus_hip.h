@@ -55,7 +55,10 @@ int lotus_streamlink_destroy(unsigned long long link);
  * (no process-wide state: two models with different precisions can share a process).  0 = fp32 MFMA, exact products
  * (the 1e-4 logit parity mode); 1 = bf16 operands, fp32 accumulate (the bf16 compute mode of BASELINE configs[4]);
  * 3 = bf16x3 split products (a = hi + lo; hi*hi + hi*lo + lo*hi).  Packed convolution weights must be used with the
- * precision they were packed for. */
+ * precision they were packed for.  In the bf16-storage twins (lotus_hip_b16.h) lotus_b16_linear_fwd / _dgrad and the
+ * composite entry points additionally accept 5 = bf16 products whose weight pointers address bf16 SHADOWS of the fp32
+ * master weights (half the weight bytes per block, nothing converted while staging); attention / convolution entry points
+ * reached through a composite see 1. */
 
 /* ---- front end (integer, bit-exact) ------------------------------------------------------- */
 /* Point.serialization grid step, PointTransformerV3/model.py:96-98: grid = int32(trunc((coord -
@@ -309,6 +312,24 @@ int lotus_cpe_bwd(const lotus_act_t* dy, const lotus_act_t* xs, const float* cw,
                   const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
                   size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                   unsigned long long link, int join, void* stream, void* side);
+/* One (Block, CABlock) pair of a stage per call (round 4): cpe -> self-attention -> mlp -> cross-attention (kv from the
+ * shared slab) -> mlp, model_ca.py:270-310, forward or backward, with the hand-overs of the pre-masked gradients wired
+ * inside — exactly the launches of the five composite calls above, bit-identical results, one host transition.  Arguments
+ * travel in three HOST arrays: P = device pointers (enum PairPtr in csrc/blocks.cpp, lotus_pair_nptr() entries), I =
+ * integers incl. seeds, strides and byte sizes (enum PairInt, lotus_pair_nint()), F = {drop_p, attn_p, scale}.
+ *   acts  [x1 | x2 | x3 | x4]           (outputs of the first four sub-blocks, kept for backward)
+ *   saved / grads / tmp = the five composites' buffers back to back (cpe, self, mlp, cross_kv, mlp; tmp + 4 M*C) */
+size_t lotus_pair_acts_floats(int M, int C);
+size_t lotus_pair_saved_floats(int M, int C, int H, int Hd, int npad);
+size_t lotus_pair_grads_floats(int C, int H, int Hd);
+size_t lotus_pair_tmp_floats(int M, int C, int Hd, int n_extra, int L, int G);
+size_t lotus_pair_ws_main_bytes(int M, int C, int H, int Hd, int nblocks_self, int nblocks_ca);
+size_t lotus_pair_ws_side_bytes(int M, int C, int Hd);
+size_t lotus_pair_ws_conv_bytes(int M, int C);
+int lotus_pair_nptr(void);
+int lotus_pair_nint(void);
+int lotus_pair_fwd(const void* const* P, const long long* I, const double* F);
+int lotus_pair_bwd(const void* const* P, const long long* I, const double* F);
 /* out[e] = sum_z part[z * stride + e] in fixed order (e.g. the key-side partial slots of the cross-attention backward) */
 int lotus_sum_slabs(const lotus_act_t* part, lotus_act_t* out, long n, long stride, int nz, void* stream);
 /* out[r][c] (row stride out_ld) = sum_z part[z * stride + r * cols + c]: the same sum written into a column slice of a wider slab */
@@ -414,9 +435,14 @@ int lotus_pos_decode_max(const lotus_act_t* xt, const float* pc, long ld, const 
 int lotus_mt_chunk(void);
 int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, int nchunks, double* partial, float* norm_out,
                     float max_norm, void* stream);
+/* shadow_ptrs (optional, device array [T] of bf16 pointers, null entries allowed): the updated parameter is also stored
+ * rounded to bf16 — the weight operand of the bf16-storage products (`precision` 5 of lotus_b16_linear_fwd / _dgrad),
+ * refreshed by the very step that changes the fp32 master (BASELINE configs[4]: bf16 weights, fp32 master weights). */
 int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const long* numel,
-                     const float* step_size, const float* decay, const int* chunks, int nchunks, float beta1, float beta2,
-                     float eps, const float* clip_coef, void* stream);
+                     const float* step_size, const float* decay, const int* chunks, int nchunks, double beta1, double beta2,
+                     double eps, const float* clip_coef, const void* shadow_ptrs, void* stream);
+/* dst[t][i] = bf16(src[t][i]): creation / refresh of the weight shadows outside an optimiser step (same tables as above) */
+int lotus_shadow_cast(const void* src_ptrs, const void* dst_ptrs, const long* numel, const int* chunks, int nchunks, void* stream);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,10 @@ struct Carve {
   float* f32(size_t n) { float* r = (float*)p; p += al4(n) * 4; return r; }
 };
 
+// precision 5 = bf16 products with the LINEAR layers' weights given as bf16 shadows (bf16-storage build, gemm.hip); the
+// attention and convolution entry points have no such operand and take the plain code
+static inline int noshadow(int precision) { return precision == 5 ? 1 : precision; }
+
 static inline int fork_side(unsigned long long link, void* main_s, void* side) {
   return side ? lotus_streamlink_wait(link, main_s, side) : 0;
 }
@@ -213,7 +217,7 @@ int lotus_selfattn_fwd(const act_t* x, const float* g, const float* b, const flo
   CHECK(lotus_linear_fwd(n, wqkv, bqkv, nullptr, qkv, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws,
                          big ? 0 : ws_bytes, big ? nullptr : counters, stream));
   CHECK(lotus_attention_fwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse,
-                            H, d, scale, 1e-6f, attn_p, attn_seed, precision, 0, stream));
+                            H, d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), 0, stream));
   return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
@@ -273,7 +277,7 @@ int lotus_selfattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, cons
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   PRODUCE_THEN_FORK(lotus_attention_bwd(qkv, 3L * C, 0, qkv, 3L * C, C, 2 * C, gidx, gidx, owner, tiles, blocks, nblocks, qnw, qnb, knw, knb,
                                         att, datt, (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra,
-                                        gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, 0, ws_main, ws_main_bytes, stream));
+                                        gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), 0, ws_main, ws_main_bytes, stream));
   CHECK(lotus_linear_wgrad(dqkv, n, dwqkv, dbqkv, M, 3 * C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dqkv, wqkv, dn, nullptr, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                            big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
@@ -332,7 +336,7 @@ int lotus_crossattn_fwd(const act_t* x, const act_t* context, const float* g, co
   CHECK(lotus_linear_fwd(context, wkv, bkv, nullptr, kv, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws,
                          bigL ? 0 : ws_bytes, bigL ? nullptr : counters, stream));
   CHECK(lotus_attention_fwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse, H,
-                            d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, stream));
+                            d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), k_max, stream));
   return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
@@ -401,7 +405,7 @@ int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, con
     if (G > 1) lotus_tls_stop_event = nullptr;
     CHECK(lotus_attention_bwd(q, (long)C, 0, kv, 2L * C, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb, att,
                               datt, (long)C, lse, dq, (long)C, 0, dkv_part, 2L * C, 0, C, (long)L * 2 * C, 0, nullptr, nullptr, 0, nullptr, gq,
-                              bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, ws_main, ws_main_bytes, stream));
+                              bq_, gk, bk_, 0, H, d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), k_max, ws_main, ws_main_bytes, stream));
     if (G > 1) {  // fixed-order sum of the key-side partial slots
       lotus_tls_stop_event = fa.ev;
       CHECK(lotus_sum_slabs(dkv_part, dkv, (long)L * 2 * C, (long)L * 2 * C, G, stream));
@@ -466,7 +470,7 @@ int lotus_crossattn_kv_fwd(const act_t* x, const act_t* kv, long kv_ld, const fl
   CHECK(lotus_linear_fwd(n, wq, bq, nullptr, q, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
                          big ? nullptr : counters, stream));
   CHECK(lotus_attention_fwd(q, (long)C, 0, kv, kv_ld, 0, C, nullptr, nullptr, nullptr, tiles, ntiles, qnw, qnb, knw, knb, att, (long)C, lse, H,
-                            d, scale, 1e-6f, attn_p, attn_seed, precision, k_max, stream));
+                            d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), k_max, stream));
   return lotus_linear_fwd(att, wp, bp, x, y, nullptr, M, C, C, LOTUS_ACT_NONE, drop_p, seed, precision, big ? nullptr : ws,
                           big ? 0 : ws_bytes, big ? nullptr : counters, stream);
 }
@@ -528,7 +532,7 @@ int lotus_crossattn_kv_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, 
   PRODUCE_THEN_FORK(lotus_attention_bwd(q, (long)C, 0, kv, kv_ld, 0, C, nullptr, nullptr, nullptr, tiles, blocks, nblocks, qnw, qnb, knw, knb,
                                         att, datt, (long)C, lse, dq, (long)C, 0, G > 1 ? dkv_part : dkv, G > 1 ? 2L * C : dkv_ld, 0, C,
                                         G > 1 ? (long)L * 2 * C : 0, 0, nullptr, nullptr, 0, nullptr, gq, bq_, gk, bk_, 0, H, d, scale,
-                                        1e-6f, attn_p, attn_seed, precision, k_max, ws_main, ws_main_bytes, stream));
+                                        1e-6f, attn_p, attn_seed, noshadow(precision), k_max, ws_main, ws_main_bytes, stream));
   if (G > 1) CHECK(lotus_sum_slabs_ld(dkv_part, dkv, L, 2 * C, dkv_ld, (long)L * 2 * C, G, stream));
   CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
@@ -570,7 +574,7 @@ int lotus_cpe_fwd(const act_t* x, const act_t* xs, const float* cw, const float*
   float* mean = sv.f32(n);
   float* rstd = sv.f32(n);
   const bool big = n > 8192;
-  CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, precision, ws_conv, ws_conv_bytes, stream));
+  CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, noshadow(precision), ws_conv, ws_conv_bytes, stream));
   CHECK(lotus_linear_fwd(c, lw, lb, nullptr, l, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
                          big ? nullptr : counters, stream));
   return lotus_layernorm_fwd(l, x, g, b, y, mean, rstd, n, C, 1e-5f, stream);
@@ -614,17 +618,199 @@ int lotus_cpe_bwd(const act_t* dy, const act_t* xs, const float* cw, const float
   CHECK(lotus_linear_wgrad(dl, c, dlw, dlb, n, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
   PRODUCE_THEN_FORK(lotus_linear_dgrad(dl, lw, dc, nullptr, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
                                        big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, precision, wws, wws_bytes, sw));
+  CHECK(lotus_subm_conv_wgrad(dc, xs, dcw, dcb, nbr27, n, 27, C, C, 0, noshadow(precision), wws, wws_bytes, sw));
   const act_t* dsrc = dc;
   if (n_dup != 0) {
     CHECK(lotus_conv_dup_fold(dc, code0, order0, n, C, dyr, stream));
     dsrc = dyr;
   }
-  CHECK(lotus_subm_conv(1, dsrc, cw, cw_packed, nullptr, add_dy ? dy : nullptr, dx_conv, nbr27, order0, n, 27, C, C, precision, ws_conv,
+  CHECK(lotus_subm_conv(1, dsrc, cw, cw_packed, nullptr, add_dy ? dy : nullptr, dx_conv, nbr27, order0, n, 27, C, C, noshadow(precision), ws_conv,
                         ws_conv_bytes, stream));
   if (n_dup != 0) CHECK(lotus_conv_dup_mask(dx_conv, add_dy ? dy : nullptr, nbr27 + (size_t)13 * n, n, C, stream));
   if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
   return LOTUS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// One (Block, CABlock) pair per call (round 4): the five sub-blocks above chained on the host side of the C-ABI —
+//   x1 = cpe(x, xs);  x2 = selfattn(x1);  x3 = ffn(x2);  x4 = crossattn_kv(x3, kv);  y = ffn(x4)
+// (model_ca.py:270-310: Block i then CABlock i of a stage) — with the backward-pass hand-overs of the pre-masked
+// gradients (ops.Handoff) wired inside.  Exactly the launches of the five composite calls in the same order on the same
+// streams, so results are bit-identical to issuing them one by one (tests/test_gpu_round4.py); what it saves is host time:
+// one Python -> C transition, one autograd node and one set of allocations per direction instead of five.
+// Arguments travel as three host arrays (indices below): device pointers P, integers I, floating-point scalars F.
+enum PairPtr {
+  PP_X, PP_XS, PP_KV, PP_Y, PP_ACTS, PP_SAVED, PP_CW, PP_CWP, PP_CB, PP_LW, PP_LB, PP_G0, PP_B0,            // cpe
+  PP_G1, PP_B1, PP_WQKV, PP_BQKV, PP_QNW, PP_QNB, PP_KNW, PP_KNB, PP_WP, PP_BP,                             // self-attention
+  PP_G2, PP_B2, PP_W1, PP_B1F, PP_W2, PP_B2F,                                                               // mlp of the Block
+  PP_G3, PP_B3, PP_WQ, PP_BQ, PP_CQNW, PP_CQNB, PP_CKNW, PP_CKNB, PP_CWP2, PP_CBP2,                         // cross-attention
+  PP_G4, PP_B4, PP_W3, PP_B3F, PP_W4, PP_B4F,                                                               // mlp of the CABlock
+  PP_NBR27, PP_ORDER0, PP_CODE0, PP_GIDX, PP_OWNER, PP_STILES, PP_SBLOCKS, PP_KEXT, PP_EXTPOS, PP_CATILES, PP_CABLOCKS,
+  PP_WS_MAIN, PP_WS_SIDE, PP_WS_CONV, PP_CNT_MAIN, PP_CNT_SIDE, PP_STREAM, PP_SIDE,
+  PP_DY, PP_DX, PP_DXS, PP_DKV, PP_GRADS, PP_TMP,                                                           // backward only
+  PP_COUNT
+};
+enum PairInt {
+  PI_M, PI_C, PI_H, PI_HD, PI_NPAD, PI_NSTILES, PI_NEXTRA, PI_L, PI_NCATILES, PI_NCABLOCKS, PI_G, PI_KMAX, PI_NDUP, PI_SAME,
+  PI_PREC, PI_KV_LD, PI_DKV_LD, PI_WS_MAIN, PI_WS_SIDE, PI_WS_CONV, PI_LINK, PI_SEED_SELF, PI_SEED_FFN1, PI_SEED_CROSS, PI_SEED_FFN2,
+  PI_COUNT
+};
+enum PairFlt { PF_DROP, PF_ATTN, PF_SCALE, PF_COUNT };
+
+static inline unsigned long long pair_mix(unsigned long long seed, unsigned long long k) {  // == ops.mix_seed (splitmix64 finaliser)
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (k + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+size_t lotus_pair_acts_floats(int M, int C) { return 4 * actf((size_t)M * C); }
+size_t lotus_pair_saved_floats(int M, int C, int H, int Hd, int npad) {
+  return lotus_cpe_saved_floats(M, C) + lotus_selfattn_saved_floats(M, C, H, npad) + 2 * lotus_ffn_saved_floats(M, C, Hd) +
+         lotus_crossattn_kv_saved_floats(M, C, H);
+}
+size_t lotus_pair_grads_floats(int C, int H, int Hd) {
+  return lotus_cpe_grads_floats(C) + lotus_selfattn_grads_floats(C, H) + 2 * lotus_ffn_grads_floats(C, Hd) + lotus_crossattn_kv_grads_floats(C, H);
+}
+size_t lotus_pair_tmp_floats(int M, int C, int Hd, int n_extra, int L, int G) {
+  return lotus_cpe_tmp_floats(M, C) + lotus_selfattn_tmp_floats(M, C, n_extra) + 2 * lotus_ffn_tmp_floats(M, C, Hd) +
+         lotus_crossattn_kv_tmp_floats(M, C, L, G) + 4 * actf((size_t)M * C);
+}
+static inline size_t max3(size_t a, size_t b, size_t c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+size_t lotus_pair_ws_main_bytes(int M, int C, int H, int Hd, int nblocks_self, int nblocks_ca) {
+  return max3(max3(lotus_cpe_ws_main_bytes(M, C), lotus_selfattn_ws_main_bytes(M, C, H, nblocks_self), lotus_ffn_ws_main_bytes(M, C, Hd)),
+              lotus_crossattn_kv_ws_main_bytes(M, C, H, nblocks_ca), 0);
+}
+size_t lotus_pair_ws_side_bytes(int M, int C, int Hd) {
+  return max3(max3(lotus_cpe_ws_side_bytes(M, C), lotus_selfattn_ws_side_bytes(M, C), lotus_ffn_ws_side_bytes(M, C, Hd)),
+              lotus_crossattn_kv_ws_side_bytes(M, C), 0);
+}
+size_t lotus_pair_ws_conv_bytes(int M, int C) { return lotus_cpe_ws_conv_bytes(M, C); }
+int lotus_pair_nptr(void) { return PP_COUNT; }
+int lotus_pair_nint(void) { return PI_COUNT; }
+
+#define PPTR(T, i) ((T)P[i])
+int lotus_pair_fwd(const void* const* P, const long long* I, const double* F) {
+  const int M = (int)I[PI_M], C = (int)I[PI_C], H = (int)I[PI_H], Hd = (int)I[PI_HD], npad = (int)I[PI_NPAD];
+  const int prec = (int)I[PI_PREC];
+  const float drop = (float)F[PF_DROP], attn_p = (float)F[PF_ATTN], scale = (float)F[PF_SCALE];
+  void* ws = PPTR(void*, PP_WS_MAIN);
+  const size_t ws_b = (size_t)I[PI_WS_MAIN];
+  void* cnt = PPTR(void*, PP_CNT_MAIN);
+  void* st = PPTR(void*, PP_STREAM);
+  const size_t a = actf((size_t)M * C);
+  float* acts = PPTR(float*, PP_ACTS);
+  act_t* x1 = (act_t*)acts;
+  act_t* x2 = (act_t*)(acts + a);
+  act_t* x3 = (act_t*)(acts + 2 * a);
+  act_t* x4 = (act_t*)(acts + 3 * a);
+  float* sv_cpe = PPTR(float*, PP_SAVED);
+  float* sv_self = sv_cpe + lotus_cpe_saved_floats(M, C);
+  float* sv_ffn1 = sv_self + lotus_selfattn_saved_floats(M, C, H, npad);
+  float* sv_cross = sv_ffn1 + lotus_ffn_saved_floats(M, C, Hd);
+  float* sv_ffn2 = sv_cross + lotus_crossattn_kv_saved_floats(M, C, H);
+  const unsigned long long s_self = (unsigned long long)I[PI_SEED_SELF], s_f1 = (unsigned long long)I[PI_SEED_FFN1];
+  const unsigned long long s_cross = (unsigned long long)I[PI_SEED_CROSS], s_f2 = (unsigned long long)I[PI_SEED_FFN2];
+  CHECK(lotus_cpe_fwd(PPTR(const act_t*, PP_X), PPTR(const act_t*, PP_XS), PPTR(const float*, PP_CW), PPTR(const float*, PP_CWP),
+                      PPTR(const float*, PP_CB), PPTR(const float*, PP_LW), PPTR(const float*, PP_LB), PPTR(const float*, PP_G0),
+                      PPTR(const float*, PP_B0), x1, sv_cpe, PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), M, C, prec, ws, ws_b,
+                      PPTR(void*, PP_WS_CONV), (size_t)I[PI_WS_CONV], cnt, st));
+  CHECK(lotus_selfattn_fwd(x1, PPTR(const float*, PP_G1), PPTR(const float*, PP_B1), PPTR(const float*, PP_WQKV), PPTR(const float*, PP_BQKV),
+                           PPTR(const float*, PP_QNW), PPTR(const float*, PP_QNB), PPTR(const float*, PP_KNW), PPTR(const float*, PP_KNB),
+                           PPTR(const float*, PP_WP), PPTR(const float*, PP_BP), x2, sv_self, PPTR(const int*, PP_GIDX),
+                           PPTR(const int*, PP_OWNER), PPTR(const int*, PP_STILES), (int)I[PI_NSTILES], npad, M, C, H, scale, drop, s_self,
+                           attn_p, pair_mix(s_self, 1), prec, ws, ws_b, cnt, st));
+  CHECK(lotus_ffn_fwd(x2, PPTR(const float*, PP_G2), PPTR(const float*, PP_B2), PPTR(const float*, PP_W1), PPTR(const float*, PP_B1F),
+                      PPTR(const float*, PP_W2), PPTR(const float*, PP_B2F), x3, sv_ffn1, M, C, Hd, drop, s_f1, pair_mix(s_f1, 1), prec, ws,
+                      ws_b, cnt, st));
+  CHECK(lotus_crossattn_kv_fwd(x3, PPTR(const act_t*, PP_KV), (long)I[PI_KV_LD], PPTR(const float*, PP_G3), PPTR(const float*, PP_B3),
+                               PPTR(const float*, PP_WQ), PPTR(const float*, PP_BQ), PPTR(const float*, PP_CQNW), PPTR(const float*, PP_CQNB),
+                               PPTR(const float*, PP_CKNW), PPTR(const float*, PP_CKNB), PPTR(const float*, PP_CWP2),
+                               PPTR(const float*, PP_CBP2), x4, sv_cross, PPTR(const int*, PP_CATILES), (int)I[PI_NCATILES], M, C, H, scale,
+                               drop, s_cross, attn_p, pair_mix(s_cross, 1), prec, (int)I[PI_KMAX], ws, ws_b, cnt, st));
+  return lotus_ffn_fwd(x4, PPTR(const float*, PP_G4), PPTR(const float*, PP_B4), PPTR(const float*, PP_W3), PPTR(const float*, PP_B3F),
+                       PPTR(const float*, PP_W4), PPTR(const float*, PP_B4F), PPTR(act_t*, PP_Y), sv_ffn2, M, C, Hd, drop, s_f2,
+                       pair_mix(s_f2, 1), prec, ws, ws_b, cnt, st);
+}
+
+// grads: [cpe | self | ffn1 | cross | ffn2] in the layouts of the five composites; dxs = input gradient of the convolution
+// (added into dx when xs is x: PI_SAME).
+int lotus_pair_bwd(const void* const* P, const long long* I, const double* F) {
+  const int M = (int)I[PI_M], C = (int)I[PI_C], H = (int)I[PI_H], Hd = (int)I[PI_HD], npad = (int)I[PI_NPAD];
+  const int n_extra = (int)I[PI_NEXTRA], L = (int)I[PI_L], G = (int)I[PI_G], prec = (int)I[PI_PREC];
+  const float drop = (float)F[PF_DROP], attn_p = (float)F[PF_ATTN], scale = (float)F[PF_SCALE];
+  void* wm = PPTR(void*, PP_WS_MAIN);
+  void* wsd = PPTR(void*, PP_WS_SIDE);
+  const size_t wm_b = (size_t)I[PI_WS_MAIN], wsd_b = (size_t)I[PI_WS_SIDE];
+  void* cm = PPTR(void*, PP_CNT_MAIN);
+  void* cs = PPTR(void*, PP_CNT_SIDE);
+  void* st = PPTR(void*, PP_STREAM);
+  void* side = PPTR(void*, PP_SIDE);
+  const unsigned long long link = (unsigned long long)I[PI_LINK];
+  const size_t a = actf((size_t)M * C);
+  float* acts = PPTR(float*, PP_ACTS);
+  const act_t* x1 = (const act_t*)acts;
+  const act_t* x2 = (const act_t*)(acts + a);
+  const act_t* x3 = (const act_t*)(acts + 2 * a);
+  const act_t* x4 = (const act_t*)(acts + 3 * a);
+  const float* sv_cpe = PPTR(const float*, PP_SAVED);
+  const float* sv_self = sv_cpe + lotus_cpe_saved_floats(M, C);
+  const float* sv_ffn1 = sv_self + lotus_selfattn_saved_floats(M, C, H, npad);
+  const float* sv_cross = sv_ffn1 + lotus_ffn_saved_floats(M, C, Hd);
+  const float* sv_ffn2 = sv_cross + lotus_crossattn_kv_saved_floats(M, C, H);
+  float* g_cpe = PPTR(float*, PP_GRADS);
+  float* g_self = g_cpe + lotus_cpe_grads_floats(C);
+  float* g_ffn1 = g_self + lotus_selfattn_grads_floats(C, H);
+  float* g_cross = g_ffn1 + lotus_ffn_grads_floats(C, Hd);
+  float* g_ffn2 = g_cross + lotus_crossattn_kv_grads_floats(C, H);
+  float* t_cpe = PPTR(float*, PP_TMP);
+  float* t_self = t_cpe + lotus_cpe_tmp_floats(M, C);
+  float* t_ffn1 = t_self + lotus_selfattn_tmp_floats(M, C, n_extra);
+  float* t_cross = t_ffn1 + lotus_ffn_tmp_floats(M, C, Hd);
+  float* t_ffn2 = t_cross + lotus_crossattn_kv_tmp_floats(M, C, L, G);
+  float* t_rest = t_ffn2 + lotus_ffn_tmp_floats(M, C, Hd);
+  act_t* d4 = (act_t*)t_rest;            // d x4, d x3, d x2 are temporaries; d x1 = the gradient the cpe receives
+  act_t* d3 = (act_t*)(t_rest + a);
+  act_t* d2 = (act_t*)(t_rest + 2 * a);
+  // the pre-masked gradients handed from a sub-block's LayerNorm backward to its predecessor live in the predecessor's tmp
+  // head (its `dz` slot is unused then): cross <- ffn2, ffn1 <- cross, self <- ffn1
+  act_t* dz_cross = (act_t*)t_cross;     // first slice of the cross-attention tmp (dzb)
+  act_t* dz_ffn1 = (act_t*)t_ffn1;       // first slice of the mlp tmp (dz2)
+  act_t* dz_self = (act_t*)t_self;       // first slice of the self-attention tmp (dzb)
+  const unsigned long long s_self = (unsigned long long)I[PI_SEED_SELF], s_f1 = (unsigned long long)I[PI_SEED_FFN1];
+  const unsigned long long s_cross = (unsigned long long)I[PI_SEED_CROSS], s_f2 = (unsigned long long)I[PI_SEED_FFN2];
+  const bool hand = drop > 0.f;
+  // d x1 (what the cpe backward receives).  Encoder (xs is x): a temporary, the cpe backward writes conv-gradient + d x1
+  // to PP_DX.  Decoder (xs = the stale skip branch): d x1 IS the gradient of x (the residual passes it through) and the
+  // convolution's input gradient goes to PP_DXS.
+  const int same = (int)I[PI_SAME];
+  act_t* d1 = same ? (act_t*)(t_rest + 3 * a) : PPTR(act_t*, PP_DX);
+  // mlp of the CABlock: dz_out masks d x4 with the cross-attention's projection dropout (drop, s_cross)
+  CHECK(lotus_ffn_bwd(PPTR(const act_t*, PP_DY), nullptr, x4, PPTR(const float*, PP_G4), PPTR(const float*, PP_W3), PPTR(const float*, PP_W4),
+                      sv_ffn2, d4, hand ? dz_cross : nullptr, hand ? drop : 0.f, s_cross, g_ffn2, t_ffn2, M, C, Hd, drop, s_f2, pair_mix(s_f2, 1),
+                      prec, wm, wm_b, wsd, wsd_b, cm, cs, link, 0, st, side));
+  // cross-attention: dz_out masks d x3 with the fc2 dropout of the Block's mlp (drop, mix(s_f1, 1))
+  CHECK(lotus_crossattn_kv_bwd(d4, hand ? dz_cross : nullptr, x3, PPTR(const act_t*, PP_KV), (long)I[PI_KV_LD], PPTR(const float*, PP_G3),
+                               PPTR(const float*, PP_WQ), PPTR(const float*, PP_CQNW), PPTR(const float*, PP_CQNB), PPTR(const float*, PP_CKNW),
+                               PPTR(const float*, PP_CKNB), PPTR(const float*, PP_CWP2), sv_cross, d3, PPTR(act_t*, PP_DKV), (long)I[PI_DKV_LD],
+                               hand ? dz_ffn1 : nullptr, hand ? drop : 0.f, pair_mix(s_f1, 1), g_cross, t_cross, PPTR(const int*, PP_CATILES),
+                               PPTR(const int*, PP_CABLOCKS), (int)I[PI_NCABLOCKS], G, M, C, H, L, scale, drop, s_cross, attn_p,
+                               pair_mix(s_cross, 1), prec, (int)I[PI_KMAX], wm, wm_b, wsd, wsd_b, cm, cs, link, 0, st, side));
+  // mlp of the Block: dz_out masks d x2 with the self-attention's projection dropout (drop, s_self)
+  CHECK(lotus_ffn_bwd(d3, hand ? dz_ffn1 : nullptr, x2, PPTR(const float*, PP_G2), PPTR(const float*, PP_W1), PPTR(const float*, PP_W2), sv_ffn1,
+                      d2, hand ? dz_self : nullptr, hand ? drop : 0.f, s_self, g_ffn1, t_ffn1, M, C, Hd, drop, s_f1, pair_mix(s_f1, 1), prec, wm,
+                      wm_b, wsd, wsd_b, cm, cs, link, 0, st, side));
+  CHECK(lotus_selfattn_bwd(d2, hand ? dz_self : nullptr, x1, PPTR(const float*, PP_G1), PPTR(const float*, PP_WQKV), PPTR(const float*, PP_QNW),
+                           PPTR(const float*, PP_QNB), PPTR(const float*, PP_KNW), PPTR(const float*, PP_KNB), PPTR(const float*, PP_WP), sv_self,
+                           d1, g_self, t_self, PPTR(const int*, PP_GIDX), PPTR(const int*, PP_OWNER), PPTR(const int*, PP_STILES),
+                           PPTR(const int*, PP_SBLOCKS), (int)I[PI_NSTILES], PPTR(const int*, PP_KEXT), PPTR(const int*, PP_EXTPOS), n_extra, npad,
+                           M, C, H, scale, drop, s_self, attn_p, pair_mix(s_self, 1), prec, wm, wm_b, wsd, wsd_b, cm, cs, link, 0, st, side));
+  // cpe: d x = d x1 (+ the convolution's input gradient when xs is x); separate xs -> its gradient goes to dxs
+  return lotus_cpe_bwd(d1, PPTR(const act_t*, PP_XS), PPTR(const float*, PP_CW), PPTR(const float*, PP_CWP), PPTR(const float*, PP_LW),
+                       PPTR(const float*, PP_G0), sv_cpe, same ? PPTR(act_t*, PP_DX) : PPTR(act_t*, PP_DXS), same, g_cpe, t_cpe,
+                       PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), PPTR(const long long*, PP_CODE0), (int)I[PI_NDUP], M, C, prec, wm,
+                       wm_b, PPTR(void*, PP_WS_CONV), (size_t)I[PI_WS_CONV], wsd, wsd_b, cm, cs, link, 0, st, side);
+}
+#undef PPTR
 
 }  // extern "C"

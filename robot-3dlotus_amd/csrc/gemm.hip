@@ -46,6 +46,7 @@ struct GemmP {
   float* bias_out;   // wgrad, fused: final column sums (bias gradient)
   int accumulate;    // wgrad, fused: C / bias_out += result
   int c_float;       // fwd / dgrad: C is an fp32 split-K partial slab, not an activation tensor
+  int b_act;         // fwd / dgrad, bf16-storage build: the weight matrix B is a bf16 SHADOW of the fp32 master (precision | 4)
 };
 
 // Partial tiles of a fused split-K product travel between blocks that may sit on different XCDs (one L2 each).  An
@@ -681,7 +682,12 @@ static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweep
   do {                                                                                                                           \
     using TB_ = std::conditional_t<SUM_A, act_t, float>;                                                                         \
     if constexpr (LOTUS_ACT_IS_BF16 && !SUM_A) {                                                                                 \
-      if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p); \
+      if (p.b_act) { /* bf16 weight shadow: half the weight bytes per block, no conversion while staging */                      \
+        if constexpr (PREC_ == 1 && FAST) {                                                                                      \
+          if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, float>), grid_, block, 0, st, p); \
+          else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, act_t>), grid_, block, 0, st, p); \
+        }                                                                                                                        \
+      } else if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p); \
       else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, act_t>), grid_, block, 0, st, p);   \
     } else {                                                                                                                     \
       LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p);      \
@@ -723,6 +729,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
     return LOTUS_OK;
+  }
+  if (p.b_act && !(LOTUS_ACT_IS_BF16 && g_prec == 1 && !SUM_A && FAST && (A_KC || p.M % 4 == 0) && tile != 1)) {
+    lotus_set_error("lotus_linear: bf16 weight shadows (precision 5) need the bf16-storage build and 16-byte aligned operands whose "
+                    "widths are multiples of 4");
+    return LOTUS_E_UNSUPPORTED;
   }
   if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
     // bf16 / bf16x3 operand path (forward and input-gradient products)
@@ -939,7 +950,11 @@ int lotus_linear_fwd(const act_t* x, const float* w, const float* bias, const ac
                      act_t* pre, int M, int N, int K, int act, float drop_p, unsigned long long drop_seed,
                      int precision, void* workspace, size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && M >= 0 && N > 0 && K > 0, "lotus_linear_fwd: bad arguments");
-  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_fwd: precision must be 0, 1 or 3");
+  // precision 5 (bf16-storage build only) = precision 1 with `w` pointing at a bf16 shadow of the weights
+  const int w_shadow = precision == 5;
+  LOTUS_CHECK_ARG(!w_shadow || LOTUS_ACT_IS_BF16, "lotus_linear_fwd: precision 5 (bf16 weight shadow) exists in the bf16-storage build only");
+  if (w_shadow) precision = 1;
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_fwd: precision must be 0, 1 or 3 (5 with bf16 weights)");
   LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_fwd: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   if (M == 0) return LOTUS_OK;
   GemmP p;
@@ -948,7 +963,7 @@ int lotus_linear_fwd(const act_t* x, const float* w, const float* bias, const ac
   p.lda = K; p.ldb = K; p.ldc = N;
   p.bias = bias; p.residual = residual; p.pre = pre; p.act = act;
   p.klen = cdiv(K, GEMM_KALIGN) * GEMM_KALIGN;
-  p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K); p.prec = precision;
+  p.a_vec = vec_ok(x, K); p.b_vec = vec_ok(w, K); p.prec = precision; p.b_act = w_shadow;
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, true>(p, workspace, workspace_bytes, (unsigned*)counters, (hipStream_t)stream);
 }
@@ -960,7 +975,11 @@ int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* 
                        int N, int K, int act, float drop_p, unsigned long long drop_seed, int precision, void* workspace,
                        size_t workspace_bytes, void* counters, void* stream) {
   LOTUS_CHECK_ARG(dy && w && dx && M >= 0 && N > 0 && K > 0, "lotus_linear_dgrad: bad arguments");
-  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_dgrad: precision must be 0, 1 or 3");
+  // precision 5 (bf16-storage build only) = precision 1 with `w` pointing at a bf16 shadow of the weights
+  const int w_shadow = precision == 5;
+  LOTUS_CHECK_ARG(!w_shadow || LOTUS_ACT_IS_BF16, "lotus_linear_dgrad: precision 5 (bf16 weight shadow) exists in the bf16-storage build only");
+  if (w_shadow) precision = 1;
+  LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_dgrad: precision must be 0, 1 or 3 (5 with bf16 weights)");
   LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_dgrad: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   if (M == 0) return LOTUS_OK;
   GemmP p;
@@ -970,7 +989,7 @@ int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* 
   p.act = LOTUS_ACT_NONE;
   p.mulpre = pre; p.dact = act; p.residual = add;
   p.klen = cdiv(N, GEMM_KALIGN) * GEMM_KALIGN;
-  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K); p.prec = precision;
+  p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K); p.prec = precision; p.b_act = w_shadow;
   set_drop(p, drop_p, drop_seed);
   return run_gemm_splitk<true, false>(p, workspace, workspace_bytes, (unsigned*)counters, (hipStream_t)stream);
 }
@@ -1000,6 +1019,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
                        int accumulate, int precision, void* workspace, size_t workspace_bytes, void* counters,
                        void* stream) {
   LOTUS_CHECK_ARG(dy && x && dw && M >= 0 && N > 0 && K > 0, "lotus_linear_wgrad: bad arguments");
+  if (precision == 5) precision = 1;  // (the shadow flag of the forward / input-gradient products: no weights are read here)
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_linear_wgrad: precision must be 0, 1 or 3");
   LOTUS_CHECK_ARG(!(LOTUS_ACT_IS_BF16 && precision == 3), "lotus_linear_wgrad: bf16x3 operands (precision 3) are not built for bf16 activation storage; use 1 (bf16) or 0");
   hipStream_t st = (hipStream_t)stream;

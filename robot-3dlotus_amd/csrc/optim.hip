@@ -62,13 +62,20 @@ struct AdamP {
   const float* decay;      // [T]  lr * weight_decay (0 = none)                                         (adamw.py:109-110)
   const int* chunks;       // [nchunks][2] tensor, chunk
   const float* clip;       // device scalar (mt_norm_finish_kernel out + 1) or null
-  float beta1, beta2, eps;
+  // optional bf16 shadows of the parameters (null table / null entries = none): the updated value is stored a second time,
+  // rounded to bf16 — the weight operand of the bf16-storage products (BASELINE configs[4]: "bf16 weights with fp32
+  // master weights") refreshed by the step that changes the master, one extra 2-byte store per element
+  unsigned short* const* shadow;
+  // omb = 1 - beta evaluated in DOUBLE by the host and rounded once, as the reference's `addcmul_(g, g, value=1.0 - beta2)`
+  // does (adamw.py:86-87: a Python float); 1.f - beta2 in fp32 is off by 1e-6 relative (cancellation), which showed up as
+  // 8 ulp in exp_avg_sq
+  float beta1, beta2, omb1, omb2, eps;
 };
 
 __device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, float ss, float dec, float b1, float b2,
-                                          float eps) {
-  m = m * b1 + g * (1.f - b1);
-  v = v * b2 + (g * g) * (1.f - b2);
+                                          float omb1, float omb2, float eps) {
+  m = m * b1 + g * omb1;
+  v = v * b2 + (g * g) * omb2;
   const float denom = sqrtf(v) + eps;
   p = p + (-ss) * (m / denom);
   if (dec > 0.f) p = p + (-dec) * p;
@@ -83,7 +90,8 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(AdamP a) {
   float* v = a.v[t];
   const long n = a.numel[t], beg = (long)c * MT_CHUNK;
   const float ss = a.step_size[t], dec = a.decay[t], coef = a.clip ? a.clip[0] : 1.f;
-  const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0;
+  __bf16* sh = a.shadow ? reinterpret_cast<__bf16*>(a.shadow[t]) : nullptr;
+  const bool vec = ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | (((uintptr_t)sh) << 1)) & 15) == 0;
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const long i = beg + (long)(it * 256 + threadIdx.x) * 4;
@@ -91,15 +99,19 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(AdamP a) {
     if (vec && i + 3 < n) {
       float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
       const float4 gv = *reinterpret_cast<const float4*>(g + i);
-      adam_elem(pv.x, gv.x * coef, mv.x, vv.x, ss, dec, a.beta1, a.beta2, a.eps);
-      adam_elem(pv.y, gv.y * coef, mv.y, vv.y, ss, dec, a.beta1, a.beta2, a.eps);
-      adam_elem(pv.z, gv.z * coef, mv.z, vv.z, ss, dec, a.beta1, a.beta2, a.eps);
-      adam_elem(pv.w, gv.w * coef, mv.w, vv.w, ss, dec, a.beta1, a.beta2, a.eps);
+      adam_elem(pv.x, gv.x * coef, mv.x, vv.x, ss, dec, a.beta1, a.beta2, a.omb1, a.omb2, a.eps);
+      adam_elem(pv.y, gv.y * coef, mv.y, vv.y, ss, dec, a.beta1, a.beta2, a.omb1, a.omb2, a.eps);
+      adam_elem(pv.z, gv.z * coef, mv.z, vv.z, ss, dec, a.beta1, a.beta2, a.omb1, a.omb2, a.eps);
+      adam_elem(pv.w, gv.w * coef, mv.w, vv.w, ss, dec, a.beta1, a.beta2, a.omb1, a.omb2, a.eps);
       *reinterpret_cast<float4*>(p + i) = pv;
       *reinterpret_cast<float4*>(m + i) = mv;
       *reinterpret_cast<float4*>(v + i) = vv;
+      if (sh) st4(sh + i, pv);
     } else {
-      for (int e = 0; e < 4 && i + e < n; ++e) adam_elem(p[i + e], g[i + e] * coef, m[i + e], v[i + e], ss, dec, a.beta1, a.beta2, a.eps);
+      for (int e = 0; e < 4 && i + e < n; ++e) {
+        adam_elem(p[i + e], g[i + e] * coef, m[i + e], v[i + e], ss, dec, a.beta1, a.beta2, a.omb1, a.omb2, a.eps);
+        if (sh) sh[i + e] = (__bf16)p[i + e];
+      }
     }
   }
 }
@@ -124,18 +136,49 @@ int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, in
 // One AdamW step for every tensor.  step_size / decay are per-tensor device arrays (see AdamP); clip_coef (device scalar,
 // optional) scales the gradients first (clip_grad_norm_ folded into the update instead of rewriting the gradients).
 int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const long* numel,
-                     const float* step_size, const float* decay, const int* chunks, int nchunks, float beta1, float beta2,
-                     float eps, const float* clip_coef, void* stream) {
+                     const float* step_size, const float* decay, const int* chunks, int nchunks, double beta1, double beta2,
+                     double eps, const float* clip_coef, const void* shadow_ptrs, void* stream) {
   LOTUS_CHECK_ARG(p_ptrs && g_ptrs && m_ptrs && v_ptrs && numel && step_size && decay && chunks && nchunks >= 0,
                   "lotus_adamw_step: bad arguments");
   if (nchunks == 0) return LOTUS_OK;
   AdamP a;
   a.p = (float* const*)p_ptrs; a.g = (const float* const*)g_ptrs; a.m = (float* const*)m_ptrs; a.v = (float* const*)v_ptrs;
   a.numel = numel; a.step_size = step_size; a.decay = decay; a.chunks = chunks; a.clip = clip_coef;
-  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
+  a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.shadow = (unsigned short* const*)shadow_ptrs;
   LOTUS_LAUNCH(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
   LOTUS_LAUNCH_CHECK("lotus_adamw_step");
   return LOTUS_OK;
 }
 
+// dst[t][i] = bf16(src[t][i]) for every tensor of the tables (creation / refresh of weight shadows outside an optimiser step)
+int lotus_shadow_cast(const void* src_ptrs, const void* dst_ptrs, const long* numel, const int* chunks, int nchunks, void* stream);
+
 }  // extern "C"
+
+__global__ __launch_bounds__(256) void mt_cast_bf16_kernel(const float* const* __restrict__ src, unsigned short* const* __restrict__ dst,
+                                                           const long* __restrict__ numel, const int* __restrict__ chunks) {
+  const int t = chunks[2 * blockIdx.x], c = chunks[2 * blockIdx.x + 1];
+  const float* s = src[t];
+  __bf16* d = reinterpret_cast<__bf16*>(dst[t]);
+  const long n = numel[t], beg = (long)c * MT_CHUNK;
+  const bool vec = ((((uintptr_t)s) | (((uintptr_t)d) << 1)) & 15) == 0;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const long i = beg + (long)(it * 256 + threadIdx.x) * 4;
+    if (i >= n) break;
+    if (vec && i + 3 < n) st4(d + i, *reinterpret_cast<const float4*>(s + i));
+    else
+      for (int e = 0; e < 4 && i + e < n; ++e) d[i + e] = (__bf16)s[i + e];
+  }
+}
+
+extern "C" int lotus_shadow_cast(const void* src_ptrs, const void* dst_ptrs, const long* numel, const int* chunks, int nchunks, void* stream) {
+  LOTUS_CHECK_ARG(src_ptrs && dst_ptrs && numel && chunks && nchunks >= 0, "lotus_shadow_cast: bad arguments");
+  if (nchunks == 0) return LOTUS_OK;
+  LOTUS_LAUNCH(mt_cast_bf16_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const float* const*)src_ptrs,
+               (unsigned short* const*)dst_ptrs, numel, chunks);
+  LOTUS_LAUNCH_CHECK("lotus_shadow_cast");
+  return LOTUS_OK;
+}

@@ -106,16 +106,19 @@ class storage:
     (one bf16 MFMA product, fp32 accumulate).  Like the precision, the storage type is captured per autograd node and
     replayed in its backward, so models of both kinds coexist in one process."""
 
-    def __init__(self, dtype):
+    def __init__(self, dtype, shadows=False):
         assert dtype in (None, torch.float32, torch.bfloat16), dtype
         self.bf = dtype is torch.bfloat16
+        # shadows: the dense layers read bf16 SHADOWS of their weights (WeightShadows) where a parameter carries one —
+        # precision code 5 of the lotus_b16_linear_* entry points; master weights, gradients and the optimiser stay fp32
+        self.code = 5 if (self.bf and shadows) else 1
 
     def __enter__(self):
         global _PREC
         self.prev = (_capi.BF16, _PREC)
         _capi.BF16 = self.bf
         if self.bf:
-            _PREC = 1
+            _PREC = self.code
         return self
 
     def __exit__(self, *a):
@@ -318,11 +321,76 @@ def _counters_for(dev, ptr):
     return c
 
 
+def _pa(prec=None):
+    """Operand precision for the attention / convolution entry points (and for dense layers given fp32 master weights):
+    the shadow flag (5) only concerns the weight pointer of lotus_linear_fwd / _dgrad."""
+    code = _PREC if prec is None else prec
+    return 1 if code == 5 else code
+
+
+def _wk(*ws):
+    """-> (weights to hand to the kernels, precision code): in shadow mode (precision 5) and when EVERY given parameter
+    carries a bf16 shadow (WeightShadows), the shadows and 5; else the fp32 masters and the plain code."""
+    if _PREC == 5:
+        sh = [getattr(w, "_lotus_b16", None) for w in ws]
+        if all(t is not None for t in sh):
+            return sh, 5
+    return list(ws), _pa()
+
+
+class WeightShadows:
+    """bf16 shadows of a model's dense-layer weights: BASELINE configs[4] stores "bf16 activations / weights with fp32 master
+    weights" (job_scripts/train_3dlotus_policy_peract.sh:42-44,61).  The fp32 Parameter stays what autograd, the optimiser
+    and the checkpoint see; `p._lotus_b16` is what the bf16-storage products read.  The fused AdamW (optim.AdamW) rewrites
+    the shadow in the launch that updates the master; any other in-place change of a master (another optimiser,
+    load_state_dict, .copy_) bumps the tensor's version counter and refresh() recasts — one multi-tensor launch."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.dtype == torch.float32 and p.numel() % 4 == 0]
+        self.tables = None
+
+    def refresh(self):
+        stale = False
+        for p in self.params:
+            sh = getattr(p, "_lotus_b16", None)
+            if sh is None or sh.device != p.device or sh.shape != p.shape:
+                p._lotus_b16 = torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
+                p._lotus_b16_ver = -1
+                self.tables = None
+            if p._lotus_b16_ver != p._version:
+                stale = True
+        if not stale:
+            return
+        dev = self.params[0].device
+        key = tuple(p.data_ptr() for p in self.params)
+        if self.tables is None or self.tables[0] != key:
+            import numpy as np
+            chunk = query("lotus_mt_chunk")
+            numel = [p.numel() for p in self.params]
+            ch = [(t, c) for t, n in enumerate(numel) for c in range((n + chunk - 1) // chunk)]
+            i64 = lambda v: torch.tensor(v, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)  # noqa: E731
+            self.tables = (key, i64(list(key)), i64([p._lotus_b16.data_ptr() for p in self.params]), i64(numel),
+                           torch.from_numpy(np.asarray(ch, dtype=np.int32)).pin_memory().to(dev, non_blocking=True), len(ch))
+        _, src, dst, numel, chunks, nch = self.tables
+        call("lotus_shadow_cast", src, dst, numel, chunks, nch)
+        for p in self.params:
+            p._lotus_b16_ver = p._version
+
+
 def _empty_like_rows(x, cols):
     return torch.empty(x.shape[0], cols, dtype=x.dtype, device=x.device)
 
 
 # ------------------------------------------------------------------------------------ primitives
+def _wprec(w, prec=None):
+    """Precision code of a dense product from the weight tensor it is given: a bf16 weight IS a shadow (code 5), an fp32
+    weight never is — a wrong pairing would make the kernel misread the matrix."""
+    if w.dtype == torch.bfloat16:
+        assert _capi.BF16, "bf16 weight shadows belong to the bf16-storage mode"
+        return 5
+    return _pa(prec)
+
+
 def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0, seed=0, prec=None):
     M, K = x.shape
     N = w.shape[0]
@@ -334,7 +402,7 @@ def linear_fwd(x, w, b, residual=None, act=ACT_NONE, save_pre=False, drop_p=0.0,
     ws = _ws(nb, x.device) if nb else None
     with _Timed(("fwd", M, N, K)):
         call("lotus_linear_fwd", x, w, b, residual, y, pre, M, N, K, act, float(drop_p), int(seed),
-             _PREC if prec is None else prec, ws, nb, _counters(x.device) if nb else None)
+             _wprec(w, prec), ws, nb, _counters(x.device) if nb else None)
     return y, pre
 
 
@@ -348,7 +416,7 @@ def linear_dgrad(dy, w, pre=None, add=None, act=ACT_NONE, drop_p=0.0, seed=0, pr
     ws = _ws(nb, dy.device) if nb else None
     with _Timed(("dgrad", M, N, K)):
         call("lotus_linear_dgrad", dy, w, dx, pre, add, M, N, K, act, float(drop_p), int(seed),
-             _PREC if prec is None else prec, ws, nb, _counters(dy.device) if nb else None)
+             _wprec(w, prec), ws, nb, _counters(dy.device) if nb else None)
     return dx
 
 
@@ -369,7 +437,7 @@ def linear_wgrad(dy, x, need_bias=True, prec=None, into=None):
     with _OnSide(dy, x):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         with _Timed(("wgrad", M, N, K)):
-            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0 if into is None else 1, _PREC if prec is None else prec, ws,
+            call("lotus_linear_wgrad", dy, x, dw, db, M, N, K, 0 if into is None else 1, _pa(prec), ws,
                  ws.numel(), _counters(dy.device))
     return dw, db
 
@@ -442,7 +510,7 @@ def conv_weight_t(w, prec=None):
     cout, cin = w.shape[0], w.shape[-1]
     T = w.numel() // (cout * cin)
     wt = torch.empty(2 * w.numel(), dtype=torch.float32, device=w.device)
-    call("lotus_conv_weight_transpose", w, wt, cout, T, cin, _PREC if prec is None else prec)
+    call("lotus_conv_weight_transpose", w, wt, cout, T, cin, _pa(prec))
     return wt
 
 
@@ -457,7 +525,7 @@ def prepack_conv_weights(weights):
         with _OnSide(*weights):
             for w, o in zip(weights, outs):
                 cout, cin = w.shape[0], w.shape[-1]
-                call("lotus_conv_weight_transpose", w, o, cout, w.numel() // (cout * cin), cin, _PREC)
+                call("lotus_conv_weight_transpose", w, o, cout, w.numel() // (cout * cin), cin, _pa())
     finally:
         _IN_NODE -= 1
     return outs
@@ -476,7 +544,7 @@ def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None):
         ws = _conv_ws(n, cin, cout, x.device)
     else:  # thin-input stem kernel: room for the transposed weights
         ws = WS.get(4 * T * cin * cout, x.device, slot=2) if cin <= 8 else None
-    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, _PREC if prec is None else prec, ws,
+    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, _pa(prec), ws,
          ws.numel() if ws is not None else 0)
     return y
 
@@ -494,7 +562,7 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
         dy = dyr
     dx = torch.empty(n, cin, dtype=dy.dtype, device=dy.device)
     ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
-    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _PREC if prec is None else prec, ws,
+    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _pa(prec), ws,
          ws.numel() if ws is not None else 0)
     if dups:
         call("lotus_conv_dup_mask", dx, add, nbr[T // 2], n, cin)
@@ -512,7 +580,7 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None):
     with _OnSide(dy, x, nbr):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         # thin-input stem (cin <= 8): one VALU kernel in every mode, exact fp32
-        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, _PREC if prec is None else prec, ws, ws.numel())
+        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, _pa(prec), ws, ws.numel())
     return dw, db
 
 
@@ -718,7 +786,7 @@ def attention_fwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, ti
                   drop_p=0.0, seed=0, prec=None, k_max=0):
     call("lotus_attention_fwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, ntiles,
          qn[0], qn[1], kn[0], kn[1], out, out.stride(0), lse, H, d, float(d ** -0.5), 1e-6, float(drop_p), int(seed),
-         _PREC if prec is None else prec, int(k_max))
+         _pa(prec), int(k_max))
 
 
 def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks, qn, kn, out,
@@ -730,7 +798,7 @@ def attention_bwd(q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, ti
     call("lotus_attention_bwd", q, q_ld, q_off, kv, kv_ld, k_off, v_off, qidx, kidx, owner, tiles, blocks, nblocks,
          qn[0], qn[1], kn[0], kn[1], out, dout, out.stride(0), lse, dq, dq_ld, dq_off, dkv, dkv_ld, dk_off, dv_off,
          part_stride, atomic, kext, ext_pos, n_extra, dkv_extra, grads[0], grads[1], grads[2], grads[3], 0, H, d, float(d ** -0.5), 1e-6, float(drop_p),
-         int(seed), _PREC if prec is None else prec, int(k_max), ws, ws.numel())
+         int(seed), _pa(prec), int(k_max), ws, ws.numel())
     return grads
 
 
@@ -776,6 +844,12 @@ def _sizes(kind, *dims):
             v = (query("lotus_crossattn_kv_saved_floats", M, C, H), query("lotus_crossattn_kv_grads_floats", C, H),
                  query("lotus_crossattn_kv_tmp_floats", M, C, L, G), query("lotus_crossattn_kv_ws_main_bytes", M, C, H, nblocks),
                  query("lotus_crossattn_kv_ws_side_bytes", M, C))
+        elif kind == "pair":
+            M, C, H, Hd, npad, nst, n_extra, L, nca, G = dims
+            v = (query("lotus_pair_acts_floats", M, C), query("lotus_pair_saved_floats", M, C, H, Hd, npad),
+                 query("lotus_pair_grads_floats", C, H, Hd), query("lotus_pair_tmp_floats", M, C, Hd, n_extra, L, G),
+                 query("lotus_pair_ws_main_bytes", M, C, H, Hd, nst, nca), query("lotus_pair_ws_side_bytes", M, C, Hd),
+                 query("lotus_pair_ws_conv_bytes", M, C))
         elif kind == "cpe":
             n, C = dims
             v = (query("lotus_cpe_saved_floats", n, C), query("lotus_cpe_grads_floats", C), query("lotus_cpe_tmp_floats", n, C),
@@ -820,6 +894,8 @@ class CpeFn(torch.autograd.Function):
             wt = conv_weight_t(cw)
         ctx.lvl, ctx.same = lvl, same
         n_, C = x.shape
+        (lwk,), pc = _wk(lw)
+        ctx.wk, ctx.pc = (lwk,), pc
         ctx.comp = composites_enabled() and C % 64 == 0 and (C == 64 or C % 128 == 0) and cw.shape[0] == C and cw.shape[-1] == C
         if ctx.comp:
             n_saved, _, _, ws_main, _, ws_conv = _sizes("cpe", n_, C)
@@ -827,12 +903,12 @@ class CpeFn(torch.autograd.Function):
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
             wc = WS.get(ws_conv, x.device, slot=2)
-            _capi.call_raw("lotus_cpe_fwd", x, xs, cw, wt, cb, lw, lb, g, b, y, saved, lvl.nbr27, lvl.order[0], n_, C, _PREC, ws,
+            _capi.call_raw("lotus_cpe_fwd", x, xs, cw, wt, cb, lwk, lb, g, b, y, saved, lvl.nbr27, lvl.order[0], n_, C, pc, ws,
                            ws.numel(), wc, wc.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(xs, cw, lw, g, saved, wt)
             return y
         c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt)
-        l, _ = linear_fwd(c, lw, lb)
+        l, _ = linear_fwd(c, lwk, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
         ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd, wt)
         return y
@@ -852,8 +928,8 @@ class CpeFn(torch.autograd.Function):
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27), n_)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             wc = WS.get(ws_conv, dev, slot=2)
-            _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, lw, g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
-                           lvl.order[0], lvl.code[0], lvl.n_dup, n_, C, _PREC, wsm, wsm.numel(), wc, wc.numel(), wss,
+            _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, ctx.wk[0], g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
+                           lvl.order[0], lvl.code[0], lvl.n_dup, n_, C, ctx.pc, wsm, wsm.numel(), wc, wc.numel(), wss,
                            wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             o1 = 2 * _al4(C)
             o2 = o1 + _al4(C * C + C)
@@ -866,7 +942,7 @@ class CpeFn(torch.autograd.Function):
         xs, cw, lw, g, c, l, mean, rstd, wt = ctx.saved_tensors
         dl, dg, db = ln_bwd(dy, l, mean, rstd, g)
         dlw, dlb = linear_wgrad(dl, c)
-        dc = linear_dgrad(dl, lw)
+        dc = linear_dgrad(dl, ctx.wk[0])
         dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
         if ctx.same:  # d x = dy (residual) + conv dgrad
             dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt, lvl=lvl)
@@ -890,6 +966,8 @@ class FfnFn(torch.autograd.Function):
         if hand_in is not None:
             hand_in.arm(drop_p, mix_seed(seed, 1))
         ctx.comp = composites_enabled() and x.shape[1] % 4 == 0 and dpath == 0.0
+        (w1k, w2k), pc = _wk(w1, w2)
+        ctx.wk, ctx.pc = (w1k, w2k), pc
         if ctx.comp:
             M, C = x.shape
             Hd = w1.shape[0]
@@ -897,17 +975,17 @@ class FfnFn(torch.autograd.Function):
             saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
-            _capi.call_raw("lotus_ffn_fwd", x, g, b, w1, b1, w2, b2, y, saved, M, C, Hd, float(drop_p), int(seed),
-                           mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+            _capi.call_raw("lotus_ffn_fwd", x, g, b, w1k, b1, w2k, b2, y, saved, M, C, Hd, float(drop_p), int(seed),
+                           mix_seed(seed, 1), pc, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(x, g, w1, w2, saved)
             return y
         n, mean, rstd = ln_fwd(x, g, b)
-        a, hpre = linear_fwd(n, w1, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
+        a, hpre = linear_fwd(n, w1k, b1, act=ACT_GELU, save_pre=True, drop_p=drop_p, seed=seed)
         if dpath > 0.0:
-            br, _ = linear_fwd(a, w2, b2, drop_p=drop_p, seed=mix_seed(seed, 1))
+            br, _ = linear_fwd(a, w2k, b2, drop_p=drop_p, seed=mix_seed(seed, 1))
             y = drop_path(br, x, dpath, mix_seed(seed, 5))
         else:
-            y, _ = linear_fwd(a, w2, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
+            y, _ = linear_fwd(a, w2k, b2, residual=x, drop_p=drop_p, seed=mix_seed(seed, 1))
         ctx.save_for_backward(x, g, w1, w2, n, hpre, a, mean, rstd)
         return y
 
@@ -932,8 +1010,8 @@ class FfnFn(torch.autograd.Function):
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), M)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
-            _capi.call_raw("lotus_ffn_bwd", dy, dz_in, x, g, w1, w2, saved, dx, dz_out, po, so, grads, tmp, M, C, Hd, float(p),
-                           int(seed), mix_seed(seed, 1), _PREC, wsm, wsm.numel(), wss, wss.numel() if wss is not None else 0,
+            _capi.call_raw("lotus_ffn_bwd", dy, dz_in, x, g, ctx.wk[0], ctx.wk[1], saved, dx, dz_out, po, so, grads, tmp, M, C, Hd, float(p),
+                           int(seed), mix_seed(seed, 1), ctx.pc, wsm, wsm.numel(), wss, wss.numel() if wss is not None else 0,
                            _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             o1 = 2 * _al4(C)
             o2 = o1 + _al4(Hd * C + Hd)
@@ -943,9 +1021,9 @@ class FfnFn(torch.autograd.Function):
         dyb = drop_path(dy, None, ctx.dpath, mix_seed(seed, 5)) if ctx.dpath > 0.0 else dy
         dz2 = _masked(dyb, p, mix_seed(seed, 1), hand_in)
         dw2, db2 = linear_wgrad(dz2, a)
-        dh = linear_dgrad(dz2, w2, pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
+        dh = linear_dgrad(dz2, ctx.wk[1], pre=hpre, act=ACT_GELU, drop_p=p, seed=seed)
         dw1, db1 = linear_wgrad(dh, n)
-        dn = linear_dgrad(dh, w1)
+        dn = linear_dgrad(dh, ctx.wk[0])
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
         return dx, dg, db, dw1, db1, dw2, db2, None, None, None, None, None
 
@@ -965,27 +1043,29 @@ class SelfAttnFn(torch.autograd.Function):
         if hand_in is not None:
             hand_in.arm(drop_p, seed)
         ctx.comp = composites_enabled() and C % 4 == 0 and dpath == 0.0
+        (wqkvk, wpk), pc = _wk(wqkv, wp)
+        ctx.wk, ctx.pc = (wqkvk, wpk), pc
         if ctx.comp:
             n_saved, _, _, ws_main, _ = _sizes("self", N, C, H, lvl.npad, lvl.n_self_tiles, lvl.n_extra)
             saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
-            _capi.call_raw("lotus_selfattn_fwd", x, g, b, wqkv, bqkv, qnw, qnb, knw, knb, wp, bp, y, saved, lvl.gidx, lvl.owner,
+            _capi.call_raw("lotus_selfattn_fwd", x, g, b, wqkvk, bqkv, qnw, qnb, knw, knb, wpk, bp, y, saved, lvl.gidx, lvl.owner,
                            lvl.self_tiles, lvl.n_self_tiles, lvl.npad, N, C, H, float(d ** -0.5), float(drop_p), int(seed),
-                           float(attn_p), mix_seed(seed, 1), _PREC, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+                           float(attn_p), mix_seed(seed, 1), pc, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, saved)
             return y
         n, mean, rstd = ln_fwd(x, g, b)
-        qkv, _ = linear_fwd(n, wqkv, bqkv)
+        qkv, _ = linear_fwd(n, wqkvk, bqkv)
         att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(lvl.npad, H, dtype=torch.float32, device=x.device)
         attention_fwd(qkv, 3 * C, 0, qkv, 3 * C, C, 2 * C, lvl.gidx, lvl.gidx, lvl.owner, lvl.self_tiles,
                       lvl.n_self_tiles, (qnw, qnb), (knw, knb), att, lse, H, d, attn_p, mix_seed(seed, 1))
         if dpath > 0.0:
-            br, _ = linear_fwd(att, wp, bp, drop_p=drop_p, seed=seed)
+            br, _ = linear_fwd(att, wpk, bp, drop_p=drop_p, seed=seed)
             y = drop_path(br, x, dpath, mix_seed(seed, 5))
         else:
-            y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+            y, _ = linear_fwd(att, wpk, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, g, wqkv, qnw, qnb, knw, knb, wp, n, qkv, att, lse, mean, rstd)
         return y
 
@@ -1004,9 +1084,9 @@ class SelfAttnFn(torch.autograd.Function):
             dz_in = ctx.hand_in.take(dy) if ctx.hand_in is not None else None
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), N)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
-            _capi.call_raw("lotus_selfattn_bwd", dy, dz_in, x, g, wqkv, qnw, qnb, knw, knb, wp, saved, dx, grads, tmp, lvl.gidx,
+            _capi.call_raw("lotus_selfattn_bwd", dy, dz_in, x, g, ctx.wk[0], qnw, qnb, knw, knb, ctx.wk[1], saved, dx, grads, tmp, lvl.gidx,
                            lvl.owner, lvl.self_tiles, lvl.self_blocks, lvl.n_self_tiles, lvl.kext, lvl.ext_pos, lvl.n_extra, lvl.npad,
-                           N, C, H, float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, wsm, wsm.numel(),
+                           N, C, H, float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), ctx.pc, wsm, wsm.numel(),
                            wss, wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             d4 = _al4(d)
             o1 = 2 * _al4(C)
@@ -1021,7 +1101,7 @@ class SelfAttnFn(torch.autograd.Function):
         dyb = drop_path(dy, None, ctx.dpath, mix_seed(seed, 5)) if ctx.dpath > 0.0 else dy
         dz = _masked(dyb, p, seed, ctx.hand_in)
         dwp, dbp = linear_wgrad(dz, att)
-        datt = linear_dgrad(dz, wp)
+        datt = linear_dgrad(dz, ctx.wk[1])
         # every (point, q|k|v column) is written exactly once by its owner position; the k/v gradients of the
         # borrowed tail-patch copies go to a small side buffer and are added afterwards (no atomics, no memset)
         dqkv = torch.empty(N, 3 * C, dtype=x.dtype, device=x.device)
@@ -1031,7 +1111,7 @@ class SelfAttnFn(torch.autograd.Function):
                                        datt, lse, dqkv, 3 * C, 0, dqkv, 3 * C, C, 2 * C, 0, 0, H, d, attn_p, mix_seed(seed, 1),
                                        lvl.kext, lvl.ext_pos, lvl.n_extra, extra)
         dwqkv, dbqkv = linear_wgrad(dqkv, n)
-        dn = linear_dgrad(dqkv, wqkv)
+        dn = linear_dgrad(dqkv, ctx.wk[0])
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy)
         return dx, dg, db, dwqkv, dbqkv, gq, bq, gk, bk, dwp, dbp, None, None, None, None, None, None, None
 
@@ -1049,25 +1129,27 @@ class CrossAttnFn(torch.autograd.Function):
         if hand_in is not None:
             hand_in.arm(drop_p, seed)
         ctx.comp = composites_enabled() and C % 4 == 0
+        (wqk, wkvk, wpk), pc = _wk(wq, wkv, wp)
+        ctx.wk, ctx.pc = (wqk, wkvk, wpk), pc
         if ctx.comp:
             L, Cc = context.shape
             n_saved, _, _, ws_main, _ = _sizes("cross", N, C, H, L, Cc, lvl.n_ca_blocks, lvl.ca_groups)
             saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
-            _capi.call_raw("lotus_crossattn_fwd", x, context, g, b, wq, bq, wkv, bkv, qnw, qnb, knw, knb, wp, bp, y, saved,
+            _capi.call_raw("lotus_crossattn_fwd", x, context, g, b, wqk, bq, wkvk, bkv, qnw, qnb, knw, knb, wpk, bp, y, saved,
                            lvl.ca_tiles, lvl.n_ca_tiles, N, C, H, L, Cc, float(d ** -0.5), float(drop_p), int(seed), float(attn_p),
-                           mix_seed(seed, 1), _PREC, lvl.ca_kmax, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
+                           mix_seed(seed, 1), pc, lvl.ca_kmax, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved)
             return y
         n, mean, rstd = ln_fwd(x, g, b)
-        q, _ = linear_fwd(n, wq, bq)
-        kv, _ = linear_fwd(context, wkv, bkv)
+        q, _ = linear_fwd(n, wqk, bq)
+        kv, _ = linear_fwd(context, wkvk, bkv)
         att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, 2 * C, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
                       att, lse, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
-        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        y, _ = linear_fwd(att, wpk, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, n, q, kv, att, lse, mean, rstd)
         return y
 
@@ -1094,9 +1176,9 @@ class CrossAttnFn(torch.autograd.Function):
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in, context), N)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
-            _capi.call_raw("lotus_crossattn_bwd", dy, dz_in, x, context, g, wq, wkv, qnw, qnb, knw, knb, wp, saved, dx, dctx, dz_out,
+            _capi.call_raw("lotus_crossattn_bwd", dy, dz_in, x, context, g, ctx.wk[0], ctx.wk[1], qnw, qnb, knw, knb, ctx.wk[2], saved, dx, dctx, dz_out,
                            po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L, Cc, float(d ** -0.5),
-                           float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, lvl.ca_kmax, wsm, wsm.numel(), wss,
+                           float(p), int(seed), float(attn_p), mix_seed(seed, 1), ctx.pc, lvl.ca_kmax, wsm, wsm.numel(), wss,
                            wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             d4 = _al4(d)
             o1 = 2 * _al4(C)
@@ -1112,7 +1194,7 @@ class CrossAttnFn(torch.autograd.Function):
         dev = x.device
         dz = _masked(dy, p, seed, hand_in)
         dwp, dbp = linear_wgrad(dz, att)
-        datt = linear_dgrad(dz, wp)
+        datt = linear_dgrad(dz, ctx.wk[2])
         dq = torch.empty(N, C, dtype=x.dtype, device=dev)
         G, L = lvl.ca_groups, kv.shape[0]
         dkv_part = torch.empty(G, L, 2 * C, dtype=x.dtype, device=dev)
@@ -1121,9 +1203,9 @@ class CrossAttnFn(torch.autograd.Function):
                                          2 * C, 0, C, L * 2 * C, 0, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
         dkv = sum_slabs(dkv_part)
         dwkv, dbkv = linear_wgrad(dkv, context)
-        dctx = linear_dgrad(dkv, wkv) if ctx.needs_input_grad[1] else None
+        dctx = linear_dgrad(dkv, ctx.wk[1]) if ctx.needs_input_grad[1] else None
         dwq, dbq = linear_wgrad(dq, n)
-        dn = linear_dgrad(dq, wq)
+        dn = linear_dgrad(dq, ctx.wk[0])
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
         return dx, dctx, dg, db, dwq, dbq, dwkv, dbkv, gq, bq_, gk, bk_, dwp, dbp, None, None, None, None, None, None, None
 
@@ -1153,7 +1235,8 @@ class KvAllFn(torch.autograd.Function):
     @_fwd
     def forward(ctx, context, bank, *wb):
         ws, bs = wb[0::2], wb[1::2]
-        W = torch.cat(ws, 0)
+        wks, _ = _wk(*ws)   # (bf16 storage with weight shadows: the concatenation of the shadows, half the copy)
+        W = torch.cat(wks, 0)
         bias = torch.cat(bs, 0)
         kv, _ = linear_fwd(context, W, bias)
         bank.kv, bank.dkv = kv, None
@@ -1202,23 +1285,25 @@ class CrossAttnKvFn(torch.autograd.Function):
             hand_in.arm(drop_p, seed)
         L, kv_ld = kv.shape[0], kv.stride(0)
         ctx.comp = composites_enabled() and C % 4 == 0
+        (wqk, wpk), pc = _wk(wq, wp)
+        ctx.wk, ctx.pc = (wqk, wpk), pc
         if ctx.comp:
             n_saved, _, _, ws_main, _ = _sizes("crosskv", N, C, H, L, lvl.n_ca_blocks, lvl.ca_groups)
             saved = torch.empty(n_saved, dtype=torch.float32, device=x.device)
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
-            _capi.call_raw("lotus_crossattn_kv_fwd", x, kv, kv_ld, g, b, wq, bq, qnw, qnb, knw, knb, wp, bp, y, saved, lvl.ca_tiles,
-                           lvl.n_ca_tiles, N, C, H, float(d ** -0.5), float(drop_p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC,
+            _capi.call_raw("lotus_crossattn_kv_fwd", x, kv, kv_ld, g, b, wqk, bq, qnw, qnb, knw, knb, wpk, bp, y, saved, lvl.ca_tiles,
+                           lvl.n_ca_tiles, N, C, H, float(d ** -0.5), float(drop_p), int(seed), float(attn_p), mix_seed(seed, 1), pc,
                            lvl.ca_kmax, ws, ws.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(x, kv, g, wq, qnw, qnb, knw, knb, wp, saved)
             return y
         n, mean, rstd = ln_fwd(x, g, b)
-        q, _ = linear_fwd(n, wq, bq)
+        q, _ = linear_fwd(n, wqk, bq)
         att = torch.empty(N, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(N, H, dtype=torch.float32, device=x.device)
         attention_fwd(q, C, 0, kv, kv_ld, 0, C, None, None, None, lvl.ca_tiles, lvl.n_ca_tiles, (qnw, qnb), (knw, knb),
                       att, lse, H, d, attn_p, mix_seed(seed, 1), k_max=lvl.ca_kmax)
-        y, _ = linear_fwd(att, wp, bp, residual=x, drop_p=drop_p, seed=seed)
+        y, _ = linear_fwd(att, wpk, bp, residual=x, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x, kv, g, wq, qnw, qnb, knw, knb, wp, n, q, att, lse, mean, rstd)
         return y
 
@@ -1244,9 +1329,9 @@ class CrossAttnKvFn(torch.autograd.Function):
                 hand_out.ptr, hand_out.dz = dx.data_ptr(), dz_out
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, dy, dz_in), N)
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)
-            _capi.call_raw("lotus_crossattn_kv_bwd", dy, dz_in, x, kv, kv.stride(0), g, wq, qnw, qnb, knw, knb, wp, saved, dx, dkv,
+            _capi.call_raw("lotus_crossattn_kv_bwd", dy, dz_in, x, kv, kv.stride(0), g, ctx.wk[0], qnw, qnb, knw, knb, ctx.wk[1], saved, dx, dkv,
                            dkv.stride(0), dz_out, po, so, grads, tmp, lvl.ca_tiles, lvl.ca_blocks, lvl.n_ca_blocks, G, N, C, H, L,
-                           float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), _PREC, lvl.ca_kmax, wsm, wsm.numel(),
+                           float(d ** -0.5), float(p), int(seed), float(attn_p), mix_seed(seed, 1), ctx.pc, lvl.ca_kmax, wsm, wsm.numel(),
                            wss, wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             d4 = _al4(d)
             o1 = 2 * _al4(C)
@@ -1260,7 +1345,7 @@ class CrossAttnKvFn(torch.autograd.Function):
         dev = x.device
         dz = _masked(dy, p, seed, hand_in)
         dwp, dbp = linear_wgrad(dz, att)
-        datt = linear_dgrad(dz, wp)
+        datt = linear_dgrad(dz, ctx.wk[1])
         dq = torch.empty(N, C, dtype=x.dtype, device=dev)
         G, L = lvl.ca_groups, kv.shape[0]
         if G > 1:
@@ -1274,9 +1359,148 @@ class CrossAttnKvFn(torch.autograd.Function):
         if G > 1:
             call("lotus_sum_slabs_ld", dkv_part, dkv, L, 2 * C, dkv.stride(0), L * 2 * C, G)
         dwq, dbq = linear_wgrad(dq, n)
-        dn = linear_dgrad(dq, wq)
+        dn = linear_dgrad(dq, ctx.wk[0])
         dx, dg, db = ln_bwd(dn, x, mean, rstd, g, add=dy, hand=hand_out)
         return (dx, dkv, dg, db, dwq, dbq, gq, bq_, gk, bk_, dwp, dbp) + (None,) * 9
+
+
+# ------------------------------------------------------------------------------------ (Block, CABlock) pair in one call
+_PAIR = os.environ.get("LOTUS_PAIR", "1") != "0"
+_PP = None  # index tables of csrc/blocks.cpp: enum PairPtr / PairInt (kept in step by tests/test_gpu_round4.py)
+_PP_NAMES = ("X XS KV Y ACTS SAVED CW CWP CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2 B2 W1 B1F W2 B2F G3 B3 WQ BQ CQNW CQNB "
+             "CKNW CKNB CWP2 CBP2 G4 B4 W3 B3F W4 B4F NBR27 ORDER0 CODE0 GIDX OWNER STILES SBLOCKS KEXT EXTPOS CATILES CABLOCKS WS_MAIN "
+             "WS_SIDE WS_CONV CNT_MAIN CNT_SIDE STREAM SIDE DY DX DXS DKV GRADS TMP").split()
+_PI_NAMES = ("M C H HD NPAD NSTILES NEXTRA L NCATILES NCABLOCKS G KMAX NDUP SAME PREC KV_LD DKV_LD WS_MAIN WS_SIDE WS_CONV LINK SEED_SELF "
+             "SEED_FFN1 SEED_CROSS SEED_FFN2").split()
+# parameter slots of PairFn in call order -> their PairPtr names
+_PAIR_PARAM_SLOTS = ("CW CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2 B2 W1 B1F W2 B2F G3 B3 WQ BQ CQNW CQNB CKNW CKNB CWP2 CBP2 "
+                     "G4 B4 W3 B3F W4 B4F").split()
+_PAIR_LINEAR = (2, 8, 14, 18, 20, 24, 30, 34, 36)   # indices (in that order) of the dense-layer weights: candidates for bf16 shadows
+
+
+def pair_enabled():
+    return _PAIR and composites_enabled()
+
+
+def set_pair(on):
+    global _PAIR
+    _PAIR = bool(on)
+
+
+def _pair_tables():
+    global _PP
+    if _PP is None:
+        import numpy as np
+        assert query("lotus_pair_nptr") == len(_PP_NAMES) and query("lotus_pair_nint") == len(_PI_NAMES), \
+            "ops._PP_NAMES / _PI_NAMES are out of step with enum PairPtr / PairInt of csrc/blocks.cpp"
+        _PP = (np, {n: i for i, n in enumerate(_PP_NAMES)}, {n: i for i, n in enumerate(_PI_NAMES)},
+               [_PP_NAMES.index(n) for n in _PAIR_PARAM_SLOTS])
+    return _PP
+
+
+def _pair_grad_sizes(C, H, Hd):
+    key = ("pairgrads", C, H, Hd)
+    v = _SIZE_CACHE.get(key)
+    if v is None:
+        d = C // H
+        assert C % 4 == 0 and d % 4 == 0 and Hd % 4 == 0
+        cpe = [C, C, C * C, C, 27 * C * C, C]
+        att = [C, C, 3 * C * C, 3 * C, d, d, d, d, C * C, C]
+        ffn = [C, C, Hd * C, Hd, C * Hd, C]
+        ca = [C, C, C * C, C, d, d, d, d, C * C, C]
+        v = _SIZE_CACHE[key] = cpe + att + ffn + ca + ffn
+    return v
+
+
+class PairFn(torch.autograd.Function):
+    """Block i + CABlock i of a stage (model_ca.py:270-310) as ONE autograd node over csrc/blocks.cpp lotus_pair_fwd / _bwd:
+    the launches of CpeFn -> SelfAttnFn -> FfnFn -> CrossAttnKvFn -> FfnFn in the same order on the same streams
+    (bit-identical, tests/test_gpu_round4.py), one Python -> C transition and one set of buffers per direction.
+    Inputs: x, xs (x itself in the encoder, the stale skip branch for the first Block of a decoder stage), the block's
+    KvBank slice, the packed convolution weights, the 38 parameters in _PAIR_PARAM_SLOTS order, and a meta tuple."""
+
+    @_fwd
+    def forward(ctx, x, xs, kv, wt, *rest):
+        np, PP, PI, slots = _pair_tables()
+        params, meta = rest[:38], rest[38]
+        lvl, lvl_ca, H, Hd, drop_p, attn_p, s_self, s_f1, s_cross, s_f2, bank, bidx = meta
+        M, C = x.shape
+        L = kv.shape[0]
+        same = xs is x
+        dev = x.device
+        n_acts, n_saved, n_grads, n_tmp, ws_main, ws_side, ws_conv = _sizes(
+            "pair", M, C, H, Hd, lvl.npad, lvl.n_self_tiles, lvl.n_extra, L, lvl_ca.n_ca_blocks, lvl_ca.ca_groups)
+        acts = torch.empty(n_acts, dtype=torch.float32, device=dev)
+        saved = torch.empty(n_saved, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        ws = _ws(ws_main, dev)
+        wc = WS.get(ws_conv, dev, slot=2)
+        # dense-layer weights: bf16 shadows when this forward runs in shadow mode and every one of them has a shadow
+        lin = [params[i] for i in _PAIR_LINEAR]
+        link, pc = _wk(*lin)
+        P = np.zeros(len(_PP_NAMES), dtype=np.uint64)
+        I = np.zeros(len(_PI_NAMES), dtype=np.uint64)
+        for slot, t in zip(slots, params):
+            P[slot] = t.data_ptr()
+        for i, t in zip(_PAIR_LINEAR, link):
+            P[slots[i]] = t.data_ptr()
+        P[PP["X"]], P[PP["XS"]], P[PP["KV"]], P[PP["Y"]] = x.data_ptr(), xs.data_ptr(), kv.data_ptr(), y.data_ptr()
+        P[PP["ACTS"]], P[PP["SAVED"]], P[PP["CWP"]] = acts.data_ptr(), saved.data_ptr(), wt.data_ptr()
+        P[PP["NBR27"]], P[PP["ORDER0"]], P[PP["CODE0"]] = lvl.nbr27.data_ptr(), lvl.order[0].data_ptr(), lvl.code[0].data_ptr()
+        P[PP["GIDX"]], P[PP["OWNER"]], P[PP["STILES"]] = lvl.gidx.data_ptr(), lvl.owner.data_ptr(), lvl.self_tiles.data_ptr()
+        P[PP["SBLOCKS"]], P[PP["KEXT"]], P[PP["EXTPOS"]] = lvl.self_blocks.data_ptr(), lvl.kext.data_ptr(), lvl.ext_pos.data_ptr()
+        P[PP["CATILES"]], P[PP["CABLOCKS"]] = lvl_ca.ca_tiles.data_ptr(), lvl_ca.ca_blocks.data_ptr()
+        P[PP["WS_MAIN"]], P[PP["WS_CONV"]] = ws.data_ptr(), wc.data_ptr()
+        P[PP["CNT_MAIN"]], P[PP["STREAM"]] = _counters(dev).data_ptr(), _capi.stream_ptr()
+        for k, v_ in (("M", M), ("C", C), ("H", H), ("HD", Hd), ("NPAD", lvl.npad), ("NSTILES", lvl.n_self_tiles),
+                      ("NEXTRA", lvl.n_extra), ("L", L), ("NCATILES", lvl_ca.n_ca_tiles), ("NCABLOCKS", lvl_ca.n_ca_blocks),
+                      ("G", lvl_ca.ca_groups), ("KMAX", lvl_ca.ca_kmax), ("NDUP", lvl.n_dup & 0xFFFFFFFF), ("SAME", 1 if same else 0),
+                      ("PREC", pc), ("KV_LD", kv.stride(0)), ("WS_MAIN", ws.numel()), ("WS_CONV", wc.numel()),
+                      ("SEED_SELF", s_self), ("SEED_FFN1", s_f1), ("SEED_CROSS", s_cross), ("SEED_FFN2", s_f2)):
+            I[PI[k]] = v_
+        F = np.array([float(drop_p), float(attn_p), float((C // H) ** -0.5)], dtype=np.float64)
+        _capi.call_raw("lotus_pair_fwd", P.ctypes.data, I.ctypes.data, F.ctypes.data)
+        ctx.save_for_backward(xs, kv, wt, acts, saved)
+        ctx.keep = (params, link)   # parameters (leaves) and their shadows: referenced, not version-tracked
+        ctx.tabs = (P, I, F)
+        ctx.meta = (lvl, lvl_ca, H, Hd, same, bank, bidx, M, C, L)
+        return y
+
+    @_joined
+    def backward(ctx, dy):
+        np, PP, PI, slots = _pair_tables()
+        xs, kv, wt, acts, saved = ctx.saved_tensors
+        params, _ = ctx.keep
+        lvl, lvl_ca, H, Hd, same, bank, bidx, M, C, L = ctx.meta
+        P, I, F = ctx.tabs
+        dev = xs.device
+        dy = dy.contiguous()
+        _, _, n_grads, n_tmp, ws_main, ws_side, ws_conv = _sizes(
+            "pair", M, C, H, Hd, lvl.npad, lvl.n_self_tiles, lvl.n_extra, L, lvl_ca.n_ca_blocks, lvl_ca.ca_groups)
+        grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+        tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
+        dx = torch.empty_like(dy)
+        dxs = None if same else torch.empty_like(xs)
+        dkv = bank.grad_slice(bidx)
+        side, wss, cs = _side_ctx(dev, ws_side, (saved, acts, tmp, dy, xs, kv, lvl.nbr27), M)
+        wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)
+        wc = WS.get(ws_conv, dev, slot=2)
+        P[PP["DY"]], P[PP["DX"]], P[PP["DXS"]] = dy.data_ptr(), dx.data_ptr(), (0 if dxs is None else dxs.data_ptr())
+        P[PP["DKV"]], P[PP["GRADS"]], P[PP["TMP"]] = dkv.data_ptr(), grads.data_ptr(), tmp.data_ptr()
+        P[PP["WS_MAIN"]], P[PP["WS_CONV"]], P[PP["WS_SIDE"]] = wsm.data_ptr(), wc.data_ptr(), (0 if wss is None else wss.data_ptr())
+        P[PP["CNT_MAIN"]], P[PP["CNT_SIDE"]] = _counters(dev).data_ptr(), (0 if cs is None else cs.data_ptr())
+        P[PP["STREAM"]], P[PP["SIDE"]] = _capi.stream_ptr(), side
+        I[PI["WS_MAIN"]], I[PI["WS_CONV"]], I[PI["WS_SIDE"]] = wsm.numel(), wc.numel(), (0 if wss is None else wss.numel())
+        I[PI["DKV_LD"]], I[PI["LINK"]] = dkv.stride(0), _LINK
+        _capi.call_raw("lotus_pair_bwd", P.ctypes.data, I.ctypes.data, F.ctypes.data)
+        g = grads.split(_pair_grad_sizes(C, H, Hd))
+        cw = params[0]
+        out = (g[4].view(cw.shape), g[5], g[2].view(C, C), g[3], g[0], g[1],                                  # cpe
+               g[6], g[7], g[8].view(3 * C, C), g[9], g[10], g[11], g[12], g[13], g[14].view(C, C), g[15],     # self-attention
+               g[16], g[17], g[18].view(Hd, C), g[19], g[20].view(C, Hd), g[21],                               # mlp
+               g[22], g[23], g[24].view(C, C), g[25], g[26], g[27], g[28], g[29], g[30].view(C, C), g[31],     # cross-attention
+               g[32], g[33], g[34].view(Hd, C), g[35], g[36].view(C, Hd), g[37])                               # mlp
+        return (dx, dxs, dkv, None) + out + (None,)
 
 
 class StemFn(torch.autograd.Function):
@@ -1306,7 +1530,9 @@ class PoolFn(torch.autograd.Function):
 
     @_fwd
     def forward(ctx, x, w, bias, g, b, rmean, rvar, child, training):
-        proj, _ = linear_fwd(x, w, bias)
+        (wk,), _ = _wk(w)
+        ctx.wk = wk
+        proj, _ = linear_fwd(x, wk, bias)
         C = w.shape[0]
         pooled = torch.empty(child.n, C, dtype=x.dtype, device=x.device)
         arg = torch.empty(child.n, C, dtype=torch.int32, device=x.device)
@@ -1327,7 +1553,7 @@ class PoolFn(torch.autograd.Function):
         dproj = torch.empty(x.shape[0], C, dtype=x.dtype, device=x.device)
         call("lotus_pool_max_bwd", dpool, arg, child.cluster, x.shape[0], C, dproj)
         dw, dbias = linear_wgrad(dproj, x)
-        dx = linear_dgrad(dproj, w)
+        dx = linear_dgrad(dproj, ctx.wk)
         return dx, dw, dbias, dg, db, None, None, None, None
 
 
@@ -1337,8 +1563,10 @@ class UnpoolFn(torch.autograd.Function):
 
     @_fwd
     def forward(ctx, xc, xp, wu, bu, gu, betau, rmu, rvu, ws_, bs, gs, betas, rms, rvs, child, training):
-        lu, _ = linear_fwd(xc, wu, bu)
-        ls, _ = linear_fwd(xp, ws_, bs)
+        (wuk, wsk), _ = _wk(wu, ws_)
+        ctx.wk = (wuk, wsk)
+        lu, _ = linear_fwd(xc, wuk, bu)
+        ls, _ = linear_fwd(xp, wsk, bs)
         (up, mu, iu), (skip, ms, is_) = bn_fwd_pair(lu, (gu, betau, rmu, rvu), ls, (gs, betas, rms, rvs), training, ACT_GELU)
         x = torch.empty_like(skip)
         call("lotus_unpool_fwd", skip, up, child.cluster, skip.shape[0], skip.shape[1], x)
@@ -1358,9 +1586,9 @@ class UnpoolFn(torch.autograd.Function):
         (dlu, dgu, dbetau), (dls, dgs, dbetas) = bn_bwd_pair((dup, lu, mu, iu, gu, betau), (dsk, ls, ms, is_, gs, betas),
                                                             training, ACT_GELU)
         dwu, dbu = linear_wgrad(dlu, xc)
-        dxc = linear_dgrad(dlu, wu)
+        dxc = linear_dgrad(dlu, ctx.wk[0])
         dws, dbs = linear_wgrad(dls, xp)
-        dxp = linear_dgrad(dls, ws_)
+        dxp = linear_dgrad(dls, ctx.wk[1])
         return dxc, dxp, dwu, dbu, dgu, dbetau, None, None, dws, dbs, dgs, dbetas, None, None, None, None
 
 

@@ -88,6 +88,10 @@ class AdamW(torch.optim.Optimizer):
                   v=ptr([self.state[p]["exp_avg_sq"] for p, _ in plist]),
                   ptrs=[(p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p, _ in plist],
                   partial=torch.empty(max(len(ch), 1), dtype=torch.float64, device=dev))
+        # bf16 weight shadows (ops.WeightShadows, bf16-storage mode): the step rewrites them together with their masters
+        sh = [getattr(p, "_lotus_b16", None) for p, _ in plist]
+        tb["shadow_ptrs"] = [0 if t is None else t.data_ptr() for t in sh]
+        tb["shadow"] = torch.tensor(tb["shadow_ptrs"], dtype=torch.int64, device=dev) if any(tb["shadow_ptrs"]) else None
         self._tables = tb
 
     def _tables_ok(self):
@@ -97,8 +101,16 @@ class AdamW(torch.optim.Optimizer):
         plist = [(p, g) for g in self.param_groups for p in g["params"]]
         if len(plist) != tb["T"]:
             return False
-        return all(len(self.state[p]) and (p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) == q
-                   for (p, _), q in zip(plist, tb["ptrs"]))
+        if not all(len(self.state[p]) and (p.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) == q
+                   for (p, _), q in zip(plist, tb["ptrs"])):
+            return False
+        # a shadow attached (or moved) after the tables were built must be picked up: the step changes the master through a
+        # raw pointer, i.e. without bumping the version counter WeightShadows.refresh() looks at
+        for (p, _), q in zip(plist, tb["shadow_ptrs"]):
+            t = getattr(p, "_lotus_b16", None)
+            if (0 if t is None else t.data_ptr()) != q:
+                return False
+        return True
 
     def _grad_table(self):
         """Per step: gradient pointers (fresh tensors every backward), step sizes and decays -> one pinned upload."""
@@ -159,7 +171,7 @@ class AdamW(torch.optim.Optimizer):
             assert tuple(g["betas"]) == tuple(g0["betas"]) and g["eps"] == g0["eps"], "per-group betas / eps are not built"
         clip = self._clip[1:2] if self._clip is not None else None
         call("lotus_adamw_step", tb["p"], dv[:T], tb["m"], tb["v"], tb["numel"], fl[:T], fl[T:2 * T], tb["chunks"], tb["nchunks"],
-             float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip)
+             float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip, tb["shadow"])
         self._clip = None
         return loss
 

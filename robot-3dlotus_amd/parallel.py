@@ -232,11 +232,18 @@ class GradReducer:
             if not self._flushed[b] and (self.world > 1 or self._pending[b] > 0):
                 self._flush(b)
         self._next = len(self.buckets)
+        timed = self.time_exposed and self.flat.is_cuda
+        if timed:  # how long the backward stream sits behind the last bucket's all-reduce ("exposed" communication)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for h in self._handles:
             h.wait()
         self._handles = []
         if self._comm is not None:
             torch.cuda.current_stream().wait_stream(self._comm)
+        if timed:
+            e1.record()
+            self.exposed_events.append((e0, e1))
         self._keep = []
         if self.world > 1:
             self._sync_usage()
@@ -256,20 +263,35 @@ class GradReducer:
         if self._unused is None or not u.is_cuda:                          # first step (one blocking read) / host tensors
             self._unused = {i for i, f in enumerate(u.tolist()) if not f}
         else:
+            # (a rank-local "my pattern changed -> read now" shortcut would make the flip step exact on THAT
+            # rank only, and ranks that apply different unused sets to one optimiser step diverge; every rank therefore reads
+            # the same one-step-old flags.  An exact flip without a host sync needs the flags on the device side of the
+            # optimiser — a mask argument of lotus_adamw_step — which is not built.)
             if self._usage_pending is not None:                           # last step's flags (long finished)
                 host, ev = self._usage_pending
-                if ev is not None:
-                    ev.synchronize()
+                ev.synchronize()
                 self._unused = {i for i, f in enumerate(host.tolist()) if not f}
-            host = torch.empty(u.shape, dtype=u.dtype, pin_memory=True)
+            else:
+                host, ev = torch.empty(u.shape, dtype=u.dtype, pin_memory=True), torch.cuda.Event()  # reused every step
             host.copy_(u, non_blocking=True)
-            ev = torch.cuda.Event()
             ev.record()
             self._usage_pending = (host, ev)
         for i in self._unused:
             self.params[i].grad = None
 
+
     _unused, _usage_pending = None, None
+    time_exposed = False   # bench.py: record an event pair around the wait in finish()
+    exposed_events = []
+
+    def exposed_comm_ms(self):
+        """Mean GPU time per step the backward stream spent waiting in finish() (time_exposed = True), then reset."""
+        ev, GradReducer.exposed_events = self.exposed_events, []
+        self.exposed_events = []
+        if not ev:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev)
 
 
 _BN_GROUP = None
@@ -294,12 +316,29 @@ def enable_sync_batchnorm(group=None):
     def reduce(sums):
         global BN_MESSAGES
         BN_MESSAGES += 1
+        if BN_TIMING is not None and sums.is_cuda:  # bench.py: event pair around every statistics message
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            e1.record()
+            BN_TIMING.append((e0, e1))
+            return
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # in place, no host sync
 
     ops.BnState.reduce = reduce
 
 
 BN_MESSAGES = 0  # SyncBN all-reduces issued by this process (bench.py reports the count per step)
+BN_TIMING = None  # set to a list to collect (start, end) events of every SyncBN message (bench.py: syncbn_ms per step)
+
+
+def shard_loss_scale(n_local, n_global, world):
+    """Factor for a rank's loss when the ranks hold DIFFERENT numbers of clouds (e.g. shard_clouds on a batch that does not
+    divide evenly): every loss of the model is a mean over the rank's clouds, and the reducer averages the ranks' gradients
+    (DistributedDataParallel semantics, genrobo3d/train/utils/distributed.py:196-205), which weights a cloud on a small
+    shard more than one on a large shard.  loss * n_local * world / n_global restores the gradient of the mean over ALL
+    clouds; with equal shards the factor is 1."""
+    return float(n_local) * float(world) / float(n_global)
 
 
 def shard_clouds(counts, world):

@@ -5,6 +5,8 @@ Module surface kept from the reference: `cls(config.MODEL)`,
 `(final_pred_actions, losses{pos,rot,open,total})`, kwarg `compute_final_action`, properties
 `num_parameters` / `num_trainable_parameters`, and the 460-entry state_dict (Appendix B).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -131,9 +133,24 @@ class SimplePolicyPTV3CA(BaseModel):
     # BASELINE configs[4] (RLBench-18 / PerAct, bf16); runs the lotus_b16_* twins of the C-ABI (include/lotus_hip_b16.h)
     act_storage = None
 
+    # bf16 storage only: the dense layers of the backbone read bf16 SHADOWS of their fp32 master weights (ops.WeightShadows;
+    # refreshed by the fused AdamW in the launch that updates the masters) — "bf16 activations / weights with fp32 master
+    # weights", job_scripts/train_3dlotus_policy_peract.sh:42-44,61.  False keeps converting the fp32 masters per block.
+    weight_shadows = os.environ.get("LOTUS_W_SHADOW", "1") != "0"
+
+    def _shadows(self):
+        ws = getattr(self, "_weight_shadow_set", None)
+        if ws is None:
+            ws = ops.WeightShadows([m.weight for m in self.ptv3_model.modules() if isinstance(m, nn.Linear)])
+            object.__setattr__(self, "_weight_shadow_set", ws)
+        ws.refresh()
+        return ws
+
     def forward(self, batch, compute_loss=False, **kwargs):
         if self.act_storage == "bf16":
-            with ops.storage(torch.bfloat16):
+            if self.weight_shadows:
+                self._shadows()
+            with ops.storage(torch.bfloat16, shadows=self.weight_shadows):
                 return self._forward(batch, compute_loss, **kwargs)
         with ops.precision(self.gemm_precision):
             return self._forward(batch, compute_loss, **kwargs)

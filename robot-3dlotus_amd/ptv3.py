@@ -222,6 +222,7 @@ class PointTransformerV3CA(nn.Module):
         # projections of the shared context are evaluated as one product at the top of forward (ops.KvAllFn)
         self._cablocks = [m for m in self.modules() if isinstance(m, CABlock)]
         self._cab_index = {id(m): i for i, m in enumerate(self._cablocks)}
+        self._pair_params = {}  # (Block, CABlock) -> their 38 parameters in ops._PAIR_PARAM_SLOTS order (module walks cost host time)
         self.kv_group = os.environ.get("LOTUS_KV_GROUP", "1") != "0"
         self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
         self._seed_base = None
@@ -230,10 +231,6 @@ class PointTransformerV3CA(nn.Module):
         self._nbt = None
         self._sync_bn_checked = False
         self.register_load_state_dict_post_hook(lambda m, _keys: setattr(m, "_step", None))
-
-    def _apply(self, fn, *a, **kw):  # .to() / .cuda() replace the buffers: drop the cached handles
-        self._nbt = None
-        return super()._apply(fn, *a, **kw)
 
     def _bn_counters(self):
         """num_batches_tracked of every norm layer — BatchNorm1d, or SyncBatchNorm after convert_sync_batchnorm (not a
@@ -264,6 +261,36 @@ class PointTransformerV3CA(nn.Module):
                 and any(isinstance(m, nn.SyncBatchNorm) for m in self.modules())):
             from . import parallel
             parallel.enable_sync_batchnorm()
+
+    def _pair(self, blk, cab, x, xs, lvl_o, lvl, p, si, pa, wt, bank, mlp_ratio_hd=None):
+        """Block + CABlock as one autograd node (ops.PairFn): same seeds, same launches, same results as blk.run(...) followed by
+        cab.run(...), a fifth of the host work."""
+        key = (id(blk), id(cab))
+        ps = self._pair_params.get(key)
+        if ps is None:
+            c0, c1, c2 = blk.cpe[0], blk.cpe[1], blk.cpe[2]
+            a, n1, n2, m = blk.attn, blk.norm1[0], blk.norm2[0], blk.mlp[0]
+            ca, cn1, cn2, cm = cab.attn, cab.norm1[0], cab.norm2[0], cab.mlp[0]
+            ps = (c0.weight, c0.bias, c1.weight, c1.bias, c2.weight, c2.bias,
+                  n1.weight, n1.bias, a.qkv.weight, a.qkv.bias, a.q_norm.weight, a.q_norm.bias, a.k_norm.weight, a.k_norm.bias,
+                  a.proj.weight, a.proj.bias, n2.weight, n2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                  cn1.weight, cn1.bias, ca.q.weight, ca.q.bias, ca.q_norm.weight, ca.q_norm.bias, ca.k_norm.weight, ca.k_norm.bias,
+                  ca.proj.weight, ca.proj.bias, cn2.weight, cn2.bias, cm.fc1.weight, cm.fc1.bias, cm.fc2.weight, cm.fc2.bias)
+            self._pair_params[key] = ps
+        sc = ops.mix_seed(si, 8)  # the CABlock's seed (cab.run(..., ops.mix_seed(si, 8), ...))
+        meta = (lvl_o, lvl, blk.num_heads, ps[18].shape[0], p, pa, si, ops.mix_seed(si, 2), sc, ops.mix_seed(sc, 2), bank,
+                self._cab_index[id(cab)])
+        return ops.PairFn.apply(x, xs, bank.slice(self._cab_index[id(cab)]), wt, *ps, meta)
+
+    def _pair_ok(self, blk, bank, dpath):
+        c = blk.cpe[0].weight.shape[0]
+        return (bank is not None and dpath == 0.0 and ops.pair_enabled() and c % 64 == 0 and (c == 64 or c % 128 == 0)
+                and c // blk.num_heads % 4 == 0)
+
+    def _apply(self, fn, *a, **kw):  # (parameters may be replaced: drop the cached tuples)
+        self._pair_params = {}
+        self._nbt = None
+        return super()._apply(fn, *a, **kw)
 
     def _pack(self, feat, lvl):
         return PointDict(feat=feat, coord=lvl.coord, offset=lvl.off[1:].long(), level=lvl)
@@ -364,8 +391,11 @@ class PointTransformerV3CA(nn.Module):
             for i in range(self.enc_depths[s]):
                 blk, cab = getattr(enc, f"block{i}"), getattr(enc, f"ca_block{i}")
                 si = seed if i == 0 else ops.mix_seed(seed, 16 + i)
-                x, hand = blk.run(x, x, lvl.for_order(i % n_ord), p, si, pa, packs[blk],
-                                  self.enc_drop_path[s][i] if training else 0.0)
+                dpath = self.enc_drop_path[s][i] if training else 0.0
+                if self._pair_ok(blk, bank, dpath):
+                    x = self._pair(blk, cab, x, x, lvl.for_order(i % n_ord), lvl, p, si, pa, packs[blk], bank)
+                    continue
+                x, hand = blk.run(x, x, lvl.for_order(i % n_ord), p, si, pa, packs[blk], dpath)
                 x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand, bank, cidx[id(cab)])
             skips.append(x)
         outs = [self._pack(x, levels[-1])]
@@ -382,8 +412,11 @@ class PointTransformerV3CA(nn.Module):
                 si = seed if j == 0 else ops.mix_seed(seed, 16 + j)
                 # only the first Block of a decoder stage sees the stale skip branch in its CPE convolution (Trap 3):
                 # every Block / CABlock ends with sparse_conv_feat.replace_feature(feat) (model.py:678, model_ca.py:151)
-                x, hand = blk.run(x, skip if j == 0 else x, lvl.for_order(j % n_ord), p, si, pa, packs[blk],
-                                  self.dec_drop_path[s][j] if training else 0.0)
+                dpath = self.dec_drop_path[s][j] if training else 0.0
+                if self._pair_ok(blk, bank, dpath):
+                    x = self._pair(blk, cab, x, skip if j == 0 else x, lvl.for_order(j % n_ord), lvl, p, si, pa, packs[blk], bank)
+                    continue
+                x, hand = blk.run(x, skip if j == 0 else x, lvl.for_order(j % n_ord), p, si, pa, packs[blk], dpath)
                 x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand, bank, cidx[id(cab)])
             outs.append(self._pack(x, lvl))
         return outs if return_dec_layers else outs[-1]

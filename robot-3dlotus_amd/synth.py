@@ -142,3 +142,41 @@ def augment_clouds(batch, seed=0, max_rot_deg=45.0, noise=0.002):
         start += n
     batch["pc_fts"] = torch.from_numpy(pc)
     return batch
+
+
+def take_clouds(batch, idx):
+    """The sub-batch holding clouds `idx` (in that order) of a synth_batch() dict — what one rank of a data-parallel run gets
+    (parallel.shard_clouds)."""
+    npts, tl = batch["npoints_in_batch"], batch["txt_lens"]
+    po, to = np.concatenate([[0], np.cumsum(npts)]), np.concatenate([[0], np.cumsum(tl)])
+    n2 = [npts[i] for i in idx]
+    out = {
+        "pc_fts": torch.cat([batch["pc_fts"][po[i]:po[i + 1]] for i in idx], 0),
+        "npoints_in_batch": n2,
+        "offset": torch.from_numpy(np.cumsum(n2)).long(),
+        "txt_embeds": torch.cat([batch["txt_embeds"][to[i]:to[i + 1]] for i in idx], 0),
+        "txt_lens": [tl[i] for i in idx],
+        "gt_actions": batch["gt_actions"][list(idx)],
+        "disc_pos_probs": [batch["disc_pos_probs"][i] for i in idx],
+        "ee_poses": batch["ee_poses"][list(idx)],
+        "step_ids": batch["step_ids"][list(idx)],
+    }
+    return out
+
+
+def align_extents(batch):
+    """Give every cloud of a synth_batch() the SAME bounding box by moving its first two points to two common corners (one
+    cell outside the batch's extent).  The reference voxelises relative to the minimum over the rank-local batch and derives
+    the serialisation depth from its maximum (PointTransformerV3/model.py:96-110), so in general a sharded batch is not the
+    full batch split up; with a common box every shard sees the lattice origin and depth of the full batch, which makes
+    "data-parallel over shards == one process over the whole batch" a testable identity."""
+    pc = batch["pc_fts"].clone()
+    lo = pc[:, :3].min(0)[0] - 0.01
+    hi = pc[:, :3].max(0)[0] + 0.01
+    off = np.concatenate([[0], np.cumsum(batch["npoints_in_batch"])])
+    for b in range(len(batch["npoints_in_batch"])):
+        pc[off[b], :3] = lo
+        pc[off[b] + 1, :3] = hi
+    out = dict(batch)
+    out["pc_fts"] = pc
+    return out

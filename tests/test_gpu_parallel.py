@@ -98,6 +98,35 @@ def _worker_body(rank, world, port, q):
     dist.all_gather(rvs, rv)
     res["cross_rank_rv_diff"] = (rvs[0] - rvs[1]).abs().max().item()
     res["finite"] = bool(torch.isfinite(g_r).all())
+    # (c) UNEQUAL shards of one batch (3 clouds / 1 cloud) against a single process on the whole batch.  With a common
+    # bounding box (synth.align_extents) every shard has the lattice origin and serialisation depth of the full batch, the
+    # BatchNorm statistics are over all points (SyncBN messages carry the counts), and parallel.shard_loss_scale turns the
+    # rank average of per-rank means into the mean over all clouds — so every gradient must agree with the one-process run.
+    full = synth.align_extents(synth.synth_batch(4, 500, ragged=True, seed=70))
+    shards = [[0, 1, 2], [3]]
+    parallel.enable_sync_batchnorm()
+    m3 = build()
+    red3 = parallel.GradReducer(m3, bucket_mb=0.5)
+    red3.zero_grad()
+    mine = synth.take_clouds(full, shards[rank])
+    _, l3 = m3(dev(mine), compute_loss=True, compute_final_action=False)
+    (l3["total"] * parallel.shard_loss_scale(len(shards[rank]), 4, world)).backward()
+    red3.finish()
+    torch.cuda.synchronize()
+    g3 = torch.cat([p.grad.flatten() for p in m3.parameters()]).clone()
+    rv3 = m3.ptv3_model.enc.enc1.down.norm[0].running_var.clone()
+    ops.BnState.reduce = None
+    m4 = build()
+    g4 = run(m4, full, None)
+    res["unequal_shards_rel_err"] = ((g3 - g4).norm() / g4.norm()).item()
+    per = []
+    o = 0
+    for p_ in m4.parameters():
+        a, b = g3[o:o + p_.numel()], g4[o:o + p_.numel()]
+        per.append(((a - b).norm() / (b.norm() + 1e-3 * g4.norm())).item())
+        o += p_.numel()
+    res["unequal_shards_worst_param"] = max(per)
+    res["unequal_shards_rv_err"] = (rv3 - m4.ptv3_model.enc.enc1.down.norm[0].running_var).abs().max().item()
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -139,6 +168,8 @@ def test_two_rank_data_parallel_on_device():
         assert res["replicated_rv_err"] < 1e-6, res
         assert res["cross_rank_diff"] == 0.0, res
         assert res["cross_rank_rv_diff"] == 0.0, res
+        assert res["unequal_shards_rel_err"] < 1e-5 and res["unequal_shards_worst_param"] < 1e-5, res
+        assert res["unequal_shards_rv_err"] < 1e-6, res
 
 
 def test_bench_self_launches_its_ranks():

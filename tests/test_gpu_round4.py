@@ -163,3 +163,115 @@ def test_model_with_grouped_kv_matches_per_block_projections(preset, n):
     gmax = max(float(v.norm()) for v in ga.values())
     worst = max((float((ga[k] - gb[k]).norm()) / (float(ga[k].norm()) + 1e-3 * gmax), k) for k in ga)
     assert worst[0] <= 1e-5, worst
+
+
+def _peract_model(shadows, seed=93):
+    from robot_3dlotus_amd import config as lcfg
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("peract")
+    sd = seeded_state_dict(gu.state_template(cfg), seed, "scaled")
+    m = SimplePolicyPTV3CA(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().train()
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0
+    m.act_proj_head.dropout = 0.0
+    m.act_storage = "bf16"
+    m.weight_shadows = shadows
+    m.ptv3_model.order_perms = [[3, 1, 0, 2], [0, 2, 1, 3], [1, 0, 3, 2], [2, 3, 1, 0], [0, 1, 2, 3]]
+    return m
+
+
+def test_bf16_weight_shadows_are_bit_identical_to_per_block_conversion_and_follow_the_optimiser():
+    """BASELINE configs[4], "bf16 weights with fp32 master weights": with ops.WeightShadows the dense layers read a bf16 copy
+    of every weight (precision 5) instead of converting the fp32 master per block — the MFMA operands are the same bf16
+    values, so logits, losses and every gradient are BIT-identical.  The fused AdamW rewrites the shadows in the launch that
+    updates the masters (no version bump involved), another in-place change of a master triggers a recast."""
+    from types import SimpleNamespace
+    from robot_3dlotus_amd import optim as loptim, synth
+
+    batch = synth.augment_clouds(synth.synth_batch(2, 2048, ragged=True, seed=323), seed=10, max_rot_deg=45.0)
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v))
+           for k, v in batch.items()}
+    res = []
+    for shadows in (False, True):
+        m = _peract_model(shadows)
+        _, losses = m(dict(dev), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        torch.cuda.synchronize()
+        res.append((m, m.last_pred[0].detach().clone(), losses["total"].detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    (m0, x0, l0, g0), (m1, x1, l1, g1) = res
+    n_sh = sum(1 for p in m1.parameters() if getattr(p, "_lotus_b16", None) is not None)
+    assert n_sh >= 80 and not any(hasattr(p, "_lotus_b16") for p in m0.parameters())
+    assert torch.equal(x0, x1) and torch.equal(l0, l1)
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # the optimiser step keeps shadow == bf16(master) without any recast
+    topts = SimpleNamespace(learning_rate=1e-3, weight_decay=0.05, optim="adamw", betas=[0.9, 0.98], lr_sched="cosine",
+                            warmup_steps=1, num_train_steps=100, grad_norm=10.0)
+    opt, _ = loptim.build_optimizer(m1, topts)
+    before = {id(p): p.detach().clone() for p in m1.parameters()}
+    opt.clip_grad_norm_(10.0)
+    opt.step()
+    torch.cuda.synchronize()
+    changed = 0
+    for p in m1.parameters():
+        sh = getattr(p, "_lotus_b16", None)
+        if sh is not None:
+            assert torch.equal(sh, p.detach().to(torch.bfloat16)), "shadow not refreshed by the fused AdamW"
+            changed += int(not torch.equal(before[id(p)], p.detach()))
+    assert changed >= 80
+    # any other in-place update bumps the version counter -> the next forward recasts
+    w = m1.ptv3_model.enc.enc0.block0.mlp[0].fc1.weight
+    with torch.no_grad():
+        w.mul_(1.5)
+    assert not torch.equal(w._lotus_b16, w.detach().to(torch.bfloat16))
+    for p in m1.parameters():
+        p.grad = None
+    m1(dict(dev), compute_loss=True, compute_final_action=False)
+    torch.cuda.synchronize()
+    assert torch.equal(w._lotus_b16, w.detach().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("join", ["node", "end"])
+@pytest.mark.parametrize("preset,n,aug,storage", [("tiny", 700, False, None), ("v1", 900, True, None), ("v1", 900, False, "bf16")])
+def test_pair_node_is_bit_identical_to_the_five_sub_block_nodes(preset, n, aug, storage, join):
+    """ops.PairFn (one autograd node + one C call per (Block, CABlock) pair and direction, csrc/blocks.cpp lotus_pair_*)
+    against the five per-sub-block nodes it replaces: train mode with dropout ON, encoder and decoder stages (the decoder's
+    first Block convolves the stale skip branch), duplicate voxels, both weight-gradient join modes, fp32 and bf16 storage —
+    logits, losses and every gradient bit for bit."""
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset(preset)
+    sd = seeded_state_dict(gu.state_template(cfg), 9, "scaled")
+    batch = synth.synth_batch(3, n, ragged=True, seed=6)
+    if aug:
+        batch = synth.augment_clouds(batch, seed=7)
+    perms = [[1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 0, 2, 3]][:len(cfg.ptv3_config.enc_channels)]
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v))
+           for k, v in batch.items()}
+    res = []
+    try:
+        ops.set_wgrad_join(join)
+        for pair in (False, True):
+            ops.set_pair(pair)
+            torch.manual_seed(3)
+            m = SimplePolicyPTV3CA(cfg)
+            m.load_state_dict(sd)
+            m = m.cuda().train()
+            m.act_storage = storage
+            m.ptv3_model.order_perms = perms
+            _, losses = m(dict(dev), compute_loss=True, compute_final_action=False)
+            losses["total"].backward()
+            torch.cuda.synchronize()
+            res.append((m.last_pred[0].detach().clone(), losses["total"].detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    finally:
+        ops.set_pair(True)
+        ops.set_wgrad_join("node")
+    (xa, la, ga), (xb, lb, gb) = res
+    assert torch.equal(xa, xb) and torch.equal(la, lb)
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))

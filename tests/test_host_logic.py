@@ -283,3 +283,81 @@ def test_dropout_seed_streams():
     assert len(seeds) == 4 * 50 * 12
     lows = sorted(s & 0xFFFFFFFF for s in seeds)
     assert min(b - a for a, b in zip(lows, lows[1:])) > 0 and len({s >> 32 for s in seeds}) == len(seeds)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world 4, UNEQUAL shards: clouds assigned by parallel.shard_clouds (snake order over the point counts),
+# every rank's loss — a mean over ITS clouds, like every loss of the model — scaled by parallel.shard_loss_scale, gradients
+# averaged by the GradReducer: the result must be the gradient of the mean over ALL clouds computed by one process.
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from robot_3dlotus_amd import parallel
+
+    torch.manual_seed(0)
+    torch.set_num_threads(1)
+    r, _, w = parallel.init_distributed(backend="gloo")
+    counts = [5, 17, 3, 9, 12, 7, 4, 21, 6, 11, 8]          # 11 clouds over 4 ranks: shards of 3 / 3 / 3 / 2 clouds
+    g = torch.Generator().manual_seed(7)
+    clouds = [torch.randn(n, 6, generator=g) for n in counts]
+    tgts = [torch.randn(4, generator=g) for _ in counts]
+
+    def net():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.GELU(), torch.nn.Linear(16, 4))
+
+    def cloud_loss(m, i):  # per-cloud loss: features max-pooled over the cloud's points (as the policy head does)
+        return (m(clouds[i]).max(0)[0] - tgts[i]).square().mean()
+
+    shards = parallel.shard_clouds(counts, w)
+    assert sorted(i for s_ in shards for i in s_) == list(range(len(counts))) and len({len(s_) for s_ in shards}) > 1
+    mine = shards[r]
+    m = net()
+    red = parallel.GradReducer(m, bucket_mb=0.00005)
+    ok = True
+    for step in range(2):
+        red.zero_grad()
+        loss = sum(cloud_loss(m, i) for i in mine) / len(mine)
+        (loss * parallel.shard_loss_scale(len(mine), len(counts), w)).backward()
+        red.finish()
+        got = torch.cat([p.grad.flatten() for p in m.parameters()])
+        ref = net()
+        (sum(cloud_loss(ref, i) for i in range(len(counts))) / len(counts)).backward()
+        want = torch.cat([p.grad.flatten() for p in ref.parameters()])
+        ok = ok and float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # and WITHOUT the scale the plain rank average is a different (shard-size weighted) gradient: the factor matters
+        if step == 0:
+            red.zero_grad()
+            (sum(cloud_loss(m, i) for i in mine) / len(mine)).backward()
+            red.finish()
+            plain = torch.cat([p.grad.flatten() for p in m.parameters()])
+            ok = ok and float((plain - want).abs().max()) > 1e-4 * float(want.abs().max())
+    pts = [sum(counts[i] for i in s_) for s_ in shards]
+    q.put((rank, bool(ok), {"points_per_rank": pts, "imbalance": max(pts) / (sum(pts) / w)}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_shards_world4_gloo_match_the_single_process_gradient():
+    import queue
+
+    def run(port):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_shard_worker, args=(r, 4, port, q)) for r in range(4)]
+        for p in ps:
+            p.start()
+        try:
+            res = [q.get(timeout=120) for _ in ps]
+        except queue.Empty:
+            res = None
+        for p in ps:
+            p.join(timeout=5 if res is None else 60)
+            if p.is_alive():
+                p.kill()
+        return res
+
+    res = run(30500 + (os.getpid() % 2000)) or run(34500 + (os.getpid() % 2000))
+    assert res is not None, "gloo workers did not finish"
+    assert all(r[1] for r in res), res
+    assert res[0][2]["imbalance"] < 1.25, res[0][2]   # snake assignment keeps the point counts within 25 % of the mean
