@@ -10,6 +10,10 @@ Per kernel family (counter passes serialise the kernels, so durations are stand-
   * MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (SIMD-cycles of the launch) with SIMD-cycles = GRBM_GUI_ACTIVE / 8 XCDs
     x 1024 SIMDs.  Calibration: the 65536 x 128 x 512 fp32 GEMM issues 2 M N K / 4096 = 2 097 152 v_mfma_f32_32x32x2_f32
     of 64 cycles each = 134 217 728 busy cycles — exactly the counter value;
+    NORMALISATION: GRBM_GUI_ACTIVE spans more than the kernel's own execution (`effective_clock_GHz` =
+    GRBM_GUI_ACTIVE / 8 / duration reads 2.6-2.9 for short kernels, above the 2.4 GHz maximum), so this quotient UNDERSTATES the
+    utilisation by up to ~1.2x; `mfma_util_time` = busy cycles / (stand-alone duration x 2.4 GHz x 1024 SIMDs) is the
+    time-normalised figure at the peak clock (an upper bound of the error the other way: the clock may sit below 2.4 GHz);
   * where the waves' time goes: SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY (issue stalls: MFMA RAW / pipe) / SQ_WAIT_ANY
     (parked on s_waitcnt or a barrier) as fractions of SQ_WAVE_CYCLES; SQ_WAIT_INST_LDS share.
 The .so hash the passes ran against is stored; bench.py only reports `traffic` when it matches the library it loaded."""
@@ -77,8 +81,10 @@ def main(tag, fetch_dir, write_dir, sq_dir, sha_file):
     lines = [f"# {tag}: SQ / HBM counters per kernel family (rocprofv3 --pmc, kernels serialised)\n",
              "MFMA util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); wave-time split = fractions of SQ_WAVE_CYCLES; "
              "GB/s = (2 x FETCH_SIZE + WRITE_SIZE) / stand-alone duration.\n",
-             "| kernel family | launches/step | avg us | HBM MB/launch (fetch + write) | GB/s | MFMA util | active | issue-stall | parked (waitcnt/barrier) | LDS-issue share |",
-             "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+             "MFMA util (time) = the same busy cycles / (stand-alone duration x 2.4 GHz x 1024 SIMDs): GRBM_GUI_ACTIVE covers more than the "
+             "kernel (effective clock > 2.4 GHz on short kernels), so the first column is a lower bound.\n",
+             "| kernel family | launches/step | avg us | HBM MB/launch (fetch + write) | GB/s | MFMA util | MFMA util (time) | active | issue-stall | parked (waitcnt/barrier) | LDS-issue share |",
+             "|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     steps = 5.0  # 2 warm-up + 3 timed steps in every pass
     for f, v in sorted(fam.items(), key=lambda kv: -kv[1]["dur_s"]):
         nf, nw, ns = max(v["n_f"], 1), max(v["n_w"], 1), max(v["n_s"], 1)
@@ -87,17 +93,18 @@ def main(tag, fetch_dir, write_dir, sq_dir, sha_file):
         gbps = (fetch + write) / (dur_us * 1e-6) / 1e9 if dur_us else 0.0
         simd_cycles = v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
         util = v["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles if simd_cycles else 0.0
+        util_t = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["dur_s"] * 2.4 * 1024.0) if v["dur_s"] else 0.0  # dur in ns x 2.4 cycles/ns
         wc = max(v["SQ_WAVE_CYCLES"], 1.0)
         rec = {"launches_per_step": round(v["n_s"] / steps, 1), "avg_us": round(dur_us, 2),
                "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                "hbm_bytes_per_launch": round(fetch + write), "achieved_GBps": round(gbps, 1),
-               "mfma_util": round(util, 4), "wave_active": round(v["SQ_ACTIVE_INST_ANY"] / wc, 4),
+               "mfma_util": round(util, 4), "mfma_util_time": round(util_t, 4), "wave_active": round(v["SQ_ACTIVE_INST_ANY"] / wc, 4),
                "wave_issue_stall": round(v["SQ_WAIT_INST_ANY"] / wc, 4), "wave_parked": round(v["SQ_WAIT_ANY"] / wc, 4),
                "lds_issue_stall": round(v["SQ_WAIT_INST_LDS"] / wc, 4),
                "effective_clock_GHz": round(v["GRBM_GUI_ACTIVE"] / 8.0 / max(v["dur_s"], 1.0), 3)}
         out["kernels"][f] = rec
         lines.append(f"| `{f}` | {rec['launches_per_step']} | {rec['avg_us']} | {fetch / 1e6:.2f} + {write / 1e6:.2f} | {gbps:.0f} | "
-                     f"{util:.3f} | {rec['wave_active']:.2f} | {rec['wave_issue_stall']:.2f} | {rec['wave_parked']:.2f} | {rec['lds_issue_stall']:.3f} |")
+                     f"{util:.3f} | {util_t:.3f} | {rec['wave_active']:.2f} | {rec['wave_issue_stall']:.2f} | {rec['wave_parked']:.2f} | {rec['lds_issue_stall']:.3f} |")
     json.dump(out, open(os.path.join(here, f"{tag}_pmc.json"), "w"), indent=1)
     open(os.path.join(here, f"{tag}_sq.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))

@@ -36,9 +36,16 @@ def _compile(job):
     deps = [os.path.join(HERE, src)] + [os.path.join(HERE, h) for h in HEADERS] + PUBLIC + ([RENAME] if b16 else [])
     if not _stale(obj, deps):
         return obj, ""
-    extra = ["-DLOTUS_ACT_BF16", "-include", RENAME] if b16 else []
-    cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(HERE, src), "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    # Reproducible objects: hipcc derives the compilation-unit id (-cuid, baked into symbol names of
+    # the device code) from the ABSOLUTE input path and embeds the output name, so the same sources built in another
+    # directory gave a library with a different hash than the one the profiles were taken on.  Compile with relative
+    # names from the source directory and a fixed cuid per object: the bytes then depend on the sources and the
+    # toolchain only.
+    extra = ["-DLOTUS_ACT_BF16", "-include", os.path.basename(RENAME)] if b16 else []
+    oname = os.path.basename(obj)
+    cmd = ([HIPCC] + FLAGS + ["-cuid=lotus-" + os.path.splitext(oname)[0], "-ffile-prefix-map=" + HERE + "=."] + extra +
+           (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", oname])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=HERE)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
     return obj, r.stderr
@@ -58,8 +65,8 @@ def build(force=False):
     with cf.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 8)) as ex:
         objs = [o for o, _ in ex.map(_compile, jobs)]
     if _stale(LIB, objs):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
-                           capture_output=True, text=True)
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.basename(LIB)] +
+                           [os.path.basename(o) for o in objs], capture_output=True, text=True, cwd=HERE)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
     build_fastcall()

@@ -181,36 +181,39 @@ class FrontEnd:
             return (start, arr.size)
 
         ctx_off = np.concatenate([[0], np.cumsum(ctx_counts)]).astype(np.int64)
+        ctx_cnt = np.asarray(ctx_counts, dtype=np.int64)
         plans = []
+        ar_b = np.arange(B)
         for s in range(Lv):
+            # vectorised over the clouds (a Python loop per cloud and tile cost 0.7 ms of host time per step)
             c = cnt_h[s].astype(np.int64)
             off = np.concatenate([[0], np.cumsum(c)])
             cpad = np.where(c > K, (c + K - 1) // K * K, c)
             offp = np.concatenate([[0], np.cumsum(cpad)])
-            tiles, blocks = [], []
-            for b in range(B):
-                if c[b] == 0:
-                    continue
-                if c[b] <= K:
-                    segs = [(offp[b], c[b])]
-                else:
-                    segs = [(offp[b] + i * K, K) for i in range(int(cpad[b] // K))]
-                for st, ln in segs:
-                    blocks.append((len(tiles), 1, 1, 0, st, ln))
-                    tiles.append((st, ln, st, ln))
-            ca_tiles, ca_blocks = [], []
-            max_t = int(max(1, max((c[b] + 127) // 128 for b in range(B))))
-            G = min(8, max_t)
-            for b in range(B):
-                base = len(ca_tiles)
-                nt = int((c[b] + 127) // 128)
-                for i in range(nt):
-                    ca_tiles.append((off[b] + i * 128, min(128, c[b] - i * 128), ctx_off[b], ctx_counts[b]))
-                for g in range(G):
-                    ca_blocks.append((base + g, max(0, (nt - g + G - 1) // G), G, g, ctx_off[b], ctx_counts[b]))
+            # self-attention patches: one tile per patch of <= K serialised points (a short cloud is one tile)
+            nseg = np.where(c == 0, 0, np.where(c <= K, 1, cpad // K))
+            nt_self = int(nseg.sum())
+            cb = np.repeat(ar_b, nseg)
+            within = np.arange(nt_self) - np.repeat(np.cumsum(nseg) - nseg, nseg)
+            st = offp[cb] + within * K
+            ln = np.where(c[cb] <= K, c[cb], K)
+            tiles = np.stack([st, ln, st, ln], 1)
+            blocks = np.stack([np.arange(nt_self), np.ones(nt_self, np.int64), np.ones(nt_self, np.int64), np.zeros(nt_self, np.int64), st, ln], 1)
+            # cross-attention: 128-row tiles of a cloud's points x that cloud's instruction tokens; backward blocks = G
+            # interleaved tile groups per cloud (one key-side partial slot each)
+            nt = (c + 127) // 128
+            G = int(min(8, max(1, int(nt.max()) if B else 1)))
+            n_ca = int(nt.sum())
+            cbt = np.repeat(ar_b, nt)
+            base = np.cumsum(nt) - nt
+            ti = np.arange(n_ca) - np.repeat(base, nt)
+            ca_tiles = np.stack([off[cbt] + ti * 128, np.minimum(128, c[cbt] - ti * 128), ctx_off[cbt], ctx_cnt[cbt]], 1)
+            gb = np.repeat(ar_b, G)
+            gg = np.tile(np.arange(G), B)
+            ca_blocks = np.stack([base[gb] + gg, np.maximum(0, (nt[gb] - gg + G - 1) // G), np.full(B * G, G), gg, ctx_off[gb], ctx_cnt[gb]], 1)
             plans.append(dict(off=push(off), offp=push(offp), tiles=push(tiles), blocks=push(blocks),
-                              ca_tiles=push(ca_tiles), ca_blocks=push(ca_blocks), n_tiles=len(tiles),
-                              n_ca_tiles=len(ca_tiles), n_ca_blocks=len(ca_blocks), G=G, npad=int(offp[-1]),
+                              ca_tiles=push(ca_tiles), ca_blocks=push(ca_blocks), n_tiles=nt_self,
+                              n_ca_tiles=n_ca, n_ca_blocks=B * G, G=G, npad=int(offp[-1]),
                               off_host=off))
         ntab = sum(a.size for a in host_tabs)
         tabs_h = torch.empty(ntab, dtype=torch.int32, pin_memory=True)  # pinned: the upload must not drain the queue

@@ -1365,7 +1365,14 @@ class CrossAttnKvFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------ (Block, CABlock) pair in one call
-_PAIR = os.environ.get("LOTUS_PAIR", "1") != "0"
+# "auto" (default): the pair node is used where the step is HOST-bound — bf16 storage, or fewer than ~40 k points per
+# step — and the five sub-block nodes where it is GPU-bound.  Measured on MI355X (A/B inside one call): the pair node lowers
+# the host's enqueue time per step from 12.1 to 8.4 ms and lifts the PerAct bf16 step at 16 clouds from 1216-1356 to
+# 1447-1452 samples/s, but costs the fp32 step at 16 x 4096 points 1.5 % (880 -> 866): its temporaries of all five
+# sub-blocks are one allocation per pair, while separate nodes hand the same few hundred MB back to the allocator and get
+# them again for the next sub-block (smaller live footprint in the 256 MB Infinity Cache / TLB).
+_PAIR = {"0": False, "1": True}.get(os.environ.get("LOTUS_PAIR", "auto"), "auto")
+_PAIR_AUTO_ROWS = 40000
 _PP = None  # index tables of csrc/blocks.cpp: enum PairPtr / PairInt (kept in step by tests/test_gpu_round4.py)
 _PP_NAMES = ("X XS KV Y ACTS SAVED CW CWP CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2 B2 W1 B1F W2 B2F G3 B3 WQ BQ CQNW CQNB "
              "CKNW CKNB CWP2 CBP2 G4 B4 W3 B3F W4 B4F NBR27 ORDER0 CODE0 GIDX OWNER STILES SBLOCKS KEXT EXTPOS CATILES CABLOCKS WS_MAIN "
@@ -1378,13 +1385,19 @@ _PAIR_PARAM_SLOTS = ("CW CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2
 _PAIR_LINEAR = (2, 8, 14, 18, 20, 24, 30, 34, 36)   # indices (in that order) of the dense-layer weights: candidates for bf16 shadows
 
 
-def pair_enabled():
-    return _PAIR and composites_enabled()
+def pair_enabled(rows0=0):
+    """rows0: points of the step at the input level (the "auto" rule looks at it)."""
+    if not composites_enabled():
+        return False
+    if _PAIR == "auto":
+        return _capi.BF16 or rows0 <= _PAIR_AUTO_ROWS
+    return _PAIR
 
 
 def set_pair(on):
+    """True / False, or "auto" (see above)."""
     global _PAIR
-    _PAIR = bool(on)
+    _PAIR = on if on == "auto" else bool(on)
 
 
 def _pair_tables():

@@ -284,7 +284,7 @@ class PointTransformerV3CA(nn.Module):
 
     def _pair_ok(self, blk, bank, dpath):
         c = blk.cpe[0].weight.shape[0]
-        return (bank is not None and dpath == 0.0 and ops.pair_enabled() and c % 64 == 0 and (c == 64 or c % 128 == 0)
+        return (bank is not None and dpath == 0.0 and self._pair_on and c % 64 == 0 and (c == 64 or c % 128 == 0)
                 and c // blk.num_heads % 4 == 0)
 
     def _apply(self, fn, *a, **kw):  # (parameters may be replaced: drop the cached tuples)
@@ -373,6 +373,7 @@ class PointTransformerV3CA(nn.Module):
                              st.norm.running_var, levels[0], training)
         ops.sync_side_stream()  # the packed convolution weights (they overlapped the stem)
         bank, cidx = None, self._cab_index
+        self._pair_on = ops.pair_enabled(levels[0].n)
         if self.kv_group and context is not None and len(self._cablocks) > 1:
             bank = ops.KvBank()
             wb = []

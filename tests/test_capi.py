@@ -132,3 +132,34 @@ def test_documented_ctypes_binding_runs_the_model_on_the_gpu(built):
     r = subprocess.run([sys.executable, "-c", _CTYPES_SMOKE.format(root=root)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, LOTUS_NO_FASTCALL="1"))
     assert r.returncode == 0 and "ctypes-path ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_objects_do_not_depend_on_the_build_directory(tmp_path):
+    """a library rebuilt from the same sources in another checkout must hash like the one the committed
+    counter profiles were taken on.  hipcc derives its compilation-unit id from the absolute input path unless told otherwise;
+    build.py therefore compiles with relative names and a fixed -cuid.  One small translation unit, two directories."""
+    import hashlib
+    import shutil
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "robot-3dlotus_amd", "csrc")
+    sys.path.insert(0, csrc)
+    import build as lbuild
+
+    if not os.path.exists(lbuild.HIPCC):
+        pytest.skip("hipcc not installed")
+    hashes = []
+    for name in ("a", "deeper/nested/b"):
+        d = tmp_path / name / "robot-3dlotus_amd" / "csrc"
+        d.mkdir(parents=True)
+        inc = tmp_path / name / "include"
+        inc.mkdir()
+        for f in ("optim.hip", "common.h"):
+            shutil.copy(os.path.join(csrc, f), d / f)
+        cmd = [lbuild.HIPCC] + lbuild.FLAGS + ["-cuid=lotus-optim", f"-ffile-prefix-map={d}=.", "-x", "hip", "-c", "optim.hip", "-o", "optim.o"]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes.append(hashlib.sha256((d / "optim.o").read_bytes()).hexdigest())
+    assert hashes[0] == hashes[1]

@@ -269,7 +269,7 @@ def test_pair_node_is_bit_identical_to_the_five_sub_block_nodes(preset, n, aug, 
             torch.cuda.synchronize()
             res.append((m.last_pred[0].detach().clone(), losses["total"].detach().clone(), [p.grad.clone() for p in m.parameters()]))
     finally:
-        ops.set_pair(True)
+        ops.set_pair("auto")
         ops.set_wgrad_join("node")
     (xa, la, ga), (xb, lb, gb) = res
     assert torch.equal(xa, xb) and torch.equal(la, lb)
