@@ -3,15 +3,16 @@
 # 1. the three counter passes (profiles/pmc_passes.sh)  2. a kernel trace of 30 steps  3. the bench lines quoted in
 # profiles/<tag>_bench.json.  Everything lands under gpurun_out/; profiles/assemble.py turns it into the committed files.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/prof gpurun_out/bench_$TAG
 bash profiles/pmc_passes.sh $TAG > gpurun_out/pmc_${TAG}.log 2>&1
+BENCH_ARGS="--workload peract" bash profiles/pmc_passes.sh ${TAG}p > gpurun_out/pmc_${TAG}p.log 2>&1
 rm -f gpurun_out/prof/${TAG}z_*
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}z -- python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-other-modes --no-roofline --no-fresh-batches > gpurun_out/prof/${TAG}z.log 2>&1
 O=gpurun_out/bench_$TAG
 python bench.py --steps 30 --warmup 10 2>$O/headline.err | tail -1 > $O/headline.json
-Q="--no-cpu-baseline --no-roofline --no-fresh-batches"
+Q="--no-cpu-baseline --no-roofline --no-fresh-batches --no-side-workloads"
 python bench.py --with-optimizer $Q --no-other-modes 2>/dev/null | tail -1 > $O/with_optimizer.json
 python bench.py --workload mp $Q --no-other-modes 2>/dev/null | tail -1 > $O/mp.json
 python bench.py --workload peract $Q --no-other-modes 2>/dev/null | tail -1 > $O/peract.json

@@ -4,7 +4,7 @@
 # Separate --pmc passes with --kernel-trace only (FETCH_SIZE and WRITE_SIZE do not fit one pass; MI355X_MICROARCH.md
 # "rocprofv3 PMC slots").  Outputs land in gpurun_out/pmc_<tag>_{fetch,write,sq}/.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-other-modes --no-fresh-batches ${BENCH_ARGS:-}"  # e.g. BENCH_ARGS="--workload peract" with tag r03p
 mkdir -p gpurun_out

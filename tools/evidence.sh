@@ -1,0 +1,20 @@
+#!/bin/bash
+# Round evidence in ONE gpurun call: full GPU test suite (-> parity ledger), counter passes, kernel traces, bench lines; the
+# summaries are assembled on the box and copied to gpurun_out/profiles_<tag>/ (the raw traces are too large to travel back).
+TAG=${1:-r04}
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+rm -f gpurun_out/parity_ledger.json
+python -m pytest tests -m gpu -q --timeout 1200 2>&1 | tail -8 > gpurun_out/gpu_tests_$TAG.log
+bash profiles/collect.sh $TAG > gpurun_out/collect_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o ${TAG}pz -- python bench.py --workload peract --steps 20 --warmup 10 --no-cpu-baseline --no-other-modes --no-roofline --no-fresh-batches > gpurun_out/prof/${TAG}pz.log 2>&1
+python profiles/assemble.py $TAG > gpurun_out/assemble_$TAG.log 2>&1
+python profiles/pmc_report.py ${TAG}p gpurun_out/pmc_${TAG}p_fetch gpurun_out/pmc_${TAG}p_write gpurun_out/pmc_${TAG}p_sq gpurun_out/pmc_${TAG}p_so.sha >> gpurun_out/assemble_$TAG.log 2>&1
+python profiles/summarize.py gpurun_out/prof/${TAG}pz_results.db 30 > profiles/${TAG}p_kernels.md 2>> gpurun_out/assemble_$TAG.log
+python tools/host_floor.py > gpurun_out/host_floor_$TAG.txt 2>&1
+LOTUS_PAIR=0 python tools/host_floor.py > gpurun_out/host_floor_${TAG}_nopair.txt 2>&1
+mkdir -p gpurun_out/profiles_$TAG
+cp profiles/${TAG}* gpurun_out/profiles_$TAG/ 2>/dev/null
+cp gpurun_out/parity_ledger.json gpurun_out/profiles_$TAG/${TAG}_parity.json 2>/dev/null
+rm -rf gpurun_out/pmc_${TAG}_fetch gpurun_out/pmc_${TAG}_write gpurun_out/pmc_${TAG}_sq gpurun_out/pmc_${TAG}p_fetch gpurun_out/pmc_${TAG}p_write gpurun_out/pmc_${TAG}p_sq gpurun_out/prof
+cat gpurun_out/gpu_tests_$TAG.log; tail -5 gpurun_out/assemble_$TAG.log; cat gpurun_out/host_floor_$TAG.txt | head -3; du -sh gpurun_out
