@@ -205,7 +205,9 @@ int lotus_batchnorm_bwd_apply(const lotus_act_t* dy, const lotus_act_t* x, const
  * drop_p / drop_seed: dropout on the probabilities (flash-attn dropout_p), regenerated in backward.
  * k_max: the caller's upper bound of k_len over all tiles (0 = unknown).  With identity-indexed rows (qidx = kidx = owner =
  * null) and 0 < k_max <= 32 — the point <-> instruction cross attention, whose key side is a cloud's 6-19 tokens — the call
- * takes the short-key kernels (one lane per query, keys / values as LDS broadcast rows, exact fp32 whatever `precision`). */
+ * takes the short-key kernels (one lane per query, keys / values as LDS broadcast rows, exact fp32 whatever `precision`).
+ * k_max is a HARD contract: every tile's k_len must be <= k_max.  The backward kernel of that family keeps per-query state in
+ * registers across a tile's key chunks and traps (GPU fault, loud) on a block that walks several tiles with k_len > 32. */
 int lotus_attention_fwd(const lotus_act_t* q, long q_ld, int q_off, const lotus_act_t* kv, long kv_ld, int k_off, int v_off,
                         const int* qidx, const int* kidx, const int* owner, const int* tiles, int ntiles,
                         const float* qn_w, const float* qn_b, const float* kn_w, const float* kn_b, lotus_act_t* out,

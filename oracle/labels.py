@@ -7,6 +7,9 @@ numpy restatement of genrobo3d/utils/action_position_utils.py:
     back to the single nearest candidate (first index on ties); each axis is normalised to sum 1.  Layout (3, n * 2 *
     pos_bins), index n * 2 * pos_bins + b.
   * get_best_pos_from_disc_pos(best='max') (:48-64): per axis the candidate coordinate of the first arg-max.
+  * get_best_pos_from_disc_pos(best='ens1') (:66-85): per axis the probabilities of all candidates are summed per 5 mm cell
+    (round(candidate / 0.005)), visiting the candidates in order of decreasing probability; the first cell (in that visiting
+    order) with the strictly largest sum wins and the answer is cell * 0.005.
 Arithmetic follows the reference: float64 candidates / distances (np.arange * float), 'plain' output float32, 'dist'
 output float64.
 
@@ -44,3 +47,24 @@ def best_pos_max(disc_pos_prob, xyz, pos_bin_size=0.01, pos_bins=50):
     cands = candidates(xyz, pos_bin_size, pos_bins).transpose(1, 0, 2).reshape(3, -1)
     idxs = np.argmax(disc_pos_prob, -1)
     return cands[np.arange(3), idxs]
+
+
+def best_pos_ens1(disc_pos_prob, xyz, pos_bin_size=0.01, pos_bins=50):
+    """get_best_pos_from_disc_pos(best='ens1'), utils/action_position_utils.py:66-85, loop for loop (dict insertion order,
+    strict '>' when scanning the sums, accumulation in the probabilities' own dtype starting from int 0)."""
+    import collections
+
+    cands = candidates(xyz, pos_bin_size, pos_bins).transpose(1, 0, 2).reshape(3, -1)
+    vox = np.round(cands / 0.005).astype(np.int32)
+    idxs = np.argsort(-disc_pos_prob, -1)
+    best = []
+    for i in range(3):
+        sums = collections.defaultdict(int)
+        for k in idxs[i]:
+            sums[vox[i, k].item()] += disc_pos_prob[i, k]
+        bi, bv = None, -np.inf
+        for k, v in sums.items():
+            if v > bv:
+                bv, bi = v, k
+        best.append(bi * 0.005)
+    return np.array(best)

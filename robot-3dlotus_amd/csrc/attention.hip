@@ -1021,6 +1021,11 @@ __global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
   const int* bd = p.blocks + blockIdx.x * 6;
   const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3], k_start = bd[4], k_len = bd[5];
   const int n_chunks = (k_len + 31) >> 5;
+  // The per-query state (dx, dsum, ...) lives in registers across the key chunks of ONE tile; a block that walks several
+  // tiles must therefore see a single chunk (<= 32 keys).  That is what the caller promises with k_max <= 32 (the
+  // cross-attention's instruction tokens); a tile list that breaks the promise would give wrong d q / d k / d v silently
+  //  — stop the kernel loudly instead.
+  if (n_chunks > 1 && n_tiles > 1) __builtin_trap();
   for (int i = tid; i < 128 * ILD; i += 128) { qh_s[i] = 0.f; do_s[i] = 0.f; }  // columns >= D stay zero for the MFMA operands
   const unsigned s0 = (unsigned)p.drop_seed;
   const int qi = tid;

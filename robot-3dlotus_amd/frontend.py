@@ -20,7 +20,7 @@ class Level:
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
                  "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
-                 "coord", "parent", "n_dup", "patch", "_views", "ca_kmax")
+                 "coord", "parent", "n_dup", "patch", "_views", "ca_kmax", "_patch_args")
 
     def for_order(self, k):
         """The level as the k-th block of a stage sees it: `Block(order_index = i % len(order))` attends along curve slot k
@@ -31,8 +31,15 @@ class Level:
         if v is None:
             v = Level()
             for name in Level.__slots__:
-                if name not in ("_views",) and hasattr(self, name):
+                if name not in ("_views",) and hasattr(self, name):  # (shares `patch` / `_patch_args` with the base level)
                     setattr(v, name, getattr(self, name))
+            while len(self.patch) <= k:  # built on first use: a stage of depth 1 never asks for the other curve slots
+                j = len(self.patch)
+                order, off, offp, B, K, i32 = self._patch_args
+                tabs_k = (torch.empty(self.npad, **i32), torch.empty(self.npad, **i32), torch.empty(self.npad, **i32),
+                          torch.empty(max(self.n_extra, 1), **i32))
+                call("lotus_fe_patch", order[j], off, offp, B, K, self.npad, *tabs_k)
+                self.patch.append(tabs_k)
             v.gidx, v.owner, v.kext, v.ext_pos = self.patch[k]
             v._views = {}
             self._views[k] = v
@@ -249,12 +256,10 @@ class FrontEnd:
             lv.ext_pos = torch.empty(max(lv.n_extra, 1), **i32)
             call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner, lv.kext,
                  lv.ext_pos)
+            # deeper stages: block i attends along curve slot i % 4 — those tables are built by Level.for_order on first use
+            # (every level used to get max(depths) tables although most stages of [2, 2, 2, 6, 2] need 2)
             lv.patch, lv._views = [(lv.gidx, lv.owner, lv.kext, lv.ext_pos)], {}
-            for k in range(1, self.n_patch_orders):  # deeper stages: block i attends along curve slot i % 4
-                tabs_k = (torch.empty(lv.npad, **i32), torch.empty(lv.npad, **i32), torch.empty(lv.npad, **i32),
-                          torch.empty(max(lv.n_extra, 1), **i32))
-                call("lotus_fe_patch", r["order"][k], lv.off, view(pl["offp"]), B, K, lv.npad, *tabs_k)
-                lv.patch.append(tabs_k)
+            lv._patch_args = (r["order"], lv.off, view(pl["offp"]), B, K, i32)
             lv.self_tiles, lv.self_blocks = view(pl["tiles"], 4), view(pl["blocks"], 6)
             lv.n_self_tiles = pl["n_tiles"]
             lv.ca_tiles, lv.ca_blocks = view(pl["ca_tiles"], 4), view(pl["ca_blocks"], 6)

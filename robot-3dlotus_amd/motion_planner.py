@@ -141,7 +141,12 @@ class MotionPlannerPTV3CA(BaseModel):
             return None, losses                                  # trainer discards the actions (see policy.py)
         if decode:   # :238-267, best_disc_pos == 'max'; one launch pair per step instead of B*T host round trips
             pcf = batch["pc_fts"] if batch["pc_fts"].stride(1) == 1 else batch["pc_fts"].contiguous()
-            pos = torch.stack([ops.pos_decode_max(xt.detach(), pcf, lvl.off, B, nb, act.pos_bin_size) for xt in xts], 1)
+            best = act.get("best_disc_pos", "max")   # motion_planner_ptv3.py:263
+            if best == "ens1":
+                cnts = list(batch["npoints_in_batch"])
+                pos = torch.stack([ops.pos_decode_ens1(xt.detach(), pcf, cnts, nb, act.pos_bin_size) for xt in xts], 1)
+            else:
+                pos = torch.stack([ops.pos_decode_max(xt.detach(), pcf, lvl.off, B, nb, act.pos_bin_size) for xt in xts], 1)
             pos = pos.float()                                    # reference: .float() at :266
         else:
             pos = batch["gt_trajs"][..., :3].float()

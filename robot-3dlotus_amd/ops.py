@@ -612,6 +612,38 @@ def pos_decode_max(xt, pc_fts, off, B, nb, bin_size):
     return out
 
 
+def pos_decode_ens1(xt, pc_fts, counts, nb, bin_size):
+    """get_best_pos_from_disc_pos(best='ens1') (utils/action_position_utils.py:66-85) for every cloud: f64 [B, 3].  An
+    evaluation-time option of the reference (eval_simple_policy.py:63,83), evaluated on the host like there: per (cloud,
+    axis) the softmax of the logits (on the device), then the probabilities summed per 5 mm cell in order of decreasing
+    probability (sequential float32 accumulation, as the reference's dict of numpy scalars does it), the first cell with the
+    strictly largest sum wins.  Vectorised: sort, np.add.at over cell ids in first-appearance order."""
+    import numpy as np
+
+    B = len(counts)
+    pos_bins = nb // 2
+    shift = np.arange(-pos_bins, pos_bins) * bin_size                      # float64, as the reference builds it
+    out = np.zeros((B, 3), dtype=np.float64)
+    xyz_all = pc_fts[:, :3].detach().float().cpu().numpy()
+    lo = 0
+    for b, n in enumerate(counts):
+        lg = xt[lo:lo + n].detach().float().view(n, 3, nb).permute(1, 0, 2).reshape(3, n * nb)   # 'n (c b) -> c (n b)'
+        prob = torch.softmax(lg, -1).cpu().numpy()
+        xyz = xyz_all[lo:lo + n]
+        for c in range(3):
+            cands = (xyz[:, c:c + 1] + shift[None, :]).reshape(-1)          # float32 + float64 -> float64
+            vox = np.round(cands / 0.005).astype(np.int32)
+            order = np.argsort(-prob[c])
+            v_s, p_s = vox[order], prob[c][order]
+            uniq, first, inv = np.unique(v_s, return_index=True, return_inverse=True)
+            acc = np.zeros(len(uniq), dtype=p_s.dtype)
+            np.add.at(acc, inv, p_s)                                        # sequential, in visiting order
+            visit = np.argsort(first, kind="stable")                        # cells in order of first appearance
+            out[b, c] = int(uniq[visit[np.argmax(acc[visit])]]) * 0.005     # argmax: the first of the largest sums
+        lo += n
+    return torch.from_numpy(out).to(xt.device)
+
+
 def sum_slabs(part):
     """part [G, ...] -> sum over G in fixed order (one launch; G == 1: the slab itself)."""
     if part.shape[0] == 1:

@@ -212,7 +212,13 @@ class SimplePolicyPTV3CA(BaseModel):
             return None, {"pos": losses[0], "rot": losses[1], "open": losses[2], "total": losses[3]}
         if decode:
             pc = batch["pc_fts"] if batch["pc_fts"].stride(1) == 1 else batch["pc_fts"].contiguous()
-            pos = ops.pos_decode_max(xt, pc, lvl.off, B, nb, act.pos_bin_size)  # f64 [B, 3], one launch pair
+            best = act.get("best_disc_pos", "max")   # simple_policy_ptv3.py:266 (set by the evaluation scripts)
+            if best == "ens1":
+                pos = ops.pos_decode_ens1(xt, pc, list(batch["npoints_in_batch"]), nb, act.pos_bin_size)
+            elif best == "max":
+                pos = ops.pos_decode_max(xt, pc, lvl.off, B, nb, act.pos_bin_size)  # f64 [B, 3], one launch pair
+            else:
+                raise ValueError(f"best_disc_pos must be 'max' or 'ens1', got {best!r}")
         else:
             pos = gt[..., :3]
         # euler_disc decode, simple_policy_ptv3.py:292-296 (float64 on purpose)

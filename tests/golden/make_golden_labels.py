@@ -25,8 +25,12 @@ def main():
         logits = rng.standard_normal((3, n * 2 * bins)).astype(np.float32)
         logits[0, 5] = logits[0, 11] = logits[0].max() + 1.0   # tie: the first index wins
         best = get_best_pos_from_disc_pos(logits, xyz, pos_bin_size=0.01, pos_bins=bins, best="max")
+        # best='ens1' on the softmax of the logits (what the model hands over, simple_policy_ptv3.py:259-266)
+        e = np.exp(logits - logits.max(-1, keepdims=True))
+        sm = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+        ens = get_best_pos_from_disc_pos(sm, xyz, pos_bin_size=0.01, pos_bins=bins, best="ens1")
         out.update({f"kind{k}": np.array(kind), f"bins{k}": np.int64(bins), f"xyz{k}": xyz, f"gt{k}": gt, f"robot{k}": ridx,
-                    f"prob{k}": prob, f"logits{k}": logits, f"best{k}": best})
+                    f"prob{k}": prob, f"logits{k}": logits, f"best{k}": best, f"softmax{k}": sm, f"ens1_{k}": np.asarray(ens)})
     out["ncases"] = np.int64(len(cases))
     np.savez_compressed(os.path.join(HERE, "labels_cases.npz"), **out)
     print("wrote labels_cases.npz", [out[f"prob{k}"].dtype for k in range(len(cases))])

@@ -115,3 +115,34 @@ def test_policy_uses_device_labels_and_decode():
         lg = xt[:, o:o + len(p)].reshape(3, -1)
         assert np.array_equal(final[b, :3].cpu().numpy(), ol.best_pos_max(lg, p, bs, bins)), b
         o += len(p)
+
+
+def test_policy_decodes_with_best_disc_pos_ens1():
+    """forward(compute_final_action=True) with action_config.best_disc_pos = 'ens1' (the evaluation scripts' option,
+    eval_simple_policy.py:63,83): the decoded positions equal the oracle's loop-for-loop restatement of
+    get_best_pos_from_disc_pos(best='ens1') applied to the softmax of the model's own logits."""
+    import golden_util as gu
+    from oracle import labels as ol
+    from robot_3dlotus_amd import config as lcfg, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    cfg.action_config.best_disc_pos = "ens1"
+    sd = seeded_state_dict(gu.state_template(cfg), 4, "scaled")
+    m = SimplePolicyPTV3CA(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    batch = synth.synth_batch(3, 300, ragged=True, seed=9)
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v))
+           for k, v in batch.items()}
+    with torch.no_grad():
+        final = m(dev, compute_loss=False, compute_final_action=True)
+    bins, bs = cfg.action_config.pos_bins, cfg.action_config.pos_bin_size
+    xt = m.last_pred[0].float().cpu()                     # (3, N, 2 * bins)
+    counts = batch["npoints_in_batch"]
+    pcs = torch.split(batch["pc_fts"], counts)
+    for b, lg in enumerate(torch.split(xt, counts, dim=1)):
+        prob = torch.softmax(lg.reshape(3, -1), -1).numpy()
+        want = ol.best_pos_ens1(prob, pcs[b][:, :3].numpy(), bs, bins)
+        assert np.array_equal(final[b, :3].cpu().numpy(), want), (b, final[b, :3], want)
