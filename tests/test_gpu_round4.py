@@ -275,3 +275,60 @@ def test_pair_node_is_bit_identical_to_the_five_sub_block_nodes(preset, n, aug, 
     assert torch.equal(xa, xb) and torch.equal(la, lb)
     for i, (a, b) in enumerate(zip(ga, gb)):
         assert torch.equal(a, b), (i, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("shadow", [False, True])
+@pytest.mark.parametrize("M,N,K", [(65536, 128, 128), (23894, 512, 128), (23894, 128, 512), (20000, 256, 256), (16500, 192, 64),
+                                   (40000, 64, 256), (30000, 384, 128), (16385, 64, 64)])
+def test_bf16_linear_big_levels_match_float64_masters_and_shadows(M, N, K, shadow):
+    """The bf16-storage forward / input-gradient product at the row counts of levels 0-1 (every epilogue option on: bias,
+    saved pre-activation, GELU, act', dropout, residual) against (a) the float64 expression of the layer on the same
+    bf16-exact inputs (one rounding of the stored output + fp32 accumulation slack) and (b) the same layer evaluated on the
+    first 8192 rows only (another grid: the element indices — hence the dropout masks — must not depend on it); with fp32
+    master weights (rounded while staged) and with bf16 shadows (precision 5).  (Written for a streaming kernel — weights
+    resident in LDS, activation rows as MFMA fragments straight from global memory — that passed it but ran 15 % SLOWER in
+    the step than the tile kernel: 16-byte row pieces per lane are 4x the memory requests of the tile kernel's 64-byte
+    segments)"""
+    ops = _ops()
+    BF = torch.bfloat16
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    bf = lambda t: t.to(BF).float()  # noqa: E731
+    x, res = bf(torch.randn(M, K, device="cuda", generator=g)), bf(torch.randn(M, N, device="cuda", generator=g))
+    dy, pre, add = bf(torch.randn(M, N, device="cuda", generator=g)), bf(torch.randn(M, K, device="cuda", generator=g)), bf(torch.randn(M, K, device="cuda", generator=g))
+    w = bf(torch.randn(N, K, device="cuda", generator=g) / K ** 0.5)
+    b = torch.randn(N, device="cuda", generator=g)
+    wk = w.to(BF) if shadow else w
+    S = 8192
+    with ops.storage(BF):
+        y, p = ops.linear_fwd(x.to(BF), wk, b, residual=res.to(BF), act=ops.ACT_GELU, save_pre=True, drop_p=0.1, seed=1234)
+        y0, p0 = ops.linear_fwd(x[:S].to(BF).contiguous(), wk, b, residual=res[:S].to(BF).contiguous(), act=ops.ACT_GELU, save_pre=True,
+                                drop_p=0.1, seed=1234)
+        dx = ops.linear_dgrad(dy.to(BF), wk, pre=pre.to(BF), add=add.to(BF), act=ops.ACT_GELU, drop_p=0.1, seed=77)
+        dx0 = ops.linear_dgrad(dy[:S].to(BF).contiguous(), wk, pre=pre[:S].to(BF).contiguous(), add=add[:S].to(BF).contiguous(),
+                               act=ops.ACT_GELU, drop_p=0.1, seed=77)
+        yn, _ = ops.linear_fwd(x.to(BF), wk, b)   # no epilogue extras
+    torch.cuda.synchronize()
+    # (a) float64: pre-activation and the plain product exactly rounded; with dropout the kept elements are scaled by 1/0.9
+    pre64 = x.double() @ w.double().t() + b.double()
+    for name, got, ref in (("pre", p, pre64), ("plain", yn, pre64)):
+        gd, rd = got.double(), ref
+        tol = 2.0 ** -8 * rd.abs() * 1.001 + 3e-6 * float(rd.abs().max())
+        assert bool(((gd - rd).abs() <= tol).all()), (name, float(((gd - rd).abs() - tol).max()))
+        assert float((gd == rd.to(BF).double()).double().mean()) >= 0.98, name
+    full = torch.nn.functional.gelu(pre64) / 0.9 + res.double()
+    kept = (y.double() - res.double()).abs() > 0          # dropped elements equal the residual exactly
+    assert 0.88 < float(kept.double().mean()) < 0.92
+    err = ((y.double() - full).abs() - (2.0 ** -8 * full.abs() * 1.001 + 5e-6 * float(full.abs().max())))[kept]
+    assert float(err.max()) <= 0, float(err.max())
+    # (b) the tile kernel on the first rows
+    for name, a_, b_ in (("y", y[:S], y0), ("pre", p[:S], p0), ("dx", dx[:S], dx0)):
+        same = float((a_ == b_).double().mean())
+        ulp = float(((a_.double() - b_.double()).abs() / (b_.double().abs() + 1e-3)).max())
+        assert same >= 0.995 and ulp <= 2.0 ** -6, (name, same, ulp)
+    # input gradient against float64 where no dropout hit
+    pd = pre.double().requires_grad_(True)
+    torch.nn.functional.gelu(pd).sum().backward()
+    dref = (dy.double() @ w.double()) * pd.grad / 0.9
+    keptd = (dx.double() - add.double()).abs() > 0
+    errd = ((dx.double() - (dref + add.double())).abs() - (2.0 ** -8 * (dref + add.double()).abs() * 1.001 + 5e-6 * float(dref.abs().max())))[keptd]
+    assert float(errd.max()) <= 0, float(errd.max())
