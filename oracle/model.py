@@ -199,7 +199,25 @@ class Oracle:
         pc = self.q(pc32.to(self.dt))
         counts = list(batch["npoints_in_batch"])
         ctx = self.lin(self.q(batch["txt_embeds"].to(self.dt)), "txt_fc")  # simple_policy_ptv3.py:414
-        x, out = self.backbone(pc, pc32[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        ctx_counts = list(batch["txt_lens"])
+        act = self.cfg["action"]
+        if act.get("use_ee_pose") or act.get("use_step_id"):  # simple_policy_ptv3.py:419-427, base.py:52-78
+            from scipy.spatial.transform import Rotation as R
+            parts = list(torch.split(ctx, ctx_counts))
+            if act.get("use_ee_pose"):
+                a = batch["ee_poses"].to(self.dt)
+                eul = torch.from_numpy(R.from_quat(batch["ee_poses"][..., 3:7].numpy()).as_euler("xyz")).float().to(self.dt)
+                e = (self.lin(a[..., :3], "pose_embedding.pos_embedding") + self.lin(torch.cat([torch.sin(eul), torch.cos(eul)], -1), "pose_embedding.rot_embedding")
+                     + self.sd["pose_embedding.open_embedding.weight"][batch["ee_poses"][..., -1].long()])
+                e = F.layer_norm(e, (e.shape[-1],), self.sd["pose_embedding.layer_norm.weight"], self.sd["pose_embedding.layer_norm.bias"], 1e-12)
+                parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
+                ctx_counts = [c + 1 for c in ctx_counts]
+            if act.get("use_step_id"):
+                e = self.sd["stepid_embedding.weight"][batch["step_ids"].long()]
+                parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
+                ctx_counts = [c + 1 for c in ctx_counts]
+            ctx = torch.cat(parts, 0)
+        x, out = self.backbone(pc, pc32[:, :3], counts, ctx, ctx_counts, perms)
         return self.head(x, counts, batch, out, compute_loss)
 
     def backbone(self, feat, xyz, counts, ctx, ctx_counts, perms):

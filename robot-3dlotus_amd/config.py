@@ -87,6 +87,11 @@ TINY_OVERRIDES = V1_OVERRIDES + [
 TINYDEEP_OVERRIDES = TINY_OVERRIDES + ["ptv3_config.enc_depths", "[2, 5]", "ptv3_config.dec_depths", "[2]"]
 
 
+# tiny width with the two optional context tokens of SimplePolicyPTV3CA (simple_policy_ptv3.py:386-389,419-427): the current
+# end-effector pose and the key-step index are appended to every cloud's instruction tokens
+TINYCTX_OVERRIDES = TINY_OVERRIDES + ["action_config.use_ee_pose", "True", "action_config.use_step_id", "True"]
+
+
 def _parse(v):
     if not isinstance(v, str):
         return v
@@ -160,7 +165,7 @@ def preset(name="v1"):
         model["action_config"].update(_YAML_MP_DELTA["action_config"])
         return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES}[name]))
     return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES, "peract": PERACT_OVERRIDES,
-                                    "tinydeep": TINYDEEP_OVERRIDES}[name])
+                                    "tinydeep": TINYDEEP_OVERRIDES, "tinyctx": TINYCTX_OVERRIDES}[name])
 
 
 def plain(cfg):

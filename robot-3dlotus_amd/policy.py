@@ -72,6 +72,28 @@ class ActionHead(nn.Module):
                                         nn.Linear(hidden_size, self.euler_bins * 3 + 1))
 
 
+class RobotPoseEmbedding(nn.Module):
+    """genrobo3d/models/base.py:52-78: LayerNorm(Linear(xyz) + Linear(sin / cos of the xyz Euler angles) + Embedding(open)), one
+    context token per cloud.  [B, 256]-sized: plain torch arithmetic (the Euler angles come from scipy on the host, as in the
+    reference)."""
+
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.open_embedding = nn.Embedding(2, hidden_size)
+        self.pos_embedding = nn.Linear(3, hidden_size)
+        self.rot_embedding = nn.Linear(6, hidden_size)
+        self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-12)
+
+    def forward(self, actions):
+        from scipy.spatial.transform import Rotation as R
+
+        pos = self.pos_embedding(actions[..., :3])
+        opn = self.open_embedding(actions[..., -1].long())
+        eul = torch.from_numpy(R.from_quat(actions[..., 3:7].detach().cpu().numpy()).as_euler("xyz")).float().to(actions.device)
+        rot = self.rot_embedding(torch.cat([torch.sin(eul), torch.cos(eul)], -1))
+        return self.layer_norm(pos + rot + opn)
+
+
 class SimplePolicyPTV3CA(BaseModel):
     def __init__(self, config):
         super().__init__()
@@ -80,9 +102,11 @@ class SimplePolicyPTV3CA(BaseModel):
         p3 = {k: v for k, v in config.ptv3_config.items() if k in _PTV3_KEYS}
         self.ptv3_model = PointTransformerV3CA(**p3)
         act = config.action_config
-        if act.use_ee_pose or act.use_step_id:
-            raise NotImplementedError("use_ee_pose / use_step_id context tokens are not built (unused by v1)")
         self.txt_fc = nn.Linear(act.txt_ft_size, act.context_channels)
+        if act.use_ee_pose:     # simple_policy_ptv3.py:386-389 (the published v1 model sets both to False)
+            self.pose_embedding = RobotPoseEmbedding(act.context_channels)
+        if act.use_step_id:
+            self.stepid_embedding = nn.Embedding(act.max_steps, act.context_channels)
         self.act_proj_head = ActionHead(act.reduce, act.pos_pred_type, act.rot_pred_type,
                                         config.ptv3_config.dec_channels[0], act.dim_actions, dropout=act.dropout,
                                         voxel_size=act.voxel_size, pos_bins=act.pos_bins)
@@ -99,9 +123,28 @@ class SimplePolicyPTV3CA(BaseModel):
             txt, feat = txt.to(torch.bfloat16), feat.to(torch.bfloat16)
             extra["coord_src"] = batch["pc_fts"]
         ctx = ops.LinearFn.apply(txt, self.txt_fc.weight, self.txt_fc.bias)
+        ctx_counts = list(batch["txt_lens"])
+        act = self.config.action_config
+        if act.use_ee_pose or act.use_step_id:
+            # one extra context token per cloud and option, appended to that cloud's instruction tokens
+            # (simple_policy_ptv3.py:419-427): rows are placed with one index_copy per source instead of B small cats
+            tok = []
+            if act.use_ee_pose:
+                tok.append(self.pose_embedding(batch["ee_poses"].float()))
+            if act.use_step_id:
+                tok.append(self.stepid_embedding(batch["step_ids"].long()))
+            B, ne = len(ctx_counts), len(tok)
+            starts = np.concatenate([[0], np.cumsum(np.asarray(ctx_counts) + ne)])[:-1]
+            txt_pos = np.concatenate([starts[b] + np.arange(ctx_counts[b]) for b in range(B)])
+            out = ctx.new_empty(int(sum(ctx_counts)) + B * ne, ctx.shape[1])
+            out = out.index_copy(0, torch.from_numpy(txt_pos).to(ctx.device), ctx)
+            for j, t in enumerate(tok):
+                pos_j = torch.from_numpy(starts + np.asarray(ctx_counts) + j).to(ctx.device)
+                out = out.index_copy(0, pos_j, t.to(ctx.dtype))
+            ctx, ctx_counts = out, [c + ne for c in ctx_counts]
         return {"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
                 "offset": batch["offset"], "feat": feat, "context": ctx,
-                "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"]), **extra}
+                "counts": list(batch["npoints_in_batch"]), "context_counts": ctx_counts, **extra}
 
     @torch.no_grad()
     def prefetch(self, batch):

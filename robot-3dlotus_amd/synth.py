@@ -69,6 +69,12 @@ def synth_batch(batch_size=16, npoints=4096, ragged=False, seed=0, pos_bins=15, 
                          rng.integers(0, 72, size=(batch_size, 3)).astype(np.float64),
                          rng.integers(0, 2, size=(batch_size, 1)).astype(np.float64)], 1).astype(np.float32)
     npts = [len(p) for p in pcs]
+    # current end-effector pose (xyz, unit quaternion xyzw, open) and key-step index per cloud, from a generator of their own:
+    # the draws above (which the committed fixtures rebuild bit for bit) are not disturbed
+    rng2 = np.random.default_rng([seed, 0xEE])
+    quat = rng2.standard_normal((batch_size, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    ee = np.concatenate([rng2.normal(0, 0.3, size=(batch_size, 3)), quat, rng2.integers(0, 2, size=(batch_size, 1))], 1).astype(np.float32)
     return {
         "pc_fts": torch.from_numpy(np.concatenate(pcs, 0)),
         "npoints_in_batch": npts,
@@ -77,8 +83,8 @@ def synth_batch(batch_size=16, npoints=4096, ragged=False, seed=0, pos_bins=15, 
         "txt_lens": [len(t) for t in txt],
         "gt_actions": torch.from_numpy(gt),
         "disc_pos_probs": [torch.from_numpy(p) for p in probs],
-        "ee_poses": torch.zeros(batch_size, 8),
-        "step_ids": torch.zeros(batch_size, dtype=torch.long),
+        "ee_poses": torch.from_numpy(ee),
+        "step_ids": torch.from_numpy(rng2.integers(0, 30, size=batch_size)).long(),
     }
 
 

@@ -43,6 +43,8 @@ CASES = {
     # case carries the YAML's drop_path 0.1 (DropPath is the identity in eval mode, model.py:655-657)
     "tinydeep_scaled_train": ("tinydeep", 2, 700, True, 16, 4, "scaled", True),
     "tinydeep_scaled_eval": ("tinydeep", 2, 700, True, 17, 4, "scaled", False, 0.1),
+    # use_ee_pose + use_step_id: one pose token and one step token appended to every cloud's instruction tokens
+    "tinyctx_scaled_train": ("tinyctx", 3, 600, True, 18, 5, "scaled", True),
 }
 GRAD_KEYS_SAMPLE = 48  # leading entries of every gradient kept besides its norm
 

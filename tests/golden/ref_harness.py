@@ -270,7 +270,9 @@ def reference_model_config(variant="v1"):
              pos_heatmap_temp=0.1, max_steps=30, use_step_id=False, use_ee_pose=False,
              pos_pred_type="heatmap_disc", pos_bins=15)
     cfg["loss_config"].update(pos_weight=1, rot_weight=1)
-    if variant in ("tiny", "tinydeep"):
+    if variant == "tinyctx":  # the two optional context tokens (end-effector pose, key-step index)
+        a.update(use_ee_pose=True, use_step_id=True)
+    if variant in ("tiny", "tinydeep", "tinyctx"):
         p.update(enc_depths=[1, 1], enc_channels=[64, 64], enc_num_head=[2, 2], enc_patch_size=[128, 128],
                  stride=[2], dec_depths=[1], dec_channels=[64], dec_num_head=[2], dec_patch_size=[128])
     if variant == "tinydeep":  # stages deeper than one Block (order_index = i % 4 wraps at depth 5)

@@ -10,7 +10,7 @@ from weights_util import seeded_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["tiny_init_eval", "tiny_scaled_train", "v1_init_train", "v1_scaled_train", "v1_scaled_eval",
-         "tinydeep_scaled_train", "tinydeep_scaled_eval"]
+         "tinydeep_scaled_train", "tinydeep_scaled_eval", "tinyctx_scaled_train"]
 
 
 def load_case(name, state_template):
@@ -80,6 +80,12 @@ def state_template(cfg):
         for i in range(p3["dec_depths"][s]):
             block(n + f".block{i}", dc[s], dh[s]); ca(n + f".ca_block{i}", dc[s], dh[s], ctx)
     lin("txt_fc", act["context_channels"], act["txt_ft_size"])
+    if not mp and act.get("use_ee_pose"):   # base.py:52-60
+        cc = act["context_channels"]
+        t["pose_embedding.open_embedding.weight"] = torch.zeros(2, cc)
+        lin("pose_embedding.pos_embedding", cc, 3); lin("pose_embedding.rot_embedding", cc, 6); norm("pose_embedding.layer_norm", cc)
+    if not mp and act.get("use_step_id"):
+        t["stepid_embedding.weight"] = torch.zeros(act["max_steps"], act["context_channels"])
     hs = dc[0]
     if mp:  # motion_planner_ptv3.py:165-185, :41-73
         t["pc_label_embedding.weight"] = torch.zeros(4, act["pc_label_channels"])

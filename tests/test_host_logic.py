@@ -67,8 +67,16 @@ def test_yaml_default_depths_and_drop_path_construct():
 def test_unsupported_configurations_raise():
     with pytest.raises(NotImplementedError):
         SimplePolicyPTV3CA(lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["ptv3_config.enable_flash", "False"]))
-    with pytest.raises(NotImplementedError):
-        SimplePolicyPTV3CA(lcfg.load_model_config(None, lcfg.V1_OVERRIDES + ["action_config.use_ee_pose", "True"]))
+
+
+def test_context_token_options_build_the_reference_parameters():
+    """use_ee_pose / use_step_id (simple_policy_ptv3.py:386-389): parameter names and shapes of base.py:52-60."""
+    m = SimplePolicyPTV3CA(lcfg.preset("tinyctx"))
+    sd, t = m.state_dict(), gu.state_template(lcfg.preset("tinyctx"))
+    assert set(sd) == set(t) and all(tuple(sd[k].shape) == tuple(t[k].shape) for k in t)
+    cc = lcfg.preset("tinyctx").action_config.context_channels
+    assert sd["pose_embedding.rot_embedding.weight"].shape == (cc, 6) and sd["stepid_embedding.weight"].shape == (30, cc)
+    assert m.pose_embedding.layer_norm.eps == 1e-12
 
 
 def test_synthetic_batch_schema_and_voxel_uniqueness():
