@@ -179,8 +179,12 @@ __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
 }
 
+// RD = depth of the register staging ring: the global loads of slab i + RD are issued while slab i multiplies.  With bf16
+// products a 32-deep slab is two MFMAs per wave (54 ns), so at RD = 1 a block is a CHAIN of K / 32 + 1 global-load round
+// trips (7 us per 64 x 64 x 128 block, 14 us per launch at M = 65 536 = 2 rounds of resident blocks: what was measured);
+// the ring keeps RD slabs in flight per block for 8 - 12 staging registers per extra slab.
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, int PREC = 0, typename EA = float, typename EB = float,
-          typename EC = float>
+          typename EC = float, int RD = 1>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const EA* __restrict__ pA = static_cast<const EA*>(p.A);
   const EB* __restrict__ pB = static_cast<const EB*>(p.B);
@@ -239,9 +243,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   for (int i = 0; i < TM; ++i) asum[i] = 0.f;
 
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};  // bf16 path, SUM_A: this thread's partial row sums of A (exact fp32 inputs)
-  Raw4<EA> rra[A4];
-  Raw4<EB> rrb[B4];
-  auto gload = [&](int k0) {
+  Raw4<EA> rring_a[RD][A4];
+  Raw4<EB> rring_b[RD][B4];
+  auto gload = [&](Raw4<EA> (&rra)[A4], Raw4<EB> (&rrb)[B4], int k0) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
     }
   };
-  auto lstore = [&](float* Ad, float* Bd) {
+  auto lstore = [&](const Raw4<EA> (&rra)[A4], const Raw4<EB> (&rrb)[B4], float* Ad, float* Bd) {
     float4 ra[A4], rb[B4];  // the staged elements as fp32, converted HERE (behind the products of the running slab)
 #pragma unroll
     for (int t = 0; t < A4; ++t) ra[t] = unraw(rra[t]);
@@ -412,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       else pb[t] = pB + (long)(f / (BN / 4)) * p.ldb + min(n0 + (f % (BN / 4)) * 4, p.N - 4);
     }
   }
-  auto gload_full = [&](int k0) {
+  auto gload_full = [&](Raw4<EA> (&rra)[A4], Raw4<EB> (&rrb)[B4], int k0) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) rra[t] = ldraw(pa[t] + (A_KC ? (long)k0 : (long)k0 * p.lda));
 #pragma unroll
@@ -423,23 +427,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   // a second staging register set with the loads issued TWO slabs ahead and both prologue slabs in flight at once —
   // 5.91 vs 5.81 ms over the forward / input-gradient launches of a step, stand-alone: with 4 blocks per CU the other
   // waves already cover the load latency; what these launches pay is a fixed ~6 us each, see DESIGN.md.)
-  if (kbeg < kend) {
-    gload(kbeg);
-    lstore(As, Bs);
+  auto slab = [&](int cur) {
+    // only the first column block reports the column sums of A (bias gradient): the others skip the VALU adds
+    if (PREC) gemm_slab_bf16<BM, BN, BK, PREC ? PREC : 1>(reinterpret_cast<const unsigned*>(As + cur * AF), reinterpret_cast<const unsigned*>(Bs + cur * BF), wr0, wc0, acc);
+    else if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+    else gemm_slab<BM, BN, BK, A_KC, B_KC, false>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+  };
+  auto simple_loop = [&]() {  // one slab of prefetch (the next slab's global loads fly under the MFMAs of the running one)
+    gload(rring_a[0], rring_b[0], kbeg);
+    lstore(rring_a[0], rring_b[0], As, Bs);
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      if (FAST && k0 + 2 * BK <= kend) gload_full(k0 + BK);
-      else gload(k0 + BK);  // tail / past-the-end prefetch: clamped, zeroed, never consumed past kend
+      if (FAST && k0 + 2 * BK <= kend) gload_full(rring_a[0], rring_b[0], k0 + BK);
+      else gload(rring_a[0], rring_b[0], k0 + BK);  // tail / past-the-end prefetch: clamped, zeroed, never consumed past kend
       __builtin_amdgcn_sched_barrier(0);
-      // only the first column block reports the column sums of A (bias gradient): the others skip the VALU adds
-      if (PREC) gemm_slab_bf16<BM, BN, BK, PREC ? PREC : 1>(reinterpret_cast<const unsigned*>(As + cur * AF), reinterpret_cast<const unsigned*>(Bs + cur * BF), wr0, wc0, acc);
-      else if (SUM_A && bx == 0) gemm_slab<BM, BN, BK, A_KC, B_KC, true>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
-      else gemm_slab<BM, BN, BK, A_KC, B_KC, false>(As + cur * AF, Bs + cur * BF, wr0, wc0, acc, asum);
+      slab(cur);
       __builtin_amdgcn_sched_barrier(0);
       cur ^= 1;
-      lstore(As + cur * AF, Bs + cur * BF);
+      lstore(rring_a[0], rring_b[0], As + cur * AF, Bs + cur * BF);
       __syncthreads();
+    }
+  };
+  if constexpr (RD == 1 || !FAST) {
+    if (kbeg < kend) simple_loop();
+  } else if (kend - kbeg < RD * BK) {
+    if (kbeg < kend) simple_loop();
+  } else {
+    // Register ring: slot d holds slab d (mod RD); the slot whose slab has just gone to LDS is refilled with the slab RD
+    // ahead.  The prologue and the steady-state loop contain NO branch around a load: the compiler then knows how many
+    // younger loads are in flight at every LDS store and waits with a counted vmcnt instead of draining the queue (what
+    // it does as soon as a load sits behind a block-uniform branch).  Only the last < RD slabs of a reduction that is not
+    // a multiple of RD * BK are fetched conditionally.
+#pragma unroll
+    for (int d = 0; d < RD; ++d) gload_full(rring_a[d], rring_b[d], kbeg + d * BK);
+    lstore(rring_a[0], rring_b[0], As, Bs);
+    __syncthreads();
+    int cur = 0, k0 = kbeg;
+    for (; k0 + 2 * RD * BK <= kend; k0 += RD * BK) {
+#pragma unroll
+      for (int d = 0; d < RD; ++d) {
+        gload_full(rring_a[d], rring_b[d], k0 + (d + RD) * BK);
+        __builtin_amdgcn_sched_barrier(0);
+        slab(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+        lstore(rring_a[(d + 1) % RD], rring_b[(d + 1) % RD], As + cur * AF, Bs + cur * BF);
+        __syncthreads();
+      }
+    }
+    // drain: the RD slabs in the ring (all inside the range), then the < RD slabs fetched on the way
+#pragma unroll
+    for (int d = 0; d < 2 * RD - 1; ++d) {
+      const int kk = k0 + d * BK;
+      if (kk < kend) {
+        if (d < RD && kk + RD * BK < kend) {
+          if (kk + (RD + 1) * BK <= kend) gload_full(rring_a[d], rring_b[d], kk + RD * BK);
+          else gload(rring_a[d], rring_b[d], kk + RD * BK);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        slab(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+        if (kk + BK < kend) lstore(rring_a[(d + 1) % RD], rring_b[(d + 1) % RD], As + cur * AF, Bs + cur * BF);
+        __syncthreads();
+      }
     }
   }
 
@@ -678,21 +730,39 @@ static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweep
 // Element types of a launch: A is always an activation; B is the weight matrix (fp32 master) except in the weight gradient
 // (both operands are activations); C is an activation except for the weight gradient and for split-K partial slabs
 // (p.c_float).  In the fp32 build every combination is <float, float, float>.
-#define GEMM_GO(BM_, BN_, BK_, PREC_, grid_)                                                                                     \
+#define GEMM_GO_RD(BM_, BN_, BK_, PREC_, grid_, RD_)                                                                             \
   do {                                                                                                                           \
     using TB_ = std::conditional_t<SUM_A, act_t, float>;                                                                         \
     if constexpr (LOTUS_ACT_IS_BF16 && !SUM_A) {                                                                                 \
       if (p.b_act) { /* bf16 weight shadow: half the weight bytes per block, no conversion while staging */                      \
         if constexpr (PREC_ == 1 && FAST) {                                                                                      \
-          if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, float>), grid_, block, 0, st, p); \
-          else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, act_t>), grid_, block, 0, st, p); \
+          if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, float, RD_>), grid_, block, 0, st, p); \
+          else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, act_t, act_t, RD_>), grid_, block, 0, st, p); \
         }                                                                                                                        \
-      } else if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p); \
-      else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, act_t>), grid_, block, 0, st, p);   \
+      } else if (p.c_float) LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float, RD_>), grid_, block, 0, st, p); \
+      else LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, act_t, RD_>), grid_, block, 0, st, p);   \
     } else {                                                                                                                     \
-      LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float>), grid_, block, 0, st, p);      \
+      LOTUS_LAUNCH((gemm_kernel<BM_, BN_, BK_, A_KC, B_KC, SUM_A, FAST, PREC_, act_t, TB_, float, RD_>), grid_, block, 0, st, p);      \
     }                                                                                                                            \
   } while (0)
+#define GEMM_GO(BM_, BN_, BK_, PREC_, grid_) GEMM_GO_RD(BM_, BN_, BK_, PREC_, grid_, 1)
+
+// bf16 storage, bf16 products: depth of the register staging ring (LOTUS_GEMM_RING = 1 restores the one-slab prefetch)
+// Measured (tools/gemm_b16_bench.py, PerAct step): the ring pays where a launch is a latency chain — few row tiles, long
+// reductions (1450 x 512 x 512: 8.8 -> 7.4 us, 361 x 768 x 768: 11.4 -> 9.4) — and LOSES on the tall level-0 / level-1 layers
+// (65 536 x 512 x 128: 38.6 -> 63.8 us; 64 clouds 2257 -> 2158 samples/s): its 64 extra registers cut the resident blocks from 7
+// to 3 per CU, and those launches are bound by what the resident blocks stream together, not by one block's chain.
+static int bf16_ring_depth(int M) {
+  static int forced = -1, max_rows = -1;
+  if (forced < 0) { forced = tune_env("LOTUS_GEMM_RING"); max_rows = tune_env("LOTUS_GEMM_RING_ROWS"); if (max_rows <= 0) max_rows = 8192; }
+  if (forced == 1) return 1;
+  return M <= max_rows ? 4 : 1;
+}
+static int f32_ring_depth(long blocks) {  // exact-fp32 products, small grids (tuning knob, default off)
+  static int forced = -1;
+  if (forced < 0) forced = tune_env("LOTUS_GEMM_RING_F32");
+  return (forced == 2 || forced == 4) && blocks <= 2048 ? forced : 1;
+}
 
 static int bf16_slab_depth(int klen) {
   static int forced = -1;
@@ -721,6 +791,7 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
           const int bk = bf16_slab_depth(p.klen);
           if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
           else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
+          else if (bf16_ring_depth(SUM_A ? p.K : p.M) == 4) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
           else GEMM_GO(64, 64, 32, 1, g64);
         } else {
           GEMM_GO(64, 64, 32, 1, g64);
@@ -748,6 +819,7 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
           const int bk = bf16_slab_depth(min(p.klen, p.K));
           if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
           else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
+          else if (bf16_ring_depth(SUM_A ? p.K : p.M) == 4) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
           else GEMM_GO(64, 64, 32, 1, g64);
         } else GEMM_GO(64, 64, 32, 1, g64);
       } else if constexpr (!LOTUS_ACT_IS_BF16) {
@@ -795,7 +867,11 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     int bk = g_force_bk;
     if (!bk) bk = SUM_A ? 32 : (blocks64 * nz <= 512 ? 64 : (blocks64 * nz <= 2048 ? 32 : 16));
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    if (bk == 64) GEMM_GO(64, 64, 64, 0, grid);
+    const int rd = SUM_A ? 1 : f32_ring_depth(blocks64 * nz);
+    if (rd == 4) GEMM_GO_RD(64, 64, 32, 0, grid, 4);
+    else if (rd == 2 && bk == 64) GEMM_GO_RD(64, 64, 64, 0, grid, 2);
+    else if (rd == 2) GEMM_GO_RD(64, 64, 32, 0, grid, 2);
+    else if (bk == 64) GEMM_GO(64, 64, 64, 0, grid);
     else if (bk == 32) GEMM_GO(64, 64, 32, 0, grid);
     else GEMM_GO(64, 64, 16, 0, grid);
   }
