@@ -1,8 +1,8 @@
 #!/bin/bash
-# counters of ONE product: bash tools/dbg/pmc_one.sh <tag> wgrad 65536 128 128 bf16
+# SQ counters of ONE product (two passes; FETCH_SIZE / TCC_*_sum together in one pass abort rocprofv3 on this image and hang the call): bash tools/dbg/pmc_one.sh <tag> wgrad 65536 128 128 bf16
 TAG=$1; shift
 export TMPDIR=/tmp
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES" "FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum"; do
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES"; do
   n=$(echo $set | cut -d' ' -f1)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmc1_${TAG}_$n -o c -- python tools/dbg/one_gemm.py "$@" > gpurun_out/pmc1_${TAG}_$n.log 2>&1
 done
