@@ -819,6 +819,13 @@ static int tap_splits(int n, int ND) {
   const long base = (long)cdiv(n, 64 * (ND <= 64 ? 2 : 1)) * (ND <= 64 ? 1 : ND / 128);
   int nz = 1;
   while (nz < 9 && base * nz < 768) nz = nz == 1 ? 3 : 9;  // 27 taps -> 1, 3 or 9 groups
+  static int t27 = -1;
+  if (t27 < 0) { const char* e = getenv("LOTUS_CONV_NZ27_BLOCKS"); t27 = e ? atoi(e) : 0; }
+  // tuning knob, off: one tap per block for grids below t27 blocks.  Measured (tools/conv_bench.py): level 4 (361 rows, C 768)
+  // 146 -> 138 us, level 3 (1450, C 512) 213 -> 247: a block's (tap, chunk) chain is NOT what bounds the deep levels — every
+  // 64-row tile streams its taps' weights (3 x C x 128 x 4 bytes) through one CU, 23 (level 3) / 6 (level 4) times the weight
+  // tensor per launch
+  if (nz == 9 && base * 9 < t27) nz = 27;
   return nz;
 }
 
