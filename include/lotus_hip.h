@@ -101,6 +101,11 @@ int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int
 size_t lotus_fe_neighbours_workspace(int n);
 int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int* nbr, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* Tap plan of a 3^3 table (consumed by lotus_subm_conv's tap-grouped path): plan int32 [lotus_fe_tap_plan_ints(n)] =
+ * [27 pair counts (32 ints) | per tap the neighbour rows of the rows that have one, in processing order rowidx (optional),
+ * segments of n64 = roundup(n, 64) | per tap the segment position of every row or -1]. */
+size_t lotus_fe_tap_plan_ints(int n);
+int lotus_fe_tap_plan(const int* nbr27, const int* rowidx, int n, int* plan, void* stream);
 
 /* ---- dense layers (fp32 MFMA) ------------------------------------------------------------- */
 /* nn.Linear (+GELU/LeakyReLU, +Dropout, +residual): y = dropout(act(x w^T + bias)) + residual;
@@ -132,11 +137,16 @@ int lotus_linear_wgrad(const lotus_act_t* dy, const lotus_act_t* x, float* dw, f
  * for both modes, cin and cout multiples of 32) and workspace (optional) enable the pair-compacted,
  * tap-split fast path for the 3^3 convolutions.  For thin inputs (mode 0, cin <= 8, e.g. the 5^3 stem) a workspace
  * of >= T*cin*cout floats selects the active-pair VALU kernel. */
+/* tap_plan (optional; lotus_fe_tap_plan of the level's 3^3 table): for few rows and wide layers (lotus_conv_tap_eligible:
+ * fp32 storage, exact products, n <= 8192, cin, cout >= 256) the convolution runs as 27 gathered dense products in one
+ * launch + a fixed-order sum over the taps of every output row (workspace: lotus_subm_conv_workspace covers it) — the
+ * pair-compacted kernel re-streams the weight tensor once per 64-row tile there. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
+int lotus_conv_tap_eligible(int n, int cin, int cout);
 int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int cin, int precision, void* stream);
 int lotus_subm_conv(int mode, const lotus_act_t* x, const float* w, const float* w_t, const float* bias, const lotus_act_t* add,
                     lotus_act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    const int* tap_plan, void* workspace, size_t workspace_bytes, void* stream);
 /* Duplicate voxels (several points in one cell; the neighbour tables name the lowest index, `rep[p]` = centre tap
  * row nbr[T/2][p]): the true input gradient of mode 0 is dx[q] = [rep[q] == q] * sum_t W_t^T sum_{p in voxel(q) - d_t} dy[p].
  * lotus_conv_dup_fold writes dyr[r] = sum of dy over the points of r's voxel for representatives r (0 elsewhere), walking
@@ -307,11 +317,11 @@ size_t lotus_cpe_ws_main_bytes(int n, int C);
 size_t lotus_cpe_ws_conv_bytes(int n, int C);
 size_t lotus_cpe_ws_side_bytes(int n, int C);
 int lotus_cpe_fwd(const lotus_act_t* x, const lotus_act_t* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
-                  const float* lb, const float* g, const float* b, lotus_act_t* y, float* saved, const int* nbr27, const int* order0, int n,
-                  int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream);
+                  const float* lb, const float* g, const float* b, lotus_act_t* y, float* saved, const int* nbr27, const int* order0,
+                  const int* tap_plan, int n, int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream);
 int lotus_cpe_bwd(const lotus_act_t* dy, const lotus_act_t* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
                   const float* saved, lotus_act_t* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
-                  const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
+                  const int* tap_plan, const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
                   size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                   unsigned long long link, int join, void* stream, void* side);
 /* One (Block, CABlock) pair of a stage per call (round 4): cpe -> self-attention -> mlp -> cross-attention (kv from the

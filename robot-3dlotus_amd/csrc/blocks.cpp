@@ -566,15 +566,15 @@ size_t lotus_cpe_ws_side_bytes(int n, int C) {
 }
 
 int lotus_cpe_fwd(const act_t* x, const act_t* xs, const float* cw, const float* cw_packed, const float* cb, const float* lw,
-                  const float* lb, const float* g, const float* b, act_t* y, float* saved, const int* nbr27, const int* order0, int n,
-                  int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream) {
+                  const float* lb, const float* g, const float* b, act_t* y, float* saved, const int* nbr27, const int* order0,
+                  const int* tap_plan, int n, int C, int precision, void* ws, size_t ws_bytes, void* ws_conv, size_t ws_conv_bytes, void* counters, void* stream) {
   Carve sv(saved);
   act_t* c = sv.act((size_t)n * C);
   act_t* l = sv.act((size_t)n * C);
   float* mean = sv.f32(n);
   float* rstd = sv.f32(n);
   const bool big = n > 8192;
-  CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, noshadow(precision), ws_conv, ws_conv_bytes, stream));
+  CHECK(lotus_subm_conv(0, xs, cw, cw_packed, cb, nullptr, c, nbr27, order0, n, 27, C, C, noshadow(precision), tap_plan, ws_conv, ws_conv_bytes, stream));
   CHECK(lotus_linear_fwd(c, lw, lb, nullptr, l, nullptr, n, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws, big ? 0 : ws_bytes,
                          big ? nullptr : counters, stream));
   return lotus_layernorm_fwd(l, x, g, b, y, mean, rstd, n, C, 1e-5f, stream);
@@ -584,7 +584,7 @@ int lotus_cpe_fwd(const act_t* x, const act_t* xs, const float* cw, const float*
 // level holds several points per voxel (code0 / order0 of the level drive the fold, nbr27[13] the mask).
 int lotus_cpe_bwd(const act_t* dy, const act_t* xs, const float* cw, const float* cw_packed, const float* lw, const float* g,
                   const float* saved, act_t* dx_conv, int add_dy, float* grads, float* tmp, const int* nbr27, const int* order0,
-                  const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
+                  const int* tap_plan, const long long* code0, int n_dup, int n, int C, int precision, void* ws_main, size_t ws_main_bytes, void* ws_conv,
                   size_t ws_conv_bytes, void* ws_side, size_t ws_side_bytes, void* counters_main, void* counters_side,
                   unsigned long long link, int join, void* stream, void* side) {
   Carve sv(saved);
@@ -624,7 +624,7 @@ int lotus_cpe_bwd(const act_t* dy, const act_t* xs, const float* cw, const float
     CHECK(lotus_conv_dup_fold(dc, code0, order0, n, C, dyr, stream));
     dsrc = dyr;
   }
-  CHECK(lotus_subm_conv(1, dsrc, cw, cw_packed, nullptr, add_dy ? dy : nullptr, dx_conv, nbr27, order0, n, 27, C, C, noshadow(precision), ws_conv,
+  CHECK(lotus_subm_conv(1, dsrc, cw, cw_packed, nullptr, add_dy ? dy : nullptr, dx_conv, nbr27, order0, n, 27, C, C, noshadow(precision), tap_plan, ws_conv,
                         ws_conv_bytes, stream));
   if (n_dup != 0) CHECK(lotus_conv_dup_mask(dx_conv, add_dy ? dy : nullptr, nbr27 + (size_t)13 * n, n, C, stream));
   if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
@@ -645,7 +645,7 @@ enum PairPtr {
   PP_G2, PP_B2, PP_W1, PP_B1F, PP_W2, PP_B2F,                                                               // mlp of the Block
   PP_G3, PP_B3, PP_WQ, PP_BQ, PP_CQNW, PP_CQNB, PP_CKNW, PP_CKNB, PP_CWP2, PP_CBP2,                         // cross-attention
   PP_G4, PP_B4, PP_W3, PP_B3F, PP_W4, PP_B4F,                                                               // mlp of the CABlock
-  PP_NBR27, PP_ORDER0, PP_CODE0, PP_GIDX, PP_OWNER, PP_STILES, PP_SBLOCKS, PP_KEXT, PP_EXTPOS, PP_CATILES, PP_CABLOCKS,
+  PP_NBR27, PP_ORDER0, PP_TAPPLAN, PP_CODE0, PP_GIDX, PP_OWNER, PP_STILES, PP_SBLOCKS, PP_KEXT, PP_EXTPOS, PP_CATILES, PP_CABLOCKS,
   PP_WS_MAIN, PP_WS_SIDE, PP_WS_CONV, PP_CNT_MAIN, PP_CNT_SIDE, PP_STREAM, PP_SIDE,
   PP_DY, PP_DX, PP_DXS, PP_DKV, PP_GRADS, PP_TMP,                                                           // backward only
   PP_COUNT
@@ -717,7 +717,7 @@ int lotus_pair_fwd(const void* const* P, const long long* I, const double* F) {
   const unsigned long long s_cross = (unsigned long long)I[PI_SEED_CROSS], s_f2 = (unsigned long long)I[PI_SEED_FFN2];
   CHECK(lotus_cpe_fwd(PPTR(const act_t*, PP_X), PPTR(const act_t*, PP_XS), PPTR(const float*, PP_CW), PPTR(const float*, PP_CWP),
                       PPTR(const float*, PP_CB), PPTR(const float*, PP_LW), PPTR(const float*, PP_LB), PPTR(const float*, PP_G0),
-                      PPTR(const float*, PP_B0), x1, sv_cpe, PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), M, C, prec, ws, ws_b,
+                      PPTR(const float*, PP_B0), x1, sv_cpe, PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), PPTR(const int*, PP_TAPPLAN), M, C, prec, ws, ws_b,
                       PPTR(void*, PP_WS_CONV), (size_t)I[PI_WS_CONV], cnt, st));
   CHECK(lotus_selfattn_fwd(x1, PPTR(const float*, PP_G1), PPTR(const float*, PP_B1), PPTR(const float*, PP_WQKV), PPTR(const float*, PP_BQKV),
                            PPTR(const float*, PP_QNW), PPTR(const float*, PP_QNB), PPTR(const float*, PP_KNW), PPTR(const float*, PP_KNB),
@@ -812,7 +812,7 @@ int lotus_pair_bwd(const void* const* P, const long long* I, const double* F) {
   // cpe: d x = d x1 (+ the convolution's input gradient when xs is x); separate xs -> its gradient goes to dxs
   return lotus_cpe_bwd(d1, PPTR(const act_t*, PP_XS), PPTR(const float*, PP_CW), PPTR(const float*, PP_CWP), PPTR(const float*, PP_LW),
                        PPTR(const float*, PP_G0), sv_cpe, same ? PPTR(act_t*, PP_DX) : PPTR(act_t*, PP_DXS), same, g_cpe, t_cpe,
-                       PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), PPTR(const long long*, PP_CODE0), (int)I[PI_NDUP], M, C, prec, wm,
+                       PPTR(const int*, PP_NBR27), PPTR(const int*, PP_ORDER0), PPTR(const int*, PP_TAPPLAN), PPTR(const long long*, PP_CODE0), (int)I[PI_NDUP], M, C, prec, wm,
                        wm_b, PPTR(void*, PP_WS_CONV), (size_t)I[PI_WS_CONV], wsd, wsd_b, cm, cs, link, 0, st, side);
 }
 #undef PPTR

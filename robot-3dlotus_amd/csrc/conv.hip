@@ -21,6 +21,51 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
                          size_t workspace_bytes, int prec, hipStream_t st, int* rc);
 size_t lotus_conv_pairs_workspace(int n, int ND);
 int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, int prec, hipStream_t st);
+int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, const int* tg_in, const int* tg_cnt, int n64,
+                        int cin, int cout, hipStream_t st);  // gemm.hip
+
+// ---- tap-grouped path of the deep levels (few rows, wide layers) ------------------------------------------------------
+// The pair-compacted kernel streams the weights of its taps (3 x C x 128 x 4 bytes) through every 64-row tile: at level 3
+// of the bench batch (1450 rows, C = 512) that is 23x the 28 MB weight tensor per launch, at level 4 6x 64 MB, and the
+// launch is bound by that stream (213 / 146 us for 9.5 / 4 GFLOP).  Here the convolution is 27 GATHERED dense products in
+// one launch of the dense kernel (gemm.hip: rows through the tap plan of the front-end, one weight slice per row tile) into
+// a partial slab [27 x n64][C], followed by a fixed-order gather-sum over the taps of every output row.
+static int tap_rows_max() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_ROWS"); v = e ? atoi(e) : 8192; }
+  return v;
+}
+static bool tap_shape_ok(int n, int cin, int cout) {
+  return !LOTUS_ACT_IS_BF16 && n > 0 && n <= tap_rows_max() && cin >= 256 && cout >= 256 && cin % 64 == 0 && cout % 64 == 0;
+}
+static size_t tap_part_bytes(int n, int ND) { return (size_t)27 * ((n + 63) / 64 * 64) * ND * sizeof(float); }
+
+// y[i] = bias + add[i] + sum over taps t = 0..26 of part[pos[t][i]]  (rows without the tap: pos = -1)
+__global__ __launch_bounds__(256) void conv_tap_reduce_kernel(const float* __restrict__ part, const int* __restrict__ pos, int n, int ND,
+                                                              const float* __restrict__ bias, const act_t* __restrict__ add,
+                                                              act_t* __restrict__ y) {
+  const int n4 = ND / 4;
+  const long total = (long)n * n4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int i = (int)(e / n4), c = (int)(e % n4) * 4;
+    int q[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) q[t] = pos[(long)t * n + i];  // (all loads before the first dependent one)
+    float4 acc = bias ? ld4(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < 27; ++t) {
+      if (q[t] >= 0) {
+        const float4 v = ld4(part + (long)q[t] * ND + c);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (add) {
+      const float4 a = ld4(add + (long)i * ND + c);
+      acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    st4(y + (long)i * ND + c, acc);
+  }
+}
 
 struct ConvP {
   const act_t* x;   // [n][KD] gathered operand (features, or dy for dgrad)
@@ -461,7 +506,15 @@ extern "C" {
 
 size_t lotus_subm_conv_workspace(int n, int cin, int cout) {
   const size_t a = lotus_conv_pairs_workspace(n, cout), b = lotus_conv_pairs_workspace(n, cin);
-  return a > b ? a : b;
+  const size_t c = tap_shape_ok(n, cin, cout) ? tap_part_bytes(n, cin > cout ? cin : cout) : 0;
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
+}
+// 1 when lotus_subm_conv takes the tap-grouped path for this shape if it is handed a tap plan (lotus_fe_tap_plan)
+int lotus_conv_tap_eligible(int n, int cin, int cout) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("LOTUS_CONV_TAP"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on && tap_shape_ok(n, cin, cout) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -593,10 +646,25 @@ int lotus_conv_weight_transpose(const float* w, float* w_t, int cout, int T, int
 // w_t (optional) and workspace (optional) enable the pair-compacted tap-split fast path in both modes.
 int lotus_subm_conv(int mode, const act_t* x, const float* w, const float* w_t, const float* bias, const act_t* add,
                     act_t* y, const int* nbr, const int* rowidx, int n, int T, int cin, int cout, int precision,
-                    void* workspace, size_t workspace_bytes, void* stream) {
+                    const int* tap_plan, void* workspace, size_t workspace_bytes, void* stream) {
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_subm_conv: precision must be 0, 1 or 3");
   if (n == 0) return LOTUS_OK;
+  if (tap_plan && T == 27 && precision == 0 && tap_shape_ok(n, cin, cout) && workspace && ((uintptr_t)workspace) % 16 == 0 &&
+      workspace_bytes >= tap_part_bytes(n, mode == 0 ? cout : cin) &&
+      (((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16 == 0) {
+    const int n64 = (n + 63) / 64 * 64, ND = mode == 0 ? cout : cin;
+    int rc = lotus_conv_tap_gemm(mode, x, w, (float*)workspace, tap_plan + 32, tap_plan, n64, cin, cout, (hipStream_t)stream);
+    if (rc == LOTUS_OK) {
+      const long total4 = (long)n * ND / 4;
+      const int g = (int)cdiv(total4, 256);
+      LOTUS_LAUNCH(conv_tap_reduce_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                   tap_plan + 32 + 27L * n64, n, ND, bias, add, y);
+      LOTUS_LAUNCH_CHECK("lotus_subm_conv(tap-grouped)");
+      return LOTUS_OK;
+    }
+    if (rc != LOTUS_E_UNSUPPORTED) return rc;
+  }
   {
     int rc = 0;  // pair-compacted fast path (conv_pairs.hip) for the 3^3 CPE convolutions
     if (lotus_conv_pairs_try(mode, x, w, w_t, bias, add, y, nbr, rowidx, n, T, cin, cout, workspace, workspace_bytes,

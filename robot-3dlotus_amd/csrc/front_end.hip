@@ -560,6 +560,50 @@ size_t lotus_fe_neighbours_workspace(int n) {
   return cap * (sizeof(unsigned long long) + sizeof(int));
 }
 
+// Tap plan of a level (lotus_fe_tap_plan): plan = [cnt: 32 ints | in: 27 x n64 | pos: 27 x n], n64 = n rounded up to 64.
+// Block t compacts the rows that have a neighbour at tap t, walking them in processing order `rowidx` (curve order: the
+// gathered rows of consecutive pairs are close in memory): in[t * n64 + q] = neighbour row of the q-th such row,
+// pos[t * n + i] = t * n64 + q (or -1), cnt[t] = their number; in[] is padded with row 0 up to the next multiple of 64 so that
+// a 64-row tile of the grouped product only ever gathers valid rows.  Fixed order -> deterministic.
+__global__ __launch_bounds__(1024) void fe_tap_plan_kernel(const int* __restrict__ nbr, const int* __restrict__ rowidx, int n,
+                                                           int n64, int* __restrict__ plan) {
+  __shared__ int wsum[16];
+  __shared__ int base_s;
+  const int t = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  int* cnt = plan;
+  int* in = plan + 32 + (long)t * n64;
+  int* pos = plan + 32 + 27L * n64 + (long)t * n;
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < n; r0 += 1024) {
+    const int r = r0 + tid;
+    const int i = r < n ? (rowidx ? rowidx[r] : r) : -1;
+    const int j = i >= 0 ? nbr[(long)t * n + i] : -1;
+    const unsigned long long b = __ballot(j >= 0);
+    if (lane == 0) wsum[wave] = __popcll(b);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (j >= 0) {
+      const int q = off + __popcll(b & ((1ull << lane) - 1ull));
+      in[q] = j;
+      pos[i] = t * n64 + q;
+    } else if (i >= 0) {
+      pos[i] = -1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += wsum[w];
+      base_s += tot;
+    }
+    __syncthreads();
+  }
+  const int c = base_s;
+  if (tid == 0) cnt[t] = c;
+  if (c + tid < ((c + 63) & ~63)) in[c + tid] = 0;
+}
+
 // nbr int32 [ksize^3][n] (tap-major), -1 = no active site.
 int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int* nbr, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -577,6 +621,16 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
   LOTUS_LAUNCH(fe_neighbour_kernel, dim3(cdiv(n, 256), ksize * ksize * ksize), dim3(256), 0, st, grid, batch, n,
                      ksize, hk, hv, (unsigned)(cap - 1), nbr);
   LOTUS_LAUNCH_CHECK("lotus_fe_neighbours");
+  return LOTUS_OK;
+}
+
+size_t lotus_fe_tap_plan_ints(int n) { return 32 + 27 * (size_t)((n + 63) / 64 * 64) + 27 * (size_t)n; }
+
+int lotus_fe_tap_plan(const int* nbr27, const int* rowidx, int n, int* plan, void* stream) {
+  LOTUS_CHECK_ARG(nbr27 && plan && n >= 0, "lotus_fe_tap_plan: bad arguments");
+  if (n == 0) return LOTUS_OK;
+  LOTUS_LAUNCH(fe_tap_plan_kernel, dim3(27), dim3(1024), 0, (hipStream_t)stream, nbr27, rowidx, n, (n + 63) / 64 * 64, plan);
+  LOTUS_LAUNCH_CHECK("lotus_fe_tap_plan");
   return LOTUS_OK;
 }
 

@@ -47,6 +47,13 @@ struct GemmP {
   int accumulate;    // wgrad, fused: C / bias_out += result
   int c_float;       // fwd / dgrad: C is an fp32 split-K partial slab, not an activation tensor
   int b_act;         // fwd / dgrad, bf16-storage build: the weight matrix B is a bf16 SHADOW of the fp32 master (precision | 4)
+  // tap-grouped products (sparse convolution of the deep levels as 27 gathered GEMMs in one launch, conv.hip): A rows are
+  // gathered through a_rows; the M axis is 27 segments of tap_rows (a multiple of 64) rows, segment t holds tap_cnt[t] pairs
+  // (row tiles past them leave at once) and multiplies the weight slice B + (mirror ? 26 - t : t) * b_tap_stride
+  const int* a_rows;
+  const int* tap_cnt;
+  int tap_rows, b_tap_mirror;
+  long b_tap_stride;
 };
 
 // Partial tiles of a fused split-K product travel between blocks that may sit on different XCDs (one L2 each).  An
@@ -188,6 +195,7 @@ template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, i
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const EA* __restrict__ pA = static_cast<const EA*>(p.A);
   const EB* __restrict__ pB = static_cast<const EB*>(p.B);
+  const int* __restrict__ a_rows = p.a_rows;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
@@ -227,6 +235,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     bx = t - by * nbx;
   }
   const int m0 = by * BM, n0 = bx * BN;
+  if (p.tap_rows) {  // (block-uniform) this row tile's tap: its pair count and its weight slice
+    const int tap = m0 / p.tap_rows;
+    if (m0 - tap * p.tap_rows >= p.tap_cnt[tap]) return;
+    pB += (long)(p.b_tap_mirror ? 26 - tap : tap) * p.b_tap_stride;
+  }
+  auto arow = [&](int r) { r = min(r, p.M - 1); return a_rows ? a_rows[r] : r; };
   const int kbeg = bz * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         const int row = f / (BK / 4), kq = f % (BK / 4);
         if (FAST) {
           const int k = k0 + kq * 4;
-          rra[t] = rsel(k < kend, ldraw(pA + (long)min(m0 + row, p.M - 1) * p.lda + min(k, p.K - 4)));
+          rra[t] = rsel(k < kend, ldraw(pA + (long)arow(m0 + row) * p.lda + min(k, p.K - 4)));
         } else {
           rra[t] = toraw(load4_guard(pA, p.lda, m0 + row, k0 + kq * 4, p.M, kend, p.a_vec), pA);
         }
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 #pragma unroll
     for (int t = 0; t < A4; ++t) {
       const int f = tid + t * 256;
-      if (A_KC) pa[t] = pA + (long)min(m0 + f / (BK / 4), p.M - 1) * p.lda + (f % (BK / 4)) * 4;
+      if (A_KC) pa[t] = pA + (long)arow(m0 + f / (BK / 4)) * p.lda + (f % (BK / 4)) * 4;
       else if (PREC) pa[t] = pA + (long)(((tid + (t >> 1) * 256) / (BM / 4)) * 2 + (t & 1)) * p.lda + min(m0 + ((tid + (t >> 1) * 256) % (BM / 4)) * 4, p.M - 4);
       else pa[t] = pA + (long)(f / (BM / 4)) * p.lda + min(m0 + (f % (BM / 4)) * 4, p.M - 4);
     }
@@ -846,7 +860,8 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   // selects 128x128 / 128x64 tiles for them alone when the grid still fills the GPU (tuning knob)
   static int tile_fwd = -1;
   if (tile_fwd < 0) tile_fwd = tune_env("LOTUS_GEMM_TILE_FWD");
-  if (A_KC && B_KC && !SUM_A && tile_fwd && g_force_tile == 0) {
+  if (p.tap_rows) tile = 3;  // tap-grouped products: a row tile must not straddle two taps (segments are multiples of 64 rows)
+  if (A_KC && B_KC && !SUM_A && tile_fwd && g_force_tile == 0 && !p.tap_rows) {
     static int min_blocks = 0;
     if (!min_blocks) { min_blocks = tune_env("LOTUS_GEMM_TILE_FWD_MINBLOCKS"); if (min_blocks <= 0) min_blocks = 1024; }
     const long nb = tile_fwd == 1 ? (long)cdiv(p.M, 128) * cdiv(p.N, 128) : (long)cdiv(p.M, 128) * cdiv(p.N, 64);
@@ -1013,6 +1028,31 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
                      (long)p.M * p.N, nz);
   LOTUS_LAUNCH_CHECK("lotus_gemm(split-K epilogue)");
   return LOTUS_OK;
+}
+
+// Sparse convolution of a deep level as ONE launch of 27 gathered products (conv.hip, lotus_subm_conv tap path): mode 0
+// part[27 * n64][cout] = x[tg_in[.]] W_t^T, mode 1 part[27 * n64][cin] = dy[tg_in[.]] W_(26-t).  w is the module's weight
+// [cout][27][cin]: tap t is a [cout][cin] slice with row stride 27 * cin.  Exact fp32 products, fp32-storage build.
+int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, const int* tg_in, const int* tg_cnt, int n64,
+                        int cin, int cout, hipStream_t st) {
+  if constexpr (LOTUS_ACT_IS_BF16) {
+    return LOTUS_E_UNSUPPORTED;
+  } else {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.A = x; p.B = w; p.C = part;
+    p.M = 27 * n64;
+    p.N = mode == 0 ? cout : cin;
+    p.K = mode == 0 ? cin : cout;
+    p.lda = p.K; p.ldb = 27L * cin; p.ldc = p.N;
+    p.act = LOTUS_ACT_NONE;
+    p.klen = cdiv(p.K, GEMM_KALIGN) * GEMM_KALIGN;
+    p.a_vec = vec_ok(x, p.K); p.b_vec = vec_ok(w, cin) && cin % 4 == 0; p.prec = 0;
+    p.drop_inv_keep = 1.f;
+    p.a_rows = tg_in; p.tap_cnt = tg_cnt; p.tap_rows = n64; p.b_tap_mirror = mode == 1; p.b_tap_stride = cin;
+    if (!(fast_ok<true, true>(p))) return LOTUS_E_UNSUPPORTED;
+    return mode == 0 ? launch_gemm<true, true, false>(p, 1, st) : launch_gemm<true, false, false>(p, 1, st);
+  }
 }
 
 extern "C" {

@@ -20,7 +20,7 @@ class Level:
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
                  "nbr125", "gidx", "owner", "kext", "ext_pos", "n_extra", "npad", "self_tiles", "self_blocks", "n_self_tiles", "ca_tiles",
                  "ca_blocks", "n_ca_tiles", "n_ca_blocks", "ca_groups", "cluster", "seg_start", "members",
-                 "coord", "parent", "n_dup", "patch", "_views", "ca_kmax", "_patch_args")
+                 "coord", "parent", "n_dup", "patch", "_views", "ca_kmax", "_patch_args", "tap_plan")
 
     def for_order(self, k):
         """The level as the k-th block of a stage sees it: `Block(order_index = i % len(order))` attends along curve slot k
@@ -56,8 +56,11 @@ def draw_order_perms(n_levels, shuffle=True):
 
 
 class FrontEnd:
-    def __init__(self, n_levels, patch_size=128, grid_size=0.01, orders=ORDERS, n_patch_orders=1):
+    def __init__(self, n_levels, patch_size=128, grid_size=0.01, orders=ORDERS, n_patch_orders=1, conv_widths=None):
         self.n_levels = n_levels
+        # widest 3^3 convolution of every level (None: unknown): levels with few rows and wide layers get a tap plan
+        # (lotus_fe_tap_plan) for the tap-grouped convolution path, csrc/conv.hip
+        self.conv_widths = list(conv_widths) if conv_widths is not None else None
         self.n_patch_orders = max(1, min(4, int(n_patch_orders)))  # curve slots whose patch tables are built (stage depth)
         self.K = patch_size
         self.grid_size = float(np.float32(grid_size))
@@ -244,6 +247,11 @@ class FrontEnd:
             lv.code, lv.order, lv.inverse = r["code"][:, :n], r["order"][:, :n], r["inverse"][:, :n]
             lv.nbr27 = torch.empty(27, n, **i32)
             call("lotus_fe_neighbours", lv.grid, lv.batch, n, 3, lv.nbr27, ws_n, ws_n.numel())
+            lv.tap_plan = None
+            if self.conv_widths is not None and s < len(self.conv_widths) and n > 0 and \
+                    query("lotus_conv_tap_eligible", n, self.conv_widths[s], self.conv_widths[s]):
+                lv.tap_plan = torch.empty(query("lotus_fe_tap_plan_ints", n), **i32)
+                call("lotus_fe_tap_plan", lv.nbr27, lv.order[0], n, lv.tap_plan)
             lv.nbr125 = None
             if s == 0:
                 lv.nbr125 = torch.empty(125, n, **i32)

@@ -536,7 +536,7 @@ def _conv_ws(n, cin, cout, dev):
     return WS.get(nbytes, dev, slot=2) if nbytes else None
 
 
-def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None):
+def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None, tap_plan=None):
     n, cin = x.shape
     cout, T = w.shape[0], nbr.shape[0]
     y = torch.empty(n, cout, dtype=x.dtype, device=x.device)
@@ -544,12 +544,12 @@ def conv_fwd(x, w, b, nbr, rowidx, add=None, w_t=None, prec=None):
         ws = _conv_ws(n, cin, cout, x.device)
     else:  # thin-input stem kernel: room for the transposed weights
         ws = WS.get(4 * T * cin * cout, x.device, slot=2) if cin <= 8 else None
-    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, _pa(prec), ws,
+    call("lotus_subm_conv", 0, x, w, w_t, b, add, y, nbr, rowidx, n, T, cin, cout, _pa(prec), tap_plan, ws,
          ws.numel() if ws is not None else 0)
     return y
 
 
-def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
+def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None, tap_plan=None):
     """Input gradient of conv_fwd.  The kernel walks the mirrored taps of the forward table, which is the transposed
     pair list exactly when every voxel holds one point; `lvl.n_dup != 0` (augmented real clouds: 1-7 % of the points
     share a cell, SURVEY.md Trap 5) adds the fold / mask passes of lotus_conv_dup_* that make it the true gradient."""
@@ -562,7 +562,7 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None):
         dy = dyr
     dx = torch.empty(n, cin, dtype=dy.dtype, device=dy.device)
     ws = _conv_ws(n, cin, cout, dy.device) if T == 27 else None
-    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _pa(prec), ws,
+    call("lotus_subm_conv", 1, dy, w, w_t, None, add, dx, nbr, rowidx, n, T, cin, cout, _pa(prec), tap_plan, ws,
          ws.numel() if ws is not None else 0)
     if dups:
         call("lotus_conv_dup_mask", dx, add, nbr[T // 2], n, cin)
@@ -935,11 +935,11 @@ class CpeFn(torch.autograd.Function):
             y = torch.empty_like(x)
             ws = _ws(ws_main, x.device)
             wc = WS.get(ws_conv, x.device, slot=2)
-            _capi.call_raw("lotus_cpe_fwd", x, xs, cw, wt, cb, lwk, lb, g, b, y, saved, lvl.nbr27, lvl.order[0], n_, C, pc, ws,
+            _capi.call_raw("lotus_cpe_fwd", x, xs, cw, wt, cb, lwk, lb, g, b, y, saved, lvl.nbr27, lvl.order[0], lvl.tap_plan, n_, C, pc, ws,
                            ws.numel(), wc, wc.numel(), _counters(x.device), _capi.stream_ptr())
             ctx.save_for_backward(xs, cw, lw, g, saved, wt)
             return y
-        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt)
+        c = conv_fwd(xs, cw, cb, lvl.nbr27, lvl.order[0], w_t=wt, tap_plan=lvl.tap_plan)
         l, _ = linear_fwd(c, lwk, lb)
         y, mean, rstd = ln_fwd(l, g, b, res=x)
         ctx.save_for_backward(xs, cw, lw, g, c, l, mean, rstd, wt)
@@ -961,7 +961,7 @@ class CpeFn(torch.autograd.Function):
             wsm = _ws(ws_main if side else max(ws_main, ws_side), dev)  # no side stream: the weight gradients use it too
             wc = WS.get(ws_conv, dev, slot=2)
             _capi.call_raw("lotus_cpe_bwd", dy, xs, cw, wt, ctx.wk[0], g, saved, dxc, 1 if ctx.same else 0, grads, tmp, lvl.nbr27,
-                           lvl.order[0], lvl.code[0], lvl.n_dup, n_, C, ctx.pc, wsm, wsm.numel(), wc, wc.numel(), wss,
+                           lvl.order[0], lvl.tap_plan, lvl.code[0], lvl.n_dup, n_, C, ctx.pc, wsm, wsm.numel(), wc, wc.numel(), wss,
                            wss.numel() if wss is not None else 0, _counters(dev), cs, _LINK, 0, _capi.stream_ptr(), side)
             o1 = 2 * _al4(C)
             o2 = o1 + _al4(C * C + C)
@@ -977,9 +977,9 @@ class CpeFn(torch.autograd.Function):
         dc = linear_dgrad(dl, ctx.wk[0])
         dcw, dcb = conv_wgrad(dc, xs, cw.shape, lvl.nbr27)
         if ctx.same:  # d x = dy (residual) + conv dgrad
-            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt, lvl=lvl)
+            dx = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], add=dy, w_t=wt, lvl=lvl, tap_plan=lvl.tap_plan)
             return dx, None, dcw, dcb, dlw, dlb, dg, db, None, None
-        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt, lvl=lvl)
+        dxs = conv_dgrad(dc, cw, lvl.nbr27, lvl.order[0], w_t=wt, lvl=lvl, tap_plan=lvl.tap_plan)
         return dy, dxs, dcw, dcb, dlw, dlb, dg, db, None, None
 
 
@@ -1407,7 +1407,7 @@ _PAIR = {"0": False, "1": True}.get(os.environ.get("LOTUS_PAIR", "auto"), "auto"
 _PAIR_AUTO_ROWS = 40000
 _PP = None  # index tables of csrc/blocks.cpp: enum PairPtr / PairInt (kept in step by tests/test_gpu_round4.py)
 _PP_NAMES = ("X XS KV Y ACTS SAVED CW CWP CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2 B2 W1 B1F W2 B2F G3 B3 WQ BQ CQNW CQNB "
-             "CKNW CKNB CWP2 CBP2 G4 B4 W3 B3F W4 B4F NBR27 ORDER0 CODE0 GIDX OWNER STILES SBLOCKS KEXT EXTPOS CATILES CABLOCKS WS_MAIN "
+             "CKNW CKNB CWP2 CBP2 G4 B4 W3 B3F W4 B4F NBR27 ORDER0 TAPPLAN CODE0 GIDX OWNER STILES SBLOCKS KEXT EXTPOS CATILES CABLOCKS WS_MAIN "
              "WS_SIDE WS_CONV CNT_MAIN CNT_SIDE STREAM SIDE DY DX DXS DKV GRADS TMP").split()
 _PI_NAMES = ("M C H HD NPAD NSTILES NEXTRA L NCATILES NCABLOCKS G KMAX NDUP SAME PREC KV_LD DKV_LD WS_MAIN WS_SIDE WS_CONV LINK SEED_SELF "
              "SEED_FFN1 SEED_CROSS SEED_FFN2").split()
@@ -1492,6 +1492,7 @@ class PairFn(torch.autograd.Function):
         P[PP["X"]], P[PP["XS"]], P[PP["KV"]], P[PP["Y"]] = x.data_ptr(), xs.data_ptr(), kv.data_ptr(), y.data_ptr()
         P[PP["ACTS"]], P[PP["SAVED"]], P[PP["CWP"]] = acts.data_ptr(), saved.data_ptr(), wt.data_ptr()
         P[PP["NBR27"]], P[PP["ORDER0"]], P[PP["CODE0"]] = lvl.nbr27.data_ptr(), lvl.order[0].data_ptr(), lvl.code[0].data_ptr()
+        P[PP["TAPPLAN"]] = lvl.tap_plan.data_ptr() if lvl.tap_plan is not None else 0
         P[PP["GIDX"]], P[PP["OWNER"]], P[PP["STILES"]] = lvl.gidx.data_ptr(), lvl.owner.data_ptr(), lvl.self_tiles.data_ptr()
         P[PP["SBLOCKS"]], P[PP["KEXT"]], P[PP["EXTPOS"]] = lvl.self_blocks.data_ptr(), lvl.kext.data_ptr(), lvl.ext_pos.data_ptr()
         P[PP["CATILES"]], P[PP["CABLOCKS"]] = lvl_ca.ca_tiles.data_ptr(), lvl_ca.ca_blocks.data_ptr()

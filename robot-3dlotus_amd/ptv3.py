@@ -189,7 +189,8 @@ class PointTransformerV3CA(nn.Module):
         self.enc_channels, self.dec_channels = list(enc_channels), list(dec_channels) + [enc_channels[-1]]
         self.enc_depths, self.dec_depths = [int(d) for d in enc_depths], [int(d) for d in dec_depths]
         self.frontend = FrontEnd(self.num_stages, patch_size=enc_patch_size[0], orders=self.order,
-                                 n_patch_orders=max(self.enc_depths + self.dec_depths))
+                                 n_patch_orders=max(self.enc_depths + self.dec_depths),
+                                 conv_widths=[max(e, d) for e, d in zip(self.enc_channels, self.dec_channels)])
         # stochastic-depth schedule, model_ca.py:250-252,316-325: linear in the block index over the whole encoder /
         # decoder; the decoder's per-stage slice is reversed
         ed = torch.linspace(0, drop_path, sum(self.enc_depths)).tolist()

@@ -332,3 +332,52 @@ def test_bf16_linear_big_levels_match_float64_masters_and_shadows(M, N, K, shado
     keptd = (dx.double() - add.double()).abs() > 0
     errd = ((dx.double() - (dref + add.double())).abs() - (2.0 ** -8 * (dref + add.double()).abs() * 1.001 + 5e-6 * float(dref.abs().max())))[keptd]
     assert float(errd.max()) <= 0, float(errd.max())
+
+
+@pytest.mark.gpu
+def test_tap_grouped_convolution_of_the_deep_levels():
+    """lotus_subm_conv with a tap plan (27 gathered dense products + fixed-order tap sum; levels with few rows and wide
+    layers): the plan is a permutation-free compaction of the neighbour table, and forward / input gradient agree with the
+    float64 expression of spconv.SubMConv3d (model.py:615-622) and with the pair-compacted kernel."""
+    import numpy as np
+    from robot_3dlotus_amd import ops, synth
+    from robot_3dlotus_amd.frontend import FrontEnd
+    from robot_3dlotus_amd._capi import query
+
+    dev = torch.device("cuda", 0)
+    b = synth.synth_batch(3, 4096, ragged=True, seed=5)
+    levels = FrontEnd(4, conv_widths=[64, 128, 256, 512]).build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * 4)
+    assert levels[0].tap_plan is None and levels[1].tap_plan is None            # narrow layers keep the pair-compacted kernel
+    for li, C in ((2, 256), (3, 512)):
+        L = levels[li]
+        assert query("lotus_conv_tap_eligible", L.n, C, C) == 1 and L.tap_plan is not None
+        n64 = (L.n + 63) // 64 * 64
+        plan = L.tap_plan.cpu().numpy()
+        cnt, tin, pos = plan[:27], plan[32:32 + 27 * n64].reshape(27, n64), plan[32 + 27 * n64:].reshape(27, L.n)
+        nbr = L.nbr27.cpu().numpy()
+        np.testing.assert_array_equal(cnt, (nbr >= 0).sum(1))
+        for t in range(27):
+            rows = np.nonzero(pos[t] >= 0)[0]
+            assert len(rows) == cnt[t] and set(pos[t][rows] - t * n64) == set(range(cnt[t]))
+            np.testing.assert_array_equal(tin[t][pos[t][rows] - t * n64], nbr[t][rows])   # the pair (row, neighbour) survives
+            assert (tin[t][cnt[t]:(cnt[t] + 63) // 64 * 64] == 0).all()                      # padding gathers a valid row
+        torch.manual_seed(li)
+        x = torch.randn(L.n, C, device=dev)
+        w = torch.randn(C, 3, 3, 3, C, device=dev) / (C * 9) ** 0.5
+        bias, add = torch.randn(C, device=dev), torch.randn(L.n, C, device=dev)
+        wt = ops.conv_weight_t(w)
+        nb, w64 = L.nbr27.long(), w.double().reshape(C, 27, C)
+        yr, dr = bias.double()[None, :] + add.double(), add.double().clone()
+        for t in range(27):
+            m = nb[t] >= 0
+            yr[m] += x.double()[nb[t][m]] @ w64[:, t, :].T
+            dr.index_add_(0, nb[t][m], x.double()[m] @ w64[:, t, :])                         # dx[nbr] += dy W_t (transposed pair list)
+        y = ops.conv_fwd(x, w, bias, L.nbr27, L.order[0], add=add, w_t=wt, tap_plan=L.tap_plan)
+        d = ops.conv_dgrad(x, w, L.nbr27, L.order[0], add=add, w_t=wt, lvl=L, tap_plan=L.tap_plan)
+        y0 = ops.conv_fwd(x, w, bias, L.nbr27, L.order[0], add=add, w_t=wt)
+        d0 = ops.conv_dgrad(x, w, L.nbr27, L.order[0], add=add, w_t=wt, lvl=L)
+        for got, ref in ((y, yr), (d, dr), (y0, yr), (d0, dr)):
+            assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+        assert not torch.equal(y, y0) or True   # (different summation order: equal only by accident)
+        y2 = ops.conv_fwd(x, w, bias, L.nbr27, L.order[0], add=add, w_t=wt, tap_plan=L.tap_plan)
+        assert torch.equal(y, y2)                # deterministic
