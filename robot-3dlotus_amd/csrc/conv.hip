@@ -35,8 +35,14 @@ static int tap_rows_max() {
   if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_ROWS"); v = e ? atoi(e) : 8192; }
   return v;
 }
+static int tap_min_width() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_MINC"); v = e ? atoi(e) : 256; }
+  return v;
+}
 static bool tap_shape_ok(int n, int cin, int cout) {
-  return !LOTUS_ACT_IS_BF16 && n > 0 && n <= tap_rows_max() && cin >= 256 && cout >= 256 && cin % 64 == 0 && cout % 64 == 0;
+  return !LOTUS_ACT_IS_BF16 && n > 0 && n <= tap_rows_max() && cin >= tap_min_width() && cout >= tap_min_width() && cin % 64 == 0 &&
+         cout % 64 == 0;
 }
 static size_t tap_part_bytes(int n, int ND) { return (size_t)27 * ((n + 63) / 64 * 64) * ND * sizeof(float); }
 

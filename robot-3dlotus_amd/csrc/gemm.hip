@@ -883,12 +883,14 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     // slab depth (tools/gemm_sweep.py): with <= 2 blocks per CU nothing else hides the global-load latency,
     // so run deep slabs (4x the MFMA work and bytes in flight per barrier); large grids keep BK = 16 for
     // occupancy; the streamed weight-gradient operands like BK = 32
+    // (tap-grouped products: about half of the row tiles leave at once — the grid the heuristics should see is the active one)
+    const long blocks_eff = p.tap_rows ? blocks64 / 2 : blocks64;
     int bk = g_force_bk;
-    if (!bk) bk = SUM_A ? 32 : (blocks64 * nz <= 512 ? 64 : (blocks64 * nz <= 2048 ? 32 : 16));
+    if (!bk) bk = SUM_A ? 32 : (blocks_eff * nz <= 512 ? 64 : (blocks_eff * nz <= 2048 ? 32 : 16));
     dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     static int ring_wg = -1;
     if (ring_wg < 0) ring_wg = tune_env("LOTUS_GEMM_RING_WG");
-    const int rd = (SUM_A && ring_wg != 1) ? 1 : f32_ring_depth(blocks64 * nz);
+    const int rd = (SUM_A && ring_wg != 1) ? 1 : f32_ring_depth(blocks_eff * nz);
     if (rd == 4) GEMM_GO_RD(64, 64, 32, 0, grid, 4);
     else if (rd == 2 && bk == 64) GEMM_GO_RD(64, 64, 64, 0, grid, 2);
     else if (rd == 2 && bk == 16) GEMM_GO_RD(64, 64, 16, 0, grid, 2);
