@@ -514,6 +514,25 @@ def conv_weight_t(w, prec=None):
     return wt
 
 
+_NO_PACK = {}
+
+
+def conv_tap_active(lvl, C):
+    """True when the 3^3 convolutions of width C at this level take the tap-grouped path of lotus_subm_conv (exact fp32
+    products, fp32 storage, a tap plan on the level and an eligible shape): they read the module's own weight tensor, so
+    their packed copy need not be produced."""
+    return _PREC == 0 and not _capi.BF16 and getattr(lvl, "tap_plan", None) is not None and \
+        query("lotus_conv_tap_eligible", lvl.n, C, C) == 1
+
+
+def no_pack(dev):
+    """Stand-in for the packed weights of a convolution that does not read them (null pointer at the C-ABI)."""
+    t = _NO_PACK.get(dev)
+    if t is None:
+        t = _NO_PACK[dev] = torch.empty(0, dtype=torch.float32, device=dev)
+    return t
+
+
 def prepack_conv_weights(weights):
     """Pack the 3^3 convolution weights of a whole forward pass up front, on the weight-gradient stream when it is
     enabled: nine small launches leave the critical stream (they ran in front of every Block.cpe) and overlap the stem.

@@ -219,6 +219,16 @@ class PointTransformerV3CA(nn.Module):
                 dec.add_module(f"ca_block{i}", CABlock(dc[s], dec_num_head[s], ctx_channels, mlp_ratio))
             self.dec.add_module(f"dec{s}", dec)
         self._blocks = [m for m in self.modules() if isinstance(m, Block)]
+        # level every Block works at (encoder stage s -> level s; the decoder modules are stored in execution order)
+        self._block_level = {}
+        for s in range(self.num_stages):
+            for m in self.enc[s].children():
+                if isinstance(m, Block):
+                    self._block_level[id(m)] = s
+        for i, s in enumerate(reversed(range(self.num_stages - 1))):
+            for m in self.dec[i].children():
+                if isinstance(m, Block):
+                    self._block_level[id(m)] = s
         # every CABlock in execution order (module order = encoder stages, then decoder stages as they run): their kv
         # projections of the shared context are evaluated as one product at the top of forward (ops.KvAllFn)
         self._cablocks = [m for m in self.modules() if isinstance(m, CABlock)]
@@ -366,7 +376,13 @@ class PointTransformerV3CA(nn.Module):
 
         st = self.embedding.stem
         blocks = self._blocks  # every Block of the model, in module order (cached: a tree walk per forward costs 0.4 ms)
-        packs = dict(zip(blocks, ops.prepack_conv_weights([b.cpe[0].weight for b in blocks])))
+        # (convolutions on the tap-grouped path read the module's weight tensor itself: 134 of the 143 MB of packing in v1)
+        need = [b for b in blocks if not ops.conv_tap_active(levels[self._block_level[id(b)]], b.cpe[0].weight.shape[0])]
+        packs = dict(zip(need, ops.prepack_conv_weights([b.cpe[0].weight for b in need])))
+        if len(need) < len(blocks):
+            none = ops.no_pack(feat.device)
+            for b in blocks:
+                packs.setdefault(b, none)
         n_ord = len(self.order)
         # optional effective stem weight (a differentiable function of st.conv.weight) for callers whose input
         # features are a linear code of something smaller, e.g. the motion planner's label embedding
