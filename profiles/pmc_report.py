@@ -34,6 +34,10 @@ FAMILIES = [("gemm_kernel", "gemm_kernel"), ("conv_pairs_kernel", "conv_pairs_ke
 
 
 def family(name):
+    # the tap-grouped sparse convolution of the deep levels runs on the dense kernel (template flag TAP = last argument true):
+    # its launches are convolution work and get a row of their own
+    if "gemm_kernel" in name and name.split("(")[0].rstrip().endswith("true>"):
+        return "gemm_kernel<..., TAP> (tap-grouped conv, levels 2-4)"
     for key, fam in FAMILIES:
         if key in name:
             return fam

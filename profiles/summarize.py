@@ -25,7 +25,7 @@ def main(path, nsteps):
         if r[2] / tot < 0.0005:
             continue
         print(f"| {r[2] / nsteps / 1e3:.3f} | {100 * r[2] / tot:.1f} | {r[1] / nsteps:.1f} | {r[3]:.1f} | {r[4]:.1f} | "
-              f"{r[5]:.1f} | `{r[0][:100]}` |")
+              f"{r[5]:.1f} | `{r[0][:140]}` |")
 
 
 if __name__ == "__main__":

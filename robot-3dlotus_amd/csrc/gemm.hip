@@ -191,11 +191,11 @@ __device__ __forceinline__ float4 zsel(bool ok, float4 v) {
 // trips (7 us per 64 x 64 x 128 block, 14 us per launch at M = 65 536 = 2 rounds of resident blocks: what was measured);
 // the ring keeps RD slabs in flight per block for 8 - 12 staging registers per extra slab.
 template <int BM, int BN, int BK, bool A_KC, bool B_KC, bool SUM_A, bool FAST, int PREC = 0, typename EA = float, typename EB = float,
-          typename EC = float, int RD = 1>
+          typename EC = float, int RD = 1, bool TAP = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   const EA* __restrict__ pA = static_cast<const EA*>(p.A);
   const EB* __restrict__ pB = static_cast<const EB*>(p.B);
-  const int* __restrict__ a_rows = p.a_rows;
+  const int* __restrict__ a_rows = TAP ? p.a_rows : nullptr;  // (TAP: the tap-grouped convolution launches, their own kernel name in a trace)
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int A4 = BM * BK / 4 / 256, B4 = BN * BK / 4 / 256;  // float4 per thread
   static_assert(A4 >= 1 && B4 >= 1, "tile too small");
@@ -235,12 +235,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     bx = t - by * nbx;
   }
   const int m0 = by * BM, n0 = bx * BN;
-  if (p.tap_rows) {  // (block-uniform) this row tile's tap: its pair count and its weight slice
+  if constexpr (TAP) {  // (block-uniform) this row tile's tap: its pair count and its weight slice
     const int tap = m0 / p.tap_rows;
     if (m0 - tap * p.tap_rows >= p.tap_cnt[tap]) return;
     pB += (long)(p.b_tap_mirror ? 26 - tap : tap) * p.b_tap_stride;
   }
-  auto arow = [&](int r) { r = min(r, p.M - 1); return a_rows ? a_rows[r] : r; };
+  auto arow = [&](int r) { r = min(r, p.M - 1); return TAP ? a_rows[r] : r; };
   const int kbeg = bz * p.klen;
   const int kend = min(p.K, kbeg + p.klen);
   const int wr0 = (wave >> 1) * (BM / 2), wc0 = (wave & 1) * (BN / 2);
@@ -891,6 +891,18 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     static int ring_wg = -1;
     if (ring_wg < 0) ring_wg = tune_env("LOTUS_GEMM_RING_WG");
     const int rd = (SUM_A && ring_wg != 1) ? 1 : f32_ring_depth(blocks_eff * nz);
+    if (p.tap_rows) {
+      if constexpr (A_KC && !SUM_A && FAST && !LOTUS_ACT_IS_BF16) {
+        if (bk == 64) LOTUS_LAUNCH((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
+        else if (bk == 32) LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
+        else LOTUS_LAUNCH((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
+        LOTUS_LAUNCH_CHECK("lotus_gemm(tap-grouped)");
+        return LOTUS_OK;
+      } else {
+        lotus_set_error("lotus_gemm: tap-grouped products need k-contiguous, 16-byte aligned fp32 rows");
+        return LOTUS_E_UNSUPPORTED;
+      }
+    }
     if (rd == 4) GEMM_GO_RD(64, 64, 32, 0, grid, 4);
     else if (rd == 2 && bk == 64) GEMM_GO_RD(64, 64, 64, 0, grid, 2);
     else if (rd == 2 && bk == 16) GEMM_GO_RD(64, 64, 16, 0, grid, 2);
