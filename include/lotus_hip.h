@@ -138,7 +138,7 @@ int lotus_linear_wgrad(const lotus_act_t* dy, const lotus_act_t* x, float* dw, f
  * tap-split fast path for the 3^3 convolutions.  For thin inputs (mode 0, cin <= 8, e.g. the 5^3 stem) a workspace
  * of >= T*cin*cout floats selects the active-pair VALU kernel. */
 /* tap_plan (optional; lotus_fe_tap_plan of the level's 3^3 table): for few rows and wide layers (lotus_conv_tap_eligible:
- * fp32 storage, exact products, n <= 8192, cin, cout >= 256) the convolution runs as 27 gathered dense products in one
+ * fp32 storage, exact products, n <= 32768, cin, cout >= 256) the convolution runs as 27 gathered dense products in one
  * launch + a fixed-order sum over the taps of every output row (workspace: lotus_subm_conv_workspace covers it) — the
  * pair-compacted kernel re-streams the weight tensor once per 64-row tile there. */
 size_t lotus_subm_conv_workspace(int n, int cin, int cout);
