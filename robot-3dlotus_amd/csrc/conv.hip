@@ -657,20 +657,22 @@ int lotus_subm_conv(int mode, const act_t* x, const float* w, const float* w_t, 
   LOTUS_CHECK_ARG(x && w && y && nbr && n >= 0 && T > 0 && cin > 0 && cout > 0, "lotus_subm_conv: bad arguments");
   LOTUS_CHECK_ARG(precision == 0 || precision == 1 || precision == 3, "lotus_subm_conv: precision must be 0, 1 or 3");
   if (n == 0) return LOTUS_OK;
-  if (tap_plan && T == 27 && precision == 0 && tap_shape_ok(n, cin, cout) && workspace && ((uintptr_t)workspace) % 16 == 0 &&
-      workspace_bytes >= tap_part_bytes(n, mode == 0 ? cout : cin) &&
-      (((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16 == 0) {
+  if (tap_plan && T == 27 && precision == 0 && lotus_conv_tap_eligible(n, cin, cout)) {
+    // A caller that hands over a tap plan for an eligible shape has skipped the packed weights (ops.conv_tap_active): falling
+    // through to the generic kernel would be a silent 10x slowdown, so the preconditions of the path are hard errors.
+    LOTUS_CHECK_ARG(workspace && ((uintptr_t)workspace) % 16 == 0 && workspace_bytes >= tap_part_bytes(n, mode == 0 ? cout : cin),
+                    "lotus_subm_conv: the tap-grouped path needs a 16-byte aligned workspace of lotus_subm_conv_workspace(n, cin, cout) bytes");
+    LOTUS_CHECK_ARG((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16 == 0,
+                    "lotus_subm_conv: the tap-grouped path needs 16-byte aligned operands");
     const int n64 = (n + 63) / 64 * 64, ND = mode == 0 ? cout : cin;
-    int rc = lotus_conv_tap_gemm(mode, x, w, (float*)workspace, tap_plan + 32, tap_plan, n64, cin, cout, (hipStream_t)stream);
-    if (rc == LOTUS_OK) {
-      const long total4 = (long)n * ND / 4;
-      const int g = (int)cdiv(total4, 256);
-      LOTUS_LAUNCH(conv_tap_reduce_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
-                   tap_plan + 32 + 27L * n64, n, ND, bias, add, y);
-      LOTUS_LAUNCH_CHECK("lotus_subm_conv(tap-grouped)");
-      return LOTUS_OK;
-    }
-    if (rc != LOTUS_E_UNSUPPORTED) return rc;
+    const int rc = lotus_conv_tap_gemm(mode, x, w, (float*)workspace, tap_plan + 32, tap_plan, n64, cin, cout, (hipStream_t)stream);
+    if (rc != LOTUS_OK) return rc;
+    const long total4 = (long)n * ND / 4;
+    const int g = (int)cdiv(total4, 256);
+    LOTUS_LAUNCH(conv_tap_reduce_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, (const float*)workspace,
+                 tap_plan + 32 + 27L * n64, n, ND, bias, add, y);
+    LOTUS_LAUNCH_CHECK("lotus_subm_conv(tap-grouped)");
+    return LOTUS_OK;
   }
   {
     int rc = 0;  // pair-compacted fast path (conv_pairs.hip) for the 3^3 CPE convolutions

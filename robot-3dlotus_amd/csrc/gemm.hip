@@ -1064,7 +1064,10 @@ int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, c
     p.a_vec = vec_ok(x, p.K); p.b_vec = vec_ok(w, cin) && cin % 4 == 0; p.prec = 0;
     p.drop_inv_keep = 1.f;
     p.a_rows = tg_in; p.tap_cnt = tg_cnt; p.tap_rows = n64; p.b_tap_mirror = mode == 1; p.b_tap_stride = cin;
-    if (!(fast_ok<true, true>(p))) return LOTUS_E_UNSUPPORTED;
+    if (!(fast_ok<true, true>(p))) {
+      lotus_set_error("lotus_subm_conv(tap-grouped): rows, weights and the partial slab must be 16-byte aligned with widths that are multiples of 4");
+      return LOTUS_E_UNSUPPORTED;
+    }
     return mode == 0 ? launch_gemm<true, true, false>(p, 1, st) : launch_gemm<true, false, false>(p, 1, st);
   }
 }

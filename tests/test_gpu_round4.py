@@ -381,3 +381,22 @@ def test_tap_grouped_convolution_of_the_deep_levels():
         assert not torch.equal(y, y0) or True   # (different summation order: equal only by accident)
         y2 = ops.conv_fwd(x, w, bias, L.nbr27, L.order[0], add=add, w_t=wt, tap_plan=L.tap_plan)
         assert torch.equal(y, y2)                # deterministic
+
+
+@pytest.mark.gpu
+def test_tap_path_fails_loudly_without_its_workspace():
+    """A tap plan for an eligible shape means the caller has not produced the packed weights: the path's preconditions are
+    errors, not a silent fall-through to the generic kernel."""
+    from robot_3dlotus_amd import ops, synth, _capi
+    from robot_3dlotus_amd.frontend import FrontEnd
+
+    dev = torch.device("cuda", 0)
+    b = synth.synth_batch(2, 4096, seed=9)
+    L = FrontEnd(3, conv_widths=[64, 128, 256]).build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * 3)[2]
+    C = 256
+    assert L.tap_plan is not None and ops.conv_tap_active(L, C)
+    x, w = torch.randn(L.n, C, device=dev), torch.randn(C, 3, 3, 3, C, device=dev)
+    y = torch.empty(L.n, C, device=dev)
+    small = torch.empty(1024, dtype=torch.uint8, device=dev)
+    with pytest.raises(_capi.LotusError, match="workspace"):
+        ops.call("lotus_subm_conv", 0, x, w, None, None, None, y, L.nbr27, L.order[0], L.n, 27, C, C, 0, L.tap_plan, small, small.numel())
