@@ -118,6 +118,55 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmP& p, TC* __restrict__ 
   st4(C + o, make_float4(v[0], v[1], v[2], v[3]));
 }
 
+// The tail of a fused split-K block (after its raw partial tile and bias partial have been stored): release the partial
+// (agent scope: the other splits of the tile may run on another XCD / L2), count the arrival, and let the LAST block of the
+// tile sum the nz partials in fixed z order and apply the epilogue.  All reads come after the acquire fence.  Shared by
+// gemm_kernel and wgrad_stream_kernel.
+template <bool SUM_A, int BM, int BN, typename EC>
+__device__ __forceinline__ void splitk_fused_tail(const GemmP& p, int bx, int by, int m0, int n0, int tid) {
+  __shared__ int s_last;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's partial stores have been acknowledged
+  __syncthreads();
+  const int tile_id = by * (int)gridDim.x + bx;
+  if (tid == 0) s_last = __hip_atomic_fetch_add(&p.cnt[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const int nz = gridDim.z;
+  for (int i = tid; i < BM * (BN / 4); i += 256) {
+    const int row = m0 + i / (BN / 4), col = n0 + (i % (BN / 4)) * 4;
+    if (row >= p.M || col >= p.N) continue;
+    const long o = (long)row * p.ldc + col;
+    const float* q = p.part + o;
+    float4 s4 = ld_agent4(q);
+    int z = 1;
+    for (; z + 3 < nz; z += 4) {  // four independent loads in flight, summed in z order
+      const float4 v0 = ld_agent4(q + (long)z * p.part_stride);
+      const float4 v1 = ld_agent4(q + (long)(z + 1) * p.part_stride);
+      const float4 v2 = ld_agent4(q + (long)(z + 2) * p.part_stride);
+      const float4 v3 = ld_agent4(q + (long)(z + 3) * p.part_stride);
+      s4.x = (((s4.x + v0.x) + v1.x) + v2.x) + v3.x; s4.y = (((s4.y + v0.y) + v1.y) + v2.y) + v3.y;
+      s4.z = (((s4.z + v0.z) + v1.z) + v2.z) + v3.z; s4.w = (((s4.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; z < nz; ++z) {
+      const float4 v = ld_agent4(q + (long)z * p.part_stride);
+      s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
+    }
+    float v[4] = {s4.x, s4.y, s4.z, s4.w};
+    gemm_epilogue4(p, static_cast<EC*>(p.C), o, col, v);
+  }
+  if (SUM_A && p.bias_out && p.bias_part && bx == 0) {
+    for (int i = tid; i < BM; i += 256) {
+      if (m0 + i >= p.M) continue;
+      float sb = 0.f;
+      for (int z = 0; z < nz; ++z)
+        sb += __hip_atomic_load(p.bias_part + (long)z * p.bias_stride + m0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      p.bias_out[m0 + i] = p.accumulate ? p.bias_out[m0 + i] + sb : sb;
+    }
+  }
+  if (tid == 0) p.cnt[tile_id] = 0;  // ready for the next launch on this stream
+}
+
 // FAST: operands are 16-byte aligned with ld % 4 == 0 and the contiguous extents are multiples of 4,
 // so every global access is an unconditional float4 (rows / columns beyond the edge are clamped to a
 // valid address; k beyond the split range is zeroed by a select).  !FAST keeps per-element guards
@@ -602,51 +651,168 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
       }
     }
   }
-  if (FAST && fused) {
-    // release this block's partial (agent scope: the other splits of the tile may run on another XCD / L2), count it,
-    // and let the last arrival reduce.  All reads below come after the acquire fence.
-    __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this thread's partial stores have been acknowledged
-    __syncthreads();
-    const int tile_id = by * (int)gridDim.x + bx;
-    if (tid == 0) s_last = __hip_atomic_fetch_add(&p.cnt[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.z - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const int nz = gridDim.z;
-    for (int i = tid; i < BM * (BN / 4); i += 256) {
-      const int row = m0 + i / (BN / 4), col = n0 + (i % (BN / 4)) * 4;
-      if (row >= p.M || col >= p.N) continue;
-      const long o = (long)row * p.ldc + col;
-      const float* q = p.part + o;
-      float4 s4 = ld_agent4(q);
-      int z = 1;
-      for (; z + 3 < nz; z += 4) {  // four independent loads in flight, summed in z order
-        const float4 v0 = ld_agent4(q + (long)z * p.part_stride);
-        const float4 v1 = ld_agent4(q + (long)(z + 1) * p.part_stride);
-        const float4 v2 = ld_agent4(q + (long)(z + 2) * p.part_stride);
-        const float4 v3 = ld_agent4(q + (long)(z + 3) * p.part_stride);
-        s4.x = (((s4.x + v0.x) + v1.x) + v2.x) + v3.x; s4.y = (((s4.y + v0.y) + v1.y) + v2.y) + v3.y;
-        s4.z = (((s4.z + v0.z) + v1.z) + v2.z) + v3.z; s4.w = (((s4.w + v0.w) + v1.w) + v2.w) + v3.w;
-      }
-      for (; z < nz; ++z) {
-        const float4 v = ld_agent4(q + (long)z * p.part_stride);
-        s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w;
-      }
-      float v[4] = {s4.x, s4.y, s4.z, s4.w};
-      gemm_epilogue4(p, static_cast<EC*>(p.C), o, col, v);
-    }
-    if (SUM_A && p.bias_out && p.bias_part && bx == 0) {
-      for (int i = tid; i < BM; i += 256) {
-        if (m0 + i >= p.M) continue;
-        float sb = 0.f;
-        for (int z = 0; z < nz; ++z)
-          sb += __hip_atomic_load(p.bias_part + (long)z * p.bias_stride + m0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p.bias_out[m0 + i] = p.accumulate ? p.bias_out[m0 + i] + sb : sb;
-      }
-    }
-    if (tid == 0) p.cnt[tile_id] = 0;  // ready for the next launch on this stream
+  if (FAST && fused) splitk_fused_tail<SUM_A, BM, BN, EC>(p, bx, by, m0, n0, tid);
+}
+
+// ---- Streaming weight gradient (exact fp32, fp32 storage): dW[N,K] = dY[M,N]^T X[M,K] without LDS staging or barriers.
+// Both operands of a weight gradient are contiguous along their NON-reduction index, which is exactly the lane axis of the
+// 32x32x2 MFMA operands (lane = row / column of the output tile, lane half h = reduction step): a lane that owns the two
+// adjacent output rows 2 l + {0, 1} reads both with ONE 8-byte load of dY[m + h][i0 + 2 l], and the wave's load covers
+// 2 x 256 contiguous bytes.  Every wave therefore streams its own range of rows straight from global memory into MFMA
+// operand registers through a ring of D load pairs in flight (counted vmcnt waits: the steady-state loop has no branch
+// around a load), four 32 x 32 accumulators per wave (output rows 2 l + tm, columns 2 l + tn of a 64 x 64 tile) and
+// ~0.75 non-MFMA instructions per MFMA, where the LDS-tiled kernel spends 2 ds_read_b32 per MFMA on these operands (the
+// instruction-issue budget next to a busy MFMA pipe is 3-4 per MFMA over ALL waves of a SIMD).  The
+// four waves of a block own the same output tile and split the block's row range; their accumulators are summed in a
+// fixed tree through LDS ((w0 + w1) + (w2 + w3)) and leave through the same partial-slab / last-arrival epilogue as
+// gemm_kernel, so the split bookkeeping of lotus_linear_wgrad is shared.  Needs N % 64 == 0, K % 64 == 0, 8-byte aligned rows.
+template <int D>
+__global__ __launch_bounds__(256) void wgrad_stream_kernel(GemmP p) {
+  const float* __restrict__ pA = static_cast<const float*>(p.A);
+  const float* __restrict__ pB = static_cast<const float*>(p.B);
+  constexpr int TLD = 68;  // row stride of the 64 x 64 exchange tiles (float4 rows, 16-byte aligned)
+  __shared__ __attribute__((aligned(16))) float tiles[2][64 * TLD];
+  __shared__ float bsum_s[4][64];
+  const int tid = threadIdx.x, l31 = tid & 31, h = (tid >> 5) & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row ranges, pointers and loop bounds live in SGPRs
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {  // (the split-K block order of gemm_kernel: one XCD / L2 per split)
+    const int ntile = gridDim.x * gridDim.y;
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bz = xcd + 8 * (slot / ntile);
+    const int t = slot - (slot / ntile) * ntile;
+    by = t / (int)gridDim.x;
+    bx = t - by * (int)gridDim.x;
   }
+  const int m0 = by * 64, n0 = bx * 64;
+  const int per = p.klen >> 2;  // rows per wave (klen is a multiple of 64)
+  const int kb = bz * p.klen + wave * per;
+  const int rows = max(0, min(min(p.K, (bz + 1) * p.klen), kb + per) - kb);
+  const int nst = (rows + 1) >> 1;  // reduction steps of two rows (the last one may hold one row)
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float as0 = 0.f, as1 = 0.f;  // column sums of dY (bias gradient): this lane's rows of parity h
+
+  // One buffer descriptor per operand over THIS wave's rows.  The running row offset is part of the per-lane VGPR offset
+  // (one v_add per load; the scalar offset of a buffer instruction is not bounds-checked), so a load past the wave's last
+  // row returns zeros: the single row of an odd tail step and the steps that pad the range to a whole number of ring
+  // cycles multiply zeros, and the loop needs no tail code.
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(pA + (long)kb * p.lda), 0, (int)((unsigned)rows * (unsigned)p.lda * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(pB + (long)kb * p.ldb), 0, (int)((unsigned)rows * (unsigned)p.ldb * 4u), 0x00020000);
+  int oa = 4 * (h * (int)p.lda + m0 + 2 * l31), ob = 4 * (h * (int)p.ldb + n0 + 2 * l31);  // per-lane byte offsets
+  const int sa = 8 * (int)p.lda, sb = 8 * (int)p.ldb;                                      // two rows per step
+  auto lda2 = [&]() { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra_rsrc, oa, 0, 0); oa += sa; return v; };
+  auto ldb2 = [&]() { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rb_rsrc, ob, 0, 0); ob += sb; return v; };
+  const bool want_bias = p.bias_part && bx == 0;  // (block-uniform) only the first column block reports the column sums of dY
+  const int cycles = (nst + D - 1) / D;           // ring cycles of D steps (wave-uniform)
+  auto run = [&](auto bias_tag) {
+    constexpr bool BIAS = decltype(bias_tag)::value;
+    float s0[D], s1[D];  // bias gradient: one independent pair of sums per ring slot (no chain through the operand registers)
+#pragma unroll
+    for (int d = 0; d < D; ++d) s0[d] = s1[d] = 0.f;
+    auto step = [&](u32x2 au, u32x2 bu, int d) {
+      const float ax = __uint_as_float(au.x), ay = __uint_as_float(au.y), bx_ = __uint_as_float(bu.x), by_ = __uint_as_float(bu.y);
+      if (BIAS) { s0[d] += ax; s1[d] += ay; }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx_, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, by_, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bx_, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, by_, acc[1][1], 0, 0, 0);
+    };
+    u32x2 ra[D], rb[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { ra[d] = lda2(); rb[d] = ldb2(); }
+    for (int c = 1; c < cycles; ++c) {
+      // slot d's loads were issued D steps ago: 2 (D - 1) younger loads stay in flight across its wait
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        step(ra[d], rb[d], d);
+        ra[d] = lda2(); rb[d] = ldb2();
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {  // the order the scheduler has to keep: four products, then the refill of their slot
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (BIAS) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // (the sums read the slot before its refill may land)
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) step(ra[d], rb[d], d);
+    if (BIAS) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) { as0 += s0[d]; as1 += s1[d]; }
+    }
+  };
+  if (cycles > 0) {
+    if (want_bias) run(std::true_type{});
+    else run(std::false_type{});
+  }
+
+  // ---- the four waves' partial tiles -> one, in a fixed tree: (w0 + w1) + (w2 + w3)
+  // accumulator register r of tile (tm, tn): output row 2 i + tm with i = (r & 3) + 8 (r >> 2) + 4 h, column 2 l31 + tn
+  auto put = [&](float* T) {
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        *reinterpret_cast<float2*>(&T[(2 * i + tm) * TLD + 2 * l31]) = make_float2(acc[tm][0][r], acc[tm][1][r]);
+      }
+  };
+  auto add = [&](const float* T) {  // acc = acc + T (own partial first: the order of the tree)
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float2 v = *reinterpret_cast<const float2*>(&T[(2 * i + tm) * TLD + 2 * l31]);
+        acc[tm][0][r] += v.x; acc[tm][1][r] += v.y;
+      }
+  };
+  if (want_bias) {
+    as0 += __shfl_xor(as0, 32, 64); as1 += __shfl_xor(as1, 32, 64);
+    if (h == 0) { bsum_s[wave][2 * l31] = as0; bsum_s[wave][2 * l31 + 1] = as1; }
+  }
+  if (wave == 1) put(tiles[0]);
+  if (wave == 3) put(tiles[1]);
+  __syncthreads();
+  if (wave == 0) add(tiles[0]);
+  if (wave == 2) add(tiles[1]);
+  __syncthreads();
+  if (wave == 2) put(tiles[1]);
+  __syncthreads();
+  if (wave == 0) { add(tiles[1]); put(tiles[0]); }
+  __syncthreads();
+
+  const bool fused = p.cnt != nullptr && gridDim.z > 1;
+  float* __restrict__ C = static_cast<float*>(p.C) + (long)bz * p.part_stride;
+  float* __restrict__ Cp = fused ? p.part + (long)bz * p.part_stride : nullptr;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int i = tid + it * 256, row = i >> 4, c4 = i & 15;
+    const long o = (long)(m0 + row) * p.ldc + n0 + c4 * 4;
+    const float4 a4 = ld4(&tiles[0][row * TLD + c4 * 4]);
+    if (fused) {
+      st_agent4(Cp + o, a4);  // raw partial of this split
+    } else {
+      float v[4] = {a4.x, a4.y, a4.z, a4.w};
+      gemm_epilogue4(p, C, o, n0 + c4 * 4, v);
+    }
+  }
+  if (want_bias && tid < 64) {
+    const float sbias = ((bsum_s[0][tid] + bsum_s[1][tid]) + (bsum_s[2][tid] + bsum_s[3][tid]));
+    __hip_atomic_store(p.bias_part + (long)bz * p.bias_stride + m0 + tid, sbias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (fused) splitk_fused_tail<true, 64, 64, float>(p, bx, by, m0, n0, tid);
 }
 
 // out[e] = sum_z part[z * stride + e].  Block = 16 float4 columns x 16 z-lanes: coalesced 256-byte row
@@ -1148,6 +1314,33 @@ static int wgrad_splits(int M, int N, int K) {
   return nz;
 }
 
+// Weight-gradient launch.  LOTUS_WGRAD_STREAM = 1 (OPT-IN) runs the exact-fp32 products of the fp32-storage build on
+// wgrad_stream_kernel where it applies (64-aligned output, vector-aligned operands, >= LOTUS_WGRAD_STREAM_MINROWS rows,
+// default 256); gemm_kernel otherwise.  Measured (tools/wgrad_ab.py, all 35 weight-gradient shapes of a v1 step, both
+// within 1e-6 of float64): 3.37 -> 3.28 ms per step stand-alone (65536 x 384 x 128 90 -> 79 us, 361 x 768 x 768 15.8 ->
+// 12.5, 65536 x 192 x 64 32.8 -> 35.4) and no difference inside the training step (898 / 928 vs 906 / 907 samples/s over
+// two alternations: inside the box-to-box noise) — two kernels this different landing within 3 % of each other on every
+// shape says the weight gradient is bound by what they share (operand stream + partial slabs + the reduction launch behind
+// them), not by the inner loop: the LDS-tiled kernel stays the default.
+static int launch_wgrad(GemmP& p, int nz, hipStream_t st) {
+  if constexpr (!LOTUS_ACT_IS_BF16) {
+    static int mode = -1, minrows = -1;
+    if (mode < 0) {
+      mode = tune_env("LOTUS_WGRAD_STREAM");
+      minrows = tune_env("LOTUS_WGRAD_STREAM_MINROWS"); if (minrows <= 0) minrows = 256;
+    }
+    if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
+    if (mode && p.prec == 0 && g_force_tile != 1 && p.M % 64 == 0 && p.N % 64 == 0 && p.K >= minrows && p.klen % 64 == 0 &&
+        p.lda % 2 == 0 && p.ldb % 2 == 0 && fast_ok<false, false>(p)) {
+      dim3 grid(p.N / 64, p.M / 64, nz), block(256);
+      LOTUS_LAUNCH(wgrad_stream_kernel<8>, grid, block, 0, st, p);
+      LOTUS_LAUNCH_CHECK("lotus_linear_wgrad(stream)");
+      return LOTUS_OK;
+    }
+  }
+  return launch_gemm<false, false, true>(p, nz, st);
+}
+
 size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
   return (size_t)wgrad_splits(M, N, K) * ((size_t)N * K + N) * sizeof(float);
 }
@@ -1184,7 +1377,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
     GemmP q = p;
     q.C = dw; q.part = part; q.part_stride = (long)slab; q.cnt = (unsigned*)counters;
     q.bias_part = db ? part + (size_t)N * K : nullptr; q.bias_stride = (long)slab; q.bias_out = db; q.accumulate = accumulate;
-    if (fast_ok<false, false>(q)) return launch_gemm<false, false, true>(q, nz, st);
+    if (fast_ok<false, false>(q)) return launch_wgrad(q, nz, st);
   }
   if (direct) {
     p.C = dw; p.bias_part = db;
@@ -1192,7 +1385,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
     p.C = part; p.part_stride = (long)slab;
     p.bias_part = db ? part + (size_t)N * K : nullptr; p.bias_stride = (long)slab;
   }
-  int rc = launch_gemm<false, false, true>(p, nz, st);
+  int rc = launch_wgrad(p, nz, st);
   if (rc || direct) return rc;
   const long n = (long)N * K;
   if (db && db == dw + n) return lotus_reduce_parts(part, dw, (long)slab, (long)slab, nz, accumulate, st);
