@@ -7,10 +7,16 @@ spconv's neighbour lookup.  The device pipeline (csrc/front_end.hip) runs withou
 small device->host copy at the end returns the per-level point counts, after which the exactly
 sized neighbour / patch / tile tables are built.
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 
 from ._capi import call, query, WS
+
+# build the exact-size tables of a PREFETCHED front-end on the front-end stream (FrontEnd.finish)
+FINISH_ON_SIDE = os.environ.get("LOTUS_FE_FINISH_SIDE", "1") != "0"
 
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
 
@@ -160,7 +166,8 @@ class FrontEnd:
         N, B, Lv = int(pc_fts.shape[0]), len(counts), self.n_levels
         i32 = dict(dtype=torch.int32, device=dev)
         pend["event"].synchronize()
-        if pend["stream"] is not None:  # tables were allocated on the side stream and are consumed here
+        fe = pend["stream"]
+        if fe is not None:  # tables were allocated on the side stream and are consumed here
             cur = torch.cuda.current_stream()
             cur.wait_event(pend["event"])
             for t in pend["keep"]:
@@ -228,13 +235,43 @@ class FrontEnd:
         ntab = sum(a.size for a in host_tabs)
         tabs_h = torch.empty(ntab, dtype=torch.int32, pin_memory=True)  # pinned: the upload must not drain the queue
         np.concatenate(host_tabs, out=tabs_h.numpy())
+        # A prefetched front-end also builds its exact-size tables on the front-end stream: the host is ahead of the GPU
+        # when forward() gets here, so the ~0.5 ms of hash / neighbour / patch kernels run under the tail of the previous
+        # backward pass instead of in front of the stem convolution on the critical stream (the current stream waits for
+        # one event at the end; LOTUS_FE_FINISH_SIDE=0 keeps them on the current stream).
+        side = fe is not None and FINISH_ON_SIDE
+        made = []  # tensors allocated under the front-end stream and consumed on the current one
+        with (torch.cuda.stream(fe) if side else contextlib.nullcontext()):
+            levels = self._finish_tables(pend, tabs_h, plans, host_tabs, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord,
+                                         made, ws_slot=5 if side else 1)
+        if side:
+            ev = torch.cuda.Event()
+            ev.record(fe)
+            cur.wait_event(ev)
+            for t in made:
+                t.record_stream(cur)
+        return levels
+
+    def _finish_tables(self, pend, tabs_h, plans, host_tabs, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord, made, ws_slot):
+        pc_fts, counts, raw = pend["pc_fts"], pend["counts"], pend["raw"]
+        dev = pc_fts.device
+        B, Lv, K = len(counts), self.n_levels, self.K
+        i32 = dict(dtype=torch.int32, device=dev)
+        levels = []
+
+        def empty(*shape, **kw):
+            t = torch.empty(*shape, **(kw or i32))
+            made.append(t)
+            return t
+
         tabs = tabs_h.to(dev, non_blocking=True)
+        made.append(tabs)
 
         def view(sl, cols=None):
             t = tabs[sl[0]:sl[0] + sl[1]]
             return t.view(-1, cols) if cols else t
 
-        ws_n = WS.get(query("lotus_fe_neighbours_workspace", ns[0]), dev, slot=1)
+        ws_n = WS.get(query("lotus_fe_neighbours_workspace", ns[0]), dev, slot=ws_slot)
         for s in range(Lv):
             n, r, pl = ns[s], raw[s], plans[s]
             lv = Level()
@@ -245,23 +282,23 @@ class FrontEnd:
             lv.off, lv.off_host = view(pl["off"]), pl["off_host"]
             lv.grid, lv.batch = r["grid"][:n], r["batch"][:n]
             lv.code, lv.order, lv.inverse = r["code"][:, :n], r["order"][:, :n], r["inverse"][:, :n]
-            lv.nbr27 = torch.empty(27, n, **i32)
+            lv.nbr27 = empty(27, n)
             call("lotus_fe_neighbours", lv.grid, lv.batch, n, 3, lv.nbr27, ws_n, ws_n.numel())
             lv.tap_plan = None
             if self.conv_widths is not None and s < len(self.conv_widths) and n > 0 and \
                     query("lotus_conv_tap_eligible", n, self.conv_widths[s], self.conv_widths[s]):
-                lv.tap_plan = torch.empty(query("lotus_fe_tap_plan_ints", n), **i32)
+                lv.tap_plan = empty(query("lotus_fe_tap_plan_ints", n))
                 call("lotus_fe_tap_plan", lv.nbr27, lv.order[0], n, lv.tap_plan)
             lv.nbr125 = None
             if s == 0:
-                lv.nbr125 = torch.empty(125, n, **i32)
+                lv.nbr125 = empty(125, n)
                 call("lotus_fe_neighbours", lv.grid, lv.batch, n, 5, lv.nbr125, ws_n, ws_n.numel())
             lv.npad = pl["npad"]
-            lv.gidx = torch.empty(lv.npad, **i32)
-            lv.owner = torch.empty(lv.npad, **i32)
-            lv.kext = torch.empty(lv.npad, **i32)
+            lv.gidx = empty(lv.npad)
+            lv.owner = empty(lv.npad)
+            lv.kext = empty(lv.npad)
             lv.n_extra = lv.npad - n
-            lv.ext_pos = torch.empty(max(lv.n_extra, 1), **i32)
+            lv.ext_pos = empty(max(lv.n_extra, 1))
             call("lotus_fe_patch", r["order"], lv.off, view(pl["offp"]), B, K, lv.npad, lv.gidx, lv.owner, lv.kext,
                  lv.ext_pos)
             # deeper stages: block i attends along curve slot i % 4 — those tables are built by Level.for_order on first use
@@ -285,6 +322,6 @@ class FrontEnd:
             levels[0].coord = pc_fts[:, :3]
             for s in range(1, Lv):
                 lv = levels[s]
-                lv.coord = torch.empty(lv.n, 3, dtype=torch.float32, device=dev)
+                lv.coord = empty(lv.n, 3, dtype=torch.float32, device=dev)
                 call("lotus_fe_pool_coord", levels[s - 1].coord.contiguous(), lv.members, lv.seg_start, lv.n, lv.coord)
         return levels

@@ -187,6 +187,20 @@ _CUR = 0        # side stream of the _OnSide block being executed
 _LINK = 0       # lotus_streamlink handle (event ring) used for every fork / join
 
 
+def _low_priority_stream():
+    """A stream of the LOWEST priority the device offers (torch.cuda.Stream only reaches 'normal'); tuning knob
+    LOTUS_SIDE_LOWPRIO=1: the weight-gradient queue then yields dispatch slots to every other queue."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+        return torch.cuda.Stream()
+    h = ctypes.c_void_p()
+    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) != 0:  # 1 = hipStreamNonBlocking
+        return torch.cuda.Stream()
+    return torch.cuda.ExternalStream(h.value)
+
+
 def _side():
     global SIDE, _LINK
     if not _SIDE_ON or _IN_NODE == 0:
@@ -195,7 +209,7 @@ def _side():
         # measured: more than one side stream (766 vs 796 samples/s) and CU-masked side streams (<= 796) only add
         # contention with the critical path; LOTUS_SIDE_STREAMS stays as a tuning knob
         for _ in range(_NSIDE):
-            st = torch.cuda.Stream()
+            st = _low_priority_stream() if os.environ.get("LOTUS_SIDE_LOWPRIO", "0") == "1" else torch.cuda.Stream()
             _SIDES.append((st, st.cuda_stream))
         if not _LINK:
             _LINK = query("lotus_streamlink_create", 256)
