@@ -379,29 +379,33 @@ __device__ __forceinline__ unsigned ht_hash(unsigned long long k) {
   k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
   return (unsigned)k;
 }
-__global__ void fe_hash_build_kernel(const int* __restrict__ grid, const int* __restrict__ batch, int n,
-                                     unsigned long long* __restrict__ hkeys, int* __restrict__ hvals, unsigned mask) {
+// One 16-byte slot per entry: {key (8 bytes), lowest point index (4), pad} — a probe is ONE 16-byte load instead of a key
+// load and a dependent value load from a second array (the kernel sits at the L2 random-access rate: halving the accesses
+// halves its time).  An empty slot is all ones: the whole table is initialised by a single memset, and the index is
+// merged with an UNSIGNED atomicMin.
+struct __attribute__((aligned(16))) HtSlot { unsigned long long key; unsigned val; unsigned pad; };
+__global__ void fe_hash_build_kernel(const int* __restrict__ grid, const int* __restrict__ batch, int n, HtSlot* __restrict__ ht,
+                                     unsigned mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned long long key = vox_key(batch[i], grid[(long)i * 3], grid[(long)i * 3 + 1], grid[(long)i * 3 + 2]);
   unsigned slot = ht_hash(key) & mask;
   while (true) {
-    const unsigned long long prev = atomicCAS(&hkeys[slot], HT_EMPTY, key);
+    const unsigned long long prev = atomicCAS(&ht[slot].key, HT_EMPTY, key);
     if (prev == HT_EMPTY || prev == key) {
-      atomicMin(&hvals[slot], i);  // duplicate voxels -> lowest index wins (SURVEY.md Trap 5)
+      atomicMin(&ht[slot].val, (unsigned)i);  // duplicate voxels -> lowest index wins (SURVEY.md Trap 5)
       break;
     }
     slot = (slot + 1) & mask;
   }
 }
 // nbr[t][i], t = ((dx+r)*k + (dy+r))*k + (dz+r).  One thread per (point, tap) and a fully scattering hash: ~19 M random
-// 8-byte probes per level-0 5^3 table, i.e. the kernel sits at the L2 random-access rate (540 GB/s of HBM-side traffic
-// is all it needs).  Measured and rejected: a z-local home slot (the 8 cells of a z octet in one 64-byte line) with one
-// thread probing the k cells of a (dx, dy) column — surface clouds fill whole octets, probe chains grow and the
-// per-thread chains serialise: 22 -> 65 us per launch, hash build 11 -> 28 us.
+// probes per level-0 5^3 table, i.e. the kernel sits at the L2 random-access rate.  Measured and rejected: a z-local home
+// slot (the 8 cells of a z octet in one 64-byte line) with one thread probing the k cells of a (dx, dy) column — surface
+// clouds fill whole octets, probe chains grow and the per-thread chains serialise: 22 -> 65 us per launch, hash build
+// 11 -> 28 us.
 __global__ void fe_neighbour_kernel(const int* __restrict__ grid, const int* __restrict__ batch, int n, int ksize,
-                                    const unsigned long long* __restrict__ hkeys, const int* __restrict__ hvals,
-                                    unsigned mask, int* __restrict__ nbr) {
+                                    const HtSlot* __restrict__ ht, unsigned mask, int* __restrict__ nbr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int t = blockIdx.y;
   if (i >= n) return;
@@ -413,8 +417,9 @@ __global__ void fe_neighbour_kernel(const int* __restrict__ grid, const int* __r
     const unsigned long long key = vox_key(batch[i], x, y, z);
     unsigned slot = ht_hash(key) & mask;
     while (true) {
-      const unsigned long long k = hkeys[slot];
-      if (k == key) { res = hvals[slot]; break; }
+      const uint4 s4 = *reinterpret_cast<const uint4*>(&ht[slot]);  // key and index in one access
+      const unsigned long long k = (unsigned long long)s4.x | ((unsigned long long)s4.y << 32);
+      if (k == key) { res = (int)s4.z; break; }
       if (k == HT_EMPTY) break;
       slot = (slot + 1) & mask;
     }
@@ -557,7 +562,7 @@ int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int
 size_t lotus_fe_neighbours_workspace(int n) {
   size_t cap = 1;
   while (cap < (size_t)2 * (n > 0 ? n : 1)) cap <<= 1;
-  return cap * (sizeof(unsigned long long) + sizeof(int));
+  return cap * sizeof(HtSlot);
 }
 
 // Tap plan of a level (lotus_fe_tap_plan): plan = [cnt: 32 ints | in: 27 x n64 | pos: 27 x n], n64 = n rounded up to 64.
@@ -611,15 +616,14 @@ int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int
   if (n == 0) return LOTUS_OK;
   size_t cap = 1;
   while (cap < (size_t)2 * n) cap <<= 1;
-  LOTUS_CHECK_ARG(workspace && workspace_bytes >= cap * 12, "lotus_fe_neighbours: workspace too small");
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= cap * sizeof(HtSlot) && ((uintptr_t)workspace) % 16 == 0,
+                  "lotus_fe_neighbours: workspace too small or not 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  unsigned long long* hk = (unsigned long long*)workspace;
-  int* hv = (int*)(hk + cap);
-  (void)hipMemsetAsync(hk, 0xff, cap * sizeof(unsigned long long), st);
-  (void)hipMemsetAsync(hv, 0x7f, cap * sizeof(int), st);
-  LOTUS_LAUNCH(fe_hash_build_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, grid, batch, n, hk, hv, (unsigned)(cap - 1));
+  HtSlot* ht = (HtSlot*)workspace;
+  (void)hipMemsetAsync(ht, 0xff, cap * sizeof(HtSlot), st);
+  LOTUS_LAUNCH(fe_hash_build_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, grid, batch, n, ht, (unsigned)(cap - 1));
   LOTUS_LAUNCH(fe_neighbour_kernel, dim3(cdiv(n, 256), ksize * ksize * ksize), dim3(256), 0, st, grid, batch, n,
-                     ksize, hk, hv, (unsigned)(cap - 1), nbr);
+                     ksize, ht, (unsigned)(cap - 1), nbr);
   LOTUS_LAUNCH_CHECK("lotus_fe_neighbours");
   return LOTUS_OK;
 }
