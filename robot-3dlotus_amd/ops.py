@@ -187,19 +187,6 @@ _CUR = 0        # side stream of the _OnSide block being executed
 _LINK = 0       # lotus_streamlink handle (event ring) used for every fork / join
 
 
-def _cu_masked_stream(pattern):
-    """A stream restricted to the CUs whose bit is set in `pattern` (32 bits, repeated over the 256 CUs); tuning knob
-    LOTUS_SIDE_CUMASK=0x...: the weight-gradient queue then never occupies the masked-out CUs, which stay free for the
-    critical stream's small launches."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    words = (ctypes.c_uint32 * 8)(*([pattern & 0xFFFFFFFF] * 8))
-    h = ctypes.c_void_p()
-    if hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, words) != 0:
-        return torch.cuda.Stream()
-    return torch.cuda.ExternalStream(h.value)
-
-
 def _low_priority_stream():
     """A stream of the LOWEST priority the device offers (torch.cuda.Stream only reaches 'normal'); tuning knob
     LOTUS_SIDE_LOWPRIO=1: the weight-gradient queue then yields dispatch slots to every other queue."""
@@ -222,10 +209,9 @@ def _side():
         # measured: more than one side stream (766 vs 796 samples/s) and CU-masked side streams (<= 796) only add
         # contention with the critical path; LOTUS_SIDE_STREAMS stays as a tuning knob
         for _ in range(_NSIDE):
-            if os.environ.get("LOTUS_SIDE_CUMASK"):
-                st = _cu_masked_stream(int(os.environ["LOTUS_SIDE_CUMASK"], 16))
-            else:
-                st = _low_priority_stream() if os.environ.get("LOTUS_SIDE_LOWPRIO", "0") == "1" else torch.cuda.Stream()
+            # (measured again in round 4 with hipExtStreamCreateWithCUMask: side stream on 7/8, 3/4 or 31/32 of the CUs gives
+            # 923-931 / 929-932 / 875-879 samples/s against 930: reserving CUs for the critical stream buys nothing)
+            st = _low_priority_stream() if os.environ.get("LOTUS_SIDE_LOWPRIO", "0") == "1" else torch.cuda.Stream()
             _SIDES.append((st, st.cuda_stream))
         if not _LINK:
             _LINK = query("lotus_streamlink_create", 256)
