@@ -81,10 +81,18 @@ class MotionPlannerPTV3CA(BaseModel):
             feat = pre[2]   # prefetch() built it (and started the front-end on exactly this tensor)
         else:
             feat = torch.cat([batch["pc_fts"].float(), F.one_hot(labels, 4).float()], -1)
-        ctx = ops.LinearFn.apply(batch["txt_embeds"].contiguous(), self.txt_fc.weight, self.txt_fc.bias)
+        txt, extra = batch["txt_embeds"].contiguous(), {}
+        if getattr(self, "act_storage", None) == "bf16":
+            # bf16 activation storage (as SimplePolicyPTV3CA.prepare_ptv3_batch): the network inputs are rounded once here;
+            # the integer front end keeps reading the fp32 coordinates — the first three columns of the fp32 `feat`
+            extra["coord_src"] = feat
+            txt, feat_in = txt.to(torch.bfloat16), feat.to(torch.bfloat16)
+        else:
+            feat_in = feat
+        ctx = ops.LinearFn.apply(txt, self.txt_fc.weight, self.txt_fc.bias)
         return {"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
-                "feat": feat, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
-                "context_counts": list(batch["txt_lens"])}
+                "feat": feat_in, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
+                "context_counts": list(batch["txt_lens"]), **extra}
 
     @torch.no_grad()
     def prefetch(self, batch):
@@ -97,10 +105,12 @@ class MotionPlannerPTV3CA(BaseModel):
                                   "feat": feat, "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
 
     gemm_precision = None  # as SimplePolicyPTV3CA.gemm_precision
+    act_storage = None     # None / 'fp32' | 'bf16': as SimplePolicyPTV3CA.act_storage (bf16 activations in HBM, fp32 masters)
 
     def forward(self, batch, compute_loss=False, **kwargs):
-        if getattr(self, "act_storage", None) == "bf16":
-            raise NotImplementedError("bf16 activation storage is built for SimplePolicyPTV3CA (BASELINE configs[4]) only")
+        if self.act_storage == "bf16":
+            with ops.storage(torch.bfloat16):
+                return self._forward(batch, compute_loss, **kwargs)
         with ops.precision(self.gemm_precision):
             return self._forward(batch, compute_loss, **kwargs)
 
@@ -126,7 +136,7 @@ class MotionPlannerPTV3CA(BaseModel):
                                         ops.mix_seed(self.ptv3_model.last_seed, 2000)))         # T x [N, 3*nb]
         # action branch, :116-120,139-146: max over points commutes with the concatenated step embedding
         pc = ops.CloudMaxFn.apply(x, lvl)                                                         # [B, C]
-        pcs = torch.cat([pc.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(B, -1, -1)], -1).reshape(B * T, -1)
+        pcs = torch.cat([pc.unsqueeze(1).expand(-1, T, -1), te.to(pc.dtype).unsqueeze(0).expand(B, -1, -1)], -1).reshape(B * T, -1)
         a = F.dropout(F.leaky_relu(ops.LinearFn.apply(pcs, am[0].weight, am[0].bias), 0.02), p, self.training)
         ae = ops.LinearFn.apply(a, am[3].weight, am[3].bias).view(B, T, -1)
         pred_rot = ae[..., :eb * 3].reshape(B, T, eb, 3)

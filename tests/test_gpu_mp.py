@@ -108,6 +108,53 @@ def test_mp_live_oracle_parity_decode_and_determinism():
     assert torch.equal(final, final2) and all(torch.equal(losses[k], losses2[k]) for k in losses)
 
 
+def test_mp_bf16_activation_storage_forward_backward():
+    """bf16 ACTIVATION STORAGE for the motion planner (model.act_storage = 'bf16': the lotus_b16_* twins, fp32 master weights,
+    fp32 parameter gradients), as tests/test_gpu_model.py checks it for the policy: against the fp32 oracle under autograd on
+    seeded inputs with scaled weights (train mode, dropout off) — logits relative to the largest logit of each head, the
+    whole gradient in norm and direction, bf16-sized bars — and an fp32 pass after the bf16 one is bit-identical to one
+    before it."""
+    from oracle.model import Oracle
+    from robot_3dlotus_amd import config as lcfg, synth
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("mp_tiny")
+    sd = seeded_state_dict(gu.state_template(cfg), 43, "scaled")
+    batch = synth.synth_batch_mp(3, 640, ragged=True, seed=79)
+    perms = [[2, 0, 3, 1], [1, 3, 0, 2]]
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    ref = Oracle(sdg, lcfg.plain(cfg), training=True).forward_mp(batch, perms)
+    ref["losses"]["total"].backward()
+
+    def run(storage):
+        m = _build(cfg, sd, True)
+        m.act_storage = storage
+        m.ptv3_model.order_perms = perms
+        _, losses = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        return m, losses
+
+    m32, l32 = run(None)
+    x32 = m32.pred_pos().detach().clone()
+    mb, lb = run("bf16")
+    assert mb.last_pred[0][0].dtype == torch.bfloat16 and all(p.grad is None or p.grad.dtype == torch.float32 for p in mb.parameters())
+    for name, got in (("xt", mb.pred_pos()), ("xr", mb.last_pred[1]), ("xo", mb.last_pred[2]), ("xstop", mb.last_pred[3])):
+        r = ref[name].detach().numpy()
+        err = float(np.abs(got.detach().float().cpu().numpy() - r).max()) / max(1.0, float(np.abs(r).max()))
+        assert err <= 3e-2, (name, err)
+    names = [n for n, p in mb.named_parameters() if p.grad is not None]
+    g = torch.cat([dict(mb.named_parameters())[n].grad.flatten() for n in names]).cpu()
+    gref = torch.cat([sdg[n].grad.flatten() for n in names])
+    assert torch.isfinite(g).all()
+    rel = float((g - gref).norm() / gref.norm())
+    cos = float(torch.dot(g.double(), gref.double()) / (g.double().norm() * gref.double().norm()))
+    lerr = abs(lb["total"].item() - ref["losses"]["total"].item()) / max(1.0, abs(ref["losses"]["total"].item()))
+    assert lerr <= 3e-2 and rel < 0.35 and cos > 0.95, (lerr, rel, cos)
+    m32b, _ = run(None)
+    assert torch.equal(m32b.pred_pos(), x32), "fp32 forward changed after a bf16-storage pass"
+    assert all((a.grad is None and b.grad is None) or torch.equal(a.grad, b.grad) for a, b in zip(m32.parameters(), m32b.parameters()))
+
+
 def test_mp_train_step_is_deterministic():
     """Two identical training steps from the same state give bit-identical gradients (no atomics on the gradient path:
     the label-embedding gradient is a GEMM reduction)."""
