@@ -201,24 +201,30 @@ class Oracle:
         ctx = self.lin(self.q(batch["txt_embeds"].to(self.dt)), "txt_fc")  # simple_policy_ptv3.py:414
         ctx_counts = list(batch["txt_lens"])
         act = self.cfg["action"]
-        if act.get("use_ee_pose") or act.get("use_step_id"):  # simple_policy_ptv3.py:419-427, base.py:52-78
-            from scipy.spatial.transform import Rotation as R
-            parts = list(torch.split(ctx, ctx_counts))
-            if act.get("use_ee_pose"):
-                a = batch["ee_poses"].to(self.dt)
-                eul = torch.from_numpy(R.from_quat(batch["ee_poses"][..., 3:7].numpy()).as_euler("xyz")).float().to(self.dt)
-                e = (self.lin(a[..., :3], "pose_embedding.pos_embedding") + self.lin(torch.cat([torch.sin(eul), torch.cos(eul)], -1), "pose_embedding.rot_embedding")
-                     + self.sd["pose_embedding.open_embedding.weight"][batch["ee_poses"][..., -1].long()])
-                e = F.layer_norm(e, (e.shape[-1],), self.sd["pose_embedding.layer_norm.weight"], self.sd["pose_embedding.layer_norm.bias"], 1e-12)
-                parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
-                ctx_counts = [c + 1 for c in ctx_counts]
-            if act.get("use_step_id"):
-                e = self.sd["stepid_embedding.weight"][batch["step_ids"].long()]
-                parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
-                ctx_counts = [c + 1 for c in ctx_counts]
-            ctx = torch.cat(parts, 0)
+        ctx, ctx_counts = self.context_tokens(ctx, ctx_counts, batch, act.get("use_ee_pose"), act.get("use_step_id"))
         x, out = self.backbone(pc, pc32[:, :3], counts, ctx, ctx_counts, perms)
         return self.head(x, counts, batch, out, compute_loss)
+
+    def context_tokens(self, ctx, ctx_counts, batch, use_ee_pose, use_step_id):
+        """One extra context token per cloud and option, appended to that cloud's instruction tokens
+        (simple_policy_ptv3.py:419-427, motion_planner_ptv3.py:451-457; RobotPoseEmbedding base.py:52-78)."""
+        if not (use_ee_pose or use_step_id):
+            return ctx, ctx_counts
+        from scipy.spatial.transform import Rotation as R
+        parts = list(torch.split(ctx, ctx_counts))
+        if use_ee_pose:
+            a = batch["ee_poses"].to(self.dt)
+            eul = torch.from_numpy(R.from_quat(batch["ee_poses"][..., 3:7].numpy()).as_euler("xyz")).float().to(self.dt)
+            e = (self.lin(a[..., :3], "pose_embedding.pos_embedding") + self.lin(torch.cat([torch.sin(eul), torch.cos(eul)], -1), "pose_embedding.rot_embedding")
+                 + self.sd["pose_embedding.open_embedding.weight"][batch["ee_poses"][..., -1].long()])
+            e = F.layer_norm(e, (e.shape[-1],), self.sd["pose_embedding.layer_norm.weight"], self.sd["pose_embedding.layer_norm.bias"], 1e-12)
+            parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
+            ctx_counts = [c + 1 for c in ctx_counts]
+        if use_step_id:
+            e = self.sd["stepid_embedding.weight"][batch["step_ids"].long()]
+            parts = [torch.cat([c, t_.unsqueeze(0)], 0) for c, t_ in zip(parts, e)]
+            ctx_counts = [c + 1 for c in ctx_counts]
+        return torch.cat(parts, 0), ctx_counts
 
     def backbone(self, feat, xyz, counts, ctx, ctx_counts, perms):
         """PointTransformerV3CA.forward, PointTransformerV3/model_ca.py:314-347: embedding, encoder, decoder.
@@ -322,7 +328,8 @@ class Oracle:
         counts = list(batch["npoints_in_batch"])
         feat = torch.cat([pc, sd["pc_label_embedding.weight"][batch["pc_labels"].long()]], -1)   # :441-442
         ctx = self.lin(batch["txt_embeds"].to(self.dt), "txt_fc")                                  # :447
-        x, out = self.backbone(feat, pc32[:, :3], counts, ctx, list(batch["txt_lens"]), perms)
+        ctx, ctx_counts = self.context_tokens(ctx, list(batch["txt_lens"]), batch, act.get("use_ee_pose"), False)  # :451-457
+        x, out = self.backbone(feat, pc32[:, :3], counts, ctx, ctx_counts, perms)
         T, B = act["max_traj_len"], len(counts)
         te = sd["act_proj_head.traj_embedding.weight"]
         pe = torch.cat([x.unsqueeze(1).expand(-1, T, -1), te.unsqueeze(0).expand(x.shape[0], -1, -1)], -1)  # :90-97

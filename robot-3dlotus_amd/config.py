@@ -150,6 +150,8 @@ MP_OVERRIDES = [
     "ptv3_config.pdnorm_ln", "False", "ptv3_config.pdnorm_adaptive", "False",
 ]
 MP_TINY_OVERRIDES = MP_OVERRIDES + TINY_OVERRIDES[len(V1_OVERRIDES):]
+# the YAML's own use_ee_pose = True (motion_planner_ptv3.yaml:151; the published job script switches it off)
+MP_TINYCTX_OVERRIDES = MP_TINY_OVERRIDES + ["action_config.use_ee_pose", "True"]
 
 
 # job_scripts/train_3dlotus_policy_peract.sh:55-75: the v1 model; `txt_reduce attn` is set but SimplePolicyPTV3CA ignores it
@@ -159,11 +161,11 @@ PERACT_OVERRIDES = V1_OVERRIDES + ["action_config.txt_reduce", "attn"]
 def preset(name="v1"):
     """'v1' / 'tiny': 3D-LOTUS policy; 'peract': the RLBench-18task (PerAct) variant of BASELINE configs[4] (same network;
     its bf16 compute mode is ops.set_gemm_precision("bf16")); 'mp' / 'mp_tiny': 3D-LOTUS++ motion planner (configs[3])."""
-    if name in ("mp", "mp_tiny"):
+    if name in ("mp", "mp_tiny", "mp_tinyctx"):
         model = copy.deepcopy(_YAML_MODEL)
         model["model_class"] = _YAML_MP_DELTA["model_class"]
         model["action_config"].update(_YAML_MP_DELTA["action_config"])
-        return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES}[name]))
+        return to_cfg(merge_overrides(model, {"mp": MP_OVERRIDES, "mp_tiny": MP_TINY_OVERRIDES, "mp_tinyctx": MP_TINYCTX_OVERRIDES}[name]))
     return load_model_config(None, {"v1": V1_OVERRIDES, "tiny": TINY_OVERRIDES, "peract": PERACT_OVERRIDES,
                                     "tinydeep": TINYDEEP_OVERRIDES, "tinyctx": TINYCTX_OVERRIDES}[name])
 

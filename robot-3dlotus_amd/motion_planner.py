@@ -19,7 +19,7 @@ import torch.nn.functional as F
 
 from . import ops
 from .config import to_cfg
-from .policy import BaseModel, _PTV3_KEYS
+from .policy import BaseModel, RobotPoseEmbedding, _PTV3_KEYS
 from .ptv3 import PointTransformerV3CA
 
 
@@ -58,7 +58,7 @@ class MotionPlannerPTV3CA(BaseModel):
         if act.txt_reduce == "attn":
             self.txt_attn_fc = nn.Linear(act.txt_ft_size, 1)               # built, never used by the CA variant
         if act.use_ee_pose:
-            raise NotImplementedError("use_ee_pose context token is not built (unused by 3D-LOTUS++ v1)")
+            self.pose_embedding = RobotPoseEmbedding(act.context_channels)   # one extra context token per cloud (:421-422)
         self.act_proj_head = TrajectoryActionHead(
             act.reduce, act.pos_pred_type, act.rot_pred_type, config.ptv3_config.dec_channels[0], act.dim_actions,
             act.max_traj_len, dropout=act.dropout, voxel_size=act.voxel_size, pos_bins=act.pos_bins,
@@ -90,9 +90,12 @@ class MotionPlannerPTV3CA(BaseModel):
         else:
             feat_in = feat
         ctx = ops.LinearFn.apply(txt, self.txt_fc.weight, self.txt_fc.bias)
+        ctx_counts = list(batch["txt_lens"])
+        if self.config.action_config.use_ee_pose:   # motion_planner_ptv3.py:451-457
+            ctx, ctx_counts = self.append_context_tokens(ctx, ctx_counts, [self.pose_embedding(batch["ee_poses"].float())])
         return {"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
                 "feat": feat_in, "stem_weight": w_eff.contiguous(), "context": ctx, "counts": list(batch["npoints_in_batch"]),
-                "context_counts": list(batch["txt_lens"]), **extra}
+                "context_counts": ctx_counts, **extra}
 
     @torch.no_grad()
     def prefetch(self, batch):
@@ -102,7 +105,8 @@ class MotionPlannerPTV3CA(BaseModel):
         feat = torch.cat([batch["pc_fts"].float(), F.one_hot(batch["pc_labels"].long(), 4).float()], -1)
         self._pre = (batch["pc_fts"], batch["pc_labels"], feat)
         self.ptv3_model.prefetch({"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
-                                  "feat": feat, "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])})
+                                  "feat": feat, "counts": list(batch["npoints_in_batch"]),
+                                  "context_counts": [c + int(bool(self.config.action_config.use_ee_pose)) for c in batch["txt_lens"]]})
 
     gemm_precision = None  # as SimplePolicyPTV3CA.gemm_precision
     act_storage = None     # None / 'fp32' | 'bf16': as SimplePolicyPTV3CA.act_storage (bf16 activations in HBM, fp32 masters)

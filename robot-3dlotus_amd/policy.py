@@ -44,6 +44,23 @@ class BaseModel(nn.Module):
                 batch[k] = v.to(device, non_blocking=v.device.type == "cpu" and v.is_pinned())
         return batch
 
+    @staticmethod
+    def append_context_tokens(ctx, ctx_counts, tok):
+        """One extra context token per cloud and entry of `tok` ([B, C] each), appended to that cloud's instruction tokens
+        (simple_policy_ptv3.py:419-427, motion_planner_ptv3.py:451-457): rows are placed with one index_copy per source
+        instead of B small cats.  Returns (context, counts)."""
+        if not tok:
+            return ctx, ctx_counts
+        B, ne = len(ctx_counts), len(tok)
+        starts = np.concatenate([[0], np.cumsum(np.asarray(ctx_counts) + ne)])[:-1]
+        txt_pos = np.concatenate([starts[b] + np.arange(ctx_counts[b]) for b in range(B)])
+        out = ctx.new_empty(int(sum(ctx_counts)) + B * ne, ctx.shape[1])
+        out = out.index_copy(0, torch.from_numpy(txt_pos).to(ctx.device), ctx)
+        for j, t in enumerate(tok):
+            pos_j = torch.from_numpy(starts + np.asarray(ctx_counts) + j).to(ctx.device)
+            out = out.index_copy(0, pos_j, t.to(ctx.dtype))
+        return out, [c + ne for c in ctx_counts]
+
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):
             nn.init.trunc_normal_(m.weight, std=0.02)
@@ -125,23 +142,12 @@ class SimplePolicyPTV3CA(BaseModel):
         ctx = ops.LinearFn.apply(txt, self.txt_fc.weight, self.txt_fc.bias)
         ctx_counts = list(batch["txt_lens"])
         act = self.config.action_config
-        if act.use_ee_pose or act.use_step_id:
-            # one extra context token per cloud and option, appended to that cloud's instruction tokens
-            # (simple_policy_ptv3.py:419-427): rows are placed with one index_copy per source instead of B small cats
-            tok = []
-            if act.use_ee_pose:
-                tok.append(self.pose_embedding(batch["ee_poses"].float()))
-            if act.use_step_id:
-                tok.append(self.stepid_embedding(batch["step_ids"].long()))
-            B, ne = len(ctx_counts), len(tok)
-            starts = np.concatenate([[0], np.cumsum(np.asarray(ctx_counts) + ne)])[:-1]
-            txt_pos = np.concatenate([starts[b] + np.arange(ctx_counts[b]) for b in range(B)])
-            out = ctx.new_empty(int(sum(ctx_counts)) + B * ne, ctx.shape[1])
-            out = out.index_copy(0, torch.from_numpy(txt_pos).to(ctx.device), ctx)
-            for j, t in enumerate(tok):
-                pos_j = torch.from_numpy(starts + np.asarray(ctx_counts) + j).to(ctx.device)
-                out = out.index_copy(0, pos_j, t.to(ctx.dtype))
-            ctx, ctx_counts = out, [c + ne for c in ctx_counts]
+        tok = []
+        if act.use_ee_pose:
+            tok.append(self.pose_embedding(batch["ee_poses"].float()))
+        if act.use_step_id:
+            tok.append(self.stepid_embedding(batch["step_ids"].long()))
+        ctx, ctx_counts = self.append_context_tokens(ctx, ctx_counts, tok)
         return {"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
                 "offset": batch["offset"], "feat": feat, "context": ctx,
                 "counts": list(batch["npoints_in_batch"]), "context_counts": ctx_counts, **extra}

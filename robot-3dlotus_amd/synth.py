@@ -115,7 +115,14 @@ def synth_batch_mp(batch_size=8, npoints=4096, ragged=False, seed=0, pos_bins=15
         trajs.append(tr); stops.append(st); lens.append(tl)
     npts = [len(p) for p in pcs]
     masks = np.arange(T)[None, :] < np.array(lens)[:, None]
+    # current end-effector pose per cloud (xyz, unit quaternion xyzw, open) for action_config.use_ee_pose, from a generator of
+    # its own: the draws above (which the committed fixtures rebuild bit for bit) are not disturbed
+    rng2 = np.random.default_rng([seed, 0xEE])
+    quat = rng2.standard_normal((batch_size, 4))
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    ee = np.concatenate([rng2.normal(0, 0.3, size=(batch_size, 3)), quat, rng2.integers(0, 2, size=(batch_size, 1))], 1).astype(np.float32)
     return {
+        "ee_poses": torch.from_numpy(ee),
         "pc_fts": torch.from_numpy(np.concatenate(pcs, 0)),
         "pc_labels": torch.from_numpy(np.concatenate(labels, 0)),
         "npoints_in_batch": npts,

@@ -31,6 +31,8 @@ CASES = {
     "mp_tiny_scaled_train": ("mp_tiny", 2, 512, True, 31, 5, "scaled", True),
     "mp_init_train": ("mp", 2, 768, True, 32, 6, "init", True),
     "mp_scaled_eval": ("mp", 2, 768, True, 33, 7, "scaled", False),
+    # the YAML's own use_ee_pose = True: one RobotPoseEmbedding token appended to every cloud's instruction tokens
+    "mp_tinyctx_scaled_train": ("mp_tinyctx", 2, 512, True, 34, 8, "scaled", True),
 }
 
 

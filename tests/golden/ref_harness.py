@@ -328,9 +328,11 @@ def reference_mp_config(variant="mp"):
              pos_pred_type="heatmap_disc", pos_heatmap_temp=0.1, max_steps=30, max_traj_len=5, pos_bins=15,
              txt_reduce="attn", use_ee_pose=False)
     cfg["loss_config"].update(pos_weight=1, rot_weight=1)
-    if variant == "mp_tiny":
+    if variant in ("mp_tiny", "mp_tinyctx"):
         p.update(enc_depths=[1, 1], enc_channels=[64, 64], enc_num_head=[2, 2], enc_patch_size=[128, 128],
                  stride=[2], dec_depths=[1], dec_channels=[64], dec_num_head=[2], dec_patch_size=[128])
+    if variant == "mp_tinyctx":   # the YAML's own use_ee_pose = True (motion_planner_ptv3.yaml:151)
+        a.update(use_ee_pose=True)
     return to_cfg(cfg)
 
 

@@ -80,7 +80,7 @@ def state_template(cfg):
         for i in range(p3["dec_depths"][s]):
             block(n + f".block{i}", dc[s], dh[s]); ca(n + f".ca_block{i}", dc[s], dh[s], ctx)
     lin("txt_fc", act["context_channels"], act["txt_ft_size"])
-    if not mp and act.get("use_ee_pose"):   # base.py:52-60
+    if act.get("use_ee_pose"):   # base.py:52-60 (policy and motion planner)
         cc = act["context_channels"]
         t["pose_embedding.open_embedding.weight"] = torch.zeros(2, cc)
         lin("pose_embedding.pos_embedding", cc, 3); lin("pose_embedding.rot_embedding", cc, 6); norm("pose_embedding.layer_norm", cc)
@@ -100,7 +100,7 @@ def state_template(cfg):
     return t
 
 
-MP_CASES = ["mp_tiny_scaled_train", "mp_init_train", "mp_scaled_eval"]
+MP_CASES = ["mp_tiny_scaled_train", "mp_init_train", "mp_scaled_eval", "mp_tinyctx_scaled_train"]
 
 
 def load_case_mp(name):
