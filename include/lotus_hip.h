@@ -97,7 +97,8 @@ int lotus_fe_pool_coord(const float* pcoord, const int* order0, const int* seg_s
 int lotus_fe_patch(const int* order, const int* off, const int* offp, int B, int K, int npad, int* gidx, int* owner,
                    int* kext, int* ext_pos, void* stream);
 /* spconv submanifold neighbour lookup (SubMConv3d call sites model.py:615-622, :844-853): tap-major
- * nbr int32 [ksize^3][n], -1 = absent, duplicates -> lowest index (SURVEY.md Trap 5). */
+ * nbr int32 [ksize^3][n], -1 = absent, duplicates -> lowest index (SURVEY.md Trap 5).  workspace: the hash table,
+ * lotus_fe_neighbours_workspace(n) bytes, 16-byte aligned (16-byte {key, index} slots). */
 size_t lotus_fe_neighbours_workspace(int n);
 int lotus_fe_neighbours(const int* grid, const int* batch, int n, int ksize, int* nbr, void* workspace,
                         size_t workspace_bytes, void* stream);

@@ -1331,7 +1331,8 @@ static int launch_wgrad(GemmP& p, int nz, hipStream_t st) {
     }
     if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
     if (mode && p.prec == 0 && g_force_tile != 1 && p.M % 64 == 0 && p.N % 64 == 0 && p.K >= minrows && p.klen % 64 == 0 &&
-        p.lda % 2 == 0 && p.ldb % 2 == 0 && fast_ok<false, false>(p)) {
+        p.lda % 2 == 0 && p.ldb % 2 == 0 && (long)(p.klen / 4 + 2) * (p.lda > p.ldb ? p.lda : p.ldb) * 4 < (1L << 31) &&  // 32-bit buffer offsets
+        fast_ok<false, false>(p)) {
       dim3 grid(p.N / 64, p.M / 64, nz), block(256);
       LOTUS_LAUNCH(wgrad_stream_kernel<8>, grid, block, 0, st, p);
       LOTUS_LAUNCH_CHECK("lotus_linear_wgrad(stream)");
