@@ -64,6 +64,7 @@ class _Timed:
 # not hand their memory to the main stream early.
 SIDE = None
 _SIDE_ON = os.environ.get("LOTUS_SIDE_STREAM", "1") != "0"
+_STEM_WGRAD_MAIN = os.environ.get("LOTUS_STEM_WGRAD_MAIN", "1") != "0"
 _JOIN = "node"
 _END_CB_PENDING = False
 
@@ -604,7 +605,9 @@ def conv_dgrad(dy, w, nbr, rowidx, add=None, w_t=None, lvl=None, prec=None, tap_
     return dx
 
 
-def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None):
+def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None, side=True):
+    """side=False keeps the launch on the current stream (the stem: the last weight gradient of a backward pass, when the
+    critical stream has nothing left to do and the side stream still has a queue)."""
     n, cout = dy.shape
     cin, T = x.shape[1], nbr.shape[0]
     nw = cout * T * cin
@@ -612,6 +615,10 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None):
     dw = buf[:nw].view(w_shape)
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
+    if not side:
+        ws = WS.get(nbytes, dy.device, slot=0)
+        call("lotus_subm_conv_wgrad", dy, x, dw, db, nbr, n, T, cin, cout, 0, _pa(prec), ws, ws.numel())
+        return dw, db
     with _OnSide(dy, x, nbr):
         ws = _side_ws(nbytes, dy.device) if _side() is not None else WS.get(nbytes, dy.device, slot=0)
         # thin-input stem (cin <= 8): one VALU kernel in every mode, exact fp32
@@ -1600,7 +1607,9 @@ class StemFn(torch.autograd.Function):
         x, cw, g, b, c, mean, invstd = ctx.saved_tensors
         lvl, training = ctx.meta
         dc, dg, db = bn_bwd(dy.contiguous(), c, mean, invstd, g, b, training, ACT_GELU)
-        dcw, _ = conv_wgrad(dc, x, cw.shape, lvl.nbr125, need_bias=False)
+        # policy (no input gradient): this is the LAST weight gradient of the backward pass and the critical stream has
+        # nothing after the BatchNorm backward above — run it here instead of queueing it behind the side stream's tail
+        dcw, _ = conv_wgrad(dc, x, cw.shape, lvl.nbr125, need_bias=False, side=ctx.needs_input_grad[0] or not _STEM_WGRAD_MAIN)
         # the policy feeds raw point features (no gradient); the motion planner concatenates a learned label embedding
         dx = conv_dgrad(dc, cw, lvl.nbr125, lvl.order[0], lvl=lvl) if ctx.needs_input_grad[0] else None
         return dx, dcw, dg, db, None, None, None, None
