@@ -242,8 +242,8 @@ class FrontEnd:
         side = fe is not None and FINISH_ON_SIDE
         made = []  # tensors allocated under the front-end stream and consumed on the current one
         with (torch.cuda.stream(fe) if side else contextlib.nullcontext()):
-            levels = self._finish_tables(pend, tabs_h, plans, host_tabs, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord,
-                                         made, ws_slot=5 if side else 1)
+            levels = self._finish_tables(pend, tabs_h, plans, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord, made,
+                                         ws_slot=5 if side else 1)
         if side:
             ev = torch.cuda.Event()
             ev.record(fe)
@@ -252,7 +252,7 @@ class FrontEnd:
                 t.record_stream(cur)
         return levels
 
-    def _finish_tables(self, pend, tabs_h, plans, host_tabs, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord, made, ws_slot):
+    def _finish_tables(self, pend, tabs_h, plans, ns, cnt_h, depth0, meta_h, ctx_counts, need_coord, made, ws_slot):
         pc_fts, counts, raw = pend["pc_fts"], pend["counts"], pend["raw"]
         dev = pc_fts.device
         B, Lv, K = len(counts), self.n_levels, self.K
