@@ -12,13 +12,15 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
-HEADERS = ["common.h", "mma.h"]
+SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
+HEADERS = ["common.h", "mma.h", "gemm_common.h", "gemm_dma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# per-source extras: the LDS-DMA GEMM keeps its MFMA accumulators in VGPRs (its epilogue stores straight from them)
+SOURCE_FLAGS = {"gemm_dma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 LIB = os.path.join(HERE, "liblotus_hip.so")
 # The translation units that touch activation tensors are compiled twice: act_t = float (lotus_*) and, with
 # -DLOTUS_ACT_BF16 and the generated rename header, act_t = bf16 (lotus_b16_*, include/lotus_hip_b16.h) — gen_twin.py.
-ACT_SOURCES = ["blocks.cpp", "gemm.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "pool_head.hip"]
+ACT_SOURCES = ["blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "pool_head.hip"]
 RENAME = os.path.join(HERE, "lotus_rename_b16.h")
 PUBLIC = [os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "lotus_hip.h")]
 
@@ -43,7 +45,7 @@ def _compile(job):
     # toolchain only.
     extra = ["-DLOTUS_ACT_BF16", "-include", os.path.basename(RENAME)] if b16 else []
     oname = os.path.basename(obj)
-    cmd = ([HIPCC] + FLAGS + ["-cuid=lotus-" + os.path.splitext(oname)[0], "-ffile-prefix-map=" + HERE + "=."] + extra +
+    cmd = ([HIPCC] + FLAGS + SOURCE_FLAGS.get(src, []) + ["-cuid=lotus-" + os.path.splitext(oname)[0], "-ffile-prefix-map=" + HERE + "=."] + extra +
            (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", src, "-o", oname])
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=HERE)
     if r.returncode != 0:

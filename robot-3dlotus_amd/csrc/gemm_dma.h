@@ -1,0 +1,381 @@
+// lotus-hip: dense exact-fp32 GEMM with LDS-DMA operand staging and a VALU-free data path (round 5) — the nn.Linear call
+// sites of the hot path (/root/reference/genrobo3d/models/PointTransformerV3/model.py:543-583, model_ca.py:46-101).
+//
+// The rule this kernel is built around was measured this round (tools/ubench/mfma_coissue.hip):
+// on gfx950 an fp32 MFMA (`v_mfma_f32_32x32x2_f32`, 64 cycles) and ANY vector-ALU instruction — of the same wave or of
+// another wave of the SIMD — never overlap: a co-resident wave's VALU instructions are starved while MFMAs are issued
+// back to back, and each VALU instruction of the MFMA wave itself adds ~5 cycles.  Scalar-ALU, LDS and vector-memory
+// instructions DO issue beside the MFMAs.  So the time of a SIMD is 64 x (MFMAs) + ~5 x (VALU instructions) of everything
+// resident on it, and a dense layer is MFMA-bound only if its data path uses no VALU:
+//  * operands go global -> LDS with `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per wave instruction): no staging
+//    registers, no ds_write pass; the per-lane offset is loop invariant, the buffer descriptor lives in SGPRs and is
+//    advanced with scalar instructions, out-of-range rows / reduction tails read as zeros through the descriptor's bounds
+//    check, and NST - 1 slabs are in flight across `s_barrier` under counted `s_waitcnt vmcnt(N)` (the DMA statements are
+//    inline asm: the compiler would otherwise drain them with vmcnt(0) in front of every ds_read of the running slab);
+//  * the LDS image of a k-contiguous operand is lane-linear [rows][BK] (what LDS-DMA writes) with the 16-byte chunks of
+//    a row XOR-swizzled on the SOURCE side, so a lane's fragment run is read with conflict-free ds_read_b128 at
+//    loop-invariant addresses (+ immediate stage offsets);
+//  * block tiles up to 128 x 128 with a 64 x 64 wave tile (2 x 2 accumulators of 32 x 32): 0.25 LDS reads per MFMA;
+//  * the product is computed TRANSPOSED (MFMA "A" operand = the weight-side fragment, "B" operand = the activation-side
+//    fragment): a lane owns ONE output row and four consecutive accumulator registers are four consecutive output
+//    columns.  The accumulators are VGPRs (this translation unit is compiled with -mllvm -amdgpu-mfma-vgpr-form), so the
+//    epilogue is `buffer_store_dwordx4` straight from them: one per-lane byte offset per row, immediate offsets for the
+//    columns, bounds-checked rows — no accumulator copies, no 64-bit address arithmetic, no LDS staging;
+//  * the bias is the INITIAL value of the accumulators (loaded straight into them), not an addition behind the products.
+// Per output element: the products in the k order of gemm_kernel with the same slab depth (MFMA step s of lane half h
+// multiplies k = h * BK / 2 + s), on top of the bias instead of under it.
+#pragma once
+#include "gemm_common.h"
+
+namespace LOTUS_NS {
+
+typedef int dma_i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned dma_u32x4 __attribute__((ext_vector_type(4)));
+typedef float dma_f32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0): an access at byte offset >= bytes returns zero / is dropped and touches no memory
+__device__ __forceinline__ dma_i32x4 dma_rsrc(unsigned long long base, unsigned bytes) {
+  dma_i32x4 r;
+  r.x = (int)(unsigned)base;
+  r.y = (int)(unsigned)(base >> 32);
+  r.z = (int)bytes;
+  r.w = 0x00020000;
+  return r;
+}
+
+// one LDS-DMA wave instruction: lane l copies the 16 bytes at rsrc.base + voff(l) to LDS byte address lds + 16 l.
+// M0 (the LDS destination base) is written in the statement that reads it and restored (compiler-reserved register).
+__device__ __forceinline__ void dma16(dma_i32x4 rsrc, int voff, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds), "v"(voff), "s"(rsrc)
+               : "memory");
+}
+
+template <int N> __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"i"(N) : "memory"); }
+
+// k-contiguous operand: rows of BK floats, 16-byte chunk c of row r stored at chunk position c ^ swz(r)
+template <int BK>
+__device__ __forceinline__ int kc_swz(int row) {
+  return BK == 64 ? (row & 15) : BK == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3);
+}
+
+// one element of the epilogue behind the bias: activation, act'(pre of the producing layer), dropout — the part of
+// gemm_epilogue4 that is arithmetic (the loads / stores around it are buffer instructions at the call site)
+__device__ __forceinline__ float dma_epi_math(const GemmP& p, float v, float mp, unsigned long long idx) {
+  if (p.act != LOTUS_ACT_NONE) v = act_f(v, p.act);
+  if (p.mulpre) v *= act_grad_f(mp, p.dact);
+  if (p.drop_thresh) v *= dropout_scale(p.drop_seed, idx, p.drop_thresh, p.drop_inv_keep);
+  return v;
+}
+
+// XKC / WKC: the activation-side (rows of C) / weight-side (columns of C) operand is contiguous along the reduction
+// index (image [R][BK], swizzled); otherwise it is contiguous along its own output index (image [BK][R]).
+//   fwd (1, 1), dgrad (1, 0), wgrad (0, 0)
+// EPI: 0 = bias / saved pre-activation / residual only (no per-element arithmetic besides the residual add), 1 = everything
+// ABL (kernel lab only): 1 skips the epilogue stores, 2 the DMA (operands are whatever the LDS holds), 3 both
+template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
+  constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32, KS = BK / 2;
+  constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;  // floats per image / stage
+  constexpr int TA = A_FL / 1024, TB = B_FL / 1024, D = TA + TB;       // DMA instructions per wave and slab
+  static_assert(TA >= 1 && TB >= 1 && (TM == 1 || TM == 2) && (TN == 1 || TN == 2), "tile");
+  static_assert(NST >= 2 && NST <= 4 && D * (NST - 2) < 64, "stages");
+  __shared__ __attribute__((aligned(1024))) float smem[NST * ST_FL];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = tid & 31, h = (tid >> 5) & 1;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order (as gemm_kernel): split-K launches give XCD c the splits z = c (mod 8); otherwise every XCD walks a
+  // contiguous run of the row-major tile list, so the column blocks of one row tile share an L2
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bz = xcd + 8 * (slot / tiles);
+    const int t = slot - (slot / tiles) * tiles;
+    by = t / (int)gridDim.x;
+    bx = t - by * (int)gridDim.x;
+  } else {
+    const int nbx = gridDim.x, total = nbx * gridDim.y;
+    const int lin = by * nbx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    by = t / nbx;
+    bx = t - by * nbx;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
+  const int kbeg = bz * p.klen, kend = min(p.K, kbeg + p.klen);
+  const int nslab = (kend - kbeg + BK - 1) / BK;
+  const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
+
+  // ---- DMA plan: per-lane byte offsets (loop invariant) and the two descriptors at slab 0
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) float*)smem;
+  int voa[TA], vob[TB];
+  unsigned long long base_a, base_b;
+  long rec_a, rec_b;        // bytes still inside the operand, seen from the descriptor base
+  unsigned step_a, step_b;  // descriptor advance per slab
+  if (XKC) {
+    constexpr int CH = BK / 4, RPI = 64 / CH;
+    const int row0 = lane / CH, slot = lane % CH;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+      const int row = (wave * TA + t) * RPI + row0;
+      voa[t] = row * (lda * 4) + ((slot ^ kc_swz<BK>(row)) << 4);
+    }
+    base_a = (unsigned long long)(static_cast<const float*>(p.A) + (long)m0 * p.lda + kbeg);
+    rec_a = ((long)(min(BM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 4;
+    step_a = BK * 4;
+  } else {
+    constexpr int C4 = BM / 4, RPI = 64 / C4;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) voa[t] = (((wave * TA + t) * RPI + lane / C4) * lda + m0 + (lane % C4) * 4) * 4;
+    base_a = (unsigned long long)(static_cast<const float*>(p.A) + (long)kbeg * p.lda);
+    rec_a = (long)(kend - kbeg) * p.lda * 4;
+    step_a = BK * (unsigned)lda * 4;
+  }
+  if (WKC) {
+    constexpr int CH = BK / 4, RPI = 64 / CH;
+    const int row0 = lane / CH, slot = lane % CH;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) {
+      const int row = (wave * TB + t) * RPI + row0;
+      vob[t] = row * (ldb * 4) + ((slot ^ kc_swz<BK>(row)) << 4);
+    }
+    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)n0 * p.ldb + kbeg);
+    rec_b = ((long)(min(BN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 4;
+    step_b = BK * 4;
+  } else {
+    constexpr int C4 = BN / 4, RPI = 64 / C4;
+#pragma unroll
+    for (int t = 0; t < TB; ++t) vob[t] = (((wave * TB + t) * RPI + lane / C4) * ldb + n0 + (lane % C4) * 4) * 4;
+    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)kbeg * p.ldb);
+    rec_b = (long)(kend - kbeg) * p.ldb * 4;
+    step_b = BK * (unsigned)ldb * 4;
+  }
+  auto issue = [&](int slab, int stage) {  // the DMA instructions of this wave for one slab (all wave-uniform scalars)
+    const dma_i32x4 ra = dma_rsrc(base_a + (unsigned long long)slab * step_a, (unsigned)max(0L, rec_a - (long)slab * step_a));
+    const dma_i32x4 rb = dma_rsrc(base_b + (unsigned long long)slab * step_b, (unsigned)max(0L, rec_b - (long)slab * step_b));
+    const unsigned la = lds0 + (unsigned)(stage * ST_FL * 4) + (unsigned)(wave * TA) * 1024u;
+    const unsigned lb = lds0 + (unsigned)((stage * ST_FL + A_FL) * 4) + (unsigned)(wave * TB) * 1024u;
+#pragma unroll
+    for (int t = 0; t < TA; ++t) dma16(ra, voa[t], la + t * 1024u);
+#pragma unroll
+    for (int t = 0; t < TB; ++t) dma16(rb, vob[t], lb + t * 1024u);
+  };
+  long long* dbg = (ABL & 8) ? reinterpret_cast<long long*>(p.bias_part) + (long)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;  // lab: phase timestamps
+  if ((ABL & 8) && tid == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    dbg[0] = (long long)wall_clock64(); dbg[1] = clock64(); dbg[6] = hwid; dbg[7] = xcc;
+  }
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nslab && !(ABL & 2)) issue(s, s);
+
+  // ---- accumulators, initialised with the bias of their columns: register r of tile (tm, tn) is column
+  // n0 + wn WTN + tn 32 + (r & 3) + 8 (r >> 2) + 4 h of row m0 + wm WTM + tm 32 + l31
+  const bool fused = p.cnt != nullptr && gridDim.z > 1;
+  const int colb = n0 + wn * WTN + 4 * h;
+  f32x16 acc[TM][TN];
+  if (p.bias && !fused && bz == 0) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 b4 = ld4(p.bias + min(colb + tn * 32 + 8 * g, p.N - 4));
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          acc[tm][tn][4 * g] = b4.x; acc[tm][tn][4 * g + 1] = b4.y; acc[tm][tn][4 * g + 2] = b4.z; acc[tm][tn][4 * g + 3] = b4.w;
+        }
+      }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  }
+  float asum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) asum[i] = 0.f;
+  const bool want_sum = SUM_A && p.bias_part && bx == 0 && wn == 0;  // (wave-uniform) column sums of the activation-side operand
+
+  // fragment addresses (floats, inside a stage)
+  int xoff[TM][XKC ? KS / 4 : 1], woff[TN][WKC ? KS / 4 : 1];
+  if (XKC) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int row = wm * WTM + tm * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) xoff[tm][q] = row * BK + (((h * (KS / 4) + q) ^ kc_swz<BK>(row)) << 2);
+    }
+  } else {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) xoff[tm][0] = h * KS * BM + wm * WTM + tm * 32 + l31;
+  }
+  if (WKC) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      const int row = wn * WTN + tn * 32 + l31;
+#pragma unroll
+      for (int q = 0; q < KS / 4; ++q) woff[tn][q] = A_FL + row * BK + (((h * (KS / 4) + q) ^ kc_swz<BK>(row)) << 2);
+    }
+  } else {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) woff[tn][0] = A_FL + h * KS * BN + wn * WTN + tn * 32 + l31;
+  }
+
+  auto compute = [&](const float* __restrict__ st, auto sum_tag) {
+    constexpr bool SUM = decltype(sum_tag)::value;
+    float xf[TM][KS], wf[TN][KS];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      if (XKC) {
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          const float4 v = ld4(st + xoff[tm][q]);
+          xf[tm][4 * q] = v.x; xf[tm][4 * q + 1] = v.y; xf[tm][4 * q + 2] = v.z; xf[tm][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[tm][s] = st[xoff[tm][0] + s * BM];
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      if (WKC) {
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+          const float4 v = ld4(st + woff[tn][q]);
+          wf[tn][4 * q] = v.x; wf[tn][4 * q + 1] = v.y; wf[tn][4 * q + 2] = v.z; wf[tn][4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) wf[tn][s] = st[woff[tn][0] + s * BN];
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        if (SUM) asum[tm] += xf[tm][s];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[tn][s], xf[tm][s], acc[tm][tn], 0, 0, 0);
+      }
+  };
+
+  // ---- slab pipeline: NST - 1 slabs in flight; one barrier per slab.  At the top of iteration i this wave's DMAs of slab
+  // i have landed (counted vmcnt: the younger slabs stay in flight) and its fragment reads of slab i - 1 have returned
+  // (lgkmcnt); behind the barrier that holds for every wave, so slab i may be read and the stage of slab i - 1 refilled.
+  for (int i0 = 0; i0 < nslab; i0 += NST) {
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {
+      const int i = i0 + s;
+      if (i < nslab) {
+        if (i + NST - 2 < nslab) dma_wait<D*(NST - 2)>();
+        else dma_wait<0>();
+        __builtin_amdgcn_s_barrier();
+        if ((ABL & 8) && i == 0 && tid == 0) dbg[2] = clock64();
+        if (i + NST - 1 < nslab && !(ABL & 2)) issue(i + NST - 1, (s + NST - 1) % NST);
+        if (want_sum) compute(smem + s * ST_FL, std::true_type{});
+        else compute(smem + s * ST_FL, std::false_type{});
+      }
+    }
+  }
+
+  if ((ABL & 8) && tid == 0) dbg[3] = clock64();
+  // ---- epilogue, straight from the accumulator registers with buffer instructions: one byte offset per output row,
+  // immediate offsets for the 16-byte column pieces, rows past M dropped by the descriptor
+  const unsigned cbytes = (unsigned)min((long)p.M * p.ldc * 4, 0xfffffffcL);
+  const long zoff = (long)bz * p.part_stride;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
+      fused ? (void*)(p.part + zoff) : (void*)(static_cast<float*>(p.C) + zoff), 0, (int)cbytes, 0x00020000);
+  const bool full_cols = n0 + BN <= p.N;  // (block-uniform) no column predicate
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int row = m0 + wm * WTM + tm * 32 + l31;
+    const int vo = (row * ldc + colb) * 4;
+    if (ABL & 1) {  // lab: keep the accumulators alive without storing them
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r]));
+      continue;
+    }
+    auto store_rows = [&](__amdgpu_buffer_rsrc_t rs, auto aux_tag) {  // this lane's 4 TN pieces of row tm
+      constexpr int AUX = decltype(aux_tag)::value;
+      auto go = [&](auto pred_tag) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const dma_f32x4 v = {acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]};
+            if (!decltype(pred_tag)::value || colb + tn * 32 + 8 * g < p.N)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, v), rs, vo + (tn * 32 + 8 * g) * 4, 0, AUX);
+          }
+      };
+      if (full_cols) go(std::false_type{});  // (block-uniform branch: the common case carries no column predicate)
+      else go(std::true_type{});
+    };
+    if (fused) {  // raw partial of this split, write-through (sc1): read by the last block of the tile, possibly on another XCD
+      store_rows(rc, std::integral_constant<int, 16>{});
+      continue;
+    }
+    if (p.pre) store_rows(__builtin_amdgcn_make_buffer_rsrc((void*)p.pre, 0, (int)cbytes, 0x00020000), std::integral_constant<int, 0>{});
+    if (EPI == 1) {
+      if (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh) {
+        // (a null mulpre reads zeros through an empty descriptor: the values are unused)
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(p.mulpre ? (void*)p.mulpre : p.C, 0, p.mulpre ? (int)cbytes : 0, 0x00020000);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          dma_f32x4 mp[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) mp[g] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, vo + (tn * 32 + 8 * g) * 4, 0, 0));
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[tm][tn][4 * g + e] = dma_epi_math(p, acc[tm][tn][4 * g + e], mp[g][e], (unsigned long long)((long)row * ldc + colb + tn * 32 + 8 * g + e));
+        }
+      }
+    }
+    if (p.residual) {
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)cbytes, 0x00020000);
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        dma_f32x4 r4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) r4[g] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vo + (tn * 32 + 8 * g) * 4, 0, 0));
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[tm][tn][4 * g + e] += r4[g][e];
+      }
+    }
+    store_rows(rc, std::integral_constant<int, 0>{});
+  }
+  if (ABL & 8) {
+    if (tid == 0) dbg[4] = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { dbg[5] = clock64(); }
+  }
+  if (SUM_A) {
+    if (want_sum) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const float s = asum[tm] + __shfl_xor(asum[tm], 32, 64);
+        const int row = m0 + wm * WTM + tm * 32 + l31;
+        if (h == 0 && row < p.M) __hip_atomic_store(p.bias_part + (long)bz * p.bias_stride + row, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  if (fused) splitk_fused_tail<SUM_A, BM, BN, float>(p, bx, by, m0, n0, tid);
+}
+
+}  // namespace LOTUS_NS

@@ -1,0 +1,66 @@
+// lotus-hip: host side of the LDS-DMA dense kernels (gemm_dma.h) — which products they take and on which tile.  Its own
+// translation unit because it is compiled with -mllvm -amdgpu-mfma-vgpr-form (accumulators in VGPRs: the epilogue stores
+// straight from them); gemm.hip keeps the default register form for the kernels that were tuned with it.
+#include "gemm_dma.h"
+#include <stdlib.h>
+
+namespace LOTUS_NS {
+
+static int dma_env(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+// layout: 0 forward (both operands k-contiguous), 1 input gradient (A k-contiguous, B column-contiguous), 2 weight gradient
+// (both operands contiguous along their output index, column sums of A on request).  Returns LOTUS_GEMM_DMA_NA when the
+// product is outside what these kernels take (the caller then runs gemm_kernel).
+int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
+  if constexpr (LOTUS_ACT_IS_BF16) {
+    return LOTUS_GEMM_DMA_NA;  // (bf16 activation storage: gemm_kernel's bf16 paths)
+  } else {
+    // LOTUS_GEMM_DMA: 0 = off; LOTUS_GEMM_DMA_MINROWS: smallest row count (forward / input gradient: rows of the activation
+    // operand; weight gradient: length of the reduction) these kernels are used from.  Measured (tools/lab/gemm_lab, MI355X):
+    // they win from ~16 k rows; below that the grids are too small for 128-row tiles and gemm_kernel's deep-slab / split-K
+    // forms are the better fit.
+    static int on = -1, minrows = 0;
+    if (on < 0) { on = dma_env("LOTUS_GEMM_DMA", 1); minrows = dma_env("LOTUS_GEMM_DMA_MINROWS", 16384); }
+    if (!on || p.prec != 0 || p.tap_rows || p.b_act) return LOTUS_GEMM_DMA_NA;
+    const int rows = layout == 2 ? p.K : p.M;
+    if (rows < minrows) return LOTUS_GEMM_DMA_NA;
+    if (layout == 2) return LOTUS_GEMM_DMA_NA;  // (weight gradient: not routed yet)
+    const bool epi = p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh;
+    if (p.accumulate && !(p.cnt && nz > 1)) return LOTUS_GEMM_DMA_NA;
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    const long abytes = layout == 2 ? (long)p.K * p.lda * 4 : (long)p.M * p.lda * 4;
+    const long bbytes = layout == 0 ? (long)p.N * p.ldb * 4 : (long)p.K * p.ldb * 4;
+    if (!al16(p.A) || !al16(p.B) || !al16(p.C) || (p.lda & 3) || (p.ldb & 3) || (p.ldc & 3) || (p.N & 3) || (p.part_stride & 3) ||
+        (p.bias && !al16(p.bias)) || (p.residual && !al16(p.residual)) || (p.pre && !al16(p.pre)) || (p.mulpre && !al16(p.mulpre)) ||
+        (p.part && !al16(p.part)) || abytes >= (1L << 32) || bbytes >= (1L << 32) || (long)p.M * p.ldc * 4 >= (1L << 32))
+      return LOTUS_GEMM_DMA_NA;
+    // a k-contiguous operand is staged in whole slabs: the reduction (and every split of it) must be a multiple of the slab depth
+    const bool wide = p.N > 64;
+    const int bk = wide ? 16 : 32;
+    const bool kc_any = layout != 2;
+    if (kc_any && ((p.K % bk) || (nz > 1 && (p.klen % bk)))) return LOTUS_GEMM_DMA_NA;
+    if (layout == 1 && (p.N & 3)) return LOTUS_GEMM_DMA_NA;
+    dim3 block(256);
+#define DMA_GO(BM, BN, BK, NST, XKC, WKC, SUMA)                                                                         \
+  do {                                                                                                                  \
+    dim3 grid(cdiv(p.N, BN), cdiv(p.M, BM), nz);                                                                        \
+    if (epi) LOTUS_LAUNCH((gemm_dma_kernel<BM, BN, BK, NST, XKC, WKC, SUMA, 1>), grid, block, 0, st, p);                \
+    else LOTUS_LAUNCH((gemm_dma_kernel<BM, BN, BK, NST, XKC, WKC, SUMA, 0>), grid, block, 0, st, p);                    \
+  } while (0)
+    if (layout == 0) {
+      if (wide) DMA_GO(128, 128, 16, 3, true, true, false);
+      else DMA_GO(128, 64, 32, 2, true, true, false);
+    } else {
+      if (wide) DMA_GO(128, 128, 16, 3, true, false, false);
+      else DMA_GO(128, 64, 32, 2, true, false, false);
+    }
+#undef DMA_GO
+    LOTUS_LAUNCH_CHECK("lotus_gemm(dma)");
+    return LOTUS_OK;
+  }
+}
+
+}  // namespace LOTUS_NS

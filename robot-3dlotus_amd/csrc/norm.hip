@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
   const int gsize = min(BN_GS, nb - group * BN_GS);
   double* gpart = p.part + (long)nb * ncol;  // [ngroups][2C]
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores above have been acknowledged (explicit, see gemm_common.h)
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(p.cnt + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)gsize - 1;
   __syncthreads();
@@ -384,6 +385,7 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
   }
   if (threadIdx.x == 0) p.cnt[1 + group] = 0;  // ready for the next launch on this stream
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-through stores above have been acknowledged (explicit, see gemm_common.h)
   __syncthreads();
   if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(p.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)ngroups - 1;
   __syncthreads();
