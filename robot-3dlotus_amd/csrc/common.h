@@ -108,13 +108,32 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 #define LOTUS_ACT_GELU 1
 #define LOTUS_ACT_LEAKY 2  // LeakyReLU(0.02), simple_policy_ptv3.py:42
 
-__device__ __forceinline__ float gelu_f(float x) {  // exact erf form (nn.GELU default)
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+// GELU (exact erf form, nn.GELU default) with ONE short branch-free evaluation of the normal distribution function.
+// On gfx950 every vector-ALU instruction of an fp32-MFMA kernel is time the MFMA pipe stands still (DESIGN.md section 4,
+// round 5), and libm's erff costs ~35 of them per element (two polynomial branches under exec masks + an exp with error
+// compensation): GELU on the [65536, 512] hidden layer was as expensive as the product that feeds it.  Here
+//   erfc(t) = 2^-q(t),  q = degree-8 minimax fit of -log2 erfc on [0, 4] weighted by erfc (|error of 2^-q| <= 1.1e-7,
+//   tools/fit_erfc.py), erfc(t > 4) < 1.6e-8 is held at erfc(4);   2 Phi(x) = erfc(-x / sqrt 2) = x >= 0 ? 2 - e : e
+// costs 8 fma + v_exp_f32 + 5: |gelu - exact| <= 1.2e-7 max(1, |gelu|), |gelu' - exact| <= 1.3e-7 (float64 reference,
+// 4 M points in [-12, 12]); negative arguments have no cancellation (erfc is formed directly).
+__device__ __forceinline__ float lotus_two_phi(float x) {  // 2 Phi(x)
+  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+  float q = 4.435278970e-05f;
+  q = fmaf(q, t, -4.369438975e-04f);
+  q = fmaf(q, t, 1.460380852e-03f);
+  q = fmaf(q, t, 8.251661202e-04f);
+  q = fmaf(q, t, -2.830188721e-02f);
+  q = fmaf(q, t, 1.485066414e-01f);
+  q = fmaf(q, t, 9.184098244e-01f);
+  q = fmaf(q, t, 1.627909303e+00f);
+  q = fmaf(q, t, -2.171762503e-08f);
+  const float e = __builtin_amdgcn_exp2f(-q);  // v_exp_f32: erfc(t)
+  return x >= 0.f ? 2.0f - e : e;
 }
+__device__ __forceinline__ float gelu_f(float x) { return (0.5f * x) * lotus_two_phi(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);  // exp(-x^2 / 2) / sqrt(2 pi)
+  return fmaf(x, pdf, 0.5f * lotus_two_phi(x));
 }
 __device__ __forceinline__ float act_f(float x, int act) {
   if (act == LOTUS_ACT_GELU) return gelu_f(x);
@@ -140,8 +159,20 @@ __device__ __forceinline__ uint32_t lotus_hash32(uint64_t seed, uint64_t idx) {
   x ^= x >> 16;
   return x;
 }
+// One 32-bit hash decides TWO consecutive elements (its halves against the upper 16 bits of the threshold: the drop
+// probability is quantised to 2^-16): the hash is three integer multiplies (quarter rate) + five logic operations of
+// vector ALU, which an fp32-MFMA kernel pays in MFMA time (round 5).
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
-  return lotus_hash32(seed, idx) >= thresh ? inv_keep : 0.f;
+  const uint32_t hv = lotus_hash32(seed, idx >> 1);
+  return ((idx & 1) ? (hv >> 16) : (hv & 0xffffu)) >= (thresh >> 16) ? inv_keep : 0.f;
+}
+// the scales of elements idx4 .. idx4 + 3, idx4 a multiple of 4: two hashes
+__device__ __forceinline__ void dropout_scale4(uint64_t seed, uint64_t idx4, uint32_t thresh, float inv_keep, float (&m)[4]) {
+  const uint32_t h0 = lotus_hash32(seed, idx4 >> 1), h1 = lotus_hash32(seed, (idx4 >> 1) + 1), t16 = thresh >> 16;
+  m[0] = (h0 & 0xffffu) >= t16 ? inv_keep : 0.f;
+  m[1] = (h0 >> 16) >= t16 ? inv_keep : 0.f;
+  m[2] = (h1 & 0xffffu) >= t16 ? inv_keep : 0.f;
+  m[3] = (h1 >> 16) >= t16 ? inv_keep : 0.f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

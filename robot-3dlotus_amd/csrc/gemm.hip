@@ -998,8 +998,10 @@ __global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, 
       for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
     }
     if (p.drop_thresh) {
+      float dm[4];
+      dropout_scale4(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep, dm);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
+      for (int e = 0; e < 4; ++e) v[e] *= dm[e];
     }
     if (p.residual) {
       const float4 r4 = ld4(p.residual + o);
@@ -1157,6 +1159,7 @@ int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* 
 static int wgrad_splits(int M, int N, int K) {
   if (g_force_nz < 0) g_force_nz = tune_env("LOTUS_GEMM_NZ");
   if (g_force_nz > 0) return (M / g_force_nz >= 16) ? g_force_nz : 1;
+  if (const int dz = gemm_dma_wgrad_splits(M, N, K)) return dz;  // tall products on the LDS-DMA kernels: their own tiling
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
   if (tiles >= 128 && M < 1024) return 1;  // deep levels: the second (reduce) launch costs more than it hides

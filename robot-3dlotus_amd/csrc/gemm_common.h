@@ -96,8 +96,10 @@ __device__ __forceinline__ void gemm_epilogue4(const GemmP& p, TC* __restrict__ 
     for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mv[e], p.dact);
   }
   if (p.drop_thresh) {
+    float dm[4];
+    dropout_scale4(p.drop_seed, (unsigned long long)o, p.drop_thresh, p.drop_inv_keep, dm);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dropout_scale(p.drop_seed, (unsigned long long)(o + e), p.drop_thresh, p.drop_inv_keep);
+    for (int e = 0; e < 4; ++e) v[e] *= dm[e];
   }
   if (p.residual) {
     const float4 r4 = ld4(p.residual + o);
@@ -166,5 +168,6 @@ __device__ __forceinline__ void splitk_fused_tail(const GemmP& p, int bx, int by
 // gemm_dma.hip: the LDS-DMA kernels for tall products (returns LOTUS_GEMM_DMA_NA when a product is not theirs)
 #define LOTUS_GEMM_DMA_NA (-100)
 int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st);
+int gemm_dma_wgrad_splits(int M, int N, int K);
 
 }  // namespace LOTUS_NS

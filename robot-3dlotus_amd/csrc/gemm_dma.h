@@ -19,8 +19,9 @@
 //  * the product is computed TRANSPOSED (MFMA "A" operand = the weight-side fragment, "B" operand = the activation-side
 //    fragment): a lane owns ONE output row and four consecutive accumulator registers are four consecutive output
 //    columns.  The accumulators are VGPRs (this translation unit is compiled with -mllvm -amdgpu-mfma-vgpr-form), so the
-//    epilogue is `buffer_store_dwordx4` straight from them: one per-lane byte offset per row, immediate offsets for the
-//    columns, bounds-checked rows — no accumulator copies, no 64-bit address arithmetic, no LDS staging;
+//    epilogue moves them with ds_write_b128 into a wave-private LDS tile, reads whole rows back and leaves with
+//    `buffer_store_dwordx4`: one per-lane byte offset per 32 rows, the row advance in the scalar offset — no accumulator
+//    copies, no 64-bit address arithmetic, 4 x 256 contiguous bytes per store instruction;
 //  * the bias is the INITIAL value of the accumulators (loaded straight into them), not an addition behind the products.
 // Per output element: the products in the k order of gemm_kernel with the same slab depth (MFMA step s of lane half h
 // multiplies k = h * BK / 2 + s), on top of the bias instead of under it.
@@ -61,13 +62,23 @@ __device__ __forceinline__ int kc_swz(int row) {
   return BK == 64 ? (row & 15) : BK == 32 ? ((row >> 1) & 7) : ((row >> 2) & 3);
 }
 
-// one element of the epilogue behind the bias: activation, act'(pre of the producing layer), dropout — the part of
-// gemm_epilogue4 that is arithmetic (the loads / stores around it are buffer instructions at the call site)
-__device__ __forceinline__ float dma_epi_math(const GemmP& p, float v, float mp, unsigned long long idx) {
-  if (p.act != LOTUS_ACT_NONE) v = act_f(v, p.act);
-  if (p.mulpre) v *= act_grad_f(mp, p.dact);
-  if (p.drop_thresh) v *= dropout_scale(p.drop_seed, idx, p.drop_thresh, p.drop_inv_keep);
-  return v;
+// four consecutive elements of the epilogue behind the bias: activation, act'(pre of the producing layer), dropout — the
+// part of gemm_epilogue4 that is arithmetic (the loads / stores around it are buffer instructions at the call site)
+__device__ __forceinline__ void dma_epi_math4(const GemmP& p, float (&v)[4], const dma_f32x4 mp, unsigned long long idx4) {
+  if (p.act != LOTUS_ACT_NONE) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+  }
+  if (p.mulpre) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= act_grad_f(mp[e], p.dact);
+  }
+  if (p.drop_thresh) {
+    float dm[4];
+    dropout_scale4(p.drop_seed, idx4, p.drop_thresh, p.drop_inv_keep, dm);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dm[e];
+  }
 }
 
 // XKC / WKC: the activation-side (rows of C) / weight-side (columns of C) operand is contiguous along the reduction
@@ -82,7 +93,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   constexpr int TA = A_FL / 1024, TB = B_FL / 1024, D = TA + TB;       // DMA instructions per wave and slab
   static_assert(TA >= 1 && TB >= 1 && (TM == 1 || TM == 2) && (TN == 1 || TN == 2), "tile");
   static_assert(NST >= 2 && NST <= 4 && D * (NST - 2) < 64, "stages");
-  __shared__ __attribute__((aligned(1024))) float smem[NST * ST_FL];
+  constexpr int EP_FL = 4 * 32 * (WTN + 4);  // epilogue: one [32][WTN + 4] tile per wave
+  __shared__ __attribute__((aligned(1024))) float smem[NST * ST_FL > EP_FL ? NST * ST_FL : EP_FL];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = tid & 31, h = (tid >> 5) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -290,17 +302,31 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   }
 
   if ((ABL & 8) && tid == 0) dbg[3] = clock64();
-  // ---- epilogue, straight from the accumulator registers with buffer instructions: one byte offset per output row,
-  // immediate offsets for the 16-byte column pieces, rows past M dropped by the descriptor
+  // ---- epilogue without vector-ALU work in its data path.  The lane that owns output row l31 writes its 16-byte
+  // accumulator quads into a wave-private LDS tile [32][WTN + 4] (ds_write_b128 straight from the accumulator VGPRs), the
+  // wave reads the tile back as whole rows (WTN / 4 lanes per row) and leaves with buffer instructions that cover 4 x 256
+  // (8 x 128) contiguous bytes each; the per-lane byte offset is computed once per 32 rows, the row advance is the scalar
+  // offset of the instruction.  (Measured, tools/lab: storing row-per-lane — 32 rows x 32 bytes per instruction — straight from
+  // the accumulators is 7-13 % slower on the store-heavy layers: the CU's one vector-memory path then holds back the operand
+  // DMAs of the other resident blocks; non-temporal stores 2-3x slower.)
+  constexpr int TLD = WTN + 4, LPR = WTN / 4, RPI = 64 / LPR, NIT = 32 / RPI;
   const unsigned cbytes = (unsigned)min((long)p.M * p.ldc * 4, 0xfffffffcL);
   const long zoff = (long)bz * p.part_stride;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
       fused ? (void*)(p.part + zoff) : (void*)(static_cast<float*>(p.C) + zoff), 0, (int)cbytes, 0x00020000);
-  const bool full_cols = n0 + BN <= p.N;  // (block-uniform) no column predicate
+  // (an absent tensor gets an empty descriptor: its loads return zeros, nothing below stores through it)
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(p.pre ? (void*)p.pre : p.C, 0, p.pre ? (int)cbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(p.residual ? (void*)p.residual : p.C, 0, p.residual ? (int)cbytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(p.mulpre ? (void*)p.mulpre : p.C, 0, p.mulpre ? (int)cbytes : 0, 0x00020000);
+  dma_wait<0>();
+  __builtin_amdgcn_s_barrier();  // every wave has read its last slab: the stages are free
+  float* vt = smem + wave * (32 * TLD);
+  const int c4 = lane % LPR, rsub = lane / LPR;
+  const int colw = n0 + wn * WTN + c4 * 4;
+  const bool full_rows = m0 + BM <= p.M;  // (block-uniform) the scalar row advance is not bounds-checked: whole tiles only
+  const bool math = EPI == 1 && (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh);
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    const int row = m0 + wm * WTM + tm * 32 + l31;
-    const int vo = (row * ldc + colb) * 4;
     if (ABL & 1) {  // lab: keep the accumulators alive without storing them
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
@@ -308,57 +334,59 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
         for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[tm][tn][r]));
       continue;
     }
-    auto store_rows = [&](__amdgpu_buffer_rsrc_t rs, auto aux_tag) {  // this lane's 4 TN pieces of row tm
-      constexpr int AUX = decltype(aux_tag)::value;
-      auto go = [&](auto pred_tag) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const dma_f32x4 v = {acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]};
-            if (!decltype(pred_tag)::value || colb + tn * 32 + 8 * g < p.N)
-              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, v), rs, vo + (tn * 32 + 8 * g) * 4, 0, AUX);
-          }
-      };
-      if (full_cols) go(std::false_type{});  // (block-uniform branch: the common case carries no column predicate)
-      else go(std::true_type{});
+      for (int g = 0; g < 4; ++g)
+        st4(vt + l31 * TLD + tn * 32 + 8 * g + 4 * h, make_float4(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
+    const int row0 = m0 + wm * WTM + tm * 32 + rsub;
+    const int vo = (row0 * ldc + colw) * 4;
+    if (colw >= p.N) continue;
+    auto ld = [&](__amdgpu_buffer_rsrc_t rs, int it) {
+      return full_rows ? __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, it * RPI * ldc * 4, 0))
+                       : __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo + it * RPI * ldc * 4, 0, 0));
     };
+    auto st = [&](__amdgpu_buffer_rsrc_t rs, int it, dma_f32x4 v, auto aux_tag) {
+      constexpr int AUX = decltype(aux_tag)::value;
+      if (full_rows) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, v), rs, vo, it * RPI * ldc * 4, AUX);
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, v), rs, vo + it * RPI * ldc * 4, 0, AUX);
+    };
+    dma_f32x4 v[NIT], r4[NIT], mp[NIT];
+    if (p.residual) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) r4[it] = ld(rr, it);
+    }
+    if (math && p.mulpre) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) mp[it] = ld(rm, it);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const float4 t4 = ld4(vt + (it * RPI + rsub) * TLD + c4 * 4);
+      v[it] = dma_f32x4{t4.x, t4.y, t4.z, t4.w};
+    }
     if (fused) {  // raw partial of this split, write-through (sc1): read by the last block of the tile, possibly on another XCD
-      store_rows(rc, std::integral_constant<int, 16>{});
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) st(rc, it, v[it], std::integral_constant<int, 16>{});
       continue;
     }
-    if (p.pre) store_rows(__builtin_amdgcn_make_buffer_rsrc((void*)p.pre, 0, (int)cbytes, 0x00020000), std::integral_constant<int, 0>{});
-    if (EPI == 1) {
-      if (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh) {
-        // (a null mulpre reads zeros through an empty descriptor: the values are unused)
-        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(p.mulpre ? (void*)p.mulpre : p.C, 0, p.mulpre ? (int)cbytes : 0, 0x00020000);
+    if (p.pre) {
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          dma_f32x4 mp[4];
+      for (int it = 0; it < NIT; ++it) st(rp, it, v[it], std::integral_constant<int, 0>{});
+    }
+    if (math) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) mp[g] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, vo + (tn * 32 + 8 * g) * 4, 0, 0));
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[tm][tn][4 * g + e] = dma_epi_math(p, acc[tm][tn][4 * g + e], mp[g][e], (unsigned long long)((long)row * ldc + colb + tn * 32 + 8 * g + e));
-        }
+      for (int it = 0; it < NIT; ++it) {
+        float w4[4] = {v[it][0], v[it][1], v[it][2], v[it][3]};
+        dma_epi_math4(p, w4, mp[it], (unsigned long long)((long)(row0 + it * RPI) * ldc + colw));
+        v[it] = dma_f32x4{w4[0], w4[1], w4[2], w4[3]};
       }
     }
-    if (p.residual) {
-      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (int)cbytes, 0x00020000);
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        dma_f32x4 r4[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) r4[g] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vo + (tn * 32 + 8 * g) * 4, 0, 0));
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[tm][tn][4 * g + e] += r4[g][e];
-      }
+    for (int it = 0; it < NIT; ++it) {
+      if (p.residual) v[it] += r4[it];
+      st(rc, it, v[it], std::integral_constant<int, 0>{});
     }
-    store_rows(rc, std::integral_constant<int, 0>{});
   }
   if (ABL & 8) {
     if (tid == 0) dbg[4] = clock64();

@@ -27,7 +27,6 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     if (!on || p.prec != 0 || p.tap_rows || p.b_act) return LOTUS_GEMM_DMA_NA;
     const int rows = layout == 2 ? p.K : p.M;
     if (rows < minrows) return LOTUS_GEMM_DMA_NA;
-    if (layout == 2) return LOTUS_GEMM_DMA_NA;  // (weight gradient: not routed yet)
     const bool epi = p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh;
     if (p.accumulate && !(p.cnt && nz > 1)) return LOTUS_GEMM_DMA_NA;
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
@@ -40,9 +39,15 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     // a k-contiguous operand is staged in whole slabs: the reduction (and every split of it) must be a multiple of the slab depth
     const bool wide = p.N > 64;
     const int bk = wide ? 16 : 32;
+    // 128-row tiles need a grid that fills the GPU: measured in the step (bench.py --gemm-report), the level-1 products
+    // (23 894 rows) with <= 128 output columns — 187 blocks — lose 10-20 % to gemm_kernel's 64 x 64 tiles, the 512-wide ones win
+    static int minblocks = -1;
+    if (minblocks < 0) minblocks = dma_env("LOTUS_GEMM_DMA_MINBLOCKS", 400);
+    if (layout != 2 && (long)cdiv(p.M, 128) * cdiv(p.N, wide ? 128 : 64) * nz < minblocks) return LOTUS_GEMM_DMA_NA;
+    if (layout == 2 && gemm_dma_wgrad_splits(p.K, p.M, p.N) != nz) return LOTUS_GEMM_DMA_NA;  // (split plan of another kernel)
     const bool kc_any = layout != 2;
     if (kc_any && ((p.K % bk) || (nz > 1 && (p.klen % bk)))) return LOTUS_GEMM_DMA_NA;
-    if (layout == 1 && (p.N & 3)) return LOTUS_GEMM_DMA_NA;
+    if (layout == 2 && ((p.M & 3) || (nz > 1 && (p.klen % 32)))) return LOTUS_GEMM_DMA_NA;
     dim3 block(256);
 #define DMA_GO(BM, BN, BK, NST, XKC, WKC, SUMA)                                                                         \
   do {                                                                                                                  \
@@ -53,13 +58,43 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     if (layout == 0) {
       if (wide) DMA_GO(128, 128, 16, 3, true, true, false);
       else DMA_GO(128, 64, 32, 2, true, true, false);
-    } else {
+    } else if (layout == 1) {
       if (wide) DMA_GO(128, 128, 16, 3, true, false, false);
       else DMA_GO(128, 64, 32, 2, true, false, false);
+    } else {  // weight gradient: rows of dW = p.M, columns = p.N, reduction over the activation rows
+      const bool tall = p.M > 64;
+      if (tall && wide) DMA_GO(128, 128, 16, 3, false, false, true);
+      else if (tall) DMA_GO(128, 64, 32, 2, false, false, true);
+      else if (wide) DMA_GO(64, 128, 32, 2, false, false, true);
+      else DMA_GO(64, 64, 32, 3, false, false, true);
     }
 #undef DMA_GO
     LOTUS_LAUNCH_CHECK("lotus_gemm(dma)");
     return LOTUS_OK;
+  }
+}
+
+// Split count of a weight gradient dW[N, K] over M activation rows when it runs on these kernels (0: it does not).  Known from
+// the shape alone (the workspace query has no pointers): ~1 block per CU on 128 x 128 (64-wide where a side is 64) output
+// tiles, at least 256 rows per split, a multiple of 8 (one XCD / L2 per split, see the kernel's block order).
+int gemm_dma_wgrad_splits(int M, int N, int K) {
+  if constexpr (LOTUS_ACT_IS_BF16) {
+    return 0;
+  } else {
+    static int on = -1, minrows = 0, target = 0;
+    if (on < 0) {
+      on = dma_env("LOTUS_GEMM_DMA", 1) && dma_env("LOTUS_GEMM_DMA_WGRAD", 1);
+      minrows = dma_env("LOTUS_GEMM_DMA_MINROWS", 16384);
+      target = dma_env("LOTUS_GEMM_DMA_WGRAD_BLOCKS", 256);
+    }
+    if (!on || M < minrows || (N & 3) || (K & 3)) return 0;
+    const long tiles = (long)cdiv(N, N > 64 ? 128 : 64) * cdiv(K, K > 64 ? 128 : 64);
+    long nz = (target + tiles - 1) / tiles;
+    nz = nz >= 8 ? (nz / 8) * 8 : nz;
+    if (nz < 1) nz = 1;
+    // Measured (tools/dbg/dma_onoff.py): with fewer than ~256 rows per split a block is a cold prologue and a handful of
+    // slabs — 23 894 x 128 x 128 (one 128 x 128 tile): 33 us here against 20.8 us on gemm_kernel's 64 x 64 tiles — those stay there
+    return M / nz >= 256 ? (int)nz : 0;
   }
 }
 

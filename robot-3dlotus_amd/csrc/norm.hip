@@ -144,11 +144,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
         st4q(p.dx + (long)row * p.C, q, o);
         if (p.dz) {
           const unsigned long long e = (unsigned long long)row * p.C + 4 * q;
-          float4 z;
-          z.x = o.x * dropout_scale(p.drop_seed, e, p.drop_thresh, p.drop_inv_keep);
-          z.y = o.y * dropout_scale(p.drop_seed, e + 1, p.drop_thresh, p.drop_inv_keep);
-          z.z = o.z * dropout_scale(p.drop_seed, e + 2, p.drop_thresh, p.drop_inv_keep);
-          z.w = o.w * dropout_scale(p.drop_seed, e + 3, p.drop_thresh, p.drop_inv_keep);
+          float dm[4];
+          dropout_scale4(p.drop_seed, e, p.drop_thresh, p.drop_inv_keep, dm);
+          const float4 z = make_float4(o.x * dm[0], o.y * dm[1], o.z * dm[2], o.w * dm[3]);
           st4q(p.dz + (long)row * p.C, q, z);
         }
       }

@@ -68,6 +68,23 @@ def test_input_gradient_epilogues_against_float64(M, N, K):
     assert _err(dx, ref * mask.double().cpu() + addt.double()) <= tol * 1.2
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 128, 128), (65536, 64, 64), (40011, 512, 128), (23894, 128, 512), (16411, 192, 64), (33000, 384, 128),
+                                   (65536, 128, 64), (20000, 256, 128)])
+def test_weight_gradient_against_float64(M, N, K):
+    """dw = dy^T x, db = column sums of dy: split over the rows, partial slabs summed in a fixed order."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + 5 * K)
+    x, dy = torch.randn(M, K, generator=g), torch.randn(M, N, generator=g)
+    dw, db = ops.linear_wgrad(dy.cuda(), x.cuda())
+    tol = 4e-7 * M ** 0.5 + 1e-6
+    assert _err(dw, dy.double().t() @ x.double()) <= tol
+    assert _err(db, dy.double().sum(0)) <= tol
+    dw2, db2 = ops.linear_wgrad(dy.cuda(), x.cuda())
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "the weight gradient must be deterministic"
+    dw3, _ = ops.linear_wgrad(dy.cuda(), x.cuda(), need_bias=False)
+    assert torch.equal(dw, dw3)
+
+
 def test_ragged_rows_are_deterministic():
     ops = _ops()
     g = torch.Generator().manual_seed(5)

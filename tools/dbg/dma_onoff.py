@@ -3,7 +3,8 @@ import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 SH = [("fwd", 65536, 512, 128), ("fwd", 65536, 128, 512), ("fwd", 65536, 128, 128), ("dgrad", 65536, 512, 128), ("dgrad", 65536, 128, 512),
-      ("fwd", 23894, 512, 128), ("fwd", 65536, 64, 64), ("wgrad", 65536, 128, 128), ("wgrad", 65536, 512, 128)]
+      ("fwd", 23894, 512, 128), ("fwd", 65536, 64, 64), ("wgrad", 65536, 128, 128), ("wgrad", 65536, 512, 128), ("wgrad", 65536, 128, 512), ("wgrad", 23894, 128, 128),
+      ("wgrad", 23894, 512, 128), ("wgrad", 65536, 64, 64), ("wgrad", 65536, 256, 64), ("wgrad", 65536, 384, 128), ("wgrad", 65536, 128, 64)]
 if os.environ.get("CHILD"):
     import torch
     import robot_3dlotus_amd

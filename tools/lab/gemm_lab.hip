@@ -166,7 +166,9 @@ int main(int argc, char** argv) {
         const float t2 = time_us([&]() { launch_abl<2>(v, p, st); }, st), t3 = time_us([&]() { launch_abl<3>(v, p, st); }, st);
         printf(" %s: %.1f / %.1f / %.1f / %.1f |", vn[v], t0, t1, t2, t3);
       }
-      printf("  (MFMA roof %.1f us)\n", 2.0 * sh[0] * sh[1] * sh[2] / 157.3e6);
+      printf("  (MFMA roof %.1f us)\n   with the saved pre-activation / with a residual (128x128x16s3):", 2.0 * sh[0] * sh[1] * sh[2] / 157.3e6);
+      { GemmP q = p; q.pre = out2; printf(" %.1f", time_us([&]() { launch_abl<0>(0, q, st); }, st)); }
+      { GemmP q = p; q.residual = out2; printf(" / %.1f\n", time_us([&]() { launch_abl<0>(0, q, st); }, st)); }
     }
     return 0;
   }
