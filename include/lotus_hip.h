@@ -13,6 +13,22 @@
  *     "host".  Tensors are dense row-major (activations `lotus_act_t`, everything else fp32); indices are int32; curve codes are int64.
  *   - `stream` is a hipStream_t (the caller's current stream; 0 = default stream).
  *   - workspaces are caller-allocated; sizes come from the matching *_workspace() function.
+ *   - process-wide state: none besides the thread-local error message and the environment switches listed here, each read
+ *     ONCE per process on first use (they select between kernels / tilings that all meet the same parity bars; the defaults
+ *     are what every number in DESIGN.md was measured with; tests/test_capi.py checks this list against the library's strings):
+ *       LOTUS_GEMM_DMA=0              dense products never use the LDS-DMA kernels (gemm_dma.hip)
+ *       LOTUS_GEMM_DMA_MINROWS=n      ... only from n activation rows (default 16384)
+ *       LOTUS_GEMM_DMA_MINBLOCKS=n    ... only when their 128-row tiles give at least n blocks (default 400)
+ *       LOTUS_GEMM_DMA_WGRAD_BLOCKS=n blocks a weight gradient is split into on those kernels (default 256; 0: not used)
+ *       LOTUS_SPLITK_FUSED=0          split-K products finish in a second launch instead of the last-arriving block
+ *       LOTUS_CONV_TAP=0              deep sparse-convolution levels stay on the pair-compacted kernel
+ *       LOTUS_CONV_TAP_MINC=c         tap-grouped dense path from c channels (default 256)
+ *       LOTUS_CONV_TAP_SLAB_MB=m      ... while its partial slab stays below m MB (default 256)
+ *       LOTUS_CONV_WG_CHUNK=n         points per split of the sparse-convolution weight gradient (default 1024)
+ *       LOTUS_CONV_OS=0               bf16 operand modes use the pair-compacted convolution kernel
+ *       LOTUS_CONV_OS_F32=1|2|3       exact-fp32 products on the output-stationary convolution kernel (opt-in)
+ *       LOTUS_XQ=0|2                  cross attention on the tile kernels / patch attention on the per-query kernels
+ *   - lotus_abi_version() changes whenever an existing entry point changes its arguments (2 since round 5); bindings check it.
  */
 #ifndef LOTUS_HIP_H
 #define LOTUS_HIP_H
@@ -174,6 +190,18 @@ int lotus_layernorm_bwd(const lotus_act_t* dy, const lotus_act_t* x, const float
                         const lotus_act_t* add, lotus_act_t* dx, float* dgamma, float* dbeta, int M, int C, int accumulate,
                         lotus_act_t* dz, float drop_p, unsigned long long drop_seed, void* workspace, size_t workspace_bytes,
                         void* stream);
+/* number of partial rows lotus_layernorm_bwd(dgamma == NULL) leaves in its workspace */
+int lotus_layernorm_bwd_parts(int M, int C);
+/* the reduction of lotus_layernorm_bwd_params over an explicit number of partial rows [nparts][2][C] */
+int lotus_layernorm_bwd_params_n(const void* workspace, int nparts, int C, float* dgamma, float* dbeta, int accumulate, void* stream);
+/* nn.Linear input gradient + the backward of the nn.LayerNorm that feeds the layer (model.py:659-680: norm1 -> attn.qkv,
+ * norm2 -> mlp.fc1; model_ca.py:114-124): dn = dy w [M,K] (scratch), dx = LN'(dn) + add, dz (optional) = dx * dropout mask;
+ * *nparts (HOST int) = partial rows left in ln_workspace for lotus_layernorm_bwd_params_n.  One kernel where a 128-wide
+ * tile covers the rows (K = 64 / 128, >= 16 k rows), otherwise lotus_linear_dgrad + lotus_layernorm_bwd. */
+int lotus_linear_dgrad_ln(const lotus_act_t* dy, const float* w, const lotus_act_t* x, const float* mean, const float* rstd,
+                          const float* gamma, const lotus_act_t* add, lotus_act_t* dx, lotus_act_t* dn, lotus_act_t* dz, float dz_p,
+                          unsigned long long dz_seed, int M, int N, int K, int precision, void* workspace, size_t workspace_bytes,
+                          void* counters, void* ln_workspace, size_t ln_workspace_bytes, int* nparts, void* stream);
 /* second half of the above when it was called with dgamma == NULL: reduce the column partials left in workspace */
 int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamma, float* dbeta, int accumulate,
                                void* stream);

@@ -51,6 +51,9 @@ def parse_header(path=None):
     return protos
 
 
+ABI_VERSION = 2  # lotus_abi_version() of the library this binding matches (include/lotus_hip.h)
+
+
 class LotusError(RuntimeError):
     pass
 
@@ -69,6 +72,9 @@ class _Lib:
             f.restype = restype
             f.argtypes = argtypes
             self.fn[name] = f
+        got = self.fn["lotus_abi_version"]()
+        if got != ABI_VERSION:  # (an entry point changed its arguments: a stale library would take them misaligned, silently)
+            raise LotusError(f"{LIB_PATH} has ABI version {got}, this binding was written for {ABI_VERSION}: rebuild the library")
 
     def last_error(self):
         return self.fn["lotus_last_error"]().decode()

@@ -15,7 +15,7 @@
 
 #include "../../include/lotus_hip.h"
 
-extern thread_local hipEvent_t lotus_tls_stop_event;        // common.h: LOTUS_LAUNCH
+extern __attribute__((visibility("hidden"))) __thread hipEvent_t lotus_tls_stop_event;  // common.h: LOTUS_LAUNCH
 hipEvent_t lotus_link_next_event(unsigned long long link);  // lotus_capi.cpp
 void lotus_set_error(const char* fmt, ...);
 

@@ -10,7 +10,9 @@
 // entry point (blocks.cpp) has armed `lotus_tls_stop_event`, the launch carries that event as its completion ("stop")
 // event instead, so another stream can be ordered after THIS kernel without an event-record marker packet in the
 // launching queue (a marker between two dependent kernels of the critical stream costs it 5-10 us; measured).
-extern thread_local hipEvent_t lotus_tls_stop_event;
+// (`__thread`, not `thread_local`: a C++ thread_local extern is reached through a weak init-function symbol, and a HIDDEN weak
+// undefined symbol in position-independent code resolves to the load address instead of null — the call crashes)
+extern __attribute__((visibility("hidden"))) __thread hipEvent_t lotus_tls_stop_event;  // library-internal: not an exported symbol
 #define LOTUS_LAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
   do {                                                                                                                   \
     if (lotus_tls_stop_event)                                                                                            \

@@ -30,20 +30,24 @@ int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, c
 // launch is bound by that stream (213 / 146 us for 9.5 / 4 GFLOP).  Here the convolution is 27 GATHERED dense products in
 // one launch of the dense kernel (gemm.hip: rows through the tap plan of the front-end, one weight slice per row tile) into
 // a partial slab [27 x n64][C], followed by a fixed-order gather-sum over the taps of every output row.
-static int tap_rows_max() {
-  static int v = -1;
-  // (8192 -> 32768 rows: +0.6 % at 38 clouds, +0.7 % at 64 — level 2 of those batches; no further gain at 131072)
-  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_ROWS"); v = e ? atoi(e) : 32768; }
-  return v;
-}
+// The path is taken for layers of >= 256 channels (LOTUS_CONV_TAP_MINC) whose fp32 partial slab [27 x n64][C] stays below
+// 256 MB (LOTUS_CONV_TAP_SLAB_MB; ADVICE r4: the slab, not the row count, is what the caller's workspace has to hold — the
+// earlier row cap of 32 768 allowed 0.9 GB at C = 256 and 1.8 GB at C = 512 for a measured +0.6 %).  At the bench batch
+// that is levels 2-4 (168 / 80 / 30 MB); 64-cloud batches keep level 2 (C = 256, ~24 k rows: 670 MB) on the pair kernel.
 static int tap_min_width() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_MINC"); v = e ? atoi(e) : 256; }
   return v;
 }
+static size_t tap_slab_max() {
+  static long v = -1;
+  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_SLAB_MB"); v = e ? atol(e) : 256; }
+  return (size_t)v << 20;
+}
+static size_t tap_part_bytes(int n, int ND);
 static bool tap_shape_ok(int n, int cin, int cout) {
-  return !LOTUS_ACT_IS_BF16 && n > 0 && n <= tap_rows_max() && cin >= tap_min_width() && cout >= tap_min_width() && cin % 64 == 0 &&
-         cout % 64 == 0;
+  return !LOTUS_ACT_IS_BF16 && n > 0 && cin >= tap_min_width() && cout >= tap_min_width() && cin % 64 == 0 && cout % 64 == 0 &&
+         tap_part_bytes(n, cin > cout ? cin : cout) <= tap_slab_max();
 }
 static size_t tap_part_bytes(int n, int ND) { return (size_t)27 * ((n + 63) / 64 * 64) * ND * sizeof(float); }
 

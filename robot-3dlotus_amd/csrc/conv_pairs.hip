@@ -27,7 +27,6 @@ struct ConvP2 {
   const int* nbr;    // [T][n]
   const int* rowidx; // [n] or null
   int n, T, KD, ND, mirror;
-  int dbg;           // tuning probes (LOTUS_CONV_DBG): 1 = stop after the pair / slot tables are built
   int tpz;           // taps per blockIdx.z
   long part_stride;  // floats between z slabs (0 = single slab, epilogue applies bias/add)
 };
@@ -284,7 +283,6 @@ __global__ __launch_bounds__(256, 2) void conv_pairs_kernel(ConvP2 p) {
         }
       }
     };
-    if (p.dbg == 1) return;
     issue_fill(0);
     store_fill();
     // fold base of this lane: its wave's 32-column slice, the 4-column run 4 * hh of every 8-column group
@@ -819,22 +817,17 @@ static int tap_splits(int n, int ND) {
   const long base = (long)cdiv(n, 64 * (ND <= 64 ? 2 : 1)) * (ND <= 64 ? 1 : ND / 128);
   int nz = 1;
   while (nz < 9 && base * nz < 768) nz = nz == 1 ? 3 : 9;  // 27 taps -> 1, 3 or 9 groups
-  static int t27 = -1;
-  if (t27 < 0) { const char* e = getenv("LOTUS_CONV_NZ27_BLOCKS"); t27 = e ? atoi(e) : 0; }
-  // tuning knob, off: one tap per block for grids below t27 blocks.  Measured (tools/conv_bench.py): level 4 (361 rows, C 768)
+  // (Measured and removed, tools/conv_bench.py: one tap per block — 27 groups — on the small grids: level 4 (361 rows, C 768)
   // 146 -> 138 us, level 3 (1450, C 512) 213 -> 247: a block's (tap, chunk) chain is NOT what bounds the deep levels — every
   // 64-row tile streams its taps' weights (3 x C x 128 x 4 bytes) through one CU, 23 (level 3) / 6 (level 4) times the weight
-  // tensor per launch
-  if (nz == 9 && base * 9 < t27) nz = 27;
+  // tensor per launch; those levels now run as tap-grouped dense products, conv.hip.)
   return nz;
 }
 
 template <int NCS, int PREC>
 static int launch_pairs_p(ConvP2& p, int nz, hipStream_t st) {
   using Cfg = PairsCfg<NCS, PREC>;
-  static int pad = -1;
-  if (pad < 0) { const char* e = getenv("LOTUS_CONV_LDSPAD"); pad = e ? atoi(e) : 0; }
-  const size_t sm = Cfg::bytes() + (size_t)pad;
+  const size_t sm = Cfg::bytes();
   static bool attr_set = false;  // per instantiation; the attribute call costs host time on every launch otherwise
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)conv_pairs_kernel<NCS, PREC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); attr_set = true; }
   dim3 grid(p.ND / (32 * NCS), cdiv(p.n, Cfg::BM * Cfg::NRT), nz);
@@ -854,9 +847,6 @@ static int launch_pairs(ConvP2& p, int nz, int prec, hipStream_t st) {
 // output-stationary bf16 kernel: 128-row blocks; taps split 1 / 3 / 9 ways until the grid covers the CUs
 static int os_splits(int n, int ND) {
   const long base = (long)cdiv(n, 128) * (ND == 64 ? 1 : ND / 128);
-  static int force = -1;
-  if (force < 0) { const char* e = getenv("LOTUS_CONV_OS_NZ"); force = e ? atoi(e) : 0; }
-  if (force == 1 || force == 3 || force == 9) return force;
   int nz = 1;
   while (nz < 9 && base * nz < 256) nz = nz == 1 ? 3 : 9;
   return nz;
@@ -885,9 +875,7 @@ static int launch_os(ConvP2& p, int nz, int prec, hipStream_t st) {
     else return LOTUS_E_UNSUPPORTED;
   }
   if (prec == 3) return wide ? launch_os_t<3, 4, 64>(p, nz, st) : launch_os_t<3, 2, 64>(p, nz, st);
-  static int kch = -1;
-  if (kch < 0) { const char* e = getenv("LOTUS_CONV_OS_KCH"); kch = e ? atoi(e) : 128; }
-  if (p.KD % 128 == 0 && kch == 128) return wide ? launch_os_t<1, 4, 128>(p, nz, st) : launch_os_t<1, 2, 128>(p, nz, st);
+  if (p.KD % 128 == 0) return wide ? launch_os_t<1, 4, 128>(p, nz, st) : launch_os_t<1, 2, 128>(p, nz, st);
   return wide ? launch_os_t<1, 4, 64>(p, nz, st) : launch_os_t<1, 2, 64>(p, nz, st);
 }
 
@@ -940,7 +928,6 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
   p.n = n; p.T = T; p.KD = KD; p.ND = ND; p.mirror = mode == 1;
   p.w = w_t + (mode == 0 ? 0 : (long)cout * T * cin);
   p.tpz = cdiv(T, nz);
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("LOTUS_CONV_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   p.y = y; p.ypart = nz > 1 ? (float*)workspace : nullptr;
   p.part_stride = nz > 1 ? (long)n * ND : 0;
   if (os) *rc = launch_os(p, nz, prec, st);

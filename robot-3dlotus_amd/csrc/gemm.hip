@@ -502,167 +502,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   if (FAST && fused) splitk_fused_tail<SUM_A, BM, BN, EC>(p, bx, by, m0, n0, tid);
 }
 
-// ---- Streaming weight gradient (exact fp32, fp32 storage): dW[N,K] = dY[M,N]^T X[M,K] without LDS staging or barriers.
-// Both operands of a weight gradient are contiguous along their NON-reduction index, which is exactly the lane axis of the
-// 32x32x2 MFMA operands (lane = row / column of the output tile, lane half h = reduction step): a lane that owns the two
-// adjacent output rows 2 l + {0, 1} reads both with ONE 8-byte load of dY[m + h][i0 + 2 l], and the wave's load covers
-// 2 x 256 contiguous bytes.  Every wave therefore streams its own range of rows straight from global memory into MFMA
-// operand registers through a ring of D load pairs in flight (counted vmcnt waits: the steady-state loop has no branch
-// around a load), four 32 x 32 accumulators per wave (output rows 2 l + tm, columns 2 l + tn of a 64 x 64 tile) and
-// ~0.75 non-MFMA instructions per MFMA, where the LDS-tiled kernel spends 2 ds_read_b32 per MFMA on these operands (the
-// instruction-issue budget next to a busy MFMA pipe is 3-4 per MFMA over ALL waves of a SIMD).  The
-// four waves of a block own the same output tile and split the block's row range; their accumulators are summed in a
-// fixed tree through LDS ((w0 + w1) + (w2 + w3)) and leave through the same partial-slab / last-arrival epilogue as
-// gemm_kernel, so the split bookkeeping of lotus_linear_wgrad is shared.  Needs N % 64 == 0, K % 64 == 0, 8-byte aligned rows.
-template <int D>
-__global__ __launch_bounds__(256) void wgrad_stream_kernel(GemmP p) {
-  const float* __restrict__ pA = static_cast<const float*>(p.A);
-  const float* __restrict__ pB = static_cast<const float*>(p.B);
-  constexpr int TLD = 68;  // row stride of the 64 x 64 exchange tiles (float4 rows, 16-byte aligned)
-  __shared__ __attribute__((aligned(16))) float tiles[2][64 * TLD];
-  __shared__ float bsum_s[4][64];
-  const int tid = threadIdx.x, l31 = tid & 31, h = (tid >> 5) & 1;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row ranges, pointers and loop bounds live in SGPRs
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {  // (the split-K block order of gemm_kernel: one XCD / L2 per split)
-    const int ntile = gridDim.x * gridDim.y;
-    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    bz = xcd + 8 * (slot / ntile);
-    const int t = slot - (slot / ntile) * ntile;
-    by = t / (int)gridDim.x;
-    bx = t - by * (int)gridDim.x;
-  }
-  const int m0 = by * 64, n0 = bx * 64;
-  const int per = p.klen >> 2;  // rows per wave (klen is a multiple of 64)
-  const int kb = bz * p.klen + wave * per;
-  const int rows = max(0, min(min(p.K, (bz + 1) * p.klen), kb + per) - kb);
-  const int nst = (rows + 1) >> 1;  // reduction steps of two rows (the last one may hold one row)
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  float as0 = 0.f, as1 = 0.f;  // column sums of dY (bias gradient): this lane's rows of parity h
-
-  // One buffer descriptor per operand over THIS wave's rows.  The running row offset is part of the per-lane VGPR offset
-  // (one v_add per load; the scalar offset of a buffer instruction is not bounds-checked), so a load past the wave's last
-  // row returns zeros: the single row of an odd tail step and the steps that pad the range to a whole number of ring
-  // cycles multiply zeros, and the loop needs no tail code.
-  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(pA + (long)kb * p.lda), 0, (int)((unsigned)rows * (unsigned)p.lda * 4u), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(pB + (long)kb * p.ldb), 0, (int)((unsigned)rows * (unsigned)p.ldb * 4u), 0x00020000);
-  int oa = 4 * (h * (int)p.lda + m0 + 2 * l31), ob = 4 * (h * (int)p.ldb + n0 + 2 * l31);  // per-lane byte offsets
-  const int sa = 8 * (int)p.lda, sb = 8 * (int)p.ldb;                                      // two rows per step
-  auto lda2 = [&]() { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ra_rsrc, oa, 0, 0); oa += sa; return v; };
-  auto ldb2 = [&]() { const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rb_rsrc, ob, 0, 0); ob += sb; return v; };
-  const bool want_bias = p.bias_part && bx == 0;  // (block-uniform) only the first column block reports the column sums of dY
-  const int cycles = (nst + D - 1) / D;           // ring cycles of D steps (wave-uniform)
-  auto run = [&](auto bias_tag) {
-    constexpr bool BIAS = decltype(bias_tag)::value;
-    float s0[D], s1[D];  // bias gradient: one independent pair of sums per ring slot (no chain through the operand registers)
-#pragma unroll
-    for (int d = 0; d < D; ++d) s0[d] = s1[d] = 0.f;
-    auto step = [&](u32x2 au, u32x2 bu, int d) {
-      const float ax = __uint_as_float(au.x), ay = __uint_as_float(au.y), bx_ = __uint_as_float(bu.x), by_ = __uint_as_float(bu.y);
-      if (BIAS) { s0[d] += ax; s1[d] += ay; }
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, bx_, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax, by_, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, bx_, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ay, by_, acc[1][1], 0, 0, 0);
-    };
-    u32x2 ra[D], rb[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) { ra[d] = lda2(); rb[d] = ldb2(); }
-    for (int c = 1; c < cycles; ++c) {
-      // slot d's loads were issued D steps ago: 2 (D - 1) younger loads stay in flight across its wait
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        step(ra[d], rb[d], d);
-        ra[d] = lda2(); rb[d] = ldb2();
-      }
-#pragma unroll
-      for (int d = 0; d < D; ++d) {  // the order the scheduler has to keep: four products, then the refill of their slot
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        if (BIAS) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // (the sums read the slot before its refill may land)
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-      }
-    }
-#pragma unroll
-    for (int d = 0; d < D; ++d) step(ra[d], rb[d], d);
-    if (BIAS) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) { as0 += s0[d]; as1 += s1[d]; }
-    }
-  };
-  if (cycles > 0) {
-    if (want_bias) run(std::true_type{});
-    else run(std::false_type{});
-  }
-
-  // ---- the four waves' partial tiles -> one, in a fixed tree: (w0 + w1) + (w2 + w3)
-  // accumulator register r of tile (tm, tn): output row 2 i + tm with i = (r & 3) + 8 (r >> 2) + 4 h, column 2 l31 + tn
-  auto put = [&](float* T) {
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        *reinterpret_cast<float2*>(&T[(2 * i + tm) * TLD + 2 * l31]) = make_float2(acc[tm][0][r], acc[tm][1][r]);
-      }
-  };
-  auto add = [&](const float* T) {  // acc = acc + T (own partial first: the order of the tree)
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float2 v = *reinterpret_cast<const float2*>(&T[(2 * i + tm) * TLD + 2 * l31]);
-        acc[tm][0][r] += v.x; acc[tm][1][r] += v.y;
-      }
-  };
-  if (want_bias) {
-    as0 += __shfl_xor(as0, 32, 64); as1 += __shfl_xor(as1, 32, 64);
-    if (h == 0) { bsum_s[wave][2 * l31] = as0; bsum_s[wave][2 * l31 + 1] = as1; }
-  }
-  if (wave == 1) put(tiles[0]);
-  if (wave == 3) put(tiles[1]);
-  __syncthreads();
-  if (wave == 0) add(tiles[0]);
-  if (wave == 2) add(tiles[1]);
-  __syncthreads();
-  if (wave == 2) put(tiles[1]);
-  __syncthreads();
-  if (wave == 0) { add(tiles[1]); put(tiles[0]); }
-  __syncthreads();
-
-  const bool fused = p.cnt != nullptr && gridDim.z > 1;
-  float* __restrict__ C = static_cast<float*>(p.C) + (long)bz * p.part_stride;
-  float* __restrict__ Cp = fused ? p.part + (long)bz * p.part_stride : nullptr;
-#pragma unroll
-  for (int it = 0; it < 4; ++it) {
-    const int i = tid + it * 256, row = i >> 4, c4 = i & 15;
-    const long o = (long)(m0 + row) * p.ldc + n0 + c4 * 4;
-    const float4 a4 = ld4(&tiles[0][row * TLD + c4 * 4]);
-    if (fused) {
-      st_agent4(Cp + o, a4);  // raw partial of this split
-    } else {
-      float v[4] = {a4.x, a4.y, a4.z, a4.w};
-      gemm_epilogue4(p, C, o, n0 + c4 * 4, v);
-    }
-  }
-  if (want_bias && tid < 64) {
-    const float sbias = ((bsum_s[0][tid] + bsum_s[1][tid]) + (bsum_s[2][tid] + bsum_s[3][tid]));
-    __hip_atomic_store(p.bias_part + (long)bz * p.bias_stride + m0 + tid, sbias, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (fused) splitk_fused_tail<true, 64, 64, float>(p, bx, by, m0, n0, tid);
-}
-
 // out[e] = sum_z part[z * stride + e].  Block = 16 float4 columns x 16 z-lanes: coalesced 256-byte row
 // segments per z, 16 independent partial sums per column, fixed-order LDS tree -> deterministic.
 template <typename T>
@@ -748,11 +587,6 @@ extern "C" int lotus_sum_slabs_ld(const act_t* part, act_t* out, int rows, int c
 
 static inline int vec_ok(const void* p, long ld) { return (((uintptr_t)p) % 16 == 0) && (ld % 4 == 0); }  // (bf16 rows: 8-byte accesses, same rule)
 
-static int tune_env(const char* name) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : 0;
-}
-static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweeps: LOTUS_GEMM_TILE (1: 128x128, 3: 64x64), LOTUS_GEMM_NZ, LOTUS_GEMM_BK
 #define GEMM_KALIGN 64  // split-K ranges are multiples of the largest slab depth
 
 // Element types of a launch: A is always an activation; B is the weight matrix (fp32 master) except in the weight gradient
@@ -775,55 +609,30 @@ static int g_force_tile = -1, g_force_nz = -1, g_force_bk = -1;  // tuning sweep
   } while (0)
 #define GEMM_GO(BM_, BN_, BK_, PREC_, grid_) GEMM_GO_RD(BM_, BN_, BK_, PREC_, grid_, 1)
 
-// bf16 storage, bf16 products: depth of the register staging ring (LOTUS_GEMM_RING = 1 restores the one-slab prefetch)
-// Measured (tools/gemm_b16_bench.py, PerAct step): the ring pays where a launch is a latency chain — few row tiles, long
-// reductions (1450 x 512 x 512: 8.8 -> 7.4 us, 361 x 768 x 768: 11.4 -> 9.4) — and LOSES on the tall level-0 / level-1 layers
-// (65 536 x 512 x 128: 38.6 -> 63.8 us; 64 clouds 2257 -> 2158 samples/s): its 64 extra registers cut the resident blocks from 7
-// to 3 per CU, and those launches are bound by what the resident blocks stream together, not by one block's chain.
-static int bf16_ring_depth(int M) {
-  static int forced = -1, max_rows = -1;
-  if (forced < 0) { forced = tune_env("LOTUS_GEMM_RING"); max_rows = tune_env("LOTUS_GEMM_RING_ROWS"); if (max_rows <= 0) max_rows = 8192; }
-  if (forced == 1) return 1;
-  return M <= max_rows ? 4 : 1;
-}
-// Exact-fp32 products: two slabs of staging registers for the small grids (levels 2-4: <= 2048 blocks, where nothing else on
-// the CU hides a block's load latency).  Headline, six alternations on one box: 879.4 -> 888.5 samples/s (+1.0 %); a ring of four
-// loses (866-871: registers).  Same products in the same order: bit-identical results.  LOTUS_GEMM_RING_F32=1 switches it off.
-static int f32_ring_depth(long blocks) {
-  static int forced = -1, max_blocks = -1;
-  if (forced < 0) { forced = tune_env("LOTUS_GEMM_RING_F32"); max_blocks = tune_env("LOTUS_GEMM_RING_F32_BLOCKS"); if (max_blocks <= 0) max_blocks = 8192; }
-  const int rd = forced == 1 ? 1 : (forced == 4 ? 4 : 2);
-  return blocks <= max_blocks ? rd : 1;
-}
-
-static int bf16_slab_depth(int klen) {
-  static int forced = -1;
-  if (forced < 0) forced = tune_env("LOTUS_GEMM_BK_BF16");
-  if (forced == 32 || forced == 64 || forced == 128) return forced;
-  // measured (PerAct preset, 16 x 4096, bf16 storage): slab depth 32 / 64 / 128 -> 1134 / 1124 / 1020 samples/s: deeper slabs cost
-  // occupancy (LDS, staging registers) and the step is host-bound at this size anyway; 32 stays the default
-  (void)klen;
-  return 32;
-}
+// Tuning constants of gemm_kernel.  Every one of them was an environment switch while it was being measured (rounds 1-4;
+// DESIGN.md section 4 has the A/B of each); the losers and their code are gone, these are the values that shipped:
+//  * 64 x 64 block tiles everywhere: 128 x 128 / 128 x 64 tiles of THIS kernel win stand-alone from 4 blocks per CU but lost
+//    inside the step at every batch size (820 vs 806 samples/s at 16 clouds) — the tall products now have gemm_dma_kernel;
+//  * slab depth by grid size: <= 512 blocks 64 (nothing else on the CU hides the load latency), <= 2048 blocks 32, larger
+//    grids 16 (occupancy); streamed weight-gradient operands 32; bf16 products always 32 (64 / 128: 1124 / 1020 vs 1134 samples/s);
+//  * register staging ring: two slabs for exact-fp32 products on grids of <= 8192 blocks (+1.0 %, bit-identical; four lose to
+//    their registers), four slabs for bf16 products over <= 8192 rows (+3 % on the PerAct preset; the tall layers lose: 7 -> 3
+//    resident blocks per CU), none for weight gradients.
+constexpr long kF32RingMaxBlocks = 8192;
+constexpr int kBf16RingMaxRows = 8192;
 
 template <bool A_KC, bool B_KC, bool SUM_A, bool FAST>
 static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
   const long blocks64 = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
   dim3 block(256);
-  if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
-  if (g_force_bk < 0) g_force_bk = tune_env("LOTUS_GEMM_BK");
-  int tile = g_force_tile;
+  dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
   const int g_prec = p.prec;
   if (g_prec && SUM_A && FAST && !A_KC && !B_KC) {
     // weight gradients (split-K, 64x64 tiles): operands converted while staged; bias sums from the fp32 registers
-    dim3 g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
     if constexpr (SUM_A && !A_KC && !B_KC && FAST) {
       if (g_prec == 1) {
-        if constexpr (LOTUS_ACT_IS_BF16) {  // bf16 storage: deep slabs, see below
-          const int bk = bf16_slab_depth(p.klen);
-          if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
-          else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
-          else if (bf16_ring_depth(SUM_A ? p.K : p.M) == 4) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
+        if constexpr (LOTUS_ACT_IS_BF16) {
+          if (p.K <= kBf16RingMaxRows) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
           else GEMM_GO(64, 64, 32, 1, g64);
         } else {
           GEMM_GO(64, 64, 32, 1, g64);
@@ -833,83 +642,42 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16 wgrad)");
     return LOTUS_OK;
   }
-  if (p.b_act && !(LOTUS_ACT_IS_BF16 && g_prec == 1 && !SUM_A && FAST && (A_KC || p.M % 4 == 0) && tile != 1)) {
+  if (p.b_act && !(LOTUS_ACT_IS_BF16 && g_prec == 1 && !SUM_A && FAST && (A_KC || p.M % 4 == 0))) {
     lotus_set_error("lotus_linear: bf16 weight shadows (precision 5) need the bf16-storage build and 16-byte aligned operands whose "
                     "widths are multiples of 4");
     return LOTUS_E_UNSUPPORTED;
   }
   if (g_prec && !SUM_A && FAST && (A_KC || p.M % 4 == 0)) {
-    // bf16 / bf16x3 operand path (forward and input-gradient products)
-    dim3 g128(cdiv(p.N, 128), cdiv(p.M, 128), nz), g64(cdiv(p.N, 64), cdiv(p.M, 64), nz);
+    // bf16 / bf16x3 operand path (forward and input-gradient products).  bf16 storage: one bf16 MFMA covers 16 k, so a
+    // 32-deep slab is two MFMAs per wave between barriers and the block pays one global-load round trip per slab; the
+    // staging ring keeps four slabs in flight where the grid is small enough to afford its registers.
     if constexpr (!SUM_A && FAST) {
       if (g_prec == 1) {
-        if (tile == 1) GEMM_GO(128, 128, 16, 1, g128);  // 128x128 only when forced (LOTUS_GEMM_TILE=1), see below
-        else if constexpr (LOTUS_ACT_IS_BF16) {
-          // bf16 storage: one bf16 MFMA covers 16 k, so a 32-deep slab is two MFMAs per wave between barriers and the block
-          // pays one global-load round trip per slab — K / 32 serialised latencies.  Deep slabs (the whole reduction for
-          // K <= 128) put all of a block's loads in flight at once.
-          const int bk = bf16_slab_depth(min(p.klen, p.K));
-          if (bk == 128) GEMM_GO(64, 64, 128, 1, g64);
-          else if (bk == 64) GEMM_GO(64, 64, 64, 1, g64);
-          else if (bf16_ring_depth(SUM_A ? p.K : p.M) == 4) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
+        if constexpr (LOTUS_ACT_IS_BF16) {
+          if (p.M <= kBf16RingMaxRows) GEMM_GO_RD(64, 64, 32, 1, g64, 4);
           else GEMM_GO(64, 64, 32, 1, g64);
         } else GEMM_GO(64, 64, 32, 1, g64);
       } else if constexpr (!LOTUS_ACT_IS_BF16) {
-        if (tile == 1) GEMM_GO(128, 128, 16, 3, g128);
-        else GEMM_GO(64, 64, 32, 3, g64);
+        GEMM_GO(64, 64, 32, 3, g64);
       }
     }
     LOTUS_LAUNCH_CHECK("lotus_gemm(bf16)");
     return LOTUS_OK;
   }
-  // (Measured and rejected for the tall thin level-0 layers, M = 65536, N x K <= 256 x 256: a weights-stationary kernel —
-  // whole W in LDS, one 32-row tile per wave with A fragments straight from global memory, barrier-free MFMA chain —
-  // 26.9 vs 28.9 us stand-alone at 128 x 128, 43 vs 32 us at N = 256, slower in the step everywhere: with exactly one tile
-  // per wave the load / MFMA / store phases of a wave still run back to back, which is what bounds these sizes.)
-  // In isolation 128x128 tiles win once there are >= 4 blocks per CU, but inside the training step — with the
-  // weight-gradient stream sharing the CUs — 64x64 tiles are better or equal at every batch size measured
-  // (16 clouds: 820 vs 806 samples/s; 32: 945 vs 920; 64: 1051 vs 1032; 128: equal), so 128x128 is opt-in only
-  if (tile == 0) tile = 3;
-  // forward products (both operands k-contiguous) run while the weight-gradient stream is idle: LOTUS_GEMM_TILE_FWD = 1 / 2
-  // selects 128x128 / 128x64 tiles for them alone when the grid still fills the GPU (tuning knob)
-  static int tile_fwd = -1;
-  if (tile_fwd < 0) tile_fwd = tune_env("LOTUS_GEMM_TILE_FWD");
-  if (p.tap_rows) tile = 3;  // tap-grouped products: a row tile must not straddle two taps (segments are multiples of 64 rows)
-  if (A_KC && B_KC && !SUM_A && tile_fwd && g_force_tile == 0 && !p.tap_rows) {
-    static int min_blocks = 0;
-    if (!min_blocks) { min_blocks = tune_env("LOTUS_GEMM_TILE_FWD_MINBLOCKS"); if (min_blocks <= 0) min_blocks = 1024; }
-    const long nb = tile_fwd == 1 ? (long)cdiv(p.M, 128) * cdiv(p.N, 128) : (long)cdiv(p.M, 128) * cdiv(p.N, 64);
-    if (nb * nz >= min_blocks) tile = tile_fwd;
-  }
   if constexpr (LOTUS_ACT_IS_BF16) {
     // bf16-storage build: the exact-fp32 product path only serves the shapes the vectorised bf16 path cannot take
     // (odd widths such as the 90- and 217-wide head layers)
-    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    GEMM_GO(64, 64, 32, 0, grid);
-  } else if (tile == 1) {
-    dim3 grid(cdiv(p.N, 128), cdiv(p.M, 128), nz);
-    GEMM_GO(128, 128, 16, 0, grid);
-  } else if (tile == 2 && !SUM_A && p.M >= 2048) {  // experimental: 128 x 64 tiles (wave tile 64 x 32)
-    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 128), nz);
-    if (g_force_bk == 32) GEMM_GO(128, 64, 32, 0, grid);
-    else GEMM_GO(128, 64, 16, 0, grid);
+    GEMM_GO(64, 64, 32, 0, g64);
   } else {
-    // slab depth (tools/gemm_sweep.py): with <= 2 blocks per CU nothing else hides the global-load latency,
-    // so run deep slabs (4x the MFMA work and bytes in flight per barrier); large grids keep BK = 16 for
-    // occupancy; the streamed weight-gradient operands like BK = 32
     // (tap-grouped products: about half of the row tiles leave at once — the grid the heuristics should see is the active one)
     const long blocks_eff = p.tap_rows ? blocks64 / 2 : blocks64;
-    int bk = g_force_bk;
-    if (!bk) bk = SUM_A ? 32 : (blocks_eff * nz <= 512 ? 64 : (blocks_eff * nz <= 2048 ? 32 : 16));
-    dim3 grid(cdiv(p.N, 64), cdiv(p.M, 64), nz);
-    static int ring_wg = -1;
-    if (ring_wg < 0) ring_wg = tune_env("LOTUS_GEMM_RING_WG");
-    const int rd = (SUM_A && ring_wg != 1) ? 1 : f32_ring_depth(blocks_eff * nz);
+    const int bk = SUM_A ? 32 : (blocks_eff * nz <= 512 ? 64 : (blocks_eff * nz <= 2048 ? 32 : 16));
+    const int rd = SUM_A ? 1 : (blocks_eff * nz <= kF32RingMaxBlocks ? 2 : 1);
     if (p.tap_rows) {
       if constexpr (A_KC && !SUM_A && FAST && !LOTUS_ACT_IS_BF16) {
-        if (bk == 64) LOTUS_LAUNCH((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
-        else if (bk == 32) LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
-        else LOTUS_LAUNCH((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), grid, block, 0, st, p);
+        if (bk == 64) LOTUS_LAUNCH((gemm_kernel<64, 64, 64, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), g64, block, 0, st, p);
+        else if (bk == 32) LOTUS_LAUNCH((gemm_kernel<64, 64, 32, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), g64, block, 0, st, p);
+        else LOTUS_LAUNCH((gemm_kernel<64, 64, 16, A_KC, B_KC, SUM_A, FAST, 0, act_t, float, float, 2, true>), g64, block, 0, st, p);
         LOTUS_LAUNCH_CHECK("lotus_gemm(tap-grouped)");
         return LOTUS_OK;
       } else {
@@ -917,13 +685,12 @@ static int launch_gemm_t(GemmP& p, int nz, hipStream_t st) {
         return LOTUS_E_UNSUPPORTED;
       }
     }
-    if (rd == 4) GEMM_GO_RD(64, 64, 32, 0, grid, 4);
-    else if (rd == 2 && bk == 64) GEMM_GO_RD(64, 64, 64, 0, grid, 2);
-    else if (rd == 2 && bk == 16) GEMM_GO_RD(64, 64, 16, 0, grid, 2);
-    else if (rd == 2) GEMM_GO_RD(64, 64, 32, 0, grid, 2);
-    else if (bk == 64) GEMM_GO(64, 64, 64, 0, grid);
-    else if (bk == 32) GEMM_GO(64, 64, 32, 0, grid);
-    else GEMM_GO(64, 64, 16, 0, grid);
+    if (rd == 2 && bk == 64) GEMM_GO_RD(64, 64, 64, 0, g64, 2);
+    else if (rd == 2 && bk == 16) GEMM_GO_RD(64, 64, 16, 0, g64, 2);
+    else if (rd == 2) GEMM_GO_RD(64, 64, 32, 0, g64, 2);
+    else if (bk == 64) GEMM_GO(64, 64, 64, 0, g64);
+    else if (bk == 32) GEMM_GO(64, 64, 32, 0, g64);
+    else GEMM_GO(64, 64, 16, 0, g64);
   }
   LOTUS_LAUNCH_CHECK("lotus_gemm");
   return LOTUS_OK;
@@ -1013,18 +780,13 @@ __global__ void splitk_epilogue_kernel(GemmP p, const float* __restrict__ part, 
 
 // Few output tiles but a long reduction (deep levels: M = 361..1450, K up to 3072): split K over
 // blockIdx.z into a workspace and finish with splitk_epilogue_kernel.  Returns the split count.
-static int fwd_splits(int M, int N, int K, bool fused = false) {
-  if (g_force_nz < 0) g_force_nz = tune_env("LOTUS_GEMM_NZ");
-  if (g_force_nz > 0) return (K / g_force_nz >= 16) ? g_force_nz : 1;
+static int fwd_splits(int M, int N, int K) {
   const long blocks = (long)cdiv(M, 64) * cdiv(N, 64);
   int nz = 1;
   // fewer than 2 blocks per CU and a long reduction: split K until ~2 blocks per CU, >= 384 deep each.  (Measured with
   // the reduction fused into the GEMM: ranges of 128-256 do NOT pay off — 1450x512x512 15 -> 19.5 us, 6077x256x256
   // 16.6 -> 19 us — the fixed latency of a block, not its MFMA time, bounds these sizes.)
-  static int mink_f = 0;
-  if (!mink_f) { mink_f = tune_env("LOTUS_GEMM_MINK"); if (mink_f <= 0) mink_f = 384; }
-  const int mink = fused ? mink_f : 384;
-  while (nz < 16 && blocks * nz < 512 && K / (nz * 2) >= mink) nz *= 2;
+  while (nz < 16 && blocks * nz < 512 && K / (nz * 2) >= 384) nz *= 2;
   return nz;
 }
 
@@ -1039,12 +801,12 @@ static bool splitk_fused_enabled() {
 template <bool A_KC, bool B_KC>
 static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, unsigned* counters, hipStream_t st) {
   if (!splitk_fused_enabled()) counters = nullptr;
-  const int nz = (p.N % 4 == 0 && p.ldc == p.N) ? fwd_splits(p.M, p.N, p.K, counters != nullptr) : 1;
+  const int nz = (p.N % 4 == 0 && p.ldc == p.N) ? fwd_splits(p.M, p.N, p.K) : 1;
   const size_t need = (size_t)nz * p.M * p.N * sizeof(float);
   if (nz == 1 || !workspace || workspace_bytes < need || ((uintptr_t)workspace) % 16) return launch_gemm<A_KC, B_KC, false>(p, 1, st);
   const int klen = cdiv(cdiv(p.K, nz), GEMM_KALIGN) * GEMM_KALIGN;
   const long tiles = (long)cdiv(p.M, 64) * cdiv(p.N, 64);
-  if (counters && tiles <= LOTUS_SPLITK_MAX_TILES && g_force_tile != 1) {
+  if (counters && tiles <= LOTUS_SPLITK_MAX_TILES) {
     // one launch: partials + last-arrival reduction with the full epilogue
     GemmP q = p;
     q.part = (float*)workspace; q.part_stride = (long)p.M * p.N; q.cnt = counters; q.klen = klen;
@@ -1103,7 +865,7 @@ size_t lotus_splitk_counters_bytes(void) { return (size_t)(LOTUS_SPLITK_MAX_TILE
 size_t lotus_bn_counters_offset(void) { return (size_t)LOTUS_SPLITK_MAX_TILES * sizeof(unsigned); }
 
 size_t lotus_linear_workspace(int M, int N, int K) {
-  const int a = fwd_splits(M, N, K, true), b = fwd_splits(M, K, N, true);
+  const int a = fwd_splits(M, N, K), b = fwd_splits(M, K, N);
   const size_t wa = a > 1 ? (size_t)a * M * N * sizeof(float) : 0, wb = b > 1 ? (size_t)b * M * K * sizeof(float) : 0;
   return wa > wb ? wa : wb;
 }
@@ -1156,47 +918,58 @@ int lotus_linear_dgrad(const act_t* dy, const float* w, act_t* dx, const act_t* 
   return run_gemm_splitk<true, false>(p, workspace, workspace_bytes, (unsigned*)counters, (hipStream_t)stream);
 }
 
+// The input gradient of a linear layer whose INPUT is a LayerNorm output, together with that LayerNorm's backward:
+//   dn = dy w,   dx = LN'(dn; x, mean, rstd, gamma) + add,   dz = dx * dropout-mask(dz_p, dz_seed) (optional),
+// column partials of dgamma / dbeta left in ln_workspace as [*nparts][2][K] for lotus_layernorm_bwd_params_n.
+// Where the rows are many and one 128-wide tile covers them (K = 64 / 128: levels 0-1 of the backbone) the LayerNorm
+// backward is the EPILOGUE of the product (gemm_dma_kernel, EPI 2): dn never reaches HBM, ln_bwd_kernel's four passes over
+// [M, K] and its launch are gone.  Everywhere else: lotus_linear_dgrad into `dn`, then lotus_layernorm_bwd — same results to
+// summation order.  (model.py:659-680: norm1 -> qkv, norm2 -> fc1; model_ca.py:114-124)
+int lotus_layernorm_bwd(const act_t* dy, const act_t* x, const float* mean, const float* rstd, const float* gamma, const act_t* add,
+                        act_t* dx, float* dgamma, float* dbeta, int M, int C, int accumulate, act_t* dz, float drop_p,
+                        unsigned long long drop_seed, void* workspace, size_t workspace_bytes, void* stream);  // norm.hip
+int lotus_layernorm_bwd_parts(int M, int C);                                                                  // norm.hip
+int lotus_linear_dgrad_ln(const act_t* dy, const float* w, const act_t* x, const float* mean, const float* rstd, const float* gamma,
+                          const act_t* add, act_t* dx, act_t* dn, act_t* dz, float dz_p, unsigned long long dz_seed, int M, int N,
+                          int K, int precision, void* workspace, size_t workspace_bytes, void* counters, void* ln_workspace,
+                          size_t ln_workspace_bytes, int* nparts, void* stream) {
+  LOTUS_CHECK_ARG(dy && w && x && mean && rstd && gamma && dx && dn && nparts && ln_workspace && M >= 0 && N > 0 && K > 0,
+                  "lotus_linear_dgrad_ln: bad arguments");
+  LOTUS_CHECK_ARG(!dz || dz_p > 0.f, "lotus_linear_dgrad_ln: dz needs dz_p > 0");
+  if (M == 0) { *nparts = 0; return LOTUS_OK; }
+  if (precision == 0 && !LOTUS_ACT_IS_BF16 && (size_t)cdiv(M, 128) * 2 * K * sizeof(float) <= ln_workspace_bytes) {
+    GemmP p;
+    memset(&p, 0, sizeof(p));
+    p.A = dy; p.B = w; p.C = dx; p.M = M; p.N = K; p.K = N;
+    p.lda = N; p.ldb = K; p.ldc = K;
+    p.act = LOTUS_ACT_NONE; p.residual = add;
+    p.klen = cdiv(N, GEMM_KALIGN) * GEMM_KALIGN;
+    p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(w, K); p.prec = 0;
+    set_drop(p, dz ? dz_p : 0.f, dz_seed);
+    p.ln_x = x; p.ln_mean = mean; p.ln_rstd = rstd; p.ln_gamma = gamma; p.ln_part = (float*)ln_workspace; p.ln_dz = dz;
+    if (p.a_vec && p.b_vec && vec_ok(dx, K) && vec_ok(x, K) && (!add || vec_ok(add, K))) {
+      const int rc = launch_gemm_dma(p, 1, 1, (hipStream_t)stream);
+      if (rc != LOTUS_GEMM_DMA_NA) { *nparts = cdiv(M, 128); return rc; }
+    }
+  }
+  StopEventOnLast stop_ev;  // (an armed stop event belongs to the LAST launch: the LayerNorm backward)
+  int rc = lotus_linear_dgrad(dy, w, dn, nullptr, nullptr, M, N, K, LOTUS_ACT_NONE, 0.f, 0, precision, workspace, workspace_bytes, counters, stream);
+  if (rc) return rc;
+  stop_ev.last();
+  rc = lotus_layernorm_bwd(dn, x, mean, rstd, gamma, add, dx, nullptr, nullptr, M, K, 0, dz, dz ? dz_p : 0.f, dz_seed, ln_workspace,
+                           ln_workspace_bytes, stream);
+  *nparts = lotus_layernorm_bwd_parts(M, K);
+  return rc;
+}
+
 static int wgrad_splits(int M, int N, int K) {
-  if (g_force_nz < 0) g_force_nz = tune_env("LOTUS_GEMM_NZ");
-  if (g_force_nz > 0) return (M / g_force_nz >= 16) ? g_force_nz : 1;
   if (const int dz = gemm_dma_wgrad_splits(M, N, K)) return dz;  // tall products on the LDS-DMA kernels: their own tiling
   int nz = 1;
   const long tiles = (long)cdiv(N, 64) * cdiv(K, 64);
   if (tiles >= 128 && M < 1024) return 1;  // deep levels: the second (reduce) launch costs more than it hides
   // both operands are streamed exactly once: keep ~4 blocks per CU in flight (Little's law), >= 128 rows each
-  static int target = 0, minrows = 0;
-  if (!target) { target = tune_env("LOTUS_WGRAD_BLOCKS"); if (target <= 0) target = 1024; }
-  if (!minrows) { minrows = tune_env("LOTUS_WGRAD_MINROWS"); if (minrows <= 0) minrows = 128; }
-  while (nz < 256 && tiles * nz < target && M / (nz * 2) >= minrows) nz *= 2;
+  while (nz < 256 && tiles * nz < 1024 && M / (nz * 2) >= 128) nz *= 2;
   return nz;
-}
-
-// Weight-gradient launch.  LOTUS_WGRAD_STREAM = 1 (OPT-IN) runs the exact-fp32 products of the fp32-storage build on
-// wgrad_stream_kernel where it applies (64-aligned output, vector-aligned operands, >= LOTUS_WGRAD_STREAM_MINROWS rows,
-// default 256); gemm_kernel otherwise.  Measured (tools/wgrad_ab.py, all 35 weight-gradient shapes of a v1 step, both
-// within 1e-6 of float64): 3.37 -> 3.28 ms per step stand-alone (65536 x 384 x 128 90 -> 79 us, 361 x 768 x 768 15.8 ->
-// 12.5, 65536 x 192 x 64 32.8 -> 35.4) and no difference inside the training step (898 / 928 vs 906 / 907 samples/s over
-// two alternations: inside the box-to-box noise) — two kernels this different landing within 3 % of each other on every
-// shape says the weight gradient is bound by what they share (operand stream + partial slabs + the reduction launch behind
-// them), not by the inner loop: the LDS-tiled kernel stays the default.
-static int launch_wgrad(GemmP& p, int nz, hipStream_t st) {
-  if constexpr (!LOTUS_ACT_IS_BF16) {
-    static int mode = -1, minrows = -1;
-    if (mode < 0) {
-      mode = tune_env("LOTUS_WGRAD_STREAM");
-      minrows = tune_env("LOTUS_WGRAD_STREAM_MINROWS"); if (minrows <= 0) minrows = 256;
-    }
-    if (g_force_tile < 0) g_force_tile = tune_env("LOTUS_GEMM_TILE");
-    if (mode && p.prec == 0 && g_force_tile != 1 && p.M % 64 == 0 && p.N % 64 == 0 && p.K >= minrows && p.klen % 64 == 0 &&
-        p.lda % 2 == 0 && p.ldb % 2 == 0 && (long)(p.klen / 4 + 2) * (p.lda > p.ldb ? p.lda : p.ldb) * 4 < (1L << 31) &&  // 32-bit buffer offsets
-        fast_ok<false, false>(p)) {
-      dim3 grid(p.N / 64, p.M / 64, nz), block(256);
-      LOTUS_LAUNCH(wgrad_stream_kernel<8>, grid, block, 0, st, p);
-      LOTUS_LAUNCH_CHECK("lotus_linear_wgrad(stream)");
-      return LOTUS_OK;
-    }
-  }
-  return launch_gemm<false, false, true>(p, nz, st);
 }
 
 size_t lotus_linear_wgrad_workspace(int M, int N, int K) {
@@ -1227,15 +1000,14 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
   p.klen = cdiv(cdiv(M > 0 ? M : 1, nz), GEMM_KALIGN) * GEMM_KALIGN;
   p.a_vec = vec_ok(dy, N); p.b_vec = vec_ok(x, K); p.prec = precision;
   set_drop(p, 0.f, 0);
-  static int fuse_max = -1;
-  if (fuse_max < 0) { fuse_max = tune_env("LOTUS_WGRAD_FUSE_MAX"); if (fuse_max <= 0) fuse_max = 4; }  // measured: nz 4 fused 46 -> 41 us, nz 16 fused 42 -> 51 us
+  constexpr int fuse_max = 4;  // measured: nz 4 fused 46 -> 41 us, nz 16 fused 42 -> 51 us
   const long wtiles = (long)cdiv(N, 64) * cdiv(K, 64);
-  if (!direct && counters && splitk_fused_enabled() && nz <= fuse_max && wtiles <= LOTUS_SPLITK_MAX_TILES && g_force_tile != 1) {
+  if (!direct && counters && splitk_fused_enabled() && nz <= fuse_max && wtiles <= LOTUS_SPLITK_MAX_TILES) {
     // few splits: the last block of every output tile sums the partials (and the bias partials) itself
     GemmP q = p;
     q.C = dw; q.part = part; q.part_stride = (long)slab; q.cnt = (unsigned*)counters;
     q.bias_part = db ? part + (size_t)N * K : nullptr; q.bias_stride = (long)slab; q.bias_out = db; q.accumulate = accumulate;
-    if (fast_ok<false, false>(q)) return launch_wgrad(q, nz, st);
+    if (fast_ok<false, false>(q)) return launch_gemm<false, false, true>(q, nz, st);
   }
   if (direct) {
     p.C = dw; p.bias_part = db;
@@ -1243,7 +1015,7 @@ int lotus_linear_wgrad(const act_t* dy, const act_t* x, float* dw, float* db, in
     p.C = part; p.part_stride = (long)slab;
     p.bias_part = db ? part + (size_t)N * K : nullptr; p.bias_stride = (long)slab;
   }
-  int rc = launch_wgrad(p, nz, st);
+  int rc = launch_gemm<false, false, true>(p, nz, st);
   if (rc || direct) return rc;
   const long n = (long)N * K;
   if (db && db == dw + n) return lotus_reduce_parts(part, dw, (long)slab, (long)slab, nz, accumulate, st);

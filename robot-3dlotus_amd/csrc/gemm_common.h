@@ -45,6 +45,15 @@ struct GemmP {
   const int* tap_cnt;
   int tap_rows, b_tap_mirror;
   long b_tap_stride;
+  // LayerNorm backward fused into an input-gradient product whose block tile covers whole rows (gemm_dma_kernel, EPI 2): the
+  // product is dy of the LayerNorm output; C receives dx = LN'(dy) (+ residual), ln_dz (optional) dx times the dropout mask of
+  // drop_seed / drop_thresh, ln_part [row tiles][2][N] the column partials of dgamma / dbeta
+  const act_t* ln_x;
+  const float* ln_mean;
+  const float* ln_rstd;
+  const float* ln_gamma;
+  float* ln_part;
+  act_t* ln_dz;
 };
 
 // Partial tiles of a fused split-K product travel between blocks that may sit on different XCDs (one L2 each).  An

@@ -84,7 +84,8 @@ __device__ __forceinline__ void dma_epi_math4(const GemmP& p, float (&v)[4], con
 // XKC / WKC: the activation-side (rows of C) / weight-side (columns of C) operand is contiguous along the reduction
 // index (image [R][BK], swizzled); otherwise it is contiguous along its own output index (image [BK][R]).
 //   fwd (1, 1), dgrad (1, 0), wgrad (0, 0)
-// EPI: 0 = bias / saved pre-activation / residual only (no per-element arithmetic besides the residual add), 1 = everything
+// EPI: 0 = bias / saved pre-activation / residual only (no per-element arithmetic besides the residual add), 1 = everything,
+//      2 = LayerNorm backward of the product (input gradients whose block tile covers whole rows: BN == N; GemmP::ln_*)
 // ABL (kernel lab only): 1 skips the epilogue stores, 2 the DMA (operands are whatever the LDS holds), 3 both
 template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   constexpr int TA = A_FL / 1024, TB = B_FL / 1024, D = TA + TB;       // DMA instructions per wave and slab
   static_assert(TA >= 1 && TB >= 1 && (TM == 1 || TM == 2) && (TN == 1 || TN == 2), "tile");
   static_assert(NST >= 2 && NST <= 4 && D * (NST - 2) < 64, "stages");
-  constexpr int EP_FL = 4 * 32 * (WTN + 4);  // epilogue: one [32][WTN + 4] tile per wave
+  constexpr int EP_FL = 4 * 32 * (WTN + 4) + (EPI == 2 ? 4 * 32 * 2 + 4 * 2 * WTN : 0);  // epilogue: one [32][WTN + 4] tile per wave (+ LN sums)
   __shared__ __attribute__((aligned(1024))) float smem[NST * ST_FL > EP_FL ? NST * ST_FL : EP_FL];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = tid & 31, h = (tid >> 5) & 1;
@@ -325,6 +326,99 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   const int colw = n0 + wn * WTN + c4 * 4;
   const bool full_rows = m0 + BM <= p.M;  // (block-uniform) the scalar row advance is not bounds-checked: whole tiles only
   const bool math = EPI == 1 && (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh);
+  if constexpr (EPI == 2) {
+    // ---- LayerNorm backward of the product, in the row-contiguous layout (LPR lanes per row, 4 columns per lane): the two
+    // row sums are reduced over the lanes of a row by butterflies and over the two column waves through LDS; the column
+    // partials of dgamma / dbeta over the 128 rows of the tile go to ln_part[row tile][2][N] (fixed order throughout)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_x, 0, (int)cbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(p.ln_dz ? (void*)p.ln_dz : p.C, 0, p.ln_dz ? (int)cbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rmu = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_mean, 0, p.M * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ln_rstd, 0, p.M * 4, 0x00020000);
+    float* rowred = smem + 4 * 32 * TLD;        // [4 waves][32 rows][2]
+    float* colred = rowred + 4 * 32 * 2;        // [4 waves][2][WTN]
+    const float4 gam = ld4(p.ln_gamma + colw);
+    const float inv_c = 1.f / (float)p.N;
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, pb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          st4(vt + l31 * TLD + tn * 32 + 8 * g + 4 * h, make_float4(acc[tm][tn][4 * g], acc[tm][tn][4 * g + 1], acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]));
+      const int row0 = m0 + wm * WTM + tm * 32 + rsub;
+      const int vo = (row0 * ldc + colw) * 4;
+      dma_f32x4 xv[NIT], ad[NIT], gv[NIT];
+      float mu[NIT], rs[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {  // (VGPR row offsets: bounds-checked, the last row tile may be ragged)
+        xv[it] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vo + it * RPI * ldc * 4, 0, 0));
+        ad[it] = __builtin_bit_cast(dma_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rr, vo + it * RPI * ldc * 4, 0, 0));
+        mu[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmu, (row0 + it * RPI) * 4, 0, 0));
+        rs[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (row0 + it * RPI) * 4, 0, 0));
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const float4 t4 = ld4(vt + (it * RPI + rsub) * TLD + c4 * 4);
+        gv[it] = dma_f32x4{t4.x, t4.y, t4.z, t4.w};
+      }
+      dma_f32x4 xh[NIT], gy[NIT];
+      float s1[NIT], s2[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const float nm = -mu[it] * rs[it];
+        float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float gmv = e == 0 ? gam.x : e == 1 ? gam.y : e == 2 ? gam.z : gam.w;
+          xh[it][e] = fmaf(xv[it][e], rs[it], nm);
+          gy[it][e] = gv[it][e] * gmv;
+          a1 += gy[it][e];
+          a2 = fmaf(gy[it][e], xh[it][e], a2);
+          pg[e] = fmaf(gv[it][e], xh[it][e], pg[e]);
+          pb[e] += gv[it][e];
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        s1[it] = a1; s2[it] = a2;
+        if (c4 == 0) *reinterpret_cast<float2*>(rowred + (wave * 32 + it * RPI + rsub) * 2) = make_float2(a1, a2);
+      }
+      __syncthreads();  // (no DMA is in flight: a plain barrier)
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const float2 o2 = *reinterpret_cast<const float2*>(rowred + ((wave ^ 1) * 32 + it * RPI + rsub) * 2);
+        const float m1 = (wn == 0 ? s1[it] + o2.x : o2.x + s1[it]) * inv_c, m2 = (wn == 0 ? s2[it] + o2.y : o2.y + s2[it]) * inv_c;
+        dma_f32x4 dxv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dxv[e] = fmaf(rs[it], gy[it][e] - m1 - xh[it][e] * m2, ad[it][e]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, dxv), rc, vo + it * RPI * ldc * 4, 0, 0);
+        if (p.ln_dz) {
+          float dm[4];
+          dropout_scale4(p.drop_seed, (unsigned long long)((long)(row0 + it * RPI) * ldc + colw), p.drop_thresh, p.drop_inv_keep, dm);
+          const dma_f32x4 z = {dxv[0] * dm[0], dxv[1] * dm[1], dxv[2] * dm[2], dxv[3] * dm[3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(dma_u32x4, z), rz, vo + it * RPI * ldc * 4, 0, 0);
+        }
+      }
+      __syncthreads();  // rowred / vt are rewritten by the next pass
+    }
+    // column partials: over the row lanes of the wave (lanes with the same c4), then over the two row waves
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { pg[e] += __shfl_xor(pg[e], o, 64); pb[e] += __shfl_xor(pb[e], o, 64); }
+    }
+    if (rsub == 0) {
+      st4(colred + (wave * 2 + 0) * WTN + c4 * 4, make_float4(pg[0], pg[1], pg[2], pg[3]));
+      st4(colred + (wave * 2 + 1) * WTN + c4 * 4, make_float4(pb[0], pb[1], pb[2], pb[3]));
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {  // which = tid / BN, column = tid % BN: rows of wave (wm 0, wn) + rows of wave (wm 1, wn)
+      const int which = tid / BN, col = tid % BN, cw = col / WTN, cc = col % WTN;
+      const float sum = colred[((0 * 2 + cw) * 2 + which) * WTN + cc] + colred[((1 * 2 + cw) * 2 + which) * WTN + cc];
+      if (n0 + col < p.N) p.ln_part[((long)by * 2 + which) * p.N + n0 + col] = sum;
+    }
+    return;
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (ABL & 1) {  // lab: keep the accumulators alive without storing them

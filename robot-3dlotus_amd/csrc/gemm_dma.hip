@@ -15,6 +15,7 @@ static int dma_env(const char* name, int dflt) {
 // (both operands contiguous along their output index, column sums of A on request).  Returns LOTUS_GEMM_DMA_NA when the
 // product is outside what these kernels take (the caller then runs gemm_kernel).
 int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
+  const bool ln = p.ln_x != nullptr;  // LayerNorm backward of the product in the epilogue (layout 1, whole rows per tile)
   if constexpr (LOTUS_ACT_IS_BF16) {
     return LOTUS_GEMM_DMA_NA;  // (bf16 activation storage: gemm_kernel's bf16 paths)
   } else {
@@ -27,7 +28,7 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     if (!on || p.prec != 0 || p.tap_rows || p.b_act) return LOTUS_GEMM_DMA_NA;
     const int rows = layout == 2 ? p.K : p.M;
     if (rows < minrows) return LOTUS_GEMM_DMA_NA;
-    const bool epi = p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh;
+    const bool epi = !ln && (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh);
     if (p.accumulate && !(p.cnt && nz > 1)) return LOTUS_GEMM_DMA_NA;
     auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
     const long abytes = layout == 2 ? (long)p.K * p.lda * 4 : (long)p.M * p.lda * 4;
@@ -43,7 +44,12 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     // (23 894 rows) with <= 128 output columns — 187 blocks — lose 10-20 % to gemm_kernel's 64 x 64 tiles, the 512-wide ones win
     static int minblocks = -1;
     if (minblocks < 0) minblocks = dma_env("LOTUS_GEMM_DMA_MINBLOCKS", 400);
-    if (layout != 2 && (long)cdiv(p.M, 128) * cdiv(p.N, wide ? 128 : 64) * nz < minblocks) return LOTUS_GEMM_DMA_NA;
+    // (with the LayerNorm backward in the epilogue a whole kernel and four HBM passes go away: worth it on any grid that
+    // covers half the CUs)
+    if (layout != 2 && (long)cdiv(p.M, 128) * cdiv(p.N, wide ? 128 : 64) * nz < (ln ? 128 : minblocks)) return LOTUS_GEMM_DMA_NA;
+    if (ln && (layout != 1 || nz != 1 || (p.N != 64 && p.N != 128) || p.ldc != p.N || p.act != LOTUS_ACT_NONE || p.mulpre || p.pre ||
+               p.bias || !al16(p.ln_x) || !al16(p.ln_gamma) || (p.ln_dz && !al16(p.ln_dz)) || !p.ln_part || !p.ln_mean || !p.ln_rstd))
+      return LOTUS_GEMM_DMA_NA;
     if (layout == 2 && gemm_dma_wgrad_splits(p.K, p.M, p.N) != nz) return LOTUS_GEMM_DMA_NA;  // (split plan of another kernel)
     const bool kc_any = layout != 2;
     if (kc_any && ((p.K % bk) || (nz > 1 && (p.klen % bk)))) return LOTUS_GEMM_DMA_NA;
@@ -58,6 +64,10 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
     if (layout == 0) {
       if (wide) DMA_GO(128, 128, 16, 3, true, true, false);
       else DMA_GO(128, 64, 32, 2, true, true, false);
+    } else if (layout == 1 && ln) {
+      dim3 grid(1, cdiv(p.M, 128), 1);
+      if (wide) LOTUS_LAUNCH((gemm_dma_kernel<128, 128, 16, 3, true, false, false, 2>), grid, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_dma_kernel<128, 64, 32, 2, true, false, false, 2>), grid, block, 0, st, p);
     } else if (layout == 1) {
       if (wide) DMA_GO(128, 128, 16, 3, true, false, false);
       else DMA_GO(128, 64, 32, 2, true, false, false);
@@ -83,11 +93,11 @@ int gemm_dma_wgrad_splits(int M, int N, int K) {
   } else {
     static int on = -1, minrows = 0, target = 0;
     if (on < 0) {
-      on = dma_env("LOTUS_GEMM_DMA", 1) && dma_env("LOTUS_GEMM_DMA_WGRAD", 1);
+      on = dma_env("LOTUS_GEMM_DMA", 1);
       minrows = dma_env("LOTUS_GEMM_DMA_MINROWS", 16384);
-      target = dma_env("LOTUS_GEMM_DMA_WGRAD_BLOCKS", 256);
+      target = dma_env("LOTUS_GEMM_DMA_WGRAD_BLOCKS", 256);  // 0: weight gradients stay on gemm_kernel
     }
-    if (!on || M < minrows || (N & 3) || (K & 3)) return 0;
+    if (!on || target <= 0 || M < minrows || (N & 3) || (K & 3)) return 0;
     const long tiles = (long)cdiv(N, N > 64 ? 128 : 64) * cdiv(K, K > 64 ? 128 : 64);
     long nz = (target + tiles - 1) / tiles;
     nz = nz >= 8 ? (nz / 8) * 8 : nz;

@@ -6,7 +6,7 @@
 #include <stdlib.h>
 
 static thread_local char g_err[512] = "";
-thread_local hipEvent_t lotus_tls_stop_event = nullptr;  // see LOTUS_LAUNCH (common.h)
+__attribute__((visibility("hidden"))) __thread hipEvent_t lotus_tls_stop_event = nullptr;  // see LOTUS_LAUNCH (common.h)
 
 void lotus_set_error(const char* fmt, ...) {
   va_list ap;
@@ -17,7 +17,9 @@ void lotus_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* lotus_last_error(void) { return g_err; }
-int lotus_abi_version(void) { return 1; }
+// 2 (round 5): lotus_subm_conv / lotus_cpe_fwd / _bwd take a tap plan, lotus_adamw_step takes double betas + shadow pointers,
+// lotus_fe_neighbours needs 16-byte hash slots, the counter buffer grew by the BatchNorm counters (all round 4)
+int lotus_abi_version(void) { return 2; }
 
 // Stream link: a caller-owned ring of timing-less events used to order one stream after another without a host
 // round trip ("to" waits for everything enqueued on "from" so far, or — lotus_link_next_event — for one launch).  Re-recording a ring event later is safe:

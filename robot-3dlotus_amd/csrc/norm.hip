@@ -561,10 +561,9 @@ static int bn_grid(int M, int C) {
   const int c4 = C / 4;
   const int tpr = c4 < 256 ? c4 : 256;
   const int rslots = 256 / tpr;
-  // rows per thread (LOTUS_BN_ROWS).  Measured in the step: 16 / 4 / 2 rows -> 868 / 861 / 850 samples/s — more, smaller
-  // blocks raise the stand-alone rate of this kernel but feed more partials to the fixed-order reduction behind it
-  static int rows = 0;
-  if (!rows) { const char* e = getenv("LOTUS_BN_ROWS"); rows = e ? atoi(e) : 16; if (rows <= 0) rows = 16; }
+  // 16 rows per thread.  Measured in the step: 16 / 4 / 2 rows -> 868 / 861 / 850 samples/s — more, smaller blocks raise the
+  // stand-alone rate of this kernel but feed more partials to the fixed-order reduction behind it
+  constexpr int rows = 16;
   int g = cdiv(M, rslots * rows);
   if (g > BN_MAX_GRID) g = BN_MAX_GRID;
   if (g < 1) g = 1;
@@ -649,6 +648,22 @@ int lotus_layernorm_bwd_params(const void* workspace, int M, int C, float* dgamm
   LOTUS_LAUNCH(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream,
                      (const float*)workspace, dgamma, dbeta, grid, C, accumulate);
   LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd_params");
+  return LOTUS_OK;
+}
+
+// number of partial rows lotus_layernorm_bwd(dgamma = NULL) leaves in its workspace for (M, C)
+int lotus_layernorm_bwd_parts(int M, int C) {
+  int lpr, nv;
+  if (ln_geometry_bwd(C, &lpr, &nv)) return 0;
+  return ln_bwd_grid(M, 256 / lpr);
+}
+// lotus_layernorm_bwd_params for an explicit number of partial rows (what lotus_linear_dgrad_ln reports)
+int lotus_layernorm_bwd_params_n(const void* workspace, int nparts, int C, float* dgamma, float* dbeta, int accumulate, void* stream) {
+  LOTUS_CHECK_ARG(workspace && dgamma && dbeta && nparts >= 0 && C > 0, "lotus_layernorm_bwd_params_n: bad arguments");
+  if (nparts == 0 && accumulate) return LOTUS_OK;
+  LOTUS_LAUNCH(colpart_reduce_kernel, dim3(cdiv(2 * C, 32)), dim3(1024), 0, (hipStream_t)stream, (const float*)workspace, dgamma, dbeta,
+               nparts, C, accumulate);
+  LOTUS_LAUNCH_CHECK("lotus_layernorm_bwd_params_n");
   return LOTUS_OK;
 }
 

@@ -16,7 +16,7 @@ import torch
 from ._capi import call, query, WS
 
 # build the exact-size tables of a PREFETCHED front-end on the front-end stream (FrontEnd.finish)
-FINISH_ON_SIDE = os.environ.get("LOTUS_FE_FINISH_SIDE", "1") != "0"
+FINISH_ON_SIDE = True  # exact-size tables of a prefetched batch are built on the front-end stream (+0.6 % with fresh batches)
 
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
 

@@ -64,7 +64,7 @@ class _Timed:
 # not hand their memory to the main stream early.
 SIDE = None
 _SIDE_ON = os.environ.get("LOTUS_SIDE_STREAM", "1") != "0"
-_STEM_WGRAD_MAIN = os.environ.get("LOTUS_STEM_WGRAD_MAIN", "1") != "0"
+_STEM_WGRAD_MAIN = True  # the last weight gradient of a backward pass runs on the critical stream, idle by then (+0.45 %)
 _JOIN = "node"
 _END_CB_PENDING = False
 
@@ -181,25 +181,11 @@ def enable_side_stream(on=True):
 _IN_NODE = 0  # > 0 while a `_joined` backward is running: only then is the join guaranteed
 
 
-_NSIDE = max(1, int(os.environ.get("LOTUS_SIDE_STREAMS", "1")))
+_NSIDE = 1     # one weight-gradient stream: a second one measured 766 vs 796 samples/s (round 1), 880 vs 930 (round 4)
 _SIDES = []     # [(torch.cuda.Stream, hipStream_t)]: weight-gradient producers go round-robin over these
 _RR = 0         # next side stream
 _CUR = 0        # side stream of the _OnSide block being executed
 _LINK = 0       # lotus_streamlink handle (event ring) used for every fork / join
-
-
-def _low_priority_stream():
-    """A stream of the LOWEST priority the device offers (torch.cuda.Stream only reaches 'normal'); tuning knob
-    LOTUS_SIDE_LOWPRIO=1: the weight-gradient queue then yields dispatch slots to every other queue."""
-    import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-    if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-        return torch.cuda.Stream()
-    h = ctypes.c_void_p()
-    if hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, least.value) != 0:  # 1 = hipStreamNonBlocking
-        return torch.cuda.Stream()
-    return torch.cuda.ExternalStream(h.value)
 
 
 def _side():
@@ -207,12 +193,11 @@ def _side():
     if not _SIDE_ON or _IN_NODE == 0:
         return None
     if SIDE is None:
-        # measured: more than one side stream (766 vs 796 samples/s) and CU-masked side streams (<= 796) only add
-        # contention with the critical path; LOTUS_SIDE_STREAMS stays as a tuning knob
+        # measured and not kept: more than one side stream (766 vs 796 samples/s), CU-masked side streams (side stream on 7/8,
+        # 3/4 or 31/32 of the CUs: 923-931 / 929-932 / 875-879 against 930: reserving CUs for the critical stream buys
+        # nothing), a lowest-priority side stream (+0.1 %)
         for _ in range(_NSIDE):
-            # (measured again in round 4 with hipExtStreamCreateWithCUMask: side stream on 7/8, 3/4 or 31/32 of the CUs gives
-            # 923-931 / 929-932 / 875-879 samples/s against 930: reserving CUs for the critical stream buys nothing)
-            st = _low_priority_stream() if os.environ.get("LOTUS_SIDE_LOWPRIO", "0") == "1" else torch.cuda.Stream()
+            st = torch.cuda.Stream()
             _SIDES.append((st, st.cuda_stream))
         if not _LINK:
             _LINK = query("lotus_streamlink_create", 256)
@@ -366,6 +351,12 @@ class WeightShadows:
         self.params = [p for p in params if p.dtype == torch.float32 and p.numel() % 4 == 0]
         self.tables = None
 
+    def invalidate(self):
+        """Force the next refresh() to recast every shadow: for code that rewrites masters behind the version counter
+        (`p.data.copy_()`, `p.data = ...`, a parameter swap, another raw-pointer kernel) — ADVICE r4."""
+        for p in self.params:
+            p._lotus_b16_ver = -1
+
     def refresh(self):
         stale = False
         for p in self.params:
@@ -374,7 +365,8 @@ class WeightShadows:
                 p._lotus_b16 = torch.empty(p.shape, dtype=torch.bfloat16, device=p.device)
                 p._lotus_b16_ver = -1
                 self.tables = None
-            if p._lotus_b16_ver != p._version:
+            # a shadow is current for (version counter, storage address): `p.data = other` keeps the version but moves the storage
+            if p._lotus_b16_ver != p._version or getattr(p, "_lotus_b16_ptr", None) != p.data_ptr():
                 stale = True
         if not stale:
             return
@@ -392,6 +384,7 @@ class WeightShadows:
         call("lotus_shadow_cast", src, dst, numel, chunks, nch)
         for p in self.params:
             p._lotus_b16_ver = p._version
+            p._lotus_b16_ptr = p.data_ptr()
 
 
 def _empty_like_rows(x, cols):
@@ -756,7 +749,7 @@ def _bn_finish(x, sums, g, b, rmean, rvar, training, act, momentum, eps):
     return y, mean, invstd
 
 
-_BN_FUSED = os.environ.get("LOTUS_BN_FUSED", "1") != "0"
+_BN_FUSED = True  # one-launch BatchNorm statistics (two-level last-arrival reduction); False: the partials + reduce launches
 _BN_CNT_OFF = None
 
 
@@ -936,15 +929,11 @@ def _al4(n):
     return (n + 3) & ~3
 
 
-_SIDE_MAX_ROWS = int(os.environ.get("LOTUS_SIDE_MAX_ROWS", "0"))  # tuning: weight gradients of layers with more rows stay on
-#                                                                   the critical stream (0 = every weight gradient forks)
-
-
 def _side_ctx(dev, ws_side_bytes, reads, rows=0):
     """(side stream pointer or 0, its workspace, its counters) for a composite backward; in the deferred-join mode the
     tensors the side stream reads are announced to the allocator (as _OnSide does)."""
     global _CUR
-    if _side() is None or (_SIDE_MAX_ROWS and rows > _SIDE_MAX_ROWS):
+    if _side() is None:  # (measured and not kept: the big levels' weight gradients on the critical stream, 907 / 883 / 861 vs 930)
         return 0, None, None
     _CUR = 0
     st, ptr = _SIDES[0]

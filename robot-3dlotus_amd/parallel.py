@@ -78,15 +78,21 @@ class GradReducer:
         self._cap = int(bucket_mb * (1 << 20) / 4)
         self._layout(list(reversed(self.params)), [])
         self._handles = []
+        self.exposed_events = []
         self._avg = (self.world > 1 or self._force) and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
         self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
         self._sync = True
         self._index = {p: i for i, p in enumerate(self.params)}
         self._used = torch.zeros(len(self.params), dtype=torch.int32)  # host bitmap: parameters with a gradient this step
+        # While the arrival order is being learnt every parameter carries a hook; afterwards only the LAST-arriving parameter
+        # of each bucket does (~10 hooks instead of 421 per backward: the per-parameter hooks were most of the 5.5 % the
+        # one-rank rehearsal cost before a byte crossed a link) — _hook_last checks that the bucket is
+        # complete before it flushes, so a changed order can only delay a bucket to finish(), never drop a gradient.
+        self._hook_handles = []
         for p in self.params:
             p.grad = None
-            p.register_post_accumulate_grad_hook(self._hook)
+            self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
     def _layout(self, order, cold):
         """Contiguous buckets of >= cap elements over `order`, then one bucket with the `cold` parameters; every
@@ -140,6 +146,35 @@ class GradReducer:
             while self._next < len(self.buckets) and self._ready[self._next]:
                 self._flush(self._next)
                 self._next += 1
+
+    def _hook_last(self, p):
+        """Hook of the last-arriving parameter of a bucket (sparse mode, after the order is known)."""
+        if not self._sync:
+            return
+        b = self._slot[p]
+        if self._flushed[b]:
+            raise RuntimeError(
+                "GradReducer: a gradient arrived for a bucket that was already averaged in this step — call "
+                "reducer.zero_grad() before every optimisation step and wrap all but the last micro-batch of a "
+                "gradient-accumulation step in `with reducer.no_sync():`")
+        if any(q.grad is None for q in self._bparams[b]):
+            return  # (a parameter of the bucket has not arrived — unused this step, or a changed order: finish() flushes it)
+        self._ready[b] = True
+        while self._next < len(self.buckets) and self._ready[self._next]:
+            self._flush(self._next)
+            self._next += 1
+
+    def _sparse_hooks(self, order):
+        """Replace the per-parameter hooks by one hook per bucket, on its last parameter in arrival order."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = []
+        rank_of = {p: i for i, p in enumerate(order)}
+        for ps in self._bparams:
+            hot = [p for p in ps if p in rank_of]
+            if hot:  # (the bucket of never-seen parameters has no hook: finish() sends it)
+                last = max(hot, key=lambda q: rank_of[q])
+                self._hook_handles.append(last.register_post_accumulate_grad_hook(self._hook_last))
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -222,6 +257,8 @@ class GradReducer:
                 hot_set = set(hot)
                 self._layout(hot, [p for p in self.params if p not in hot_set])
                 self._learning = False
+                if self.sparse_hooks:
+                    self._sparse_hooks(hot)
             self._arrival, self._seen = [], set()
         self._rearm()
 
@@ -229,7 +266,8 @@ class GradReducer:
         """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser).  Afterwards
         `.grad` of every parameter is a view into the flat, rank-averaged buffer."""
         for b in range(self._next, len(self.buckets)):  # buckets some (or all) of whose parameters got no gradient
-            if not self._flushed[b] and (self.world > 1 or self._pending[b] > 0):
+            if not self._flushed[b] and (self.world > 1 or self._force or self._pending[b] > 0 or
+                                         any(p.grad is not None for p in self._bparams[b])):
                 self._flush(b)
         self._next = len(self.buckets)
         timed = self.time_exposed and self.flat.is_cuda
@@ -282,12 +320,11 @@ class GradReducer:
 
     _unused, _usage_pending = None, None
     time_exposed = False   # bench.py: record an event pair around the wait in finish()
-    exposed_events = []
+    sparse_hooks = True    # one hook per bucket once the arrival order is known (False: a hook on every parameter)
 
     def exposed_comm_ms(self):
         """Mean GPU time per step the backward stream spent waiting in finish() (time_exposed = True), then reset."""
-        ev, GradReducer.exposed_events = self.exposed_events, []
-        self.exposed_events = []
+        ev, self.exposed_events = self.exposed_events, []  # (per instance, set in __init__: two reducers never mix their events)
         if not ev:
             return None
         torch.cuda.synchronize()

@@ -65,21 +65,6 @@ def test_linear_dgrad_wgrad(M, N, K):
     assert torch.equal(dw, dw2), "wgrad must be deterministic"
 
 
-def test_linear_wgrad_streaming_kernel_opt_in():
-    """LOTUS_WGRAD_STREAM=1 (opt-in, csrc/gemm.hip wgrad_stream_kernel: operands streamed from global memory straight into
-    MFMA registers, no LDS staging): the same float64 references, odd row counts, direct / partial-slab / last-arrival
-    epilogues and the determinism check of test_linear_dgrad_wgrad.  The switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
-                        "-k", "test_linear_dgrad_wgrad"], capture_output=True, text=True, timeout=900,
-                       env=dict(os.environ, LOTUS_WGRAD_STREAM="1"), cwd=root)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
-
-
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("M,N,K", [(65536, 256, 64), (23894, 128, 512), (1000, 64, 192), (441, 3072, 768), (6077, 256, 1024)])
 def test_linear_bf16_operand_paths(prec, M, N, K):

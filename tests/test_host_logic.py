@@ -127,6 +127,8 @@ def _reducer_worker(rank, world, port, q):
     # the bucket order was re-learnt from the first backward: gradients of the LAST layer arrive first
     ok = ok and (not red._learning) and red._bparams[0][0] in set(net[3].parameters())
     ok = ok and sorted(id(p) for ps in red._bparams for p in ps) == sorted(id(p) for p in net.parameters())
+    # ... and with the order known, one hook per bucket (on its last-arriving parameter) replaces the per-parameter hooks
+    ok = ok and 1 <= len(red._hook_handles) <= len(red.buckets) < len(red.params)
     # a module with a parameter that never receives a gradient (DDP's find_unused_parameters case): the used
     # parameters are still averaged — in the learning pass (partial flush at finish()) and afterwards
     class Net2(torch.nn.Module):

@@ -1,6 +1,5 @@
 """Diagnostic: the 3^3 submanifold convolution (pair-compacted kernel) at every level of one synthetic v1 batch (16 clouds x
-4096 points), forward mode, encoder and decoder widths, fp32 / bf16 operands.   python tools/conv_bench.py
-LOTUS_CONV_DBG=1 stops the kernel after its table-building prologue (how much of a launch is not rows x weights)."""
+4096 points), forward mode, encoder and decoder widths, fp32 / bf16 operands.   python tools/conv_bench.py"""
 import os
 import sys
 

@@ -1,5 +1,5 @@
 """Diagnostic: A/B of one GEMM tuning switch over the forward / input-gradient shapes of a training step
-(tools/gemm_shapes.json), each setting in its own process.   python tools/gemm_ab.py LOTUS_GEMM_DEEP 0 1"""
+(tools/gemm_shapes.json), each setting in its own process.   python tools/gemm_ab.py LOTUS_GEMM_DMA 0 1"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
