@@ -608,11 +608,13 @@ def main():
                 sha = hashlib.sha256(open(_lc.LIB_PATH, "rb").read()).hexdigest()[:16]
                 if pmc.get("library_sha256_16") == sha:
                     k = pmc["kernels"]
-                    traffic = k["gemm_kernel"]["hbm_bytes_per_launch"]
+                    # the dense family = gemm_kernel + (round 5) gemm_dma_kernel: launch-weighted mean of their HBM bytes
+                    fams = [k[n] for n in k if n.startswith("gemm_kernel") and "TAP" not in n or n.startswith("gemm_dma_kernel")]
+                    traffic = round(sum(f["hbm_bytes_per_launch"] * f["launches_per_step"] for f in fams) / max(1e-9, sum(f["launches_per_step"] for f in fams)))
                     evidence = {"source": f"{pmc_name}, {pmc_name.replace('_pmc.json', '_sq.md')} (rocprofv3 --pmc, kernels serialised, this library build)",
                                 "attention_mfma_util": {"attn_fwd_kernel": k["attn_fwd_kernel"]["mfma_util"],
                                                         "attn_bwd_kernel": k["attn_bwd_kernel"]["mfma_util"]},
-                                "gemm_mfma_util": k["gemm_kernel"]["mfma_util"],
+                                "gemm_mfma_util": {n: k[n]["mfma_util"] for n in k if n.startswith("gemm_kernel") and "TAP" not in n or n.startswith("gemm_dma_kernel")},
                                 "neighbour_gather_GBps": {"conv_pairs_kernel (row-image fill + weights)": k["conv_pairs_kernel"]["achieved_GBps"],
                                                           "fe_neighbour_kernel (hash probe -> table)": k["fe_neighbour_kernel"]["achieved_GBps"]},
                                 "conv_pairs_fetch_bytes_per_launch": k["conv_pairs_kernel"]["fetch_bytes_per_launch"],
@@ -624,7 +626,7 @@ def main():
                 pass
             out["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                                "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
-                               "kernel": "gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
+                               "kernel": "gemm_dma_kernel + gemm_kernel (dense fp32-MFMA linear fwd/dgrad/wgrad)",
                                "launches_per_step": len(events), "ms_per_step": round(in_ms, 3),
                                "per_launch_roof": {"ms_per_step": round(roof_ms, 3), "frac": round(roof_ms / max(in_ms, 1e-9), 4),
                                                    "note": "sum over the launches of max(2MNK / 157.3 TFLOP/s, 4(MK + NK + MN) B / 6.3 TB/s) "

@@ -76,6 +76,27 @@ struct ForkAfter {
     CHECK(fa_.wait());          \
   } while (0)
 
+// The input gradient of the layer that reads a LayerNorm's output + that LayerNorm's backward (lotus_linear_dgrad_ln: ONE
+// kernel on the many-row levels with C <= 128, else the product into `dn` and lotus_layernorm_bwd); the column partials of
+// dgamma / dbeta are reduced on the weight-gradient stream when there is one.
+static int dgrad_ln(const act_t* dyl, const float* w, act_t* dn, const act_t* x, const float* mean, const float* rstd, const float* g,
+                    const act_t* add, act_t* dx, act_t* dz, float dz_p, unsigned long long dz_seed, float* dg, float* db, int M, int N,
+                    int C, int precision, void* ws, size_t ws_bytes, void* counters, float* lnp, size_t lnp_bytes,
+                    unsigned long long link, void* stream, void* side) {
+  int nparts = 0;
+  act_t* dzo = dz_p > 0.f ? dz : nullptr;
+  if (side) {
+    PRODUCE_THEN_FORK(lotus_linear_dgrad_ln(dyl, w, x, mean, rstd, g, add, dx, dn, dzo, dz_p, dz_seed, M, N, C, precision, ws, ws_bytes,
+                                            counters, lnp, lnp_bytes, &nparts, stream));
+    CHECK(lotus_layernorm_bwd_params_n(lnp, nparts, C, dg, db, 0, side));
+  } else {
+    CHECK(lotus_linear_dgrad_ln(dyl, w, x, mean, rstd, g, add, dx, dn, dzo, dz_p, dz_seed, M, N, C, precision, ws, ws_bytes, counters, lnp,
+                                lnp_bytes, &nparts, stream));
+    CHECK(lotus_layernorm_bwd_params_n(lnp, nparts, C, dg, db, 0, stream));
+  }
+  return LOTUS_OK;
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -160,17 +181,9 @@ int lotus_ffn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, const flo
   PRODUCE_THEN_FORK(lotus_linear_dgrad(dz, w2, dh, hpre, nullptr, M, C, Hd, LOTUS_ACT_GELU, drop_p, seed1, precision,
                                        big ? nullptr : ws_main, big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
   CHECK(lotus_linear_wgrad(dh, n, dw1, db1, M, Hd, C, 0, precision, wws, wws_bytes, wcnt, sw));
-  CHECK(lotus_linear_dgrad(dh, w1, dn, nullptr, nullptr, M, Hd, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  if (side) {
-    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
-                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
-    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
-    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
-  } else {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
-                              lnp, lnp_bytes, stream));
-  }
+  CHECK(dgrad_ln(dh, w1, dn, x, mean, rstd, g, dy, dx, dz_out, dz_out_p, dz_out_seed, dg, db, M, Hd, C, precision, big ? nullptr : ws_main,
+                 big ? 0 : ws_main_bytes, big ? nullptr : counters_main, lnp, lnp_bytes, link, stream, side));
+  if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
   return LOTUS_OK;
 }
 
@@ -279,15 +292,9 @@ int lotus_selfattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, cons
                                         att, datt, (long)C, lse, dqkv, 3L * C, 0, dqkv, 3L * C, C, 2 * C, 0, 0, kext, ext_pos, n_extra, extra,
                                         gq, bq, gk, bk, 0, H, d, scale, 1e-6f, attn_p, attn_seed, noshadow(precision), 0, ws_main, ws_main_bytes, stream));
   CHECK(lotus_linear_wgrad(dqkv, n, dwqkv, dbqkv, M, 3 * C, C, 0, precision, wws, wws_bytes, wcnt, sw));
-  CHECK(lotus_linear_dgrad(dqkv, wqkv, dn, nullptr, nullptr, M, 3 * C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  if (side) {
-    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
-    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
-    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
-  } else {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, nullptr, 0.f, 0, lnp, lnp_bytes, stream));
-  }
+  CHECK(dgrad_ln(dqkv, wqkv, dn, x, mean, rstd, g, dy, dx, nullptr, 0.f, 0, dg, db, M, 3 * C, C, precision, big ? nullptr : ws_main,
+                 big ? 0 : ws_main_bytes, big ? nullptr : counters_main, lnp, lnp_bytes, link, stream, side));
+  if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
   return LOTUS_OK;
 }
 
@@ -418,17 +425,9 @@ int lotus_crossattn_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, con
   if (dctx)
     CHECK(lotus_linear_dgrad(dkv_f, wkv, dctx, nullptr, nullptr, L, 2 * C, Cc, LOTUS_ACT_NONE, 0.f, 0, precision, bigL ? nullptr : ws_main,
                              bigL ? 0 : ws_main_bytes, bigL ? nullptr : counters_main, stream));
-  CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  if (side) {
-    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
-                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
-    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
-    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
-  } else {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
-                              lnp, lnp_bytes, stream));
-  }
+  CHECK(dgrad_ln(dq, wq, dn, x, mean, rstd, g, dy, dx, dz_out, dz_out_p, dz_out_seed, dg, db, M, C, C, precision, big ? nullptr : ws_main,
+                 big ? 0 : ws_main_bytes, big ? nullptr : counters_main, lnp, lnp_bytes, link, stream, side));
+  if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
   return LOTUS_OK;
 }
 
@@ -535,17 +534,9 @@ int lotus_crossattn_kv_bwd(const act_t* dy, const act_t* dz_in, const act_t* x, 
                                         1e-6f, attn_p, attn_seed, noshadow(precision), k_max, ws_main, ws_main_bytes, stream));
   if (G > 1) CHECK(lotus_sum_slabs_ld(dkv_part, dkv, L, 2 * C, dkv_ld, (long)L * 2 * C, G, stream));
   CHECK(lotus_linear_wgrad(dq, n, dwq, dbq, M, C, C, 0, precision, wws, wws_bytes, wcnt, sw));
-  CHECK(lotus_linear_dgrad(dq, wq, dn, nullptr, nullptr, M, C, C, LOTUS_ACT_NONE, 0.f, 0, precision, big ? nullptr : ws_main,
-                           big ? 0 : ws_main_bytes, big ? nullptr : counters_main, stream));
-  if (side) {
-    PRODUCE_THEN_FORK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, nullptr, nullptr, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr,
-                                          dz_out_p, dz_out_seed, lnp, lnp_bytes, stream));
-    CHECK(lotus_layernorm_bwd_params(lnp, M, C, dg, db, 0, side));
-    if (join) CHECK(lotus_streamlink_wait(link, side, stream));
-  } else {
-    CHECK(lotus_layernorm_bwd(dn, x, mean, rstd, g, dy, dx, dg, db, M, C, 0, dz_out_p > 0.f ? dz_out : nullptr, dz_out_p, dz_out_seed,
-                              lnp, lnp_bytes, stream));
-  }
+  CHECK(dgrad_ln(dq, wq, dn, x, mean, rstd, g, dy, dx, dz_out, dz_out_p, dz_out_seed, dg, db, M, C, C, precision, big ? nullptr : ws_main,
+                 big ? 0 : ws_main_bytes, big ? nullptr : counters_main, lnp, lnp_bytes, link, stream, side));
+  if (side && join) CHECK(lotus_streamlink_wait(link, side, stream));
   return LOTUS_OK;
 }
 

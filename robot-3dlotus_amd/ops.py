@@ -514,6 +514,30 @@ def ln_bwd(dy, x, mean, rstd, g, add=None, hand=None):
     return dx, dg, db
 
 
+def linear_dgrad_ln(dy, w, x, mean, rstd, g, add=None, drop=None):
+    """dx = LN'(dy w; x, mean, rstd, g) + add, dz = dx * mask(drop = (p, seed)), dgamma, dbeta: the input gradient of a linear
+    layer fused with the backward of the LayerNorm that feeds it (lotus_linear_dgrad_ln; one kernel where 128-wide tiles
+    cover whole rows of many-row levels, the two launches otherwise).  Test / diagnostic entry: the model reaches it through
+    the composite backward passes of csrc/blocks.cpp."""
+    import numpy as np
+    M, N = dy.shape
+    K = w.shape[1]
+    dx, dn = torch.empty_like(x), torch.empty_like(x)
+    dg = torch.empty(K, dtype=torch.float32, device=x.device)
+    db = torch.empty(K, dtype=torch.float32, device=x.device)
+    dz = torch.empty_like(x) if drop else None
+    dp, dseed = drop if drop else (0.0, 0)
+    nbytes = query("lotus_layernorm_bwd_workspace", M, K)
+    lws = _ws(nbytes, x.device)
+    nb = query("lotus_linear_workspace", M, N, K) if M <= 8192 else 0
+    ws = WS.get(nb, x.device, slot=5) if nb else None
+    nparts = np.zeros(1, dtype=np.int32)
+    call("lotus_linear_dgrad_ln", dy, w, x, mean, rstd, g, add, dx, dn, dz, float(dp), int(dseed), M, N, K, _pa(None), ws, nb,
+         _counters(x.device) if nb else None, lws, lws.numel(), int(nparts.ctypes.data))
+    call("lotus_layernorm_bwd_params_n", lws, int(nparts[0]), K, dg, db, 0)
+    return dx, dg, db, dz, int(nparts[0])
+
+
 def conv_weight_t(w, prec=None):
     """[cout, k,k,k, cin] -> packed MFMA weight fragments for the forward and the input-gradient convolution
     (2 * w.numel() floats; layout in csrc/conv_pairs.hip); use them with the precision they were packed for."""

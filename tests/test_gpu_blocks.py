@@ -46,8 +46,15 @@ def test_ffn_composite_is_bit_identical(M, C, join, hand):
     finally:
         ops.set_composites(True)
         ops.set_wgrad_join("node")
+    # (round 5) at >= 16 384 rows with C <= 128 the composite backward runs the LayerNorm backward as the EPILOGUE of the fc1
+    # input gradient (lotus_linear_dgrad_ln, gemm_dma_kernel EPI 2) while the per-launch reference runs the two kernels: same
+    # arithmetic in another summation order -> compared to rounding there, bit for bit everywhere else
+    fused_ln = M >= 16384 and C <= 128
     for i, (a, b) in enumerate(zip(ref, got)):
-        assert torch.equal(a, b), (i, float((a - b).abs().max()))
+        if fused_ln:
+            assert float((a - b).abs().max()) <= 3e-6 * max(1.0, float(a.abs().max())), (i, float((a - b).abs().max()))
+        else:
+            assert torch.equal(a, b), (i, float((a - b).abs().max()))
 
 
 def _levels(dup):

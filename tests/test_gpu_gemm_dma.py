@@ -85,6 +85,38 @@ def test_weight_gradient_against_float64(M, N, K):
     assert torch.equal(dw, dw3)
 
 
+@pytest.mark.parametrize("M,N,C", [(16384, 384, 128), (20011, 512, 128), (32768, 192, 64), (16500, 256, 64), (65536, 512, 128),
+                                   (4000, 384, 128), (16384, 1024, 256)])
+def test_input_gradient_with_layernorm_backward_epilogue(M, N, C):
+    """lotus_linear_dgrad_ln: dx = LN'(dy w) + add, the dropout-masked copy dz, dgamma / dbeta — against float64 autograd and
+    against the two-launch path (lotus_linear_dgrad + lotus_layernorm_bwd), which the call itself takes where the fused kernel
+    does not apply (few rows, C = 256)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + C)
+    x = torch.randn(M, C, generator=g) * 1.5 + 0.3
+    w, dy, addt = torch.randn(N, C, generator=g) / C ** 0.5, torch.randn(M, N, generator=g), torch.randn(M, C, generator=g)
+    gam, bet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xd = x.cuda()
+    _, mean, rstd = ops.ln_fwd(xd, gam.cuda(), bet.cuda())
+    dx, dg, db, dz, nparts = ops.linear_dgrad_ln(dy.cuda(), w.cuda(), xd, mean, rstd, gam.cuda(), add=addt.cuda(), drop=(0.1, 77))
+    fused = M >= 16384 and C <= 128
+    assert (nparts == (M + 127) // 128) == fused, (nparts, fused)
+    x64, g64, b64 = x.double().requires_grad_(True), gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    y = F.layer_norm(x64, (C,), g64, b64, 1e-5)
+    y.backward(dy.double() @ w.double())
+    tol = 4e-7 * N ** 0.5 + 4e-6
+    assert _err(dx, x64.grad + addt.double()) <= tol
+    assert _err(dg, g64.grad) <= 4e-7 * M ** 0.5 + 1e-5 and _err(db, b64.grad) <= 4e-7 * M ** 0.5 + 1e-5
+    mask = ops.dropout(torch.ones(M, C, device="cuda"), 0.1, 77)
+    assert torch.equal(dz, dx * mask)
+    # the two-launch path on the same inputs
+    dn = ops.linear_dgrad(dy.cuda(), w.cuda())
+    dx2, dg2, db2 = ops.ln_bwd(dn, xd, mean, rstd, gam.cuda(), add=addt.cuda())
+    assert _err(dx, dx2) <= 2e-6 and _err(dg, dg2) <= 1e-5 and _err(db, db2) <= 1e-5
+    dx3, dg3, db3, _, _ = ops.linear_dgrad_ln(dy.cuda(), w.cuda(), xd, mean, rstd, gam.cuda(), add=addt.cuda(), drop=(0.1, 77))
+    assert torch.equal(dx, dx3) and torch.equal(dg, dg3) and torch.equal(db, db3)
+
+
 def test_ragged_rows_are_deterministic():
     ops = _ops()
     g = torch.Generator().manual_seed(5)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence in ONE gpurun call: full GPU test suite (-> parity ledger), counter passes, kernel traces, bench lines; the
 # summaries are assembled on the box and copied to gpurun_out/profiles_<tag>/ (the raw traces are too large to travel back).
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 rm -f gpurun_out/parity_ledger.json
@@ -13,6 +13,20 @@ python profiles/pmc_report.py ${TAG}p gpurun_out/pmc_${TAG}p_fetch gpurun_out/pm
 python profiles/summarize.py gpurun_out/prof/${TAG}pz_results.db 30 > profiles/${TAG}p_kernels.md 2>> gpurun_out/assemble_$TAG.log
 python tools/host_floor.py > gpurun_out/host_floor_$TAG.txt 2>&1
 LOTUS_PAIR=0 python tools/host_floor.py > gpurun_out/host_floor_${TAG}_nopair.txt 2>&1
+# round 5: vector-ALU census of the step, the MFMA / VALU co-issue micro-benchmark, the kernel lab's tables, the dense family
+# shape by shape (isolated and in the step) with the LDS-DMA kernels on and off, the LayerNorm-backward epilogue A/B
+python tools/valu_census.py run > gpurun_out/census_$TAG.log 2>&1 && python tools/valu_census.py report gpurun_out/census > profiles/${TAG}_valu_census.md 2>> gpurun_out/census_$TAG.log
+rm -f gpurun_out/census/*.csv
+[ -x tools/ubench/mfma_coissue ] && tools/ubench/mfma_coissue > profiles/${TAG}_mfma_coissue.txt 2>&1
+if [ -x tools/lab/gemm_lab ]; then
+  for k in fwd dgrad wgrad; do timeout 600 tools/lab/gemm_lab tools/gemm_shapes.json $k 16000 > gpurun_out/lab_$k.txt 2>&1; done
+  cat gpurun_out/lab_fwd.txt gpurun_out/lab_dgrad.txt gpurun_out/lab_wgrad.txt | cut -c1-400 > profiles/${TAG}_gemm_lab.txt
+  timeout 300 tools/lab/gemm_lab tools/gemm_shapes.json abl | cut -c1-400 > profiles/${TAG}_gemm_lab_ablations.txt 2>&1
+fi
+python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-other-modes --no-fresh-batches --no-side-workloads --gemm-report profiles/${TAG}_gemm_report.txt > /dev/null 2>&1
+LOTUS_GEMM_DMA=0 python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-other-modes --no-fresh-batches --no-side-workloads --gemm-report profiles/${TAG}_gemm_report_dma_off.txt > /dev/null 2>&1
+python tools/dbg/dma_onoff.py > profiles/${TAG}_dma_onoff.txt 2>&1
+python tools/dbg/ln_fused_ab.py > profiles/${TAG}_ln_fused_ab.txt 2>&1
 mkdir -p gpurun_out/profiles_$TAG
 cp profiles/${TAG}* gpurun_out/profiles_$TAG/ 2>/dev/null
 cp gpurun_out/parity_ledger.json gpurun_out/profiles_$TAG/${TAG}_parity.json 2>/dev/null
