@@ -87,8 +87,9 @@ __device__ __forceinline__ void dma_epi_math4(const GemmP& p, float (&v)[4], con
 // EPI: 0 = bias / saved pre-activation / residual only (no per-element arithmetic besides the residual add), 1 = everything,
 //      2 = LayerNorm backward of the product (input gradients whose block tile covers whole rows: BN == N; GemmP::ln_*)
 // ABL (kernel lab only): 1 skips the epilogue stores, 2 the DMA (operands are whatever the LDS holds), 3 both
+// The block program: output tile (by, bx) of split bz (of nzgrid) of the product `p`.
 template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
+__device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, int bz, int nzgrid) {
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32, KS = BK / 2;
   constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;  // floats per image / stage
   constexpr int TA = A_FL / 1024, TB = B_FL / 1024, D = TA + TB;       // DMA instructions per wave and slab
@@ -100,25 +101,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, l31 = tid & 31, h = (tid >> 5) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order (as gemm_kernel): split-K launches give XCD c the splits z = c (mod 8); otherwise every XCD walks a
-  // contiguous run of the row-major tile list, so the column blocks of one row tile share an L2
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
-    const int tiles = gridDim.x * gridDim.y;
-    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const int xcd = id & 7, slot = id >> 3;
-    bz = xcd + 8 * (slot / tiles);
-    const int t = slot - (slot / tiles) * tiles;
-    by = t / (int)gridDim.x;
-    bx = t - by * (int)gridDim.x;
-  } else {
-    const int nbx = gridDim.x, total = nbx * gridDim.y;
-    const int lin = by * nbx + bx, xcd = lin & 7, slot = lin >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int t = xcd * q + min(xcd, r) + slot;
-    by = t / nbx;
-    bx = t - by * nbx;
-  }
   const int m0 = by * BM, n0 = bx * BN;
   const int kbeg = bz * p.klen, kend = min(p.K, kbeg + p.klen);
   const int nslab = (kend - kbeg + BK - 1) / BK;
@@ -192,7 +174,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
 
   // ---- accumulators, initialised with the bias of their columns: register r of tile (tm, tn) is column
   // n0 + wn WTN + tn 32 + (r & 3) + 8 (r >> 2) + 4 h of row m0 + wm WTM + tm 32 + l31
-  const bool fused = p.cnt != nullptr && gridDim.z > 1;
+  const bool fused = p.cnt != nullptr && nzgrid > 1;
   const int colb = n0 + wn * WTN + 4 * h;
   f32x16 acc[TM][TN];
   if (p.bias && !fused && bz == 0) {
@@ -499,5 +481,35 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
   }
   if (fused) splitk_fused_tail<SUM_A, BM, BN, float>(p, bx, by, m0, n0, tid);
 }
+
+template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
+  // XCD-aware tile order (as gemm_kernel): split-K launches give XCD c the splits z = c (mod 8); otherwise every XCD walks a
+  // contiguous run of the row-major tile list, so the column blocks of one row tile share an L2
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    bz = xcd + 8 * (slot / tiles);
+    const int t = slot - (slot / tiles) * tiles;
+    by = t / (int)gridDim.x;
+    bx = t - by * (int)gridDim.x;
+  } else {
+    const int nbx = gridDim.x, total = nbx * gridDim.y;
+    const int lin = by * nbx + bx, xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int t = xcd * q + min(xcd, r) + slot;
+    by = t / nbx;
+    bx = t - by * nbx;
+  }
+  gemm_dma_block<BM, BN, BK, NST, XKC, WKC, SUM_A, EPI, ABL>(p, bx, by, bz, (int)gridDim.z);
+}
+
+// (Measured and removed in round 5: a grouped launch — one block program per (problem, tile) from a device table — for the
+// DEFERRED weight gradients of the deep levels, recorded while the composite backward passes ran and flushed once per stage:
+// stand-alone 631 -> 422 us (1450 rows), 206 -> 125 us (361 rows), 645 -> 499 us (6077 rows) for the stage's 21 / 10 / 21 products,
+// -110 launches per step — and 946-949 against 943-947 samples/s in the step, inside the noise: the weight-gradient stream is not
+// what the step waits for.  DESIGN.md section 4, round 5.)
 
 }  // namespace LOTUS_NS
