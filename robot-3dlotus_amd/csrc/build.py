@@ -15,6 +15,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
 HEADERS = ["common.h", "mma.h", "gemm_common.h", "gemm_dma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# measurement builds (never the shipped library): LOTUS_BUILD_DEFINES="LOTUS_EXP_SKIP_PROBE" python build.py --force
+FLAGS += ["-D" + d for d in os.environ.get("LOTUS_BUILD_DEFINES", "").split()]
 # per-source extras: the LDS-DMA GEMM keeps its MFMA accumulators in VGPRs (its epilogue stores straight from them)
 SOURCE_FLAGS = {"gemm_dma.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 LIB = os.path.join(HERE, "liblotus_hip.so")

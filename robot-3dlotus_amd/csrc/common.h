@@ -13,8 +13,22 @@
 // (`__thread`, not `thread_local`: a C++ thread_local extern is reached through a weak init-function symbol, and a HIDDEN weak
 // undefined symbol in position-independent code resolves to the load address instead of null — the call crashes)
 extern __attribute__((visibility("hidden"))) __thread hipEvent_t lotus_tls_stop_event;  // library-internal: not an exported symbol
+#ifdef LOTUS_EXP_SKIP_PROBE  // measurement builds only (tools/dbg/skip_probe.sh): LOTUS_EXP_SKIP=substr[,substr...] drops the launches
+#include <stdlib.h>       // of the named kernels -> the step without that family = an upper bound of what speeding it up can give
+static inline int lotus_exp_skip(const char* name) {
+  const char* e = getenv("LOTUS_EXP_SKIP");
+  if (!e) return 0;
+  char buf[512]; strncpy(buf, e, 511); buf[511] = 0;
+  for (char* t = strtok(buf, ","); t; t = strtok(nullptr, ",")) if (strstr(name, t)) return 1;
+  return 0;
+}
+#define LOTUS_EXP_SKIP_CHECK(kernel) static int skip_ = -1; if (skip_ < 0) skip_ = lotus_exp_skip(#kernel); if (skip_) break;
+#else
+#define LOTUS_EXP_SKIP_CHECK(kernel)
+#endif
 #define LOTUS_LAUNCH(kernel, grid, block, lds, stream, ...)                                                              \
   do {                                                                                                                   \
+    LOTUS_EXP_SKIP_CHECK(kernel)                                                                                         \
     if (lotus_tls_stop_event)                                                                                            \
       hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, lotus_tls_stop_event, 0, __VA_ARGS__);            \
     else                                                                                                                 \
