@@ -803,6 +803,265 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(AttnP p) {
   if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
 }
 
+// ---- exact-fp32 backward, second formulation (round 5).  On gfx950 an fp32 MFMA and a vector-ALU instruction never overlap
+// on a SIMD (tools/ubench/mfma_coissue.hip), so a block's time is MFMA cycles PLUS ~5 cycles per other vector instruction;
+// attn_bwd_kernel<0> spent 11 vector instructions per MFMA and recomputed S / dP in a second orientation for dQ.  Here:
+//   * S, P and dS exist ONCE, in the orientation lane <-> key (dV, dK reduce over the queries a lane's registers run over);
+//   * dQ reduces over the keys, which sit on lanes: every wave drops its dS tile (32 keys x 32 queries) into an LDS exchange
+//     image X[key][query] (aliased onto the V image: V lives in hoisted registers by then; 16-byte chunks XOR-swizzled so that
+//     the ds_write_b128 of the producers and the ds_read_b32 of the consumers are conflict-free), and after one barrier all
+//     four waves compute one 16 x 16 quadrant each of dQn^T[d][32 queries] over ALL keys with v_mfma_f32_16x16x4_f32
+//     (same FLOP rate as the 32x32 form; no cross-wave sum, fixed order -> deterministic);
+//   * the softmax scale, log2(e) and the q_norm bias term are folded into the hoisted key fragment and into the accumulator's
+//     INITIAL value (P = exp2(acc - lse2[q]): two instructions), row / key bounds ride on +-inf instead of selects, and the
+//     dropout hash advances by compile-time constants (one multiply per element instead of two).
+// Per query tile and wave: 96 + 16 MFMA-equivalents and ~300 vector instructions (was 144 and ~750).
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int xswz(int key) { return ((key & 1) << 2) | ((key >> 1) & 3); }
+
+__global__ __launch_bounds__(256, 2) void attn_bwd2_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  AttnSmem s = carve(smem, true);
+  __shared__ float lnacc[4][32];
+  __shared__ float colred[2][8][32];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = tid & 31, hh = (tid >> 5) & 1;
+  const int h = blockIdx.y, d = p.d;
+  const int* bd = p.blocks + blockIdx.x * 6;
+  const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3];
+  const int k_start = bd[4], k_len = bd[5];
+  const int r0 = wave * 32;
+  const int ktiles = (k_len + 31) / 32;
+  float* X = s.V;  // dS exchange image [128 keys][32 queries], valid between the hoist of V and the dV staging
+
+  if (tid < AT) {
+    s.krow[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+    s.kext[tid] = (tid < k_len && p.kext) ? p.kext[k_start + tid] : -1;
+  }
+  if (tid < 4 * 32) lnacc[tid >> 5][tid & 31] = 0.f;
+  load_affine(p, s);
+  __syncthreads();
+  {
+    const RowSrc src[2] = {{s.K, p.kv, p.kv_ld, p.k_off + h * d, s.krow, k_len}, {s.V, p.kv, p.kv_ld, p.v_off + h * d, s.krow, k_len}};
+    load_rows_batch<2>(src, d);
+  }
+  __syncthreads();
+  if (tid >= AT) ln_rows<false>(s.K, s.krstd, tid - AT, k_len, d, p.eps, nullptr, nullptr);
+  __syncthreads();
+
+  const float gq_l = s.gq[l31], bq_l = s.bq[l31];
+  const float sl2 = p.scale * 1.4426950408889634f;
+  // this wave's keys: hoisted fragments (k = 2 s2 + hh).  q_norm's affine and scale * log2(e) are folded into the key
+  // fragment, (xq g + b) . kn = xq . (g kn) + b . kn; the bias term c_a starts the accumulator (-inf for absent keys)
+  const bool has_keys = r0 < k_len;
+  const int kj = r0 + l31;
+  float kb[16], vb[16], c_a = 0.f;
+  if (has_keys) {
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int k = 2 * s2 + hh;
+      const float kn = s.K[kj * ALD + k] * s.gk[k] + s.bk[k];
+      c_a += s.bq[k] * kn;
+      kb[s2] = kn * s.gq[k] * sl2;
+      vb[s2] = s.V[kj * ALD + k];
+    }
+    c_a += __shfl_xor(c_a, 32, 64);
+    c_a = kj < k_len ? c_a * sl2 : -INFINITY;
+  }
+  f32x16 acc_dv = zero16(), acc_dk = zero16();
+  // the dQ quadrant of this wave: head columns 16 dh + (lane & 15), queries 16 qh + (lane & 15) of the running query tile
+  const int dh = wave & 1, qh = wave >> 1, l15 = lane & 15, kq = lane >> 4;
+  const float gk_c = s.gk[16 * dh + l15], bk_c = s.bk[16 * dh + l15];
+  __syncthreads();  // every wave holds its V fragment: the V image may become X
+
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int tile = first_tile + ti * tile_step;
+    const int q_start = p.tiles[tile * 4 + 0], q_len = p.tiles[tile * 4 + 1];
+    if (tid < AT) {
+      s.qrow[tid] = tid < q_len ? (p.qidx ? p.qidx[q_start + tid] : q_start + tid) : -1;
+      s.qown[tid] = tid < q_len ? (p.owner ? p.owner[q_start + tid] : 1) : 0;
+      s.lse[tid] = tid < q_len ? p.lse[(long)(q_start + tid) * p.H + h] * 1.4426950408889634f : INFINITY;  // log2 units
+    }
+    __syncthreads();
+    {  // Q rows, dO rows (zero for non-owners) and D = rowsum(dO * O): twelve independent 16-byte loads per thread in flight
+      const int sub = tid & 7, rr0 = tid >> 3;
+      float4 qv[4], gv[4], ov[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rr0 + 32 * j;
+        qv[j] = gv[j] = ov[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < q_len && sub * 4 < d) {
+          qv[j] = ld4(p.q + (long)s.qrow[r] * p.q_ld + p.q_off + h * d + sub * 4);
+          if (s.qown[r]) {
+            const long o = (long)s.qrow[r] * p.out_ld + h * d + sub * 4;
+            gv[j] = ld4(p.dout + o);
+            ov[j] = ld4(p.out + o);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rr0 + 32 * j;
+        float* oq = s.Q + r * ALD + sub * 4;
+        oq[0] = qv[j].x; oq[1] = qv[j].y; oq[2] = qv[j].z; oq[3] = qv[j].w;
+        float* o = s.dO + r * ALD + sub * 4;
+        o[0] = gv[j].x; o[1] = gv[j].y; o[2] = gv[j].z; o[3] = gv[j].w;
+        float dsum = gv[j].x * ov[j].x + gv[j].y * ov[j].y + gv[j].z * ov[j].z + gv[j].w * ov[j].w;
+        dsum += __shfl_xor(dsum, 1, 64);
+        dsum += __shfl_xor(dsum, 2, 64);
+        dsum += __shfl_xor(dsum, 4, 64);
+        if (sub == 0) s.Dv[r] = dsum;
+      }
+    }
+    __syncthreads();
+    if (tid < AT) ln_rows<false>(s.Q, s.qrstd, tid, q_len, d, p.eps, nullptr, nullptr);
+    __syncthreads();
+
+    // dropout index ((tile * H + h) * 128 + q) * 128 + key: the (q, key) part only ever touches the low word (keep_lo);
+    // x0 = lo * 0x9E3779B1 + s0 advances by a compile-time constant per register
+    const unsigned long long tb = ((unsigned long long)tile * p.H + h) * AT * AT;
+    const unsigned c2 = (unsigned)(tb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+    const unsigned x_lane = ((unsigned)tb + (unsigned)kj + (unsigned)(4 * hh * AT)) * 0x9E3779B1u + (unsigned)p.drop_seed;
+    const int qtiles = (q_len + 31) / 32;
+    for (int qt = 0; qt < qtiles; ++qt) {
+      f32x16 sa, dpa;
+      if (has_keys) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = c_a; dpa[r] = 0.f; }
+        const float* qrow_p = s.Q + (qt * 32 + l31) * ALD + hh;
+        const float* dorow_p = s.dO + (qt * 32 + l31) * ALD + hh;
+#pragma unroll
+        for (int s2 = 0; s2 < 16; ++s2) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow_p[2 * s2], kb[s2], sa, 0, 0, 0);
+          dpa = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow_p[2 * s2], vb[s2], dpa, 0, 0, 0);
+        }
+        float lse4[16], d4[16];  // per-query scalars of this lane's 16 rows: four aligned runs of four queries
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const float4 a = ld4(s.lse + qt * 32 + 8 * q4 + 4 * hh);
+          const float4 b = ld4(s.Dv + qt * 32 + 8 * q4 + 4 * hh);
+          lse4[4 * q4] = a.x; lse4[4 * q4 + 1] = a.y; lse4[4 * q4 + 2] = a.z; lse4[4 * q4 + 3] = a.w;
+          d4[4 * q4] = b.x; d4[4 * q4 + 1] = b.y; d4[4 * q4 + 2] = b.z; d4[4 * q4 + 3] = b.w;
+        }
+        if (p.drop_thresh) {
+          const unsigned xq = x_lane + (unsigned)(qt * 32 * AT) * 0x9E3779B1u;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sa[r] - lse4[r]);
+            unsigned x = xq + (unsigned)(((r & 3) + 8 * (r >> 2)) * AT) * 0x9E3779B1u;
+            x ^= c2;
+            x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
+            const float t = x >= p.drop_thresh ? p.drop_inv_keep : 0.f;
+            sa[r] = e * t;                                       // dropout(P)
+            dpa[r] = (e * p.scale) * (dpa[r] * t - d4[r]);       // dS
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sa[r] - lse4[r]);
+            sa[r] = e;
+            dpa[r] = (e * p.scale) * (dpa[r] - d4[r]);
+          }
+        }
+      }
+      __syncthreads();  // (A) the dQ products of the previous query tile are done with X
+      if (has_keys) {
+        float* xr = X + kj * 32;
+        const int sw = xswz(kj);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)  // registers 4g .. 4g+3 = queries 8g + 4hh + 0..3: one 16-byte chunk
+          *reinterpret_cast<float4*>(xr + (((2 * g + hh) ^ sw) << 2)) = make_float4(dpa[4 * g], dpa[4 * g + 1], dpa[4 * g + 2], dpa[4 * g + 3]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          acc_dv = __builtin_amdgcn_mfma_f32_32x32x2f32(s.dO[qq * ALD + l31], sa[r], acc_dv, 0, 0, 0);
+          acc_dk = __builtin_amdgcn_mfma_f32_32x32x2f32(s.Q[qq * ALD + l31] * gq_l + bq_l, dpa[r], acc_dk, 0, 0, 0);
+        }
+      }
+      __syncthreads();  // (B) X holds dS of every key for this query tile; nobody reads rows qt*32.. of the dO image any more
+      {
+        // dQn^T[dcol][q] = sum_key Kn[key][dcol] dS[q][key]: A[i = dcol][k = key], B[k = key][j = q], key = 4 s + (lane >> 4)
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        const int ql = 16 * qh + l15;
+        const float* kcol = s.K + 16 * dh + l15;
+        for (int t = 0; t < ktiles; ++t) {
+#pragma unroll
+          for (int s4 = 0; s4 < 8; ++s4) {
+            const int key = 32 * t + 4 * s4 + kq;
+            const float a = kcol[key * ALD] * gk_c + bk_c;
+            const float b = X[key * 32 + ((((ql >> 2) ^ xswz(key)) << 2) | (ql & 3))];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+          }
+        }
+        float* o = s.dO + (qt * 32 + ql) * ALD + 16 * dh + 4 * kq;  // accumulator rows 4 (lane >> 4) + r, column lane & 15
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2]; o[3] = acc[3];
+      }
+    }
+    __syncthreads();
+    // rows of query tiles that were not run (q_len <= 96) still hold dO: they are beyond q_len and never read below
+    // q_norm affine gradients (column pass), then LN backward (row pass), then store
+    {  // column sums over the tile's rows with all 256 threads: 8 row slices x 32 columns, then an 8-way tree
+      const int j = tid & 31, part = tid >> 5;
+      float ag = 0.f, ab = 0.f;
+      if (j < d)
+        for (int r = part * 16; r < min(q_len, part * 16 + 16); ++r) {
+          const float g = s.dO[r * ALD + j];
+          ag += g * s.Q[r * ALD + j];
+          ab += g;
+        }
+      colred[0][part][j] = ag;
+      colred[1][part][j] = ab;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, j = tid & 31;  // 0: dgamma_q, 1: dbeta_q
+      float a = 0.f;
+      for (int k = 0; k < 8; ++k) a += colred[which][k][j];
+      lnacc[which][j] += a;
+    }
+    if (tid < AT) ln_rows_bwd(s.dO, s.Q, s.qrstd, tid, q_len, d, s.gq);
+    __syncthreads();
+    store_rows(s.dO, p.dq, p.dq_ld, p.dq_off + h * d, s.qrow, s.qown, q_len, d, 0);  // one owner per row
+    __syncthreads();
+  }
+
+  // ---- K / V gradients of this block: dV^T / dKn^T accumulators (col = key (lane), row = head column) -> V / dO images
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int dc = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    s.V[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dv[r] : 0.f;
+    s.dO[(r0 + l31) * ALD + dc] = (dc < d) ? acc_dk[r] : 0.f;
+  }
+  __syncthreads();
+  {
+    const int j = tid & 31, part = tid >> 5;
+    float ag = 0.f, ab = 0.f;
+    if (j < d)
+      for (int r = part * 16; r < min(k_len, part * 16 + 16); ++r) {
+        const float g = s.dO[r * ALD + j];
+        ag += g * s.K[r * ALD + j];
+        ab += g;
+      }
+    colred[0][part][j] = ag;
+    colred[1][part][j] = ab;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int which = tid >> 5, j = tid & 31;  // 2: dgamma_k, 3: dbeta_k
+    float a = 0.f;
+    for (int k = 0; k < 8; ++k) a += colred[which][k][j];
+    lnacc[2 + which][j] = a;
+  }
+  if (tid < AT) ln_rows_bwd(s.dO, s.K, s.krstd, tid, k_len, d, s.gk);
+  __syncthreads();
+  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+  store_rows(s.dO, dkv, p.dkv_ld, p.dk_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
+             p.dkv_extra, p.dkv_extra_ld, h * d);
+  store_rows(s.V, dkv, p.dkv_ld, p.dv_off + h * d, s.krow, nullptr, k_len, d, p.atomic_out, p.dkv_extra ? s.kext : nullptr,
+             p.dkv_extra, p.dkv_extra_ld, p.dv_off - p.dk_off + h * d);
+  if (tid < 128) p.ln_part[((long)(blockIdx.x * p.H + h) * 4 + (tid >> 5)) * 32 + (tid & 31)] = lnacc[tid >> 5][tid & 31];
+}
+
 // out[which][j] (+)= sum_b part[b][which][j]   (which: dgamma_q, dbeta_q, dgamma_k, dbeta_k)
 // one block per `which`; 32 row lanes x 32 columns, four loads in flight per lane, fixed-order tree -> deterministic
 __global__ __launch_bounds__(1024) void attn_ln_reduce_kernel(const float* __restrict__ part, float* o0, float* o1,
@@ -1400,8 +1659,8 @@ int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
     { static bool a5 = false; if (!a5) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a5 = true; } }
     LOTUS_LAUNCH(attn_bwd_kernel<1>, dim3(nblocks, H), dim3(256), sm, st, p);
   } else {
-    { static bool a6 = false; if (!a6) { (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a6 = true; } }
-    LOTUS_LAUNCH(attn_bwd_kernel<0>, dim3(nblocks, H), dim3(256), sm, st, p);
+    { static bool a6 = false; if (!a6) { (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm); a6 = true; } }
+    LOTUS_LAUNCH(attn_bwd2_kernel, dim3(nblocks, H), dim3(256), sm, st, p);
   }
   if (p.dkv_extra) {
     const int w4 = 2 * H * d / 4;

@@ -36,5 +36,13 @@ for li, L in enumerate(levels):
             row.append(f"{mode} {e0.elapsed_time(e1) * 100:7.1f} us")
         ops.set_gemm_precision("fp32")
         pairs = int((L.nbr27 >= 0).sum())
+        # fill of the 32-pair MFMA groups of the pair-compacted kernel: per (row tile of BM points in curve order, tap)
+        fills = []
+        for BM, G in ((64, 32), (128, 32), (64, 16)):
+            nb = L.nbr27 if NATURAL else L.nbr27[:, L.order[0].long()]
+            pad = (-L.n) % BM
+            act = torch.nn.functional.pad(nb >= 0, (0, pad)).reshape(27, -1, BM).sum(-1)
+            fills.append(f"BM{BM}/G{G} {float(act.sum()) / float(((act + G - 1) // G * G).sum()):.2f}")
+        row.append("group fill " + " ".join(fills))
         row.append(f"pairs/row {pairs / L.n:.1f}  useful GFLOP {2 * pairs * C * C / 1e9:.2f}")
         print("  ".join(row), flush=True)
