@@ -22,8 +22,8 @@
  *       LOTUS_GEMM_DMA_WGRAD_BLOCKS=n blocks a weight gradient is split into on those kernels (default 256; 0: not used)
  *       LOTUS_SPLITK_FUSED=0          split-K products finish in a second launch instead of the last-arriving block
  *       LOTUS_CONV_TAP=0              deep sparse-convolution levels stay on the pair-compacted kernel
- *       LOTUS_CONV_TAP_MINC=c         tap-grouped dense path from c channels (default 256)
- *       LOTUS_CONV_TAP_SLAB_MB=m      ... while its partial slab stays below m MB (default 256)
+ *       LOTUS_CONV_TAP_MINC=c         tap-grouped dense path from c channels (default 64)
+ *       LOTUS_CONV_TAP_SLAB_MB=m      ... while its partial slab stays below m MB (default 2047)
  *       LOTUS_CONV_WG_CHUNK=n         points per split of the sparse-convolution weight gradient (default 1024)
  *       LOTUS_CONV_OS=0               bf16 operand modes use the pair-compacted convolution kernel
  *       LOTUS_CONV_OS_F32=1|2|3       exact-fp32 products on the output-stationary convolution kernel (opt-in)

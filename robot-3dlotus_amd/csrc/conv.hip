@@ -22,26 +22,30 @@ int lotus_conv_pairs_try(int mode, const act_t* x, const float* w, const float* 
 size_t lotus_conv_pairs_workspace(int n, int ND);
 int lotus_conv_weight_transpose_impl(const float* w, float* wt, int cout, int T, int cin, int prec, hipStream_t st);
 int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, const int* tg_in, const int* tg_cnt, int n64,
-                        int cin, int cout, hipStream_t st);  // gemm.hip
+                        int src_rows, int cin, int cout, hipStream_t st);  // gemm.hip
 
-// ---- tap-grouped path of the deep levels (few rows, wide layers) ------------------------------------------------------
-// The pair-compacted kernel streams the weights of its taps (3 x C x 128 x 4 bytes) through every 64-row tile: at level 3
-// of the bench batch (1450 rows, C = 512) that is 23x the 28 MB weight tensor per launch, at level 4 6x 64 MB, and the
-// launch is bound by that stream (213 / 146 us for 9.5 / 4 GFLOP).  Here the convolution is 27 GATHERED dense products in
-// one launch of the dense kernel (gemm.hip: rows through the tap plan of the front-end, one weight slice per row tile) into
-// a partial slab [27 x n64][C], followed by a fixed-order gather-sum over the taps of every output row.
-// The path is taken for layers of >= 256 channels (LOTUS_CONV_TAP_MINC) whose fp32 partial slab [27 x n64][C] stays below
-// 256 MB (LOTUS_CONV_TAP_SLAB_MB; ADVICE r4: the slab, not the row count, is what the caller's workspace has to hold — the
-// earlier row cap of 32 768 allowed 0.9 GB at C = 256 and 1.8 GB at C = 512 for a measured +0.6 %).  At the bench batch
-// that is levels 2-4 (168 / 80 / 30 MB); 64-cloud batches keep level 2 (C = 256, ~24 k rows: 670 MB) on the pair kernel.
+// ---- tap-grouped path ----------------------------------------------------------------------------------------------------
+// The convolution as 27 GATHERED dense products in one launch (rows through the tap plan of the front-end, one weight slice
+// per row tile) into a partial slab [27 x n64][C], followed by a fixed-order gather-sum over the taps of every output row.
+// Round 4 introduced it for the deep levels (few rows, wide layers), where the pair-compacted kernel streams the weights of
+// its taps (3 x C x 128 x 4 bytes) through every 64-row tile: at level 3 of the bench batch (1450 rows, C = 512) 23x the
+// 28 MB weight tensor per launch.  Round 5 found the opposite end to be just as bad for the pair kernel: at 1024 points per
+// cloud a level-0 point has 2.6 active taps of 27 (level 1: 6.6), so a (64-row tile, tap) holds ~4 pairs and its 32-pair MFMA
+// groups are 22 % (46 %) full (tools/conv_bench.py) — the tap plan compacts the pairs of a tap over the WHOLE level instead,
+// the groups are full, and the cost is the partial slab's round trip through HBM (pairs x C x 4 bytes each way).  With the
+// products on the LDS-DMA tiles (gemm_dma_tap_kernel) the path is ~2x the pair kernel at every level of both bench shapes
+// (tools/dbg/tap_conv_check.py) and worth +7 % of the step; it is now taken from 64 channels up (LOTUS_CONV_TAP_MINC) for
+// every level whose slab [27 x n64][C] of fp32 stays below 2047 MB (LOTUS_CONV_TAP_SLAB_MB: the byte offsets of the DMA
+// kernel are 31-bit; only the rows of active pairs are ever touched, but the caller's workspace has to span it).  Larger
+// shapes, other widths and the bf16 operand modes stay on the pair-compacted kernel.
 static int tap_min_width() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_MINC"); v = e ? atoi(e) : 256; }
+  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_MINC"); v = e ? atoi(e) : 64; }
   return v;
 }
 static size_t tap_slab_max() {
   static long v = -1;
-  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_SLAB_MB"); v = e ? atol(e) : 256; }
+  if (v < 0) { const char* e = getenv("LOTUS_CONV_TAP_SLAB_MB"); v = e ? atol(e) : 2047; }
   return (size_t)v << 20;
 }
 static size_t tap_part_bytes(int n, int ND);
@@ -669,7 +673,7 @@ int lotus_subm_conv(int mode, const act_t* x, const float* w, const float* w_t, 
     LOTUS_CHECK_ARG((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)y) | ((uintptr_t)bias) | ((uintptr_t)add)) % 16 == 0,
                     "lotus_subm_conv: the tap-grouped path needs 16-byte aligned operands");
     const int n64 = (n + 63) / 64 * 64, ND = mode == 0 ? cout : cin;
-    const int rc = lotus_conv_tap_gemm(mode, x, w, (float*)workspace, tap_plan + 32, tap_plan, n64, cin, cout, (hipStream_t)stream);
+    const int rc = lotus_conv_tap_gemm(mode, x, w, (float*)workspace, tap_plan + 32, tap_plan, n64, n, cin, cout, (hipStream_t)stream);
     if (rc != LOTUS_OK) return rc;
     const long total4 = (long)n * ND / 4;
     const int g = (int)cdiv(total4, 256);

@@ -832,7 +832,7 @@ static int run_gemm_splitk(GemmP& p, void* workspace, size_t workspace_bytes, un
 // part[27 * n64][cout] = x[tg_in[.]] W_t^T, mode 1 part[27 * n64][cin] = dy[tg_in[.]] W_(26-t).  w is the module's weight
 // [cout][27][cin]: tap t is a [cout][cin] slice with row stride 27 * cin.  Exact fp32 products, fp32-storage build.
 int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, const int* tg_in, const int* tg_cnt, int n64,
-                        int cin, int cout, hipStream_t st) {
+                        int src_rows, int cin, int cout, hipStream_t st) {
   if constexpr (LOTUS_ACT_IS_BF16) {
     return LOTUS_E_UNSUPPORTED;
   } else {
@@ -848,6 +848,12 @@ int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, c
     p.a_vec = vec_ok(x, p.K); p.b_vec = vec_ok(w, cin) && cin % 4 == 0; p.prec = 0;
     p.drop_inv_keep = 1.f;
     p.a_rows = tg_in; p.tap_cnt = tg_cnt; p.tap_rows = n64; p.b_tap_mirror = mode == 1; p.b_tap_stride = cin;
+    p.a_src_rows = src_rows;
+    {  // the LDS-DMA tiles where they apply (gemm_dma.h, gemm_dma_tap_kernel); else the 64 x 64 kernel below
+      GemmP q = p;
+      const int rc = launch_gemm_dma_tap(q, mode, st);
+      if (rc != LOTUS_GEMM_DMA_NA) return rc;
+    }
     if (!(fast_ok<true, true>(p))) {
       lotus_set_error("lotus_subm_conv(tap-grouped): rows, weights and the partial slab must be 16-byte aligned with widths that are multiples of 4");
       return LOTUS_E_UNSUPPORTED;

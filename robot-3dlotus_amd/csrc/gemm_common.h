@@ -45,6 +45,7 @@ struct GemmP {
   const int* tap_cnt;
   int tap_rows, b_tap_mirror;
   long b_tap_stride;
+  int a_src_rows;  // rows of the gathered tensor A (bounds of the LDS-DMA descriptor; gemm_dma_tap_kernel)
   // LayerNorm backward fused into an input-gradient product whose block tile covers whole rows (gemm_dma_kernel, EPI 2): the
   // product is dy of the LayerNorm output; C receives dx = LN'(dy) (+ residual), ln_dz (optional) dx times the dropout mask of
   // drop_seed / drop_thresh, ln_part [row tiles][2][N] the column partials of dgamma / dbeta
@@ -178,5 +179,6 @@ __device__ __forceinline__ void splitk_fused_tail(const GemmP& p, int bx, int by
 #define LOTUS_GEMM_DMA_NA (-100)
 int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st);
 int gemm_dma_wgrad_splits(int M, int N, int K);
+int launch_gemm_dma_tap(GemmP& p, int layout, hipStream_t st);
 
 }  // namespace LOTUS_NS

@@ -88,8 +88,14 @@ __device__ __forceinline__ void dma_epi_math4(const GemmP& p, float (&v)[4], con
 //      2 = LayerNorm backward of the product (input gradients whose block tile covers whole rows: BN == N; GemmP::ln_*)
 // ABL (kernel lab only): 1 skips the epilogue stores, 2 the DMA (operands are whatever the LDS holds), 3 both
 // The block program: output tile (by, bx) of split bz (of nzgrid) of the product `p`.
-template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0>
-__device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, int bz, int nzgrid) {
+// TAP: a row tile of the tap-grouped sparse convolution (GemmP::a_rows ...; conv.hip): the tile starts at row `tap_m0` of the
+// partial slab, its activation rows are GATHERED through a_rows (the per-lane DMA offset is the gathered row: still loop
+// invariant), rows at and past `tap_mb` do not exist (they read as zeros and are not stored), the weight-side operand is the
+// slice of tap `tap_w`.
+template <int BM, int BN, int BK, int NST, bool XKC, bool WKC, bool SUM_A, int EPI, int ABL = 0, bool TAP = false>
+__device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, int bz, int nzgrid, int tap_m0 = 0, int tap_mb = 0,
+                                               int tap_w = 0) {
+  static_assert(!TAP || (XKC && !SUM_A && EPI == 0), "tap-grouped tiles: gathered k-contiguous rows, plain stores");
   constexpr int WTM = BM / 2, WTN = BN / 2, TM = WTM / 32, TN = WTN / 32, KS = BK / 2;
   constexpr int A_FL = BM * BK, B_FL = BN * BK, ST_FL = A_FL + B_FL;  // floats per image / stage
   constexpr int TA = A_FL / 1024, TB = B_FL / 1024, D = TA + TB;       // DMA instructions per wave and slab
@@ -101,7 +107,8 @@ __device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, i
   const int tid = threadIdx.x, lane = tid & 63, l31 = tid & 31, h = (tid >> 5) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = by * BM, n0 = bx * BN;
+  const int m0 = TAP ? tap_m0 : by * BM, n0 = bx * BN;
+  const int Mb = TAP ? tap_mb : p.M;  // row bound of this tile
   const int kbeg = bz * p.klen, kend = min(p.K, kbeg + p.klen);
   const int nslab = (kend - kbeg + BK - 1) / BK;
   const int lda = (int)p.lda, ldb = (int)p.ldb, ldc = (int)p.ldc;
@@ -118,10 +125,20 @@ __device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, i
 #pragma unroll
     for (int t = 0; t < TA; ++t) {
       const int row = (wave * TA + t) * RPI + row0;
-      voa[t] = row * (lda * 4) + ((slot ^ kc_swz<BK>(row)) << 4);
+      if (TAP) {  // gathered row (a tile row past the bound: an offset no descriptor covers -> zeros)
+        const int g = m0 + row < Mb ? p.a_rows[m0 + row] : -1;
+        voa[t] = g >= 0 ? g * (lda * 4) + ((slot ^ kc_swz<BK>(row)) << 4) : 0x7ffffff0;
+      } else {
+        voa[t] = row * (lda * 4) + ((slot ^ kc_swz<BK>(row)) << 4);
+      }
     }
-    base_a = (unsigned long long)(static_cast<const float*>(p.A) + (long)m0 * p.lda + kbeg);
-    rec_a = ((long)(min(BM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 4;
+    if (TAP) {  // the descriptor spans the whole gathered tensor
+      base_a = (unsigned long long)(static_cast<const float*>(p.A) + kbeg);
+      rec_a = ((long)(p.a_src_rows - 1) * p.lda + (kend - kbeg)) * 4;
+    } else {
+      base_a = (unsigned long long)(static_cast<const float*>(p.A) + (long)m0 * p.lda + kbeg);
+      rec_a = ((long)(min(BM, p.M - m0) - 1) * p.lda + (kend - kbeg)) * 4;
+    }
     step_a = BK * 4;
   } else {
     constexpr int C4 = BM / 4, RPI = 64 / C4;
@@ -139,14 +156,14 @@ __device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, i
       const int row = (wave * TB + t) * RPI + row0;
       vob[t] = row * (ldb * 4) + ((slot ^ kc_swz<BK>(row)) << 4);
     }
-    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)n0 * p.ldb + kbeg);
+    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)n0 * p.ldb + kbeg + (TAP ? (long)tap_w * p.b_tap_stride : 0L));
     rec_b = ((long)(min(BN, p.N - n0) - 1) * p.ldb + (kend - kbeg)) * 4;
     step_b = BK * 4;
   } else {
     constexpr int C4 = BN / 4, RPI = 64 / C4;
 #pragma unroll
     for (int t = 0; t < TB; ++t) vob[t] = (((wave * TB + t) * RPI + lane / C4) * ldb + n0 + (lane % C4) * 4) * 4;
-    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)kbeg * p.ldb);
+    base_b = (unsigned long long)(static_cast<const float*>(p.B) + (long)kbeg * p.ldb + (TAP ? (long)tap_w * p.b_tap_stride : 0L));
     rec_b = (long)(kend - kbeg) * p.ldb * 4;
     step_b = BK * (unsigned)ldb * 4;
   }
@@ -293,7 +310,7 @@ __device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, i
   // the accumulators is 7-13 % slower on the store-heavy layers: the CU's one vector-memory path then holds back the operand
   // DMAs of the other resident blocks; non-temporal stores 2-3x slower.)
   constexpr int TLD = WTN + 4, LPR = WTN / 4, RPI = 64 / LPR, NIT = 32 / RPI;
-  const unsigned cbytes = (unsigned)min((long)p.M * p.ldc * 4, 0xfffffffcL);
+  const unsigned cbytes = (unsigned)min((long)Mb * p.ldc * 4, 0xfffffffcL);
   const long zoff = (long)bz * p.part_stride;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(
       fused ? (void*)(p.part + zoff) : (void*)(static_cast<float*>(p.C) + zoff), 0, (int)cbytes, 0x00020000);
@@ -306,7 +323,7 @@ __device__ __forceinline__ void gemm_dma_block(const GemmP& p, int bx, int by, i
   float* vt = smem + wave * (32 * TLD);
   const int c4 = lane % LPR, rsub = lane / LPR;
   const int colw = n0 + wn * WTN + c4 * 4;
-  const bool full_rows = m0 + BM <= p.M;  // (block-uniform) the scalar row advance is not bounds-checked: whole tiles only
+  const bool full_rows = m0 + BM <= Mb;  // (block-uniform) the scalar row advance is not bounds-checked: whole tiles only
   const bool math = EPI == 1 && (p.act != LOTUS_ACT_NONE || p.mulpre || p.drop_thresh);
   if constexpr (EPI == 2) {
     // ---- LayerNorm backward of the product, in the row-contiguous layout (LPR lanes per row, 4 columns per lane): the two
@@ -504,6 +521,37 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(GemmP p) {
     bx = t - by * nbx;
   }
   gemm_dma_block<BM, BN, BK, NST, XKC, WKC, SUM_A, EPI, ABL>(p, bx, by, bz, (int)gridDim.z);
+}
+
+// The tap-grouped sparse convolution (conv.hip: 27 gathered products in one launch): the M axis is 27 segments of tap_rows rows,
+// segment t holds tap_cnt[t] (activation row, output row) pairs, padded with valid rows to a multiple of 64.  Block `lin` of the
+// XCD-ordered list takes the lin-th ACTIVE row tile (a scan over the 27 counters: scalar loads), so the tiles of one tap — one
+// weight slice, neighbouring gathered rows — run on one XCD; blocks past the last active tile leave at once.
+template <int BM, int BN, int BK, int NST, bool WKC>
+__global__ __launch_bounds__(256) void gemm_dma_tap_kernel(GemmP p) {
+  int nt[27], total_t = 0;  // (statically indexed, wave-uniform: scalar registers)
+#pragma unroll
+  for (int t = 0; t < 27; ++t) {
+    nt[t] = (p.tap_cnt[t] + BM - 1) / BM;
+    total_t += nt[t];
+  }
+  const int nbx = gridDim.x, total = nbx * total_t;
+  const int lin = blockIdx.y * nbx + blockIdx.x;
+  if (lin >= total) return;
+  const int xcd = lin & 7, slot = lin >> 3, q = total >> 3, r = total & 7;
+  const int tl = xcd * q + min(xcd, r) + slot;
+  int tile = tl / nbx;
+  const int bx = tl - tile * nbx;
+  int tap = 0, base = 0, c = 0;
+#pragma unroll
+  for (int t = 0; t < 26; ++t) {
+    c += nt[t];
+    if (tile >= c) { tap = t + 1; base = c; }
+  }
+  tile -= base;
+  const int cnt = p.tap_cnt[tap], seg = tap * p.tap_rows;
+  gemm_dma_block<BM, BN, BK, NST, true, WKC, false, 0, 0, true>(p, bx, 0, 0, 1, seg + tile * BM, seg + ((cnt + 63) & ~63),
+                                                                 p.b_tap_mirror ? 26 - tap : tap);
 }
 
 // (Measured and removed in round 5: a grouped launch — one block program per (problem, tile) from a device table — for the

@@ -86,6 +86,38 @@ int launch_gemm_dma(GemmP& p, int layout, int nz, hipStream_t st) {
   }
 }
 
+// The tap-grouped sparse convolution on the LDS-DMA tiles (p as lotus_conv_tap_gemm sets it up: a_rows / tap_cnt / tap_rows /
+// b_tap_*, a_src_rows; layout 0 = forward, weights k-contiguous; 1 = input gradient).  The grid covers the worst case — every
+// row of every tap active; the host does not know the pair counts — and its blocks past the last active tile leave after the
+// scan of the 27 counters.
+int launch_gemm_dma_tap(GemmP& p, int layout, hipStream_t st) {
+  if constexpr (LOTUS_ACT_IS_BF16) {
+    return LOTUS_GEMM_DMA_NA;
+  } else {
+    static int on = -1;
+    if (on < 0) on = dma_env("LOTUS_GEMM_DMA", 1);
+    auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+    const bool wide = p.N > 64;
+    const int bk = wide ? 16 : 32;
+    if (!on || p.prec != 0 || !p.a_rows || !p.tap_cnt || p.tap_rows <= 0 || (p.tap_rows & 63) || p.a_src_rows <= 0 || !al16(p.A) ||
+        !al16(p.B) || !al16(p.C) || (p.lda & 3) || (p.ldb & 3) || (p.ldc & 3) || (p.N & 3) || (p.K % bk) || (p.b_tap_stride & 3) ||
+        (long)p.a_src_rows * p.lda * 4 >= 0x7ffffff0L || (long)p.K * p.ldb * 4 >= (1L << 32) || (long)p.N * p.ldb * 4 >= (1L << 32) ||
+        (long)p.M * p.ldc * 4 >= (1L << 31) || p.bias || p.residual || p.pre || p.mulpre || p.act != LOTUS_ACT_NONE || p.drop_thresh)
+      return LOTUS_GEMM_DMA_NA;
+    p.klen = p.K;
+    const dim3 grid(cdiv(p.N, wide ? 128 : 64), 27 * cdiv(p.tap_rows, 128)), block(256);
+    if (layout == 0) {
+      if (wide) LOTUS_LAUNCH((gemm_dma_tap_kernel<128, 128, 16, 3, true>), grid, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_dma_tap_kernel<128, 64, 32, 2, true>), grid, block, 0, st, p);
+    } else {
+      if (wide) LOTUS_LAUNCH((gemm_dma_tap_kernel<128, 128, 16, 3, false>), grid, block, 0, st, p);
+      else LOTUS_LAUNCH((gemm_dma_tap_kernel<128, 64, 32, 2, false>), grid, block, 0, st, p);
+    }
+    LOTUS_LAUNCH_CHECK("lotus_subm_conv(tap-grouped, dma)");
+    return LOTUS_OK;
+  }
+}
+
 // Split count of a weight gradient dW[N, K] over M activation rows when it runs on these kernels (0: it does not).  Known from
 // the shape alone (the workspace query has no pointers): ~1 block per CU on 128 x 128 (64-wide where a side is 64) output
 // tiles, at least 256 rows per split, a multiple of 8 (one XCD / L2 per split, see the kernel's block order).

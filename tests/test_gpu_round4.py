@@ -335,9 +335,9 @@ def test_bf16_linear_big_levels_match_float64_masters_and_shadows(M, N, K, shado
 
 
 @pytest.mark.gpu
-def test_tap_grouped_convolution_of_the_deep_levels():
-    """lotus_subm_conv with a tap plan (27 gathered dense products + fixed-order tap sum; levels with few rows and wide
-    layers): the plan is a permutation-free compaction of the neighbour table, and forward / input gradient agree with the
+def test_tap_grouped_convolution_of_every_level():
+    """lotus_subm_conv with a tap plan (27 gathered dense products + fixed-order tap sum; round 4: the deep levels, round 5:
+    every level from 64 channels up, on the LDS-DMA tiles — 64-wide and 128-wide tile shapes, ragged last tiles): the plan is a permutation-free compaction of the neighbour table, and forward / input gradient agree with the
     float64 expression of spconv.SubMConv3d (model.py:615-622) and with the pair-compacted kernel."""
     import numpy as np
     from robot_3dlotus_amd import ops, synth
@@ -347,8 +347,7 @@ def test_tap_grouped_convolution_of_the_deep_levels():
     dev = torch.device("cuda", 0)
     b = synth.synth_batch(3, 4096, ragged=True, seed=5)
     levels = FrontEnd(4, conv_widths=[64, 128, 256, 512]).build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * 4)
-    assert levels[0].tap_plan is None and levels[1].tap_plan is None            # narrow layers keep the pair-compacted kernel
-    for li, C in ((2, 256), (3, 512)):
+    for li, C in ((0, 64), (1, 128), (2, 256), (3, 512)):
         L = levels[li]
         assert query("lotus_conv_tap_eligible", L.n, C, C) == 1 and L.tap_plan is not None
         n64 = (L.n + 63) // 64 * 64
