@@ -29,9 +29,9 @@ int lotus_conv_tap_gemm(int mode, const act_t* x, const float* w, float* part, c
 // per row tile) into a partial slab [27 x n64][C], followed by a fixed-order gather-sum over the taps of every output row.
 // Round 4 introduced it for the deep levels (few rows, wide layers), where the pair-compacted kernel streams the weights of
 // its taps (3 x C x 128 x 4 bytes) through every 64-row tile: at level 3 of the bench batch (1450 rows, C = 512) 23x the
-// 28 MB weight tensor per launch.  Round 5 found the opposite end to be just as bad for the pair kernel: at 1024 points per
-// cloud a level-0 point has 2.6 active taps of 27 (level 1: 6.6), so a (64-row tile, tap) holds ~4 pairs and its 32-pair MFMA
-// groups are 22 % (46 %) full (tools/conv_bench.py) — the tap plan compacts the pairs of a tap over the WHOLE level instead,
+// 28 MB weight tensor per launch.  Round 5 found the opposite end to be just as bad for the pair kernel: at 4096 points per
+// cloud a level-0 point has 7.2 active taps of 27 (level 1: 11.1; at 1024 points per cloud 2.6 / 6.6), so a (64-row tile, tap)
+// holds ~17 (~4) pairs and its 32-pair MFMA groups are 50 % / 63 % (22 % / 46 %) full (tools/conv_bench.py) — the tap plan compacts the pairs of a tap over the WHOLE level instead,
 // the groups are full, and the cost is the partial slab's round trip through HBM (pairs x C x 4 bytes each way).  With the
 // products on the LDS-DMA tiles (gemm_dma_tap_kernel) the path is ~2x the pair kernel at every level of both bench shapes
 // (tools/dbg/tap_conv_check.py) and worth +7 % of the step; it is now taken from 64 channels up (LOTUS_CONV_TAP_MINC) for

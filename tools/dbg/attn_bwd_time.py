@@ -1,4 +1,4 @@
-"""Stand-alone time of the self-attention backward per level at the headline batch (64 clouds x 1024 points), attn_drop 0.1."""
+"""Stand-alone time of the self-attention backward per level of the headline batch (CLOUDS x NPOINTS, default 16 x 4096), attn_drop 0.1."""
 import os
 import sys
 
@@ -9,11 +9,11 @@ import robot_3dlotus_amd  # noqa: E402,F401
 from robot_3dlotus_amd import ops, synth  # noqa: E402
 from robot_3dlotus_amd.frontend import FrontEnd  # noqa: E402
 
-batch = synth.synth_batch(64, 1024, seed=0)
+batch = synth.synth_batch(int(os.environ.get("CLOUDS", "16")), int(os.environ.get("NPOINTS", "4096")), seed=0)
 perms = [[0, 1, 2, 3], [1, 0, 3, 2], [2, 3, 0, 1], [3, 2, 1, 0], [0, 2, 1, 3]]
 levels = FrontEnd(5).build(batch["pc_fts"].cuda(), batch["npoints_in_batch"], batch["txt_lens"], perms)
 tot = 0.0
-for lv, C, H in ((0, 64, 2), (1, 128, 4), (2, 256, 8), (3, 512, 16), (4, 768, 32), (3, 256, 16), (2, 128, 8), (1, 64, 4), (0, 64, 4)):
+for lv, C, H in ((0, 64, 2), (1, 128, 4), (2, 256, 8), (3, 512, 16), (4, 768, 32), (3, 512, 16), (2, 256, 8), (1, 128, 4), (0, 128, 4)):
     L = levels[lv]
     d = C // H
     g = torch.Generator(device="cuda").manual_seed(lv)
