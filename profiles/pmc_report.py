@@ -23,7 +23,8 @@ import json
 import os
 import sys
 
-FAMILIES = [("gemm_dma_kernel", "gemm_dma_kernel (LDS-DMA dense kernels, levels 0-1)"), ("gemm_kernel", "gemm_kernel"), ("conv_pairs_kernel", "conv_pairs_kernel"), ("conv_os_kernel", "conv_os_kernel (bf16 modes)"),
+FAMILIES = [("gemm_dma_tap_kernel", "gemm_dma_tap_kernel (tap-grouped conv on the LDS-DMA tiles, every level)"), ("conv_tap_reduce_kernel", "conv_tap_reduce_kernel"),
+            ("attn_bwd2_kernel", "attn_bwd2_kernel"), ("gemm_dma_kernel", "gemm_dma_kernel (LDS-DMA dense kernels, levels 0-1)"), ("gemm_kernel", "gemm_kernel"), ("conv_pairs_kernel", "conv_pairs_kernel"), ("conv_os_kernel", "conv_os_kernel (bf16 modes)"),
             ("conv_wgrad_bf16_kernel", "conv_wgrad_bf16_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"),
             ("xq_fwd_kernel", "xq_fwd_kernel (cross attention)"), ("xq_bwd_kernel", "xq_bwd_kernel (cross attention)"),
             ("conv_smallcin", "conv_smallcin (stem)"), ("attn_fwd_kernel", "attn_fwd_kernel"), ("attn_bwd_kernel", "attn_bwd_kernel"),
