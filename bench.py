@@ -269,7 +269,8 @@ def main():
     reducer = None
     if world > 1 or os.environ.get("LOTUS_FORCE_REDUCER") == "1" or dist.is_initialized():  # flat-buffer bucketed RCCL all-reduce overlapped with backward + SyncBN statistics
         reducer = parallel.GradReducer(model, bucket_mb=32.0)
-        parallel.enable_sync_batchnorm()
+        if os.environ.get("LOTUS_BENCH_NO_SYNCBN") != "1":  # (diagnostic: the reducer alone; never set by the driver)
+            parallel.enable_sync_batchnorm()
     if reducer is not None:
         reducer.time_exposed = True
     host_batch = (synth.synth_batch_mp if mp else synth.synth_batch)(args.batch, args.npoints, ragged=args.ragged, seed=rank)
