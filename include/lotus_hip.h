@@ -229,6 +229,12 @@ int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_v
                                float eps, void* stream);
 int lotus_batchnorm_apply(const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, lotus_act_t* y, int M, int C, int act, void* stream);
+/* y = act(BN(x)) straight from the statistics sums (sum x, sum x^2, count; all-reduced across ranks for SyncBatchNorm): no
+ * finalisation launch between the message and the apply pass; mean / invstd are written for backward, the running
+ * averages updated (null = not tracked).  M == 0: only the statistics are finished. */
+int lotus_batchnorm_apply_sums(const lotus_act_t* x, const double* sums, const float* gamma, const float* beta, lotus_act_t* y,
+                               float* mean, float* invstd, float* running_mean, float* running_var, int M, int C, int act,
+                               float eps, float momentum, void* stream);
 int lotus_batchnorm_bwd_stats(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd,
                               const float* gamma, const float* beta, double* sums, int M, int C, int act,
                               void* workspace, size_t workspace_bytes, void* stream);

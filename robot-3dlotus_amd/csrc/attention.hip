@@ -281,67 +281,55 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnP p) {
         }
       }
   } else {
-    // (exact fp32) the query fragment carries scale * log2(e): the scores leave the MFMAs in the units of the exp2 below
-    const float sl2 = p.scale * 1.4426950408889634f;
     for (int kk = 0; kk < d; kk += 2) {
-      const float bq = s.Q[qi * ALD + kk + hh] * sl2;
+      const float bq = s.Q[qi * ALD + kk + hh];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
         if (t < ktiles) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s.K[(t * 32 + l31) * ALD + kk + hh], bq, acc[t], 0, 0, 0);
     }
   }
-  // softmax over this query's keys: registers of both lane halves.  PREC 0 works in log2 units (see above); absent keys
-  // (only the last key tile of a short patch has any) are set to -inf, exp2(-inf) = 0
-  constexpr bool L2U = PREC == 0;
+  // softmax over this query's keys: registers of both lane halves
   float m = -INFINITY;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const bool full = (t + 1) * 32 <= k_len;  // (block-uniform)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      float v = L2U ? acc[t][r] : acc[t][r] * p.scale;
-      if (!full) v = key < k_len ? v : -INFINITY;
+      const float v = key < k_len ? acc[t][r] * p.scale : -INFINITY;
       acc[t][r] = v;
       m = fmaxf(m, v);
     }
-  }
   m = fmaxf(m, __shfl_xor(m, 32, 64));
-  const float msafe = m > -INFINITY ? m : 0.f;  // (a query without keys: every term exp(-inf - 0) = 0, no NaN)
   float sum = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float e = L2U ? __builtin_amdgcn_exp2f(acc[t][r] - msafe) : __expf(acc[t][r] - msafe);
+      const float e = acc[t][r] > -INFINITY ? __expf(acc[t][r] - m) : 0.f;
       acc[t][r] = e;
       sum += e;
     }
   sum += __shfl_xor(sum, 32, 64);
   const float inv = sum > 0.f ? 1.f / sum : 0.f;
   if (p.drop_thresh) {
-    // idx = row_base + key with row_base a multiple of 128: only the low word changes with the key, the high-word / seed
-    // terms are per-lane constants and the first multiply of keep_lo advances by compile-time constants
+    // idx = row_base + key with row_base a multiple of 128: only the low word changes with the key and the
+    // high-word / seed terms are per-lane constants (keep_lo)
     const unsigned long long rb = (((unsigned long long)blockIdx.x * p.H + h) * AT + qi) * AT;
-    const unsigned c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
-    const unsigned x_lane = ((unsigned)rb + (unsigned)(4 * hh)) * 0x9E3779B1u + (unsigned)p.drop_seed;
+    const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+    const unsigned s0 = (unsigned)p.drop_seed;
     const float keep = inv * p.drop_inv_keep;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        unsigned x = x_lane + (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2)) * 0x9E3779B1u;
-        x ^= c2;
-        x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15;
-        acc[t][r] *= x >= p.drop_thresh ? keep : 0.f;
-      }
+      for (int r = 0; r < 16; ++r)
+        acc[t][r] *= keep_lo(lo0 + (unsigned)(t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh), s0, c2, p.drop_thresh) ? keep : 0.f;
   } else {
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] *= inv;
   }
-  if (hh == 0 && qi < q_len && p.lse) p.lse[(long)(q_start + qi) * p.H + h] = L2U ? (m + log2f(sum)) * 0.6931471805599453f : m + logf(sum);
+  if (hh == 0 && qi < q_len && p.lse) p.lse[(long)(q_start + qi) * p.H + h] = m + logf(sum);
   // O^T[dcol][query] = sum_key V[key][dcol] P[query][key]
   f32x16 o = zero16();
 #pragma unroll

@@ -481,6 +481,15 @@ struct BnApplyP {
   float* dbeta;
   long total4;  // M * C / 4
   int C, act, accumulate;
+  // forward from (all-reduced) statistics sums (sum x, sum x^2, count) instead of mean / invstd (lotus_batchnorm_apply_sums: the
+  // SyncBatchNorm forward without a finalisation launch): every thread derives the constants of its own column quad, the
+  // threads of the first quad row also write mean / invstd (saved for backward) and update the running averages
+  const double* fsums;
+  float* out_mean;
+  float* out_invstd;
+  float* running_mean;
+  float* running_var;
+  float eps, momentum;
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
@@ -491,11 +500,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x, step = (long)gridDim.x * 256;
   if (i0 < p.total4) {
     const int q = (int)(i0 % c4);
-    const float4 mu = ld4q(p.mean, q);
-    const float4 is = ld4q(p.invstd, q);
+    float m4[4], i4[4];
+    if (p.fsums) {  // the arithmetic of bn_finalize_kernel, per thread for its four columns
+      const double count = p.fsums[2 * p.C];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = q * 4 + e;
+        const double m = p.fsums[c] / count;
+        double var = p.fsums[p.C + c] / count - m * m;
+        if (var < 0) var = 0;
+        m4[e] = (float)m;
+        i4[e] = (float)(1.0 / sqrt(var + (double)p.eps));
+        if (i0 < c4) {
+          p.out_mean[c] = m4[e];
+          p.out_invstd[c] = i4[e];
+          if (p.running_mean) {
+            const double unbiased = count > 1 ? var * count / (count - 1) : var;
+            p.running_mean[c] = (1.f - p.momentum) * p.running_mean[c] + p.momentum * (float)m;
+            p.running_var[c] = (1.f - p.momentum) * p.running_var[c] + p.momentum * (float)unbiased;
+          }
+        }
+      }
+    } else {
+      const float4 mu = ld4q(p.mean, q);
+      const float4 is = ld4q(p.invstd, q);
+      m4[0] = mu.x; m4[1] = mu.y; m4[2] = mu.z; m4[3] = mu.w;
+      i4[0] = is.x; i4[1] = is.y; i4[2] = is.z; i4[3] = is.w;
+    }
     const float4 gm = ld4q(p.gamma, q);
     const float4 bt = ld4q(p.beta, q);
-    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
     const float g4[4] = {gm.x, gm.y, gm.z, gm.w}, b4[4] = {bt.x, bt.y, bt.z, bt.w};
     float mdz[4] = {0.f, 0.f, 0.f, 0.f}, mdx[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.dy && p.sums) {
@@ -752,6 +785,28 @@ int lotus_batchnorm_apply(const act_t* x, const float* mean, const float* invstd
   const int grid = bn_apply_grid(p.total4, C);
   LOTUS_LAUNCH(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_apply");
+  return LOTUS_OK;
+}
+
+// The same from the statistics sums = (sum x, sum x^2, count) — already all-reduced when SyncBatchNorm is on — without the
+// finalisation launch between the message and the apply pass: mean / invstd (saved for backward) and the running averages are
+// written by the apply kernel itself.  M == 0 (an empty shard): the finalisation alone.
+int lotus_batchnorm_apply_sums(const act_t* x, const double* sums, const float* gamma, const float* beta, act_t* y, float* mean,
+                               float* invstd, float* running_mean, float* running_var, int M, int C, int act, float eps,
+                               float momentum, void* stream) {
+  LOTUS_CHECK_ARG(sums && mean && invstd && C % 4 == 0 && (M == 0 || (x && y)), "lotus_batchnorm_apply_sums: bad arguments");
+  BnApplyP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.gamma = gamma; p.beta = beta; p.y = y;
+  p.total4 = (long)M * C / 4; p.C = C; p.act = act;
+  p.fsums = sums; p.out_mean = mean; p.out_invstd = invstd; p.running_mean = running_mean; p.running_var = running_var;
+  p.eps = eps; p.momentum = momentum;
+  const int grid = bn_apply_grid(p.total4, C);
+  if (M == 0 || (long)grid * 256 < C / 4)  // (fewer threads than column quads cannot happen for M >= 1; kept as a guard)
+    return lotus_batchnorm_finalize(sums, mean, invstd, running_mean, running_var, C, eps, momentum, stream) ||
+           (M ? lotus_batchnorm_apply(x, mean, invstd, gamma, beta, y, M, C, act, stream) : LOTUS_OK);
+  LOTUS_LAUNCH(bn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_apply_sums");
   return LOTUS_OK;
 }
 

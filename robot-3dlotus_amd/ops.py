@@ -764,6 +764,12 @@ def _bn_finish(x, sums, g, b, rmean, rvar, training, act, momentum, eps):
     M, C = x.shape
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if training and x.is_cuda:
+        # statistics -> (message) -> apply: the apply pass finishes mean / invstd / running averages itself (SyncBatchNorm
+        # forward: one launch less between the all-reduce and the consumer)
+        y = torch.empty_like(x)
+        call("lotus_batchnorm_apply_sums", x, sums, g, b, y, mean, invstd, rmean, rvar, M, C, act, float(eps), float(momentum))
+        return y, mean, invstd
     if training:
         call("lotus_batchnorm_finalize", sums, mean, invstd, rmean, rvar, C, float(eps), float(momentum))
     else:

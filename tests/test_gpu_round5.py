@@ -1,0 +1,39 @@
+"""Round-5 additions outside the dense kernels (tests/test_gpu_gemm_dma.py): BatchNorm apply straight from the statistics sums."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batchnorm_apply_from_sums_equals_finalize_then_apply():
+    """lotus_batchnorm_apply_sums (the SyncBatchNorm forward without the finalisation launch) against lotus_batchnorm_finalize +
+    lotus_batchnorm_apply: the same arithmetic per column -> bit-identical y, mean, invstd and running averages; widths whose
+    column period does not divide 256 threads, a single row, and an empty shard (statistics only)."""
+    from robot_3dlotus_amd import ops
+
+    dev = torch.device("cuda", 0)
+    for M, C, act in ((70001, 64, 1), (4097, 96, 0), (1, 128, 1), (333, 768, 1), (0, 64, 1)):
+        g = torch.Generator(device="cuda").manual_seed(M + C)
+        x = torch.randn(M, C, device=dev, generator=g) * 2 + 0.5
+        # statistics of a LARGER (all-rank) batch than the local rows: what the all-reduce hands back
+        xa = torch.cat([x, torch.randn(257, C, device=dev, generator=g)]).double()
+        sums = torch.cat([xa.sum(0), (xa * xa).sum(0), torch.tensor([float(xa.shape[0])], dtype=torch.float64, device=dev)])
+        gam, bet = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
+        rm0, rv0 = torch.randn(C, device=dev, generator=g), torch.rand(C, device=dev, generator=g) + 0.5
+        mean_a, inv_a, rm_a, rv_a = torch.empty(C, device=dev), torch.empty(C, device=dev), rm0.clone(), rv0.clone()
+        ops.call("lotus_batchnorm_finalize", sums, mean_a, inv_a, rm_a, rv_a, C, 1e-3, 0.01)
+        y_a = torch.empty_like(x)
+        if M:
+            ops.call("lotus_batchnorm_apply", x, mean_a, inv_a, gam, bet, y_a, M, C, act)
+        mean_b, inv_b, rm_b, rv_b = torch.empty(C, device=dev), torch.empty(C, device=dev), rm0.clone(), rv0.clone()
+        y_b = torch.empty_like(x)
+        ops.call("lotus_batchnorm_apply_sums", x, sums, gam, bet, y_b, mean_b, inv_b, rm_b, rv_b, M, C, act, 1e-3, 0.01)
+        torch.cuda.synchronize()
+        assert torch.equal(mean_a, mean_b) and torch.equal(inv_a, inv_b), (M, C)
+        assert torch.equal(rm_a, rm_b) and torch.equal(rv_a, rv_b), (M, C)
+        assert torch.equal(y_a, y_b), (M, C)
+        ref = ((x.double() - xa.mean(0)) / torch.sqrt(xa.var(0, unbiased=False) + 1e-3)) * gam.double() + bet.double()
+        if act and M:
+            ref = torch.nn.functional.gelu(ref)
+        if M:
+            assert float((y_b.double() - ref).abs().max()) < 2e-5, (M, C)
