@@ -216,8 +216,9 @@ int lotus_batchnorm_finalize(const double* sums, float* mean, float* invstd, flo
 /* One-launch statistics (round 4): the last block to arrive reduces the per-block partials in a fixed order (two levels of
  * 16) and, forward, finishes mean / invstd / running averages — lotus_batchnorm_stats + _finalize, or _bwd_stats, without
  * their second and third launch.  `counter`: 64 zeroed unsigned of the launching stream, left at zero (the tail of the
- * lotus_splitk_counters_bytes() buffer, at byte offset lotus_bn_counters_offset()).  Not for SyncBatchNorm, which needs the
- * sums between the two halves. */
+ * lotus_splitk_counters_bytes() buffer, at byte offset lotus_bn_counters_offset()).  SyncBatchNorm needs the sums between the
+ * two halves: lotus_batchnorm_stats_fused with mean == invstd == NULL leaves the sums alone (round 5), the message follows, and
+ * lotus_batchnorm_apply_sums finishes the statistics inside the apply pass. */
 size_t lotus_bn_counters_offset(void);
 int lotus_batchnorm_stats_fused(const lotus_act_t* x, double* sums, float* mean, float* invstd, float* running_mean, float* running_var,
                                 int M, int C, float eps, float momentum, void* workspace, size_t workspace_bytes, void* counter,

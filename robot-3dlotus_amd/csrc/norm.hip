@@ -725,7 +725,8 @@ int lotus_batchnorm_stats(const act_t* x, double* sums, int M, int C, void* work
 int lotus_batchnorm_stats_fused(const act_t* x, double* sums, float* mean, float* invstd, float* running_mean, float* running_var,
                                 int M, int C, float eps, float momentum, void* workspace, size_t workspace_bytes, void* counter,
                                 void* stream) {
-  LOTUS_CHECK_ARG(x && sums && mean && invstd && counter && C % 4 == 0 && M > 0, "lotus_batchnorm_stats_fused: bad arguments (C=%d)", C);
+  // (mean == invstd == null: the sums alone — the SyncBatchNorm forward, whose statistics are finished after the message)
+  LOTUS_CHECK_ARG(x && sums && (!mean == !invstd) && counter && C % 4 == 0 && M > 0, "lotus_batchnorm_stats_fused: bad arguments (C=%d)", C);
   const int grid = bn_grid_fused(M, C);
   LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)(grid + BN_COUNTERS) * 2 * C * sizeof(double), "lotus_batchnorm_stats_fused: workspace too small");
   BnStatP p;

@@ -757,6 +757,9 @@ class BnState:
 def _bn_stats(x, sums):
     M, C = x.shape
     ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
+    if _BN_FUSED and x.is_cuda and M > 0:  # one launch (last-arrival reduction), the sums alone
+        call("lotus_batchnorm_stats_fused", x, sums, None, None, None, None, M, C, 0.0, 0.0, ws, ws.numel(), _bn_counter(x.device))
+        return
     call("lotus_batchnorm_stats", x, sums, M, C, ws, ws.numel())
 
 
