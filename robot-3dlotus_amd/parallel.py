@@ -228,6 +228,8 @@ class GradReducer:
                 p.grad = v
 
     def _reduce(self, buf):
+        if _DIAG_NO_MSG:
+            return
         if self.world > 1 or self._force:
             if self._avg:
                 self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
@@ -353,6 +355,8 @@ def enable_sync_batchnorm(group=None):
     def reduce(sums):
         global BN_MESSAGES
         BN_MESSAGES += 1
+        if _DIAG_NO_MSG:  # (diagnostic, bench only: the SyncBatchNorm code path without its messages)
+            return
         if BN_TIMING is not None and sums.is_cuda:  # bench.py: event pair around every statistics message
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -365,6 +369,7 @@ def enable_sync_batchnorm(group=None):
     ops.BnState.reduce = reduce
 
 
+_DIAG_NO_MSG = os.environ.get("LOTUS_DIAG_NO_MESSAGES") == "1"  # one-rank rehearsal without the collectives: what the plumbing alone costs
 BN_MESSAGES = 0  # SyncBN all-reduces issued by this process (bench.py reports the count per step)
 BN_TIMING = None  # set to a list to collect (start, end) events of every SyncBN message (bench.py: syncbn_ms per step)
 
