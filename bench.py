@@ -613,12 +613,14 @@ def main():
                     fams = [k[n] for n in k if n.startswith("gemm_kernel") and "TAP" not in n or n.startswith("gemm_dma_kernel")]
                     traffic = round(sum(f["hbm_bytes_per_launch"] * f["launches_per_step"] for f in fams) / max(1e-9, sum(f["launches_per_step"] for f in fams)))
                     evidence = {"source": f"{pmc_name}, {pmc_name.replace('_pmc.json', '_sq.md')} (rocprofv3 --pmc, kernels serialised, this library build)",
-                                "attention_mfma_util": {"attn_fwd_kernel": k["attn_fwd_kernel"]["mfma_util"],
-                                                        "attn_bwd_kernel": k["attn_bwd_kernel"]["mfma_util"]},
+                                "attention_mfma_util": {n: k[n]["mfma_util"] for n in ("attn_fwd_kernel", "attn_bwd2_kernel", "attn_bwd_kernel") if n in k},
                                 "gemm_mfma_util": {n: k[n]["mfma_util"] for n in k if n.startswith("gemm_kernel") and "TAP" not in n or n.startswith("gemm_dma_kernel")},
-                                "neighbour_gather_GBps": {"conv_pairs_kernel (row-image fill + weights)": k["conv_pairs_kernel"]["achieved_GBps"],
-                                                          "fe_neighbour_kernel (hash probe -> table)": k["fe_neighbour_kernel"]["achieved_GBps"]},
-                                "conv_pairs_fetch_bytes_per_launch": k["conv_pairs_kernel"]["fetch_bytes_per_launch"],
+                                # the neighbour gather of the convolution: since round 5 the gathered rows of the tap-grouped products
+                                # (gemm_dma_tap_kernel) + the tap sum over the partial slab; fe_neighbour_kernel builds the tables
+                                "neighbour_gather_GBps": {n: k[n]["achieved_GBps"] for n in k
+                                                          if n.startswith(("gemm_dma_tap_kernel", "conv_tap_reduce_kernel", "conv_pairs_kernel", "fe_neighbour_kernel"))},
+                                "conv_fetch_bytes_per_launch": {n: k[n]["fetch_bytes_per_launch"] for n in k
+                                                                if n.startswith(("gemm_dma_tap_kernel", "conv_tap_reduce_kernel", "conv_pairs_kernel"))},
                                 "hbm_peak_GBps": 8000, "hbm_achievable_GBps": 6300}
                 else:
                     evidence = {"note": f"{pmc_name} was collected on library {pmc.get('library_sha256_16')}, this run loaded {sha}: "
