@@ -226,6 +226,11 @@ int lotus_batchnorm_stats_fused(const lotus_act_t* x, double* sums, float* mean,
 int lotus_batchnorm_bwd_stats_fused(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, double* sums, int M, int C, int act, void* workspace, size_t workspace_bytes,
                                     void* counter, void* stream);
+/* ... and dbeta = sum dz, dgamma = sum dz * xhat of the LOCAL rows as fp32 vectors: what a SyncBatchNorm backward keeps before its
+ * sums are all-reduced (round 5: no conversion kernels between the statistics and the message). */
+int lotus_batchnorm_bwd_stats_fused_params(const lotus_act_t* dy, const lotus_act_t* x, const float* mean, const float* invstd,
+                                           const float* gamma, const float* beta, double* sums, float* dgamma, float* dbeta, int M,
+                                           int C, int act, void* workspace, size_t workspace_bytes, void* counter, void* stream);
 int lotus_batchnorm_eval_stats(const float* running_mean, const float* running_var, float* mean, float* invstd, int C,
                                float eps, void* stream);
 int lotus_batchnorm_apply(const lotus_act_t* x, const float* mean, const float* invstd, const float* gamma,

@@ -401,12 +401,14 @@ __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
     }
     for (; g0 < ngroups; ++g0) acc += __hip_atomic_load(gpart + (long)g0 * ncol + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     p.sums[c] = acc;
+    // backward with parameter-gradient outputs (lotus_batchnorm_bwd_stats_fused_params): the LOCAL sums are dbeta | dgamma
+    if (p.dy && p.out_mean) (c < p.C ? p.out_mean : p.out_invstd)[c < p.C ? c : c - p.C] = (float)acc;
   }
   if (threadIdx.x == 0) {
     p.sums[ncol] = (double)p.M;
     *p.cnt = 0;
   }
-  if (p.out_mean) {  // forward: finish the statistics here (what bn_finalize_kernel does)
+  if (p.out_mean && !p.dy) {  // forward: finish the statistics here (what bn_finalize_kernel does)
     __syncthreads();  // sums[] written by this block's threads above
     const double count = (double)p.M;
     for (int c = threadIdx.x; c < p.C; c += 256) {
@@ -739,6 +741,11 @@ int lotus_batchnorm_stats_fused(const act_t* x, double* sums, float* mean, float
   return LOTUS_OK;
 }
 
+// The same, and dbeta = sum dz, dgamma = sum dz * xhat of the LOCAL rows as fp32 vectors (what a SyncBatchNorm backward keeps
+// before its sums are all-reduced: no conversion kernels between the statistics and the message).
+int lotus_batchnorm_bwd_stats_fused_params(const act_t* dy, const act_t* x, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, double* sums, float* dgamma, float* dbeta, int M, int C, int act,
+                                           void* workspace, size_t workspace_bytes, void* counter, void* stream);
 // One-launch backward statistics: sums = (sum dz, sum dz * xhat, M) — lotus_batchnorm_bwd_stats without the second launch.
 int lotus_batchnorm_bwd_stats_fused(const act_t* dy, const act_t* x, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, double* sums, int M, int C, int act, void* workspace, size_t workspace_bytes,
@@ -753,6 +760,22 @@ int lotus_batchnorm_bwd_stats_fused(const act_t* dy, const act_t* x, const float
   p.cnt = (unsigned*)counter; p.sums = sums;
   LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), (hipStream_t)stream, p);
   LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats_fused");
+  return LOTUS_OK;
+}
+
+int lotus_batchnorm_bwd_stats_fused_params(const act_t* dy, const act_t* x, const float* mean, const float* invstd, const float* gamma,
+                                           const float* beta, double* sums, float* dgamma, float* dbeta, int M, int C, int act,
+                                           void* workspace, size_t workspace_bytes, void* counter, void* stream) {
+  LOTUS_CHECK_ARG(dy && x && sums && dgamma && dbeta && counter && C % 4 == 0 && M > 0, "lotus_batchnorm_bwd_stats_fused_params: bad arguments");
+  const int grid = bn_grid_fused(M, C);
+  LOTUS_CHECK_ARG(workspace && workspace_bytes >= (size_t)(grid + BN_COUNTERS) * 2 * C * sizeof(double), "lotus_batchnorm_bwd_stats_fused_params: workspace too small");
+  BnStatP p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.dy = dy; p.mean = mean; p.invstd = invstd; p.gamma = gamma; p.beta = beta;
+  p.part = (double*)workspace; p.M = M; p.C = C; p.act = act;
+  p.cnt = (unsigned*)counter; p.sums = sums; p.out_mean = dbeta; p.out_invstd = dgamma;
+  LOTUS_LAUNCH(bn_stat_kernel, dim3(grid), dim3(256), bn_dyn_lds(C), (hipStream_t)stream, p);
+  LOTUS_LAUNCH_CHECK("lotus_batchnorm_bwd_stats_fused_params");
   return LOTUS_OK;
 }
 

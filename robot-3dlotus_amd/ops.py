@@ -830,9 +830,19 @@ def bn_fwd_pair(xa, pa, xb, pb, training, act, momentum=BN_MOMENTUM, eps=BN_EPS)
             _bn_finish(xb, sums[na:], *pb, training, act, momentum, eps))
 
 
-def _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums):
+def _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums, want_params=False):
+    """sums = (sum dz, sum dz * xhat, M) of the local rows; want_params: also (dgamma, dbeta) as fp32 vectors taken from those
+    LOCAL sums (SyncBatchNorm: before the all-reduce overwrites them) — written by the statistics kernel itself on the GPU."""
     M, C = x.shape
     ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
+    if want_params and _BN_FUSED and M > 0 and x.is_cuda:
+        dg = torch.empty(C, dtype=torch.float32, device=x.device)
+        db = torch.empty(C, dtype=torch.float32, device=x.device)
+        call("lotus_batchnorm_bwd_stats_fused_params", dy, x, mean, invstd, g, b, sums, dg, db, M, C, act, ws, ws.numel(), _bn_counter(x.device))
+        return dg, db
+    if want_params:
+        _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums)
+        return sums[C:2 * C].float(), sums[:C].float()
     if _BN_FUSED and M > 0:
         call("lotus_batchnorm_bwd_stats_fused", dy, x, mean, invstd, g, b, sums, M, C, act, ws, ws.numel(), _bn_counter(x.device))
     else:
@@ -858,11 +868,12 @@ def _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced):
 def bn_bwd(dy, x, mean, invstd, g, b, training, act):
     C = x.shape[1]
     sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
-    _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums)
     reduced = None
     if training and BnState.reduce is not None:
-        reduced = (sums[C:2 * C].float(), sums[:C].float())
+        reduced = _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums, want_params=True)
         BnState.reduce(sums)
+    else:
+        _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums)
     return _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced)
 
 
@@ -874,10 +885,8 @@ def bn_bwd_pair(a, bb, training, act):
     na = 2 * Ca + 1
     sums = torch.empty(na + 2 * Cb + 1, dtype=torch.float64, device=a[1].device)
     sa, sb = sums[:na], sums[na:]
-    _bn_bwd_stats(*a, act, sa)
-    _bn_bwd_stats(*bb, act, sb)
-    ra = (sa[Ca:2 * Ca].float(), sa[:Ca].float())
-    rb = (sb[Cb:2 * Cb].float(), sb[:Cb].float())
+    ra = _bn_bwd_stats(*a, act, sa, want_params=True)
+    rb = _bn_bwd_stats(*bb, act, sb, want_params=True)
     BnState.reduce(sums)
     return _bn_bwd_apply(*a, training, act, sa, ra), _bn_bwd_apply(*bb, training, act, sb, rb)
 

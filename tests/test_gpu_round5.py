@@ -37,3 +37,23 @@ def test_batchnorm_apply_from_sums_equals_finalize_then_apply():
             ref = torch.nn.functional.gelu(ref)
         if M:
             assert float((y_b.double() - ref).abs().max()) < 2e-5, (M, C)
+
+
+def test_batchnorm_backward_statistics_with_parameter_gradients():
+    """lotus_batchnorm_bwd_stats_fused_params: the sums of lotus_batchnorm_bwd_stats_fused bit for bit, and dbeta / dgamma = their
+    fp32 conversions (what the SyncBatchNorm backward took from the sums with two conversion kernels before)."""
+    from robot_3dlotus_amd import ops
+
+    dev = torch.device("cuda", 0)
+    for M, C, act in ((50001, 64, 1), (777, 256, 0), (3, 768, 1)):
+        g = torch.Generator(device="cuda").manual_seed(M)
+        x, dy = torch.randn(M, C, device=dev, generator=g), torch.randn(M, C, device=dev, generator=g)
+        mean, invstd = x.mean(0), 1.0 / torch.sqrt(x.var(0, unbiased=False) + 1e-3)
+        gam, bet = torch.rand(C, device=dev, generator=g) + 0.5, torch.randn(C, device=dev, generator=g)
+        s0 = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        s1 = torch.empty_like(s0)
+        ops._bn_bwd_stats(dy, x, mean, invstd, gam, bet, act, s0)
+        dg, db = ops._bn_bwd_stats(dy, x, mean, invstd, gam, bet, act, s1, want_params=True)
+        torch.cuda.synchronize()
+        assert torch.equal(s0, s1), (M, C)
+        assert torch.equal(db, s0[:C].float()) and torch.equal(dg, s0[C:2 * C].float()), (M, C)
