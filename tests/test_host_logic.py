@@ -371,3 +371,24 @@ def test_unequal_shards_world4_gloo_match_the_single_process_gradient():
     assert res is not None, "gloo workers did not finish"
     assert all(r[1] for r in res), res
     assert res[0][2]["imbalance"] < 1.25, res[0][2]   # snake assignment keeps the point counts within 25 % of the mean
+
+
+def test_grad_reducer_tapers_the_tail_of_the_arrival_order():
+    """The last buckets of the arrival order are small (cap/32, cap/8, cap/2 from the end): the final all-reduce of a step is the
+    one nothing overlaps.  The buckets still tile the flat buffer in order and every parameter owns one view."""
+    import torch
+    from robot_3dlotus_amd import parallel
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(*[torch.nn.Linear(64, 64, bias=(i % 3 == 0)) for i in range(40)])
+    cap_mb = 64 * 64 * 4 * 8 / (1 << 20)  # eight weight matrices per full bucket
+    red = parallel.GradReducer(net, bucket_mb=cap_mb)
+    cap = red._cap
+    sizes = [hi - lo for lo, hi in red.buckets]
+    assert sum(sizes) == red.flat.numel() and all(b[0] == a[1] for a, b in zip(red.buckets, red.buckets[1:]))
+    assert sizes[-1] <= max(cap // 32, 64 * 64) and sizes[-2] <= max(cap // 8, 64 * 64) and sizes[-3] <= cap // 2
+    assert all(n >= cap for n in sizes[:-4])          # the head follows the >= cap rule (the bucket in front of the tail may be short)
+    flat_order = [p for ps in red._bparams for p in ps]
+    assert flat_order == list(reversed(red.params))   # registration order reversed until the arrival order is learnt
+    for p, v in zip(flat_order, [v for vs in red._bviews for v in vs]):
+        assert v.shape == p.shape and v.data_ptr() >= red.flat.data_ptr()
