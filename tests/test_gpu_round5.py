@@ -57,3 +57,23 @@ def test_batchnorm_backward_statistics_with_parameter_gradients():
         torch.cuda.synchronize()
         assert torch.equal(s0, s1), (M, C)
         assert torch.equal(db, s0[:C].float()) and torch.equal(dg, s0[C:2 * C].float()), (M, C)
+
+
+def test_every_level_of_the_v1_hierarchy_takes_the_tap_grouped_convolution():
+    """Routing guard (round 5): with the model's own front-end settings every level of a v1 batch carries a tap plan and both
+    convolution widths of the level are eligible — a silent fall-back to the pair-compacted kernel would cost 7 % of the step
+    without failing any numerical test."""
+    from robot_3dlotus_amd import ops, synth
+    from robot_3dlotus_amd import config as lcfg
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from robot_3dlotus_amd._capi import query
+
+    dev = torch.device("cuda", 0)
+    model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
+    pt = model.ptv3_model
+    b = synth.synth_batch(4, 4096, seed=3)
+    levels = pt.frontend.build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * pt.num_stages)
+    for li, L in enumerate(levels):
+        assert L.tap_plan is not None, li
+        for C in {pt.enc_channels[li], pt.dec_channels[li]}:
+            assert query("lotus_conv_tap_eligible", L.n, C, C) == 1 and ops.conv_tap_active(L, C), (li, C)
