@@ -21,6 +21,26 @@ FINISH_ON_SIDE = True  # exact-size tables of a prefetched batch are built on th
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
 
 
+class _Arena:
+    """Bump allocator over ONE device block.  The front-end's tables are allocated under the front-end stream and consumed on
+    the training stream, so each of them needs `record_stream` — and the caching allocator answers every such tensor, when it is
+    freed at the end of the step, with an event record on the consuming stream: ~85 marker packets of ~4.7 us each between the
+    last kernel of a step and the first of the next (0.4 ms of an idle GPU per step, measured with tools/tail_probe.py).  Carved
+    out of one block per half of the front-end that is two events."""
+
+    def __init__(self, nbytes, dev):
+        self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        self.off = 0
+
+    def empty(self, shape, dtype):
+        n = int(np.prod(shape, dtype=np.int64)) * torch.empty(0, dtype=dtype).element_size()
+        off = (self.off + 255) & ~255
+        if off + n > self.buf.numel():
+            return None
+        self.off = off + n
+        return self.buf[off:off + n].view(dtype).view(*shape)
+
+
 class Level:
     """Index tables of one resolution level (device tensors unless noted)."""
     __slots__ = ("n", "counts", "off", "off_host", "grid", "batch", "code", "order", "inverse", "depth", "nbr27",
@@ -122,33 +142,42 @@ class FrontEnd:
         scratch = torch.empty(8, **i32)
         gmax = scratch[4:5]
         raw = []
-        keep = [meta, batch0, scratch]
-        grid = torch.empty(N, 3, **i32)
+        # every table of the sync-free half out of one block (see _Arena): per level 4 N codes + 4 N sort keys (int64), order,
+        # inverse, grid, batch, cluster, seg (int32)
+        arena = _Arena((Lv + 1) * (N + 64) * (2 * 32 + 16 + 16 + 12 + 4 + 4 + 4) + 4096, dev)
+        keep = [meta, batch0, scratch, arena.buf]
+
+        def empty(*shape, dtype=torch.int32):
+            t = arena.empty(shape, dtype)
+            if t is None:  # (cannot happen with the bound above; a plain tensor is still correct)
+                t = torch.empty(*shape, dtype=dtype, device=dev)
+                keep.append(t)
+            return t
+
+        grid = empty(N, 3)
         call("lotus_fe_grid", pc_fts, ld, N, self.grid_size, grid, gmax, scratch)
-        code = torch.empty(4, N, dtype=torch.int64, device=dev)
+        code = empty(4, N, dtype=torch.int64)
         perm0 = (np.asarray(self.order_ids, dtype=np.int32)[np.asarray(perms[0])]).astype(np.int32)
         call("lotus_fe_encode", grid, batch0, N, gmax, perm0.ctypes.data, self.depth_bound, state, code, N)
         batch = batch0
         for s in range(Lv):
-            skeys = torch.empty(4, N, dtype=torch.int64, device=dev)
-            order = torch.empty(4, N, **i32)
-            inverse = torch.empty(4, N, **i32)
+            skeys = empty(4, N, dtype=torch.int64)
+            order = empty(4, N)
+            inverse = empty(4, N)
             key_bits = max(1, 3 * max(self.depth_bound - s, 0) + bbits)
             call("lotus_fe_sort", code, N, n_dev[s:s + 1], N, key_bits, skeys, order, inverse, ws_sort, ws_sort.numel())
             raw.append(dict(grid=grid, batch=batch, code=code, order=order, inverse=inverse, skeys=skeys))
             if s + 1 < Lv:
-                cluster = torch.empty(N, **i32)
-                seg = torch.empty(N + 1, **i32)
-                ccode = torch.empty(4, N, dtype=torch.int64, device=dev)
-                cgrid = torch.empty(N, 3, **i32)
-                cbatch = torch.empty(N, **i32)
+                cluster = empty(N)
+                seg = empty(N + 1)
+                ccode = empty(4, N, dtype=torch.int64)
+                cgrid = empty(N, 3)
+                cbatch = empty(N)
                 perm = np.asarray(perms[s + 1], dtype=np.int32)
                 call("lotus_fe_pool", code, skeys, order, grid, batch, n_dev[s:s + 1], N, perm.ctypes.data, B, cluster,
                      seg, n_dev[s + 1:s + 2], ccode, cgrid, cbatch, cnts[s + 1], state[2:3] if s == 0 else None)
                 raw[-1].update(cluster=cluster, seg=seg)
                 grid, batch, code = cgrid, cbatch, ccode
-        for r in raw:
-            keep.extend(v for v in r.values() if isinstance(v, torch.Tensor))
         meta_h = torch.empty(meta.shape, dtype=torch.int32, pin_memory=True)
         meta_h.copy_(meta, non_blocking=True)
         ev = torch.cuda.Event()
@@ -259,9 +288,21 @@ class FrontEnd:
         i32 = dict(dtype=torch.int32, device=dev)
         levels = []
 
+        # the exactly sized tables out of one block (see _Arena): 27 n neighbours, the tap plan, 3 npad + n_extra patch tables
+        # and 3 n pooled coordinates per level, 125 n stem neighbours at level 0
+        need = 125 * ns[0] * 4 + 4096
+        for s_ in range(Lv):
+            n_ = ns[s_]
+            plan_ints = query("lotus_fe_tap_plan_ints", n_) if (self.conv_widths is not None and n_ > 0) else 0
+            need += 4 * (27 * n_ + plan_ints + 3 * plans[s_]["npad"] + max(plans[s_]["npad"] - n_, 1) + 3 * n_) + 8 * 256
+        arena = _Arena(need, dev)
+        made.append(arena.buf)
+
         def empty(*shape, **kw):
-            t = torch.empty(*shape, **(kw or i32))
-            made.append(t)
+            t = arena.empty(shape, kw.get("dtype", torch.int32))
+            if t is None:
+                t = torch.empty(*shape, **(kw or i32))
+                made.append(t)
             return t
 
         tabs = tabs_h.to(dev, non_blocking=True)
