@@ -174,7 +174,7 @@ class SimplePolicyPTV3CA(BaseModel):
         self.ptv3_model.prefetch({"coord": batch["pc_fts"][:, :3], "grid_size": self.config.action_config.voxel_size,
                                   "offset": batch["offset"], "feat": batch["pc_fts"], "coord_src": batch["pc_fts"],
                                   "counts": list(batch["npoints_in_batch"]), "context_counts": list(batch["txt_lens"])},
-                                 wait_current=not on_host and os.environ.get("LOTUS_TMP_NOWAIT") != "1")
+                                 wait_current=not on_host)
 
     gemm_precision = None  # 'fp32' | 'bf16x3' | 'bf16': operand precision of THIS model's products (None = ops default)
     # None / 'fp32': activations are stored in fp32 (the parity path).  'bf16': every activation tensor in HBM is bf16,
