@@ -60,7 +60,7 @@ class _Timed:
 # several nodes further down the dgrad chain.  Valid when nothing reads a parameter gradient during
 # backward — i.e. `.grad is None` on entry (zero_grad(set_to_none=True): autograd adopts the tensor without
 # touching it) and no per-parameter hooks; the GradReducer (hooks) and gradient accumulation need the
-# default "node".  Tensors the side stream reads are marked with record_stream so the caching allocator does
+# default "node".  Tensors the side stream reads are held until that join (_hold_for_side) so the caching allocator does
 # not hand their memory to the main stream early.
 SIDE = None
 _SIDE_ON = os.environ.get("LOTUS_SIDE_STREAM", "1") != "0"
@@ -246,9 +246,8 @@ class _OnSide:
         _RR = (_RR + 1) % _NSIDE
         side, ptr = _SIDES[_CUR]
         _capi.call_raw("lotus_streamlink_wait", _LINK, _capi.stream_ptr(), ptr)
-        if _JOIN == "end":  # no join at the end of the node: the allocator must know about the second reader
-            for t in self.reads:
-                t.record_stream(side)
+        if _JOIN == "end":  # no join at the end of the node: the memory must not go back to the main stream early
+            _hold_for_side(self.reads, side)
         _capi.STREAM_OVERRIDE = ptr
         return self
 
@@ -257,10 +256,28 @@ class _OnSide:
             _capi.STREAM_OVERRIDE = 0
 
 
+_HELD = []  # tensors the weight-gradient stream reads, kept alive until the end-of-backward join (deferred-join mode)
+
+
+def _hold_for_side(reads, side):
+    """Deferred-join mode: what the side stream reads must not be recycled by the main stream before the join.  Inside a
+    backward pass (the end-of-backward callback is queued) the tensors are simply HELD until that join — `record_stream` would
+    make the caching allocator answer every one of them with an event record on the side stream the moment autograd releases
+    it: ~300 marker packets of ~5 us per step in between the weight-gradient kernels.  Outside a backward pass (weight packing in
+    forward) there is no join to wait for: record_stream."""
+    if _END_CB_PENDING:
+        _HELD.extend(t for t in reads if t is not None)
+    else:
+        for t in reads:
+            if t is not None:
+                t.record_stream(side)
+
+
 def _end_of_backward():
     global _END_CB_PENDING
     _END_CB_PENDING = False
     sync_side_stream()
+    _HELD.clear()  # (freed behind the join: whatever re-uses the memory is enqueued after it)
 
 
 def _fwd(fn):
@@ -980,9 +997,7 @@ def _side_ctx(dev, ws_side_bytes, reads, rows=0):
     _CUR = 0
     st, ptr = _SIDES[0]
     if _JOIN == "end":
-        for t in reads:
-            if t is not None:
-                t.record_stream(st)
+        _hold_for_side(reads, st)
     ws = _side_ws(ws_side_bytes, dev)
     return ptr, ws, _counters_for(dev, ptr)
 
