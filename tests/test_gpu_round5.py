@@ -77,3 +77,41 @@ def test_every_level_of_the_v1_hierarchy_takes_the_tap_grouped_convolution():
         assert L.tap_plan is not None, li
         for C in {pt.enc_channels[li], pt.dec_channels[li]}:
             assert query("lotus_conv_tap_eligible", L.n, C, C) == 1 and ops.conv_tap_active(L, C), (li, C)
+
+
+def test_no_per_tensor_allocator_events_between_streams():
+    """Round 5, third session: (i) the front-end's tables of one build share ONE device block per half (one record_stream / one
+    allocator event instead of ~85 marker packets on the training stream when a step's tables are freed); (ii) in the deferred-join
+    mode the tensors the weight-gradient stream reads are held until the end-of-backward join and released there."""
+    from robot_3dlotus_amd import ops, synth
+    from robot_3dlotus_amd import config as lcfg
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+
+    dev = torch.device("cuda", 0)
+    model = SimplePolicyPTV3CA(lcfg.preset("v1")).to(dev).train()
+    pt = model.ptv3_model
+    b = synth.synth_batch(2, 2048, seed=1)
+    levels = pt.frontend.build(b["pc_fts"].to(dev), b["npoints_in_batch"], b["txt_lens"], [[0, 1, 2, 3]] * pt.num_stages)
+    finish_blocks = {t.untyped_storage().data_ptr() for L in levels for t in (L.nbr27, L.tap_plan, L.gidx, L.owner, L.kext, L.ext_pos)}
+    launch_blocks = {t.untyped_storage().data_ptr() for L in levels for t in (L.grid, L.code, L.order, L.inverse)}
+    assert len(finish_blocks) == 1 and len(launch_blocks) == 1 and finish_blocks != launch_blocks
+    import bench
+    batch = bench.dev_batch(b, dev)
+    prev = ops._JOIN
+    ops.set_wgrad_join("end")
+    try:
+        seen = []
+        orig = ops._end_of_backward
+
+        def probe():
+            seen.append(len(ops._HELD))
+            orig()
+
+        ops._end_of_backward = probe
+        _, losses = model(batch, compute_loss=True, compute_final_action=False)
+        losses["total"].backward()
+        torch.cuda.synchronize()
+    finally:
+        ops._end_of_backward = orig
+        ops.set_wgrad_join(prev)
+    assert seen and (seen[0] > 50 or ops.SIDE is None) and len(ops._HELD) == 0
