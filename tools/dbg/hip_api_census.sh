@@ -20,5 +20,14 @@ except Exception as e:
     print("query failed", e)
 for n, k in rows[:25]:
     print("%-40s %8.1f per step" % (n, k / 40.0))
+# event records / stream waits by stream argument (which queue gets the marker / barrier packet)
+try:
+    cols = [r[1] for r in c.execute("pragma table_info(region_args)")]
+    print(cols)
+    q = "select r.name, a.value, count(*) from regions r join region_args a on a.id = r.id where r.name in ('hipEventRecord', 'hipStreamWaitEvent') and a.name = 'stream' group by r.name, a.value order by count(*) desc"
+    for n, v, k in list(c.execute(q))[:16]:
+        print("%-22s stream %-20s %7.1f per step" % (n, v, k / 40.0))
+except Exception as e:
+    print("by-stream query failed:", e)
 EOF
 rm -rf gpurun_out/prof
