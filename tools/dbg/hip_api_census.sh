@@ -2,7 +2,7 @@
 # HIP runtime calls per training step (rocprofv3 --hip-runtime-trace --stats; counts over a 30-step bench run / 30):
 # event records and stream waits are marker / barrier packets in the queues, memsets and copies are extra launches
 export TMPDIR=/tmp; mkdir -p gpurun_out/prof; rm -f gpurun_out/prof/api_*
-rocprofv3 --hip-runtime-trace --stats -d gpurun_out/prof -o api -- python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-other-modes --no-roofline --no-fresh-batches --no-side-workloads > gpurun_out/prof/api.log 2>&1
+rocprofv3 --hip-runtime-trace --stats -d gpurun_out/prof -o api -- python bench.py $CENSUS_ARGS --steps 30 --warmup 10 --no-cpu-baseline --no-other-modes --no-roofline --no-fresh-batches --no-side-workloads > gpurun_out/prof/api.log 2>&1
 python - <<EOF
 import sqlite3, glob
 db = glob.glob("gpurun_out/prof/api_results.db")[0]
@@ -30,4 +30,5 @@ try:
 except Exception as e:
     print("by-stream query failed:", e)
 EOF
+[ -n "$CENSUS_EXTRA" ] && python $CENSUS_EXTRA
 rm -rf gpurun_out/prof
