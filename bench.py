@@ -254,6 +254,9 @@ def main():
                          f"(backend is {dist.get_backend() if dist.is_initialized() else None})")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    dp_stream = None
+    if dist.is_initialized() and os.environ.get("LOTUS_DIAG_NO_PRIME") != "1":
+        dp_stream = parallel.training_stream()  # the step's four streams, created back to back before any communicator exists
     torch.manual_seed(0)
     mp = args.workload == "mp"
     peract = args.workload == "peract"
@@ -292,17 +295,31 @@ def main():
     ops.set_wgrad_join("end")
     ops.set_gemm_precision(args.gemm_precision)
 
+    PREFETCH_LATE = os.environ.get("LOTUS_BENCH_PREFETCH_LATE") == "1"
+    host_t = [0.0, 0.0, 0.0, 0]  # host seconds inside forward / backward / finish of the steps (enqueue time, no synchronisation)
+
     def step():
+        t0 = time.perf_counter()
         if reducer is not None:
             reducer.zero_grad()
         else:
             for p in params:  # model.zero_grad(set_to_none=True) without the module-tree walk (2 ms of host time)
                 p.grad = None
+        # the NEXT step's batch is announced before this step's forward: its integer front-end is launched by that forward (behind
+        # this batch's own tables) and runs under it; LOTUS_BENCH_PREFETCH_LATE=1: the round-5 order (after the forward)
+        if not PREFETCH_LATE:
+            if model.ptv3_model._pending is None:
+                model.prefetch(batch)  # (first step only: this step's own front-end)
+            model.prefetch(batch)
         _, losses = model(batch, compute_loss=True, compute_final_action=False)
-        model.prefetch(batch)  # the next step's integer front-end runs under this step's backward
+        if PREFETCH_LATE:
+            model.prefetch(batch)
+        t1 = time.perf_counter()
         losses["total"].backward()
+        t2 = time.perf_counter()
         if reducer is not None:
             reducer.finish()
+        host_t[0] += t1 - t0; host_t[1] += t2 - t1; host_t[2] += time.perf_counter() - t2; host_t[3] += 1
         if opt is not None:
             gstep[0] += 1
             loptim.set_lr(opt, init_lrs, gstep[0], topts)
@@ -313,7 +330,10 @@ def main():
     # the step runs on a high-priority stream: the weight-gradient and front-end side streams then only fill
     # the CUs the critical path leaves idle instead of time-slicing with it
     torch.cuda.synchronize()
-    hi = torch.cuda.Stream(priority=-1) if os.environ.get("LOTUS_HIPRIO", "1") == "1" else torch.cuda.current_stream()
+    hp = os.environ.get("LOTUS_HIPRIO", "1")
+    hi = torch.cuda.Stream(priority=-1) if hp == "1" else (torch.cuda.Stream() if hp == "2" else torch.cuda.current_stream())
+    if dp_stream is not None:
+        hi = dp_stream
     torch.cuda.set_stream(hi)
     for _ in range(args.warmup):
         step()
@@ -324,14 +344,24 @@ def main():
     bn_msgs0 = parallel.BN_MESSAGES
     if reducer is not None:
         reducer.exposed_comm_ms()  # drop the warm-up samples
+    host_t[:] = [0.0, 0.0, 0.0, 0]
+    from robot_3dlotus_amd import frontend as lfe
+    lfe.SYNC_WAIT = [0.0]
     t0 = time.perf_counter()
+    step_marks = [] if os.environ.get("LOTUS_DIAG_STEP_TIMES") == "1" else None
     for _ in range(args.steps):
+        if step_marks is not None:
+            e_ = torch.cuda.Event(enable_timing=True); e_.record(); step_marks.append(e_)
         losses = step()
+    host_ms = [round(1e3 * v / max(1, host_t[3]), 3) for v in host_t[:3]] + [round(1e3 * lfe.SYNC_WAIT[0] / max(1, host_t[3]), 3)]
+    lfe.SYNC_WAIT = None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if step_marks:
+        print("step times ms:", " ".join("%.2f" % a.elapsed_time(b) for a, b in zip(step_marks, step_marks[1:])), file=sys.stderr)
     bn_msgs = parallel.BN_MESSAGES - bn_msgs0
     # per-rank communication figures (outside the timed region): GPU time the backward stream waited in finish() per step,
     # GPU time of the SyncBN statistics messages of one extra step, and the point counts the ranks hold
@@ -453,8 +483,10 @@ def main():
             else:
                 for p_ in params:
                     p_.grad = None
+            if i + 1 < nfresh + nwarm and not PREFETCH_LATE:
+                model.prefetch(hb[i + 1])
             _, losses = model(hb[i], compute_loss=True, compute_final_action=False)
-            if i + 1 < nfresh + nwarm:
+            if i + 1 < nfresh + nwarm and PREFETCH_LATE:
                 model.prefetch(hb[i + 1])
             losses["total"].backward()
             if reducer is not None:
@@ -492,6 +524,8 @@ def main():
             "unit": "keystep-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
+            "host_ms_per_step": {"forward": host_ms[0], "backward": host_ms[1], "finish": host_ms[2], "of_forward_waiting_for_the_prefetched_front_end": host_ms[3],
+                                 "note": "host time inside the calls of the timed steps (enqueue; a value near ms_per_step means the host waited for the GPU or bounds the step)"},
             "config": {"workload": f"3D-LOTUS v1 (68.18M params), {args.batch} key-step clouds x {args.npoints} pts "
                                    f"per GPU, fwd+loss+bwd, train mode (dropout on), fp32 exact (MFMA f32)",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
@@ -515,7 +549,10 @@ def main():
             out["comm"] = comm_stats
             out["reducer"] = {"buckets": len(sizes), "bucket_mb": [round(x, 1) for x in sizes], "last_bucket_mb": round(sizes[-1], 1),
                               "gradient_mb": round(sum(sizes), 1), "syncbn_messages_per_step": f"{bn_msgs / max(1, args.steps):.0f} (counted; one fp64 message per BN layer or merged pair and direction, own communicator)",
-                              "points_rank0": int(sum(host_batch["npoints_in_batch"]))}
+                              "points_rank0": int(sum(host_batch["npoints_in_batch"])),
+                              # collectives issued through the library's own RCCL communicators (csrc/comm.cpp): "comm" = gradient
+                              # buckets on the communication stream, "main" = SyncBN statistics + usage flags in the training stream
+                              "native_rccl_lanes": {"comm": reducer._lane_comm is not None, "main": reducer._lane_main is not None}}
         if peract:
             out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"
             out["config"]["workload"] = (f"3D-LOTUS v1 network, PerAct preset (BASELINE configs[4]), {args.batch} dense clouds x {args.npoints} pts "

@@ -28,7 +28,7 @@
  *       LOTUS_CONV_OS=0               bf16 operand modes use the pair-compacted convolution kernel
  *       LOTUS_CONV_OS_F32=1|2|3       exact-fp32 products on the output-stationary convolution kernel (opt-in)
  *       LOTUS_XQ=0|2                  cross attention on the tile kernels / patch attention on the per-query kernels
- *   - lotus_abi_version() changes whenever an existing entry point changes its arguments (2 since round 5); bindings check it.
+ *   - lotus_abi_version() changes whenever an existing entry point changes its arguments (3 since round 6: lotus_adamw_step took the usage mask; 2 in round 5); bindings check it.
  */
 #ifndef LOTUS_HIP_H
 #define LOTUS_HIP_H
@@ -66,6 +66,25 @@ int lotus_abi_version(void);
 unsigned long long lotus_streamlink_create(int nevents);
 int lotus_streamlink_wait(unsigned long long link, void* from_stream, void* to_stream);
 int lotus_streamlink_destroy(unsigned long long link);
+
+/* ---- collectives of the data-parallel step (csrc/comm.cpp): RCCL all-reduces issued straight into the caller's stream on a
+ * communicator of the library's own — ONE kernel in the stream the producer and the consumer of the message run on, where a
+ * blocking ProcessGroupNCCL collective adds ~11 us of work-object / end-event overhead per message (26 us through its own
+ * stream; tools/dbg/msg_cost.py).  Replaces the NCCL calls behind DistributedDataParallel and SyncBatchNorm
+ * (genrobo3d/train/utils/distributed.py:196-205, train/train_simple_policy.py:116-117).  RCCL is dlopen()ed, not linked:
+ *   lotus_comm_load(path)        host string or null: open `path`, else librccl.so.1 / librccl.so; idempotent
+ *   lotus_comm_unique_id(id)     rank 0: 128 host bytes for the other ranks (the caller broadcasts them, e.g. over
+ *                                torch.distributed — the bootstrap stays there)
+ *   lotus_comm_create(id, n, r)  collective over the n ranks -> opaque handle, 0 on failure (device = the caller's current one)
+ *   lotus_comm_allreduce(...)    in place on `buf`; dtype 0 = f32, 1 = f64, 2 = i32; op 0 = sum, 1 = max, 2 = average.
+ *                                Collectives of one communicator must be issued in the same order on every rank and from one
+ *                                stream at a time (parallel.py keeps one communicator per stream that sends). */
+int lotus_comm_load(const char* path);
+int lotus_comm_version(void);
+int lotus_comm_unique_id(void* id128_host);
+unsigned long long lotus_comm_create(const void* id128_host, int nranks, int rank);
+int lotus_comm_allreduce(unsigned long long comm, void* buf, size_t count, int dtype, int op, void* stream);
+int lotus_comm_destroy(unsigned long long comm);
 
 /* ---- operand precision: a PER-CALL argument (`precision`) of the dense, sparse-convolution and attention entry points
  * (no process-wide state: two models with different precisions can share a process).  0 = fp32 MFMA, exact products
@@ -491,9 +510,14 @@ int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, in
 /* shadow_ptrs (optional, device array [T] of bf16 pointers, null entries allowed): the updated parameter is also stored
  * rounded to bf16 — the weight operand of the bf16-storage products (`precision` 5 of lotus_b16_linear_fwd / _dgrad),
  * refreshed by the very step that changes the fp32 master (BASELINE configs[4]: bf16 weights, fp32 master weights). */
+/* used / used_idx (optional, device int32): usage mask of a data-parallel step — tensor t is skipped when
+ * used[used_idx ? used_idx[t] : t] == 0, i.e. when NO rank produced a gradient for it (the MAX all-reduce of the ranks'
+ * usage flags, parallel.GradReducer.used_mask): what DistributedDataParallel(find_unused_parameters=True) does with its host
+ * bitmap (genrobo3d/train/utils/distributed.py:196-205), decided on the device in the step the usage changes. */
 int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const long* numel,
                      const float* step_size, const float* decay, const int* chunks, int nchunks, double beta1, double beta2,
-                     double eps, const float* clip_coef, const void* shadow_ptrs, void* stream);
+                     double eps, const float* clip_coef, const void* shadow_ptrs, const int* used, const int* used_idx,
+                     void* stream);
 /* dst[t][i] = bf16(src[t][i]): creation / refresh of the weight shadows outside an optimiser step (same tables as above) */
 int lotus_shadow_cast(const void* src_ptrs, const void* dst_ptrs, const long* numel, const int* chunks, int nchunks, void* stream);
 

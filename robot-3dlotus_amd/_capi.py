@@ -51,7 +51,7 @@ def parse_header(path=None):
     return protos
 
 
-ABI_VERSION = 2  # lotus_abi_version() of the library this binding matches (include/lotus_hip.h)
+ABI_VERSION = 3  # lotus_abi_version() of the library this binding matches (include/lotus_hip.h)
 
 
 class LotusError(RuntimeError):
@@ -142,6 +142,35 @@ def fastcall():
     return _FAST
 
 
+# Priority of the streams the package creates (weight-gradient, front-end, communication): see DESIGN.md "streams"
+STREAM_PRIORITY = int(os.environ.get("LOTUS_STREAM_PRIO", "0"))
+
+_STEP_STREAMS = {}
+
+
+def step_stream(name):
+    """The package's stream `name` ("train", "side" = weight gradients, "comm" = gradient buckets, "fe" = front-end prefetch),
+    created on first request with STREAM_PRIORITY ("train": always high)."""
+    st = _STEP_STREAMS.get(name)
+    if st is None:
+        st = _STEP_STREAMS[name] = torch.cuda.Stream(priority=-1 if name == "train" else STREAM_PRIORITY)
+    return st
+
+
+def prime_step_streams(names=("train", "side", "comm", "fe")):
+    """Create the step's streams NOW, back to back, and put one packet into each so that their hardware queues exist.
+    Hardware queues are dealt onto the compute pipes of the GPU in creation order, and two queues of one pipe take turns
+    instead of running side by side: when the training stream and the weight-gradient stream end up on one pipe the backward
+    pass is ~6 % slower — about one process in four, when the queues are created lazily in between those of RCCL's threads
+    (measured: 12 fresh processes per setting).  Created consecutively, before any communicator, the four
+    queues sit on four different pipes in every process.  -> the training stream (make it current: torch.cuda.set_stream)."""
+    for n in names:
+        with torch.cuda.stream(step_stream(n)):
+            torch.zeros(1, device="cuda")
+    torch.cuda.synchronize()
+    return _STEP_STREAMS["train"]
+
+
 # When non-zero, every call() enqueues on this hipStream_t instead of torch's current stream (ops._OnSide: the
 # weight-gradient stream).  Cheaper than switching torch's current stream, which nothing inside those blocks needs.
 STREAM_OVERRIDE = 0
@@ -197,6 +226,26 @@ def query(name, *args):
     if F is not None:
         return getattr(F, name)(*args)
     return lib().fn[name](*args)
+
+
+def wait_event(ev):
+    """Block the host until `ev` (a torch.cuda.Event recorded earlier) has completed — by polling hipEventQuery.
+
+    NOT ev.synchronize(): on this ROCm runtime hipEventSynchronize of an event that is not yet complete enqueues a NEW
+    marker at the current TAIL of the event's hardware queue and waits for that one, i.e. for everything submitted since —
+    on the event's own stream and on every stream that shares its hardware queue (HIP maps its streams onto
+    GPU_MAX_HW_QUEUES = 4 of them per priority).  Measured in the data-parallel rehearsal: the host waited 11-16 ms per
+    step for an event the GPU had passed long before — the count copy of the prefetched front-end (its stream shared a
+    queue with the weight-gradient stream) and the one-step-old usage flags (recorded on the training stream itself) —
+    which serialised host and GPU (28 instead of 15.5 ms per step) and changed with every re-mapping of streams to queues.
+    A query never enqueues anything."""
+    if ev.query():
+        return
+    import time
+    t0 = time.perf_counter()
+    while not ev.query():
+        if time.perf_counter() - t0 > 2e-4:
+            time.sleep(2e-5)   # the GPU is far behind: stop spinning on the core the launch threads need
 
 
 class Workspace:

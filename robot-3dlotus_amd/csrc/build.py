@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["lotus_capi.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
+SOURCES = ["lotus_capi.cpp", "comm.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
 HEADERS = ["common.h", "mma.h", "gemm_common.h", "gemm_dma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # measurement builds (never the shipped library): LOTUS_BUILD_DEFINES="LOTUS_EXP_SKIP_PROBE" python build.py --force
@@ -70,7 +70,7 @@ def build(force=False):
         objs = [o for o, _ in ex.map(_compile, jobs)]
     if _stale(LIB, objs):
         r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", os.path.basename(LIB)] +
-                           [os.path.basename(o) for o in objs], capture_output=True, text=True, cwd=HERE)
+                           [os.path.basename(o) for o in objs] + ["-ldl"], capture_output=True, text=True, cwd=HERE)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr)
     build_fastcall()

@@ -19,7 +19,7 @@ extern "C" {
 const char* lotus_last_error(void) { return g_err; }
 // 2 (round 5): lotus_subm_conv / lotus_cpe_fwd / _bwd take a tap plan, lotus_adamw_step takes double betas + shadow pointers,
 // lotus_fe_neighbours needs 16-byte hash slots, the counter buffer grew by the BatchNorm counters (all round 4)
-int lotus_abi_version(void) { return 2; }
+int lotus_abi_version(void) { return 3; }
 
 // Stream link: a caller-owned ring of timing-less events used to order one stream after another without a host
 // round trip ("to" waits for everything enqueued on "from" so far, or — lotus_link_next_event — for one launch).  Re-recording a ring event later is safe:

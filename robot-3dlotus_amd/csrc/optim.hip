@@ -66,6 +66,12 @@ struct AdamP {
   // rounded to bf16 — the weight operand of the bf16-storage products (BASELINE configs[4]: "bf16 weights with fp32
   // master weights") refreshed by the step that changes the master, one extra 2-byte store per element
   unsigned short* const* shadow;
+  // optional usage mask (data-parallel training, parallel.GradReducer): used[used_idx ? used_idx[t] : t] == 0 means NO rank
+  // produced a gradient for tensor t in this step -> the tensor is skipped exactly as a null gradient is (adamw.py:67-68).  The
+  // flags are the MAX all-reduce of the ranks' per-parameter usage bits and never leave the device, so a parameter whose usage
+  // flips is handled in the step it flips in, without a host synchronisation.
+  const int* used;
+  const int* used_idx;
   // omb = 1 - beta evaluated in DOUBLE by the host and rounded once, as the reference's `addcmul_(g, g, value=1.0 - beta2)`
   // does (adamw.py:86-87: a Python float); 1.f - beta2 in fp32 is off by 1e-6 relative (cancellation), which showed up as
   // 8 ulp in exp_avg_sq
@@ -85,6 +91,7 @@ __global__ __launch_bounds__(256) void mt_adamw_kernel(AdamP a) {
   const int t = a.chunks[2 * blockIdx.x], c = a.chunks[2 * blockIdx.x + 1];
   const float* g = a.g[t];
   if (!g) return;  // parameter without a gradient this step (adamw.py:67-68)
+  if (a.used && a.used[a.used_idx ? a.used_idx[t] : t] == 0) return;  // ... on any rank (device-side usage mask)
   float* p = a.p[t];
   float* m = a.m[t];
   float* v = a.v[t];
@@ -135,9 +142,11 @@ int lotus_grad_norm(const void* g_ptrs, const long* numel, const int* chunks, in
 
 // One AdamW step for every tensor.  step_size / decay are per-tensor device arrays (see AdamP); clip_coef (device scalar,
 // optional) scales the gradients first (clip_grad_norm_ folded into the update instead of rewriting the gradients).
+// used / used_idx (device, optional): usage mask of the data-parallel step, see AdamP.
 int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs, const void* v_ptrs, const long* numel,
                      const float* step_size, const float* decay, const int* chunks, int nchunks, double beta1, double beta2,
-                     double eps, const float* clip_coef, const void* shadow_ptrs, void* stream) {
+                     double eps, const float* clip_coef, const void* shadow_ptrs, const int* used, const int* used_idx,
+                     void* stream) {
   LOTUS_CHECK_ARG(p_ptrs && g_ptrs && m_ptrs && v_ptrs && numel && step_size && decay && chunks && nchunks >= 0,
                   "lotus_adamw_step: bad arguments");
   if (nchunks == 0) return LOTUS_OK;
@@ -147,6 +156,7 @@ int lotus_adamw_step(const void* p_ptrs, const void* g_ptrs, const void* m_ptrs,
   a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps;
   a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
   a.shadow = (unsigned short* const*)shadow_ptrs;
+  a.used = used; a.used_idx = used_idx;
   LOTUS_LAUNCH(mt_adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, a);
   LOTUS_LAUNCH_CHECK("lotus_adamw_step");
   return LOTUS_OK;

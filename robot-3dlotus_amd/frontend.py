@@ -13,9 +13,11 @@ import os
 import numpy as np
 import torch
 
+from . import _capi
 from ._capi import call, query, WS
 
 # build the exact-size tables of a PREFETCHED front-end on the front-end stream (FrontEnd.finish)
+SYNC_WAIT = None  # set to [0.0] to accumulate the host time FrontEnd.finish() waits for the device (diagnostic)
 FINISH_ON_SIDE = True  # exact-size tables of a prefetched batch are built on the front-end stream (+0.6 % with fresh batches)
 
 ORDERS = ("z", "z-trans", "hilbert", "hilbert-trans")
@@ -194,7 +196,13 @@ class FrontEnd:
         dev = pc_fts.device
         N, B, Lv = int(pc_fts.shape[0]), len(counts), self.n_levels
         i32 = dict(dtype=torch.int32, device=dev)
-        pend["event"].synchronize()
+        if SYNC_WAIT is not None:  # (bench.py: host seconds spent waiting for the prefetched counts)
+            import time
+            t0 = time.perf_counter()
+            _capi.wait_event(pend["event"])
+            SYNC_WAIT[0] += time.perf_counter() - t0
+        else:
+            _capi.wait_event(pend["event"])  # (never Event.synchronize(): see _capi.wait_event)
         fe = pend["stream"]
         if fe is not None:  # tables were allocated on the side stream and are consumed here
             cur = torch.cuda.current_stream()

@@ -76,8 +76,10 @@ class MotionPlannerPTV3CA(BaseModel):
         W, E = self.ptv3_model.embedding.stem.conv.weight, self.pc_label_embedding.weight
         c_pc = batch["pc_fts"].shape[1]
         w_eff = torch.cat([W[..., :c_pc], torch.matmul(W[..., c_pc:], E.t())], -1)                  # [64,5,5,5,c_pc+4]
-        pre, self._pre = getattr(self, "_pre", None), None
-        if pre is not None and pre[0] is batch["pc_fts"] and pre[1] is batch["pc_labels"]:
+        pres = getattr(self, "_pre", None) or []
+        pre = next((q for q in pres if q[0] is batch["pc_fts"] and q[1] is batch["pc_labels"]), None)
+        self._pre = [q for q in pres if q is not pre][-1:]  # (at most one more: the batch after this one)
+        if pre is not None:
             feat = pre[2]   # prefetch() built it (and started the front-end on exactly this tensor)
         else:
             feat = torch.cat([batch["pc_fts"].float(), F.one_hot(labels, 4).float()], -1)
@@ -103,7 +105,7 @@ class MotionPlannerPTV3CA(BaseModel):
         start its integer front-end on the side stream; the following forward(batch) must get the same (device) batch."""
         batch = self.prepare_batch(batch)
         feat = torch.cat([batch["pc_fts"].float(), F.one_hot(batch["pc_labels"].long(), 4).float()], -1)
-        self._pre = (batch["pc_fts"], batch["pc_labels"], feat)
+        self._pre = ((getattr(self, "_pre", None) or []) + [(batch["pc_fts"], batch["pc_labels"], feat)])[-2:]
         self.ptv3_model.prefetch({"coord": feat[:, :3], "grid_size": self.config.action_config.voxel_size, "offset": batch["offset"],
                                   "feat": feat, "counts": list(batch["npoints_in_batch"]),
                                   "context_counts": [c + int(bool(self.config.action_config.use_ee_pose)) for c in batch["txt_lens"]]})

@@ -197,7 +197,7 @@ def _side():
         # 3/4 or 31/32 of the CUs: 923-931 / 929-932 / 875-879 against 930: reserving CUs for the critical stream buys
         # nothing), a lowest-priority side stream (+0.1 %)
         for _ in range(_NSIDE):
-            st = torch.cuda.Stream()
+            st = _capi.step_stream("side") if not _SIDES else torch.cuda.Stream(priority=_capi.STREAM_PRIORITY)
             _SIDES.append((st, st.cuda_stream))
         if not _LINK:
             _LINK = query("lotus_streamlink_create", 256)

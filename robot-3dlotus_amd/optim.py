@@ -63,6 +63,7 @@ class AdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self._tables = None
         self._clip = None  # device [norm, coefficient] of the pending clip_grad_norm_
+        self._pending_usage = []  # reducer step ids counted before their usage flags reached the host (_usage)
 
     # ---- device tables -------------------------------------------------------------------------------------------
     def _build_tables(self):
@@ -112,7 +113,36 @@ class AdamW(torch.optim.Optimizer):
                 return False
         return True
 
-    def _grad_table(self):
+    def _usage(self, reducer):
+        """Data-parallel step: which parameters are skipped is decided ON THE DEVICE by the reducer's exact usage mask; the host
+        only keeps the per-parameter step counters (bias correction) in line with it.  The flags of a step reach the host one
+        step late (parallel.GradReducer._sync_usage): a step is first counted for every parameter, and retracted for the
+        parameters nobody used once their flags are known — always before the counter is read again, because a parameter
+        skipped on the device does not read its step size.  -> (device mask, device index table, indices known unused NOW)"""
+        tb = self._tables
+        if tb.get("red") is not reducer:
+            idx = {p: i for i, p in enumerate(reducer.params)}
+            missing = [1 for p, _ in tb["plist"] if p not in idx]
+            if missing:
+                raise ValueError(f"AdamW.step(reducer=...): {len(missing)} optimiser parameters are not managed by the reducer")
+            tb["red"], tb["red_index"] = reducer, [idx[p] for p, _ in tb["plist"]]
+            tb["red_idx_dev"] = torch.tensor(tb["red_index"], dtype=torch.int32, device=tb["dev"])
+            self._pending_usage = []
+        k = reducer.step_id
+        by_red = {r: p for r, (p, _) in zip(tb["red_index"], tb["plist"])}
+        for j in list(self._pending_usage):   # steps whose flags had not arrived when they were counted
+            un = reducer.unused_of(j)
+            if un is not None:
+                for r in un:
+                    if r in by_red:
+                        self.state[by_red[r]]["step"] -= 1
+                self._pending_usage.remove(j)
+        now = reducer.unused_of(k)
+        if now is None:
+            self._pending_usage.append(k)
+        return reducer.used_mask, tb["red_idx_dev"], (now or set())
+
+    def _grad_table(self, reducer=None, known_unused=()):
         """Per step: gradient pointers (fresh tensors every backward), step sizes and decays -> one pinned upload."""
         tb = self._tables
         T = tb["T"]
@@ -120,7 +150,12 @@ class AdamW(torch.optim.Optimizer):
         hp = host.numpy()
         fl = hp[T:3 * T].view(np.float32)  # 4 T floats available; [0:T] step_size, [T:2T] decay
         for i, (p, group) in enumerate(tb["plist"]):
-            g = p.grad
+            if reducer is not None:
+                # the slice of the flat, rank-averaged buffer — also for a parameter whose `.grad` the reducer has reset to
+                # None on one-step-old knowledge: the device mask decides, from THIS step's flags
+                g = None if tb["red_index"][i] in known_unused else reducer.view_of(p)
+            else:
+                g = p.grad
             if g is None:
                 hp[i] = 0
                 continue
@@ -155,7 +190,9 @@ class AdamW(torch.optim.Optimizer):
         return out[0]
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, reducer=None):
+        """reducer: the parallel.GradReducer of a data-parallel step (after its finish()): gradients are read from its flat
+        buffer and parameters NO rank used in this step are skipped on the device (exact in the step their usage changes)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -164,14 +201,20 @@ class AdamW(torch.optim.Optimizer):
             self._build_tables()
         tb = self._tables
         T = tb["T"]
-        dv = self._grad_table()
+        used = used_idx = None
+        known = ()
+        if reducer is not None and reducer.used_mask is not None:
+            used, used_idx, known = self._usage(reducer)
+        else:
+            reducer = None
+        dv = self._grad_table(reducer, known)
         fl = dv[T:3 * T].view(torch.float32)
         g0 = self.param_groups[0]
         for g in self.param_groups:
             assert tuple(g["betas"]) == tuple(g0["betas"]) and g["eps"] == g0["eps"], "per-group betas / eps are not built"
         clip = self._clip[1:2] if self._clip is not None else None
         call("lotus_adamw_step", tb["p"], dv[:T], tb["m"], tb["v"], tb["numel"], fl[:T], fl[T:2 * T], tb["chunks"], tb["nchunks"],
-             float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip, tb["shadow"])
+             float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), clip, tb["shadow"], used, used_idx)
         self._clip = None
         return loss
 

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import _capi, ops
 
 
 def init_distributed(backend=None):
@@ -30,6 +30,7 @@ def init_distributed(backend=None):
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
             dist.init_process_group(backend=backend or "nccl", init_method="env://", rank=0, world_size=1)
+        _uniform_stream_priority()
         return 0, 0, 1
     if world == 1:
         return 0, 0, 1
@@ -41,7 +42,112 @@ def init_distributed(backend=None):
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, init_method="env://")
+    _uniform_stream_priority()
     return rank, local, world
+
+
+def _uniform_stream_priority():
+    """Data-parallel processes: every stream of the step — the training stream a trainer makes current (high priority, as
+    bench.py does), the weight-gradient, front-end and communication streams the package creates — gets the SAME, high priority.
+    HIP maps streams onto at most GPU_MAX_HW_QUEUES = 4 hardware queues PER PRIORITY: the step's four streams then own the four
+    high-priority queues, and nothing else in the process is created there (RCCL's internal streams, ProcessGroupNCCL's, the
+    null stream and torch's pool are normal priority).  With a high-priority training stream over normal-priority side streams
+    (the single-GPU arrangement) a side stream whose hardware queue lands next to the training stream's is not scheduled until
+    that one runs dry: measured, the front-end's count copy or the weight gradients then finish a whole backward pass late
+    (28 instead of 15.5 ms per step), and WHICH stream is hit changes with the order in which the process created its queues."""
+    if os.environ.get("LOTUS_STREAM_PRIO") is None and torch.cuda.is_available():
+        _capi.STREAM_PRIORITY = -1
+
+
+def training_stream():
+    """The stream a data-parallel trainer should make current for its steps (`torch.cuda.set_stream(parallel.training_stream())`
+    right after init_distributed(), before the model and the reducer are built): high priority like the package's own three
+    streams, and created together with them (see _capi.prime_step_streams)."""
+    return _capi.prime_step_streams()
+
+
+class NativeComm:
+    """An RCCL communicator of the library's own (csrc/comm.cpp, lotus_comm_*): `all_reduce` is ONE ncclAllReduce enqueued on
+    the current HIP stream — no ProcessGroupNCCL work object, end event or communicator-internal stream behind it (a blocking
+    ProcessGroupNCCL collective costs the issuing stream ~11 us beyond the collective, 26 us through its own stream:
+    tools/dbg/msg_cost.py).  torch.distributed stays the bootstrap: it carries rank 0's unique id to the other ranks.
+    Construction is a collective over `group`; one instance per stream that sends ("lanes" below)."""
+    SUM, MAX, AVG = 0, 1, 2
+    _DT = {torch.float32: 0, torch.float64: 1, torch.int32: 2}
+
+    def __init__(self, group=None):
+        import ctypes
+
+        import numpy as np
+
+        from . import _capi
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")  # the instance torch itself loaded
+        cpath = ctypes.create_string_buffer((path if os.path.exists(path) else "").encode())
+        _capi.call_raw("lotus_comm_load", ctypes.addressof(cpath))
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        idb = np.zeros(128, dtype=np.uint8)
+        if rank == 0:
+            _capi.call_raw("lotus_comm_unique_id", idb.ctypes.data)
+        t = torch.from_numpy(idb).cuda()
+        dist.broadcast(t, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        idb = np.ascontiguousarray(t.cpu().numpy())
+        self.handle = _capi.query("lotus_comm_create", idb.ctypes.data, world, rank)
+        if not self.handle:
+            raise _capi.LotusError("lotus_comm_create failed: " + _capi.lib().last_error())
+        self.world, self.rank = world, rank
+        probe = torch.full((4,), float(rank + 1), dtype=torch.float64, device="cuda")  # known answer before anything relies on it
+        self.all_reduce(probe, self.SUM)
+        if probe.tolist() != [world * (world + 1) / 2.0] * 4:
+            raise _capi.LotusError(f"native RCCL communicator: known-answer all-reduce returned {probe.tolist()}")
+
+    def all_reduce(self, t, op):
+        """In place, on the current stream (ops honour _capi.STREAM_OVERRIDE like every other launch)."""
+        from . import _capi
+        if _LANE_DIAG is not None:  # (diagnostic: host time spent inside the calls)
+            import time
+            t0 = time.perf_counter()
+            _capi.call("lotus_comm_allreduce", self.handle, t, t.numel(), self._DT[t.dtype], op)
+            d = _LANE_DIAG.setdefault((t.numel(), op), [0, 0.0, 0.0])
+            dt = time.perf_counter() - t0
+            d[0] += 1; d[1] += dt; d[2] = max(d[2], dt)
+            return
+        _capi.call("lotus_comm_allreduce", self.handle, t, t.numel(), self._DT[t.dtype], op)
+
+
+_LANES = {}
+_LANE_DIAG = {} if os.environ.get("LOTUS_DIAG_LANE_TIMING") == "1" else None
+if _LANE_DIAG is not None:
+    import atexit
+    import sys as _sys
+    atexit.register(lambda: print("lane timing (numel, op): calls, total s, max s", _LANE_DIAG, file=_sys.stderr))
+
+
+def native_comm(group, lane):
+    """The native communicator of (`group`, `lane`), created on first use — a COLLECTIVE call: every rank of the group must
+    reach it in the same order.  lane "main": collectives issued from the training stream (SyncBatchNorm statistics, usage
+    flags); lane "comm": the gradient buckets on the communication stream (one communicator per sending stream: NCCL orders
+    the collectives of a communicator, and the two streams run concurrently).  None when the group does not run over RCCL,
+    LOTUS_DP_NATIVE=0, or ANY rank failed to create it (decided together, so that no rank is left alone in a collective)."""
+    key = (id(group) if group is not None else 0, lane)
+    if key in _LANES:
+        return _LANES[key]
+    c = None
+    if (dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.cuda.is_available()
+            and os.environ.get("LOTUS_DP_NATIVE", "1") != "0" and lane in os.environ.get("LOTUS_DP_LANES", "main,comm").split(",")):
+        err = None
+        try:
+            c = NativeComm(group)
+        except Exception as e:  # noqa: BLE001 - whatever went wrong, the ProcessGroup path still works
+            err = e
+        ok = torch.tensor([0 if c is None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            if dist.get_rank(group) == 0:
+                import sys
+                print(f"lotus parallel: native RCCL lane '{lane}' unavailable ({err}); using torch.distributed collectives", file=sys.stderr)
+            c = None
+    _LANES[key] = c
+    return c
 
 
 class GradReducer:
@@ -80,15 +186,26 @@ class GradReducer:
         self._handles = []
         self.exposed_events = []
         self._avg = (self.world > 1 or self._force) and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
+        # native lanes (collective construction, same order on every rank): buckets on the communication stream, usage flags
+        # on the training stream
+        self._lane_comm = native_comm(group, "comm") if (self._avg and dev.type == "cuda") else None
+        self._lane_main = native_comm(group, "main") if (self._avg and dev.type == "cuda") else None
         self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
         self._sync = True
         self._index = {p: i for i, p in enumerate(self.params)}
-        self._used = torch.zeros(len(self.params), dtype=torch.int32)  # host bitmap: parameters with a gradient this step
+        pin = dev.type == "cuda"
+        # host bitmap: parameters with a gradient this step (two pinned buffers in turn: the upload of one step may still be in
+        # flight when the next step starts to fill its own)
+        self._used_bufs = [torch.zeros(len(self.params), dtype=torch.int32, pin_memory=pin) for _ in range(2)]
+        self._used = self._used_bufs[0]
+        self._used_np = self._used.numpy()
+        self.step_id, self._known = 0, {}
         # While the arrival order is being learnt every parameter carries a hook; afterwards only the LAST-arriving parameter
         # of each bucket does (~10 hooks instead of 421 per backward: the per-parameter hooks were most of the 5.5 % the
         # one-rank rehearsal cost before a byte crossed a link) — _hook_last checks that the bucket is
-        # complete before it flushes, so a changed order can only delay a bucket to finish(), never drop a gradient.
+        # complete (every `.grad` set: zero_grad() dropped them) before it flushes, so a changed order can only delay a bucket
+        # to finish(), never drop a gradient.  Gradient accumulation voids that check and returns to dense hooks (no_sync).
         self._hook_handles = []
         for p in self.params:
             p.grad = None
@@ -136,6 +253,10 @@ class GradReducer:
                     close()
             close()
         self._count = [len(ps) for ps in self._bparams]
+        self._view = {p: v for ps, vs in zip(self._bparams, self._bviews) for p, v in zip(ps, vs)}
+        import numpy as np
+        index = {p: i for i, p in enumerate(self.params)}
+        self._bindex = [np.asarray([index[p] for p in ps], dtype=np.int64) for ps in self._bparams]
         self._rearm()
 
     def _rearm(self):
@@ -194,6 +315,12 @@ class GradReducer:
                 last = max(hot, key=lambda q: rank_of[q])
                 self._hook_handles.append(last.register_post_accumulate_grad_hook(self._hook_last))
 
+    def _dense_hooks(self):
+        """(Back to) one counting hook on every parameter."""
+        for h in self._hook_handles:
+            h.remove()
+        self._hook_handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
     @contextlib.contextmanager
     def no_sync(self):
         """Gradient accumulation (gradient_accumulation_steps > 1 in the reference trainer): inside this context
@@ -202,6 +329,13 @@ class GradReducer:
         stream may still be writing, so the per-node join is required (ops.set_wgrad_join("node"), the default)."""
         if ops._JOIN != "node":
             raise RuntimeError("gradient accumulation needs ops.set_wgrad_join('node')")
+        # One hook per bucket is only sound while `.grad is None` tells "not arrived in THIS backward": after a local
+        # micro-batch every gradient exists, and a bucket whose last parameter (in the learnt order) arrives before another
+        # one of its parameters would be packed with that parameter's stale partial sum (ADVICE r5).  Accumulation therefore
+        # switches this reducer back to a hook on every parameter — they count the arrivals of the current backward — for good.
+        if self.sparse_hooks:
+            self.sparse_hooks = False
+            self._dense_hooks()
         self._sync = False
         try:
             yield
@@ -212,8 +346,8 @@ class GradReducer:
         ps, views = self._bparams[b], self._bviews[b]
         self._flushed[b] = True
         have = [i for i, p in enumerate(ps) if p.grad is not None]
-        for i in have:
-            self._used[self._index[ps[i]]] = 1
+        bi = self._bindex[b]
+        self._used_np[bi if len(have) == len(ps) else bi[have]] = 1  # (one vectorised store: 421 tensor element writes cost ~1 ms)
         lo, hi = self.buckets[b]
         buf = self.flat[lo:hi]
         grads = [ps[i].grad for i in have]
@@ -222,7 +356,7 @@ class GradReducer:
         def pack():
             if len(have) < len(ps):  # finish(): gradient-less parameters contribute zeros to the average
                 buf.zero_()
-            if grads:
+            if grads and not _DIAG_NO_PACK:
                 torch._foreach_copy_(dst, grads)
             self._reduce(buf)
 
@@ -232,7 +366,7 @@ class GradReducer:
             if self._comm is None:
                 # (measured, round 5: packing and reducing on the weight-gradient stream itself instead — one stream less —
                 #  924-928 against 930-944 samples/s in the one-rank rehearsal)
-                self._comm = torch.cuda.Stream()
+                self._comm = _capi.step_stream("comm")
             comm = self._comm
             comm.wait_stream(torch.cuda.current_stream())
             ops.sync_side_stream(target=comm.cuda_stream)
@@ -251,7 +385,14 @@ class GradReducer:
         if _DIAG_NO_MSG:
             return
         if self.world > 1 or self._force:
-            if self._avg:
+            if self._lane_comm is not None and buf.is_cuda:
+                self._lane_comm.all_reduce(buf, NativeComm.AVG)  # one RCCL kernel behind the pack, on the communication stream
+            elif self._avg and _AR_ON_COMM and buf.is_cuda:
+                # a BLOCKING collective of ProcessGroupNCCL runs on the current stream — here the communication stream the
+                # bucket was packed on: pack and all-reduce are two launches of ONE stream, no communicator-internal stream
+                # (one hardware queue less) and no event hand-over between the two
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group)
+            elif self._avg:
                 self._handles.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
             else:
                 buf.mul_(1.0 / self.world)
@@ -305,42 +446,63 @@ class GradReducer:
             e1.record()
             self.exposed_events.append((e0, e1))
         self._keep = []
-        if self.world > 1:
+        self.step_id += 1
+        if self.world > 1 or self._force:
             self._sync_usage()
-        self._used.zero_()
+        self._used = self._used_bufs[self.step_id % 2]
+        self._used_np = self._used.numpy()
+        self._used_np[:] = 0
 
     def _sync_usage(self):
-        """Parameters NO rank used keep .grad None, as under DistributedDataParallel(find_unused_parameters=True) and as on
-        one GPU: the optimiser skips them (no decoupled weight decay, no moment update for e.g. a head that never ran).
-        The per-parameter usage flags are MAX-reduced on the device every step (issued unconditionally: a rank-local
-        shortcut would mismatch the collective) but read by the host ONE STEP LATER through a pinned copy, so the step never
-        waits for the GPU; only the very first step blocks once.  Usage patterns are static in practice (a module either
-        takes part in the model's forward or it does not); a parameter whose global usage changes is handled one step late
-        (one update with a zero gradient, or one skipped update)."""
+        """Which parameters did NO rank use in this step?  DistributedDataParallel(find_unused_parameters=True) answers with a
+        host bitmap (genrobo3d/train/utils/distributed.py:196-205); here the per-parameter flags are MAX-reduced on the device
+        (issued unconditionally: a rank-local shortcut would mismatch the collective) and stay there:
+
+          * `used_mask` (device int32, one flag per parameter of `self.params`) is EXACT for the step just finished and is what
+            the fused optimiser consumes (optim.AdamW.step(reducer=...) -> the `used` argument of lotus_adamw_step): a parameter
+            whose global usage flips is skipped / updated in the very step it flips in, with no host synchronisation
+            (ADVICE r3 / VERDICT r5 item 1c);
+          * the HOST learns the flags one step late through a pinned copy (only the very first step blocks once) and uses them for
+            what cannot matter numerically: `.grad = None` on parameters nobody used — what one GPU and DDP show, and what a
+            non-fused optimiser keys on — and the optimiser's per-parameter step counters (`unused_of`)."""
         dev = self.flat.device
         u = self._used.to(dev, non_blocking=True)
-        dist.all_reduce(u, op=dist.ReduceOp.MAX, group=self.group)      # stream-ordered on RCCL, blocking on gloo
+        if self._lane_main is not None and u.is_cuda:
+            self._lane_main.all_reduce(u, NativeComm.MAX)
+        elif not _DIAG_NO_MSG:
+            dist.all_reduce(u, op=dist.ReduceOp.MAX, group=self.group)      # stream-ordered on RCCL, blocking on gloo
+        self.used_mask = u
+        k = self.step_id
         if self._unused is None or not u.is_cuda:                          # first step (one blocking read) / host tensors
             self._unused = {i for i, f in enumerate(u.tolist()) if not f}
+            self._known[k] = self._unused
         else:
-            # (ADVICE r3: a rank-local "my pattern changed -> read now" shortcut would make the flip step exact on THAT
-            # rank only, and ranks that apply different unused sets to one optimiser step diverge; every rank therefore reads
-            # the same one-step-old flags.  An exact flip without a host sync needs the flags on the device side of the
-            # optimiser — a mask argument of lotus_adamw_step — which is not built.)
             if self._usage_pending is not None:                           # last step's flags (long finished)
-                host, ev = self._usage_pending
-                ev.synchronize()
+                host, ev, kprev = self._usage_pending
+                _capi.wait_event(ev)  # (a query loop, never Event.synchronize(): that would wait for the tail of the training stream)
                 self._unused = {i for i, f in enumerate(host.tolist()) if not f}
+                self._known[kprev] = self._unused
             else:
                 host, ev = torch.empty(u.shape, dtype=u.dtype, pin_memory=True), torch.cuda.Event()  # reused every step
             host.copy_(u, non_blocking=True)
             ev.record()
-            self._usage_pending = (host, ev)
+            self._usage_pending = (host, ev, k)
+        for old in [j for j in self._known if j < k - 4]:
+            del self._known[old]
         for i in self._unused:
             self.params[i].grad = None
 
+    def unused_of(self, step_id):
+        """Indices (into self.params) of the parameters no rank used in finish() number `step_id`, or None while the host has
+        not seen that step's flags yet (they arrive one step late)."""
+        return self._known.get(step_id)
+
+    def view_of(self, p):
+        """The slice of the flat, rank-averaged buffer that holds p's gradient (zeros when no rank produced one)."""
+        return self._view[p]
 
     _unused, _usage_pending = None, None
+    used_mask = None       # device int32 [len(params)]: 1 = some rank produced a gradient in the step just finished (exact)
     time_exposed = False   # bench.py: record an event pair around the wait in finish()
     sparse_hooks = True    # one hook per bucket once the arrival order is known (False: a hook on every parameter)
 
@@ -362,15 +524,24 @@ def enable_sync_batchnorm(group=None):
 
     The statistics travel on their OWN communicator (collective call: every rank must enter): the messages are on the
     critical path of forward and backward, and on the communicator of the gradient buckets they would queue behind a
-    32+ MB all-reduce that is itself waiting for lagging weight gradients."""
+    32+ MB all-reduce that is itself waiting for lagging weight gradients.  Over RCCL that communicator is the native "main"
+    lane (NativeComm): each message is one RCCL kernel IN the training stream, between the statistics kernel that produces
+    the sums and the apply kernel that consumes them."""
     global _BN_GROUP
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("LOTUS_FORCE_COLLECTIVES") != "1"):
         ops.BnState.reduce = None
         return
-    if group is None:
+    lane = native_comm(group, "main")  # (collective) the statistics as RCCL kernels of the training stream itself
+    if group is None and lane is None:  # (availability of the lane is agreed by all ranks: so is this branch)
         if _BN_GROUP is None:
             _BN_GROUP = dist.new_group(backend=dist.get_backend())
         group = _BN_GROUP
+
+    def send(sums):
+        if lane is not None and sums.is_cuda:
+            lane.all_reduce(sums, NativeComm.SUM)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # in place, no host sync
 
     def reduce(sums):
         global BN_MESSAGES
@@ -380,15 +551,17 @@ def enable_sync_batchnorm(group=None):
         if BN_TIMING is not None and sums.is_cuda:  # bench.py: event pair around every statistics message
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+            send(sums)
             e1.record()
             BN_TIMING.append((e0, e1))
             return
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)  # in place, no host sync
+        send(sums)
 
     ops.BnState.reduce = reduce
 
 
+_AR_ON_COMM = os.environ.get("LOTUS_DP_AR_ON_COMM", "1") == "1"  # bucket all-reduces as launches of the communication stream itself
+_DIAG_NO_PACK = os.environ.get("LOTUS_DIAG_NO_PACK") == "1"  # (diagnostic: bucket flushes without the pack copies — wrong gradients)
 _DIAG_NO_MSG = os.environ.get("LOTUS_DIAG_NO_MESSAGES") == "1"  # one-rank rehearsal without the collectives: what the plumbing alone costs
 BN_MESSAGES = 0  # SyncBN all-reduces issued by this process (bench.py reports the count per step)
 BN_TIMING = None  # set to a list to collect (start, end) events of every SyncBN message (bench.py: syncbn_ms per step)

@@ -155,9 +155,15 @@ class SimplePolicyPTV3CA(BaseModel):
     @torch.no_grad()
     def prefetch(self, batch):
         """Optional input-pipeline hook (not in the reference): start the integer front-end of `batch` on a side
-        stream.  Call it for the NEXT batch right after the forward of the current one; the following
-        forward(batch) must get the same dict.  Purely an overlap device — results are identical."""
+        stream.  Call it for the NEXT batch BEFORE the forward of the current one (`prefetch(b[k + 1]); forward(b[k])`:
+        the pipeline then runs under forward k, see PointTransformerV3CA.prefetch) or right after it; forward(batch) must
+        later get the same dict.  Purely an overlap device — results are identical."""
         on_host = any(isinstance(v, torch.Tensor) and v.device.type == "cpu" for v in batch.values())
+        if on_host and self.ptv3_model._pending is not None:
+            # two batches ahead (see PointTransformerV3CA.prefetch): upload and pipeline are both issued by the forward of
+            # the batch in between, behind ITS tables on the front-end stream
+            self.ptv3_model._deferred = lambda: self.prefetch(batch)
+            return
         if on_host:
             # a host batch (pinned tensors of data.ptv3_collate_fn(pin=True)): upload it on the front-end stream, so
             # the H2D copies (24 MB of soft labels per 16 clouds) and the integer pipeline both run under the current

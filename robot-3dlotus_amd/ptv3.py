@@ -15,7 +15,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _capi, ops
 from .frontend import FrontEnd, draw_order_perms
 
 
@@ -238,7 +238,7 @@ class PointTransformerV3CA(nn.Module):
         self._step = None  # dropout stream position; taken from stem.norm.num_batches_tracked on first use (see _seeds)
         self._seed_base = None
         self.order_perms = None  # inject a list of permutations to override the RNG draw (tests)
-        self._pending, self._fe_stream = None, None  # prefetch() state
+        self._pending, self._deferred, self._fe_stream = None, None, None  # prefetch() state
         self._nbt = None
         self._sync_bn_checked = False
         self.register_load_state_dict_post_hook(lambda m, _keys: setattr(m, "_step", None))
@@ -330,7 +330,7 @@ class PointTransformerV3CA(nn.Module):
 
     def fe_stream(self):
         if self._fe_stream is None:
-            self._fe_stream = torch.cuda.Stream()
+            self._fe_stream = _capi.step_stream("fe")
         return self._fe_stream
 
     @torch.no_grad()
@@ -342,10 +342,23 @@ class PointTransformerV3CA(nn.Module):
         here (same count and order of torch.randperm calls as the reference's forward)."""
         self.fe_stream()
         feat, src, counts, ctx_counts, context = self._front_inputs(data_dict)
-        perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
         data_dict["feat"] = feat  # keep the tensors forward() will look at identical
         if src is not feat:
             data_dict["coord"] = src
+        if self._pending is not None:
+            # TWO batches ahead: a prefetched batch still waits for its forward, so this one belongs to the forward after it
+            # (`prefetch(batch k + 1); forward(batch k)`).  Its pipeline is launched BY that forward, right behind the
+            # exact-size tables of batch k on the front-end stream: it then runs under forward k — alone on the GPU and far
+            # from filling it — and is finished a whole backward pass before the host asks for its counts.  Launched after
+            # forward k (the other calling order) it shares the GPU with backward k and the host reaches the next forward
+            # ~9 ms of enqueue time later: the run-ahead of the host is then capped at "backward k minus the front-end", which
+            # the data-parallel step's extra host work exceeds (measured: the host waits 11 ms per step for the counts).
+            self._deferred = lambda: self._launch_prefetch(src, list(counts), wait_current)
+            return
+        self._launch_prefetch(src, counts, wait_current)
+
+    def _launch_prefetch(self, src, counts, wait_current):
+        perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
         self._pending = self.frontend.launch(src, counts, perms, stream=self._fe_stream, wait_current=wait_current)
 
     def forward(self, data_dict, return_dec_layers=False):
@@ -360,6 +373,9 @@ class PointTransformerV3CA(nn.Module):
         else:
             perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
             levels = self.frontend.build(src, counts, ctx_counts, perms, need_coord=True)
+        nxt, self._deferred = self._deferred, None
+        if nxt is not None:  # the batch after this one (prefetch() before this forward)
+            nxt()
         self.last_n_dup = levels[0].n_dup  # points sharing a voxel with an earlier point (0 for voxel-unique batches)
         training = self.training
         if not self._sync_bn_checked:

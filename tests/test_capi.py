@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(built):
     exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("lotus_")}
     assert set(protos) == exported, (set(protos) ^ exported)
     L = _capi.lib()
-    assert L.fn["lotus_abi_version"]() == _capi.ABI_VERSION == 2
+    assert L.fn["lotus_abi_version"]() == _capi.ABI_VERSION == 3
     assert L.last_error() == ""
 
 

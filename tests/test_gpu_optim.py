@@ -87,3 +87,58 @@ def test_ragged_multi_tensor_step_matches_oracle(clip):
             got = p.detach().cpu().numpy().ravel()
             assert np.abs(got - ref_p[i]).max() <= 2e-7 * max(1.0, np.abs(ref_p[i]).max()), (it, i)
             assert np.abs(opt.state[p]["exp_avg_sq"].cpu().numpy().ravel() - ref_v[i]).max() <= 1e-6 * max(1e-6, np.abs(ref_v[i]).max())
+
+
+def test_usage_mask_skips_what_no_rank_used_in_the_step_it_flips():
+    """lotus_adamw_step(..., used, used_idx): a tensor whose usage flag is 0 is skipped ON THE DEVICE — parameter, moments and
+    (host side, one step late) its step counter untouched — exactly like a parameter without a gradient on one GPU
+    (adamw.py:67-68).  The reducer stand-in delivers the flags to the host one step late, as parallel.GradReducer does."""
+    import robot_3dlotus_amd  # noqa: F401
+    from robot_3dlotus_amd import optim as lo
+
+    torch.manual_seed(0)
+    dev = torch.device("cuda")
+
+    def make():
+        torch.manual_seed(1)
+        return [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (5000, 37, 4096, 12)]
+
+    class FakeReducer:  # the protocol AdamW.step(reducer=...) uses
+        def __init__(self, params):
+            self.params, self.step_id, self.used_mask = params, 0, None
+            self.flat = [torch.zeros_like(p) for p in params]
+            self._late = {}
+
+        def finish(self, grads, used):
+            self.step_id += 1
+            for v, g in zip(self.flat, grads):
+                v.copy_(g)
+            self.used_mask = torch.tensor(used, dtype=torch.int32, device=dev)
+            self._late[self.step_id] = {i for i, u in enumerate(used) if not u}
+
+        def unused_of(self, k):  # flags of step k are known to the host from step k + 1 on
+            return self._late.get(k) if k < self.step_id else None
+
+        def view_of(self, p):
+            return self.flat[[id(q) for q in self.params].index(id(p))]
+
+    pa, pb = make(), make()
+    # the optimiser's parameter order differs from the reducer's (used_idx maps one onto the other)
+    oa = lo.AdamW([{"params": [pa[2], pa[0]], "weight_decay": 0.05}, {"params": [pa[3], pa[1]], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.98))
+    ob = lo.AdamW([{"params": [pb[2], pb[0]], "weight_decay": 0.05}, {"params": [pb[3], pb[1]], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.98))
+    red = FakeReducer(pa)
+    plans = [[1, 1, 1, 1], [1, 0, 1, 1], [1, 0, 0, 1], [1, 1, 1, 1], [1, 1, 0, 1]]
+    for step, used in enumerate(plans):
+        grads = [torch.randn_like(p) for p in pa]
+        red.finish([g if u else torch.zeros_like(g) for g, u in zip(grads, used)], used)
+        for p in pa:
+            p.grad = None                      # the fused step must not depend on .grad in reducer mode
+        oa.step(reducer=red)
+        for p, g, u in zip(pb, grads, used):   # one-GPU semantics: no gradient -> skipped
+            p.grad = g.clone() if u else None
+        ob.step()
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert torch.equal(x.detach(), y.detach()), (step, i)
+            assert torch.equal(oa.state[x]["exp_avg_sq"], ob.state[y]["exp_avg_sq"]), (step, i)
+    oa._usage(red)  # (what the next step would do first: retract the counters of the last step's skipped tensors)
+    assert [oa.state[p]["step"] - (1 if k == 2 else 0) for k, p in enumerate(pa)] == [ob.state[p]["step"] for p in pb] == [5, 3, 3, 5]

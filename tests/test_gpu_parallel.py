@@ -211,3 +211,69 @@ def test_one_rank_rccl_rehearsal_of_the_data_parallel_step():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["rccl_ranks"] == 1 and out["config"]["dist_backend"] == "nccl" and out["value"] > 0
+    # ... and the collectives of the step went through the library's own communicators (csrc/comm.cpp), not ProcessGroupNCCL
+    assert out["reducer"]["native_rccl_lanes"] == {"comm": True, "main": True}, out["reducer"]
+
+
+_NATIVE_SCRIPT = r"""
+import os, sys, json
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import torch, torch.distributed as dist
+import robot_3dlotus_amd
+from robot_3dlotus_amd import parallel
+os.environ["LOTUS_FORCE_COLLECTIVES"] = "1"
+parallel.init_distributed()
+dev = torch.device("cuda", 0)
+res = {}
+lane = parallel.native_comm(None, "main")
+res["lane"] = lane is not None
+if lane is not None:
+    a = torch.arange(257, dtype=torch.float64, device=dev); lane.all_reduce(a, parallel.NativeComm.SUM)
+    b = torch.full((1 << 20,), 3.0, device=dev); lane.all_reduce(b, parallel.NativeComm.AVG)
+    c = torch.tensor([0, 1, 0, 7], dtype=torch.int32, device=dev); lane.all_reduce(c, parallel.NativeComm.MAX)
+    res["answers"] = bool(torch.equal(a, torch.arange(257, dtype=torch.float64, device=dev)) and float(b.min()) == 3.0 == float(b.max())
+                          and c.tolist() == [0, 1, 0, 7])
+torch.manual_seed(0)
+net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 256), torch.nn.GELU(), torch.nn.Linear(256, 8)).to(dev)
+red = parallel.GradReducer(net, bucket_mb=0.05)
+res["lanes"] = [red._lane_comm is not None, red._lane_main is not None]
+x = torch.randn(32, 64, device=dev)
+for _ in range(3):
+    red.zero_grad()
+    net(x).square().sum().backward()
+    red.finish()
+got = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+for p in net.parameters():
+    p.grad = None
+for h in red._hook_handles:
+    h.remove()
+net(x).square().sum().backward()
+want = torch.cat([p.grad.flatten() for p in net.parameters()])
+res["grads_equal"] = bool(torch.equal(got, want))
+res["mask"] = red.used_mask.tolist() == [1] * len(red.params) and red.unused_of(red.step_id - 1) == set()
+torch.cuda.synchronize()
+print("RESULT " + json.dumps(res))
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_native_rccl_lanes_and_their_fallback(native):
+    """csrc/comm.cpp: all-reduces issued straight into the caller's stream on the library's own RCCL communicators (one-rank
+    communicators here: known answers for the three dtype / op pairs the step uses, the reducer's averaged gradients equal to the
+    plain backward pass bit for bit, the usage mask), and LOTUS_DP_NATIVE=0 -> the same results through ProcessGroupNCCL."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LOTUS_DP_NATIVE"] = native
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _NATIVE_SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res["grads_equal"] and res["mask"], res
+    if native == "1":
+        assert res["lane"] and res["answers"] and res["lanes"] == [True, True], res
+    else:
+        assert not res["lane"] and res["lanes"] == [False, False], res

@@ -227,7 +227,50 @@ def _reducer_worker(rank, world, port, q):
         okc = okc and all(torch.equal(gathered[0], t_) for t_ in gathered)
         if step == 1:
             okc = okc and float(n4.opt.weight.grad.abs().max()) > 0.0  # rank 0's contribution / world
+        # the usage mask the fused optimiser consumes (lotus_adamw_step `used`) is exact in the step the usage flips in, on
+        # every rank: 0 for the optional module while nobody runs it, 1 from the step ONE rank does
+        flags = red4.used_mask.tolist()
+        opt_idx = [red4._index[q] for q in n4.opt.parameters()]
+        okc = okc and [flags[i] for i in opt_idx] == [0 if step == 0 else 1] * 2 and sum(flags) == len(flags) - (2 if step == 0 else 0)
+        okc = okc and red4.unused_of(red4.step_id) == (set(opt_idx) if step == 0 else set())
+        okc = okc and all(torch.equal(red4.view_of(q), q.grad) for q in n4.parameters() if q.grad is not None)
     checks["conditional_usage"] = bool(okc)
+
+    # gradient accumulation while the arrival order CHANGES: step 1 runs b(a(x)) and teaches the order, step 2 runs
+    # a(b(x)) under no_sync() plus one syncing backward.  With one hook per bucket on its last-arriving parameter the bucket
+    # would be packed when `a` arrives — every `.grad` exists after the local micro-batch — with b's STALE partial sum.
+    class Net5(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = torch.nn.Linear(4, 4), torch.nn.Linear(4, 4)
+
+        def forward(self, x, flip):
+            return self.a(torch.relu(self.b(x))) if flip else self.b(torch.relu(self.a(x)))
+
+    torch.manual_seed(0)
+    n5, r5 = Net5(), Net5()
+    r5.load_state_dict(n5.state_dict())
+    red5 = parallel.GradReducer(n5, bucket_mb=10.0)   # one bucket
+    xin = lambda rr, k: torch.randn(3, 4, generator=torch.Generator().manual_seed(700 + rr + 13 * k))  # noqa: E731
+    red5.zero_grad()
+    n5(xin(rank, 0), False).square().sum().backward()
+    red5.finish()
+    red5.zero_grad()
+    sparse_before = len(red5._hook_handles) < len(red5.params)
+    with red5.no_sync():
+        n5(xin(rank, 1), True).square().sum().backward()
+    n5(xin(rank, 2), True).square().sum().backward()
+    red5.finish()
+    got5 = torch.cat([q.grad.flatten() for q in n5.parameters()])
+    acc5 = None
+    for rr in range(world):
+        r5.zero_grad()
+        for k in (1, 2):
+            r5(xin(rr, k), True).square().sum().backward()
+        v = torch.cat([q.grad.flatten() for q in r5.parameters()])
+        acc5 = v if acc5 is None else acc5 + v
+    checks["accumulation_with_a_changed_order"] = bool(sparse_before and torch.allclose(got5, acc5 / world, atol=1e-6)
+                                                       and len(red5._hook_handles) == len(red5.params))
     ok = all(checks.values())
     # SyncBN statistics hook: (sum, sumsq, count) vector is summed in place
     parallel.enable_sync_batchnorm()
@@ -392,3 +435,87 @@ def test_grad_reducer_tapers_the_tail_of_the_arrival_order():
     assert flat_order == list(reversed(red.params))   # registration order reversed until the arrival order is learnt
     for p, v in zip(flat_order, [v for vs in red._bviews for v in vs]):
         assert v.shape == p.shape and v.data_ptr() >= red.flat.data_ptr()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world 8: tapered buckets + unequal shards + a parameter whose usage flips from step to step, against the
+# gradient ONE process computes for the mean over all clouds.
+def _world8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from robot_3dlotus_amd import parallel
+
+    torch.set_num_threads(1)
+    r, _, w = parallel.init_distributed(backend="gloo")
+    counts = [5, 17, 3, 9, 12, 7, 4, 21, 6, 11, 8, 13, 2, 10, 15, 6, 9, 4, 14]      # 19 clouds over 8 ranks: shards of 3 / 2 clouds
+    g = torch.Generator().manual_seed(11)
+    clouds = [torch.randn(n, 8, generator=g) for n in counts]
+    tgts = [torch.randn(8, generator=g) for _ in counts]
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.body = torch.nn.Sequential(*[m for i in range(24) for m in (torch.nn.Linear(8, 8, bias=(i % 3 != 1)), torch.nn.Tanh())])
+            self.opt = torch.nn.Linear(8, 8)
+
+        def forward(self, x, use):
+            h = self.body(x)
+            return h + self.opt(h) if use else h
+
+    def cloud_loss(m, i, use):
+        return (m(clouds[i], use).max(0)[0] - tgts[i]).square().mean()
+
+    shards = parallel.shard_clouds(counts, w)
+    owner = {i: rr for rr, s_ in enumerate(shards) for i in s_}
+    mine = shards[r]
+    m = Net()
+    cap_mb = 72 * 4 * 6 / (1 << 20)                       # six layers per full bucket -> several buckets + a tapered tail
+    red = parallel.GradReducer(m, bucket_mb=cap_mb)
+    # who runs the optional module: nobody, rank 3 only, nobody again, everybody
+    plans = [set(), {3}, set(), set(range(w))]
+    ok, detail = True, {}
+    for step, users in enumerate(plans):
+        red.zero_grad()
+        loss = sum(cloud_loss(m, i, r in users) for i in mine) / len(mine)
+        (loss * parallel.shard_loss_scale(len(mine), len(counts), w)).backward()
+        red.finish()
+        ref = Net()
+        (sum(cloud_loss(ref, i, owner[i] in users) for i in range(len(counts))) / len(counts)).backward()
+        for (name, pr), pm in zip(ref.named_parameters(), m.parameters()):
+            if pr.grad is None:            # nobody used it: no gradient on any rank, flagged unused in THIS step
+                ok = ok and pm.grad is None and red.used_mask[red._index[pm]].item() == 0
+            else:
+                ok = ok and pm.grad is not None and red.used_mask[red._index[pm]].item() == 1
+                ok = ok and float((pm.grad - pr.grad).abs().max()) <= 1e-5 * max(1e-6, float(pr.grad.abs().max()))
+        if step == 1:                      # the layout in use after the order was learnt
+            sizes = [hi - lo for lo, hi in red.buckets]
+            detail["buckets"] = sizes
+            ok = ok and len(sizes) >= 5 and sizes[-2] < sizes[0] and not red._learning
+    q.put((rank, bool(ok), detail))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world8_gloo_tapered_buckets_unequal_shards_and_a_flipping_parameter():
+    import queue
+
+    def run(port):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_world8_worker, args=(r, 8, port, q)) for r in range(8)]
+        for p in ps:
+            p.start()
+        try:
+            res = [q.get(timeout=240) for _ in ps]
+        except queue.Empty:
+            res = None
+        for p in ps:
+            p.join(timeout=5 if res is None else 60)
+            if p.is_alive():
+                p.kill()
+        return res
+
+    res = run(31500 + (os.getpid() % 2000)) or run(35500 + (os.getpid() % 2000))
+    assert res is not None, "gloo workers did not finish"
+    assert all(r[1] for r in res), res
