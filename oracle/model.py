@@ -289,7 +289,10 @@ class Oracle:
     def head(self, x, counts, batch, out, compute_loss):
         """ActionHead.forward (heatmap_disc / max / euler_disc), simple_policy_ptv3.py:113-157, and
         compute_loss, :308-373."""
-        h = self.q(F.leaky_relu(self.lin(x, "act_proj_head.heatmap_mlp.0"), 0.02))
+        pre = self.lin(x, "act_proj_head.heatmap_mlp.0")
+        if self.record_arg:  # the sign pattern LeakyReLU routes the gradient by (a discrete decision, like the arg-max tables)
+            out["leaky_pre"] = pre.detach()
+        h = self.q(F.leaky_relu(pre, 0.02))
         xt = self.lin(h, "act_proj_head.heatmap_mlp.3")  # (N, 3*2*pos_bins)
         nb = xt.shape[1] // 3
         xt = xt.view(-1, 3, nb).permute(1, 0, 2)  # 'n (c b) -> c n b'

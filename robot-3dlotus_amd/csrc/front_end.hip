@@ -570,7 +570,7 @@ size_t lotus_fe_neighbours_workspace(int n) {
 // gathered rows of consecutive pairs are close in memory): in[t * n64 + q] = neighbour row of the q-th such row,
 // pos[t * n + i] = t * n64 + q (or -1), cnt[t] = their number; in[] is padded with row 0 up to the next multiple of 64 so that
 // a 64-row tile of the grouped product only ever gathers valid rows.  Fixed order -> deterministic.
-__global__ __launch_bounds__(1024) void fe_tap_plan_kernel(const int* __restrict__ nbr, const int* __restrict__ rowidx, int n,
+static __global__ __launch_bounds__(1024) void fe_tap_plan_kernel(const int* __restrict__ nbr, const int* __restrict__ rowidx, int n,
                                                            int n64, int* __restrict__ plan) {
   __shared__ int wsum[16];
   __shared__ int base_s;

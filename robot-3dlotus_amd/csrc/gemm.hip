@@ -507,30 +507,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const T* __restrict__ part, T* __restrict__ out, long n,
                                                            long stride, int nz, int accumulate) {
-  __shared__ float4 red[16][16];
+  // The partials are summed in DOUBLE (fixed order; one rounding at the end): the kernel is bound by its loads, and the sum over
+  // the splits of a 65 536-row weight gradient is where its fp32 error used to come from — the head's first layer, whose
+  // per-row terms cancel (softmax - target sums to zero per cloud), sat at 7.6e-5 of the full-size oracle test's 1e-4 bar.
+  __shared__ double red[16][16][4];
   const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const long e = ((long)blockIdx.x * 16 + q) * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
   if (e + 3 < n) {
     for (int z = zl; z < nz; z += 16) {
       const float4 v = ld4(part + (long)z * stride + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
     }
   } else if (e < n) {
-    float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int z = zl; z < nz; z += 16)
-      for (int k = 0; k < 4 && e + k < n; ++k) t[k] += ld1(part + (long)z * stride + e + k);
-    s = make_float4(t[0], t[1], t[2], t[3]);
+      for (int k = 0; k < 4 && e + k < n; ++k) s[k] += (double)ld1(part + (long)z * stride + e + k);
   }
-  red[zl][q] = s;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) red[zl][q][k] = s[k];
   __syncthreads();
   if (zl == 0 && e < n) {
-    float4 t = red[0][q];
+    double t[4] = {red[0][q][0], red[0][q][1], red[0][q][2], red[0][q][3]};
     for (int k = 1; k < 16; ++k) {
-      t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w;
+      t[0] += red[k][q][0]; t[1] += red[k][q][1]; t[2] += red[k][q][2]; t[3] += red[k][q][3];
     }
-    const float tv[4] = {t.x, t.y, t.z, t.w};
-    for (int k = 0; k < 4 && e + k < n; ++k) st1(out + e + k, accumulate ? ld1(out + e + k) + tv[k] : tv[k]);
+    for (int k = 0; k < 4 && e + k < n; ++k) st1(out + e + k, accumulate ? (float)((double)ld1(out + e + k) + t[k]) : (float)t[k]);
   }
 }
 

@@ -165,11 +165,21 @@ __global__ void cloud_max_bwd_kernel(const act_t* __restrict__ dy, const int* __
 // Position: per cloud b and axis c, soft-target cross entropy over all (point, bin) logits.
 // xt[n][3*nb] logits (n, c, bin); tgt: cloud b at tgt_off = 3*nb*off[b], laid out [3][n_b*nb].
 #define POS_CE_SPLITS 32
-// slice s of cloud b, axis c: partial (max, sum exp(x - max), sum t x, sum t) of the heatmap cross-entropy
+#define POS_CE_PART 8  // floats per slice partial: max, -, then (sum exp(x - max), sum t x, sum t) as doubles
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// slice s of cloud b, axis c: partial (max, sum exp(x - max), sum t x, sum t) of the heatmap cross-entropy.  The three sums are
+// carried in DOUBLE up to the log-sum-exp: every probability of the (cloud, axis) is exp(x - lse), so an error of lse is a
+// COMMON relative error of ~65 000 x 30 gradient entries that does not average out in the weight gradients behind them — with
+// lse ~ 12 in fp32 that was 1e-6, and the head's first layer sat at 7.6e-5 of the float64 oracle (the fp32 reference: 1.7e-4).
 __global__ __launch_bounds__(256) void pos_ce_part_kernel(const act_t* __restrict__ xt, const float* __restrict__ tgt,
                                                           const int* __restrict__ off, int nb,
-                                                          float* __restrict__ part /*[B*3][SPLITS][4]*/) {
+                                                          float* __restrict__ part /*[B*3][SPLITS][POS_CE_PART]*/) {
   __shared__ float red[4];
+  __shared__ double redd[4];
   const int s = blockIdx.x, bc = blockIdx.y, b = bc / 3, c = bc % 3;
   const int n0 = off[b], nn = off[b + 1] - n0;
   const int p0 = (int)((long)nn * s / POS_CE_SPLITS), p1 = (int)((long)nn * (s + 1) / POS_CE_SPLITS);
@@ -185,49 +195,52 @@ __global__ __launch_bounds__(256) void pos_ce_part_kernel(const act_t* __restric
   __syncthreads();
   m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   __syncthreads();
-  double se = 0, stx = 0, st = 0;
+  double v[3] = {0.0, 0.0, 0.0};
   for (int p = p0 + g; p < p1; p += 8)
     for (int j = j0; j < nb; j += 32) {
       const float x = xb[(long)p * (3 * nb) + j], t = tb[(long)p * nb + j];
-      se += expf(x - m);
-      stx += (double)t * x;
-      st += t;
+      v[0] += exp((double)x - (double)m);
+      v[1] += (double)t * x;
+      v[2] += t;
     }
-  float v[3] = {(float)se, (float)stx, (float)st};
-  float tot[3];
+  double tot[3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const float w = wave_sum(v[k]);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+    const double w = wave_sum_d(v[k]);
+    if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = w;
     __syncthreads();
-    tot[k] = ((red[0] + red[1]) + red[2]) + red[3];
+    tot[k] = ((redd[0] + redd[1]) + redd[2]) + redd[3];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    float* o = part + ((long)bc * POS_CE_SPLITS + s) * 4;
-    o[0] = m; o[1] = tot[0]; o[2] = tot[1]; o[3] = tot[2];
+    float* o = part + ((long)bc * POS_CE_SPLITS + s) * POS_CE_PART;
+    o[0] = m; o[1] = 0.f;
+    double* od = reinterpret_cast<double*>(o + 2);
+    od[0] = tot[0]; od[1] = tot[1]; od[2] = tot[2];
   }
 }
 
-// fixed-order merge of the slices: stats[bc] = (loss, lse, tsum, -)
+// fixed-order merge of the slices: stats[bc] = (loss, lse, tsum, lse - (float)lse): backward rebuilds the double lse from [1] + [3]
 __global__ __launch_bounds__(64) void pos_ce_merge_kernel(const float* __restrict__ part, float* __restrict__ stats) {
   const int bc = blockIdx.x, s = threadIdx.x;
-  float m = -INFINITY, se = 0.f, stx = 0.f, st = 0.f;
+  float m = -INFINITY;
+  double se = 0.0, stx = 0.0, st = 0.0;
   if (s < POS_CE_SPLITS) {
-    const float* o = part + ((long)bc * POS_CE_SPLITS + s) * 4;
-    m = o[0]; se = o[1]; stx = o[2]; st = o[3];
+    const float* o = part + ((long)bc * POS_CE_SPLITS + s) * POS_CE_PART;
+    const double* od = reinterpret_cast<const double*>(o + 2);
+    m = o[0]; se = od[0]; stx = od[1]; st = od[2];
   }
   const float M = wave_max(m);
-  se = wave_sum(m > -INFINITY ? se * expf(m - M) : 0.f);
-  stx = wave_sum(stx);
-  st = wave_sum(st);
+  se = wave_sum_d(m > -INFINITY ? se * exp((double)m - (double)M) : 0.0);
+  stx = wave_sum_d(stx);
+  st = wave_sum_d(st);
   if (s == 0) {
-    const float lse = M + logf(se);
+    const double lse = (double)M + log(se);
     float* o = stats + (long)bc * 4;
-    o[0] = lse * st - stx;
-    o[1] = lse;
-    o[2] = st;
-    o[3] = 0.f;
+    o[0] = (float)(lse * st - stx);
+    o[1] = (float)lse;
+    o[2] = (float)st;
+    o[3] = (float)(lse - (double)o[1]);
   }
 }
 
@@ -292,7 +305,7 @@ __global__ void pos_ce_bwd_kernel(const act_t* __restrict__ xt, const float* __r
   const float t = tgt[(long)3 * nb * n0 + (long)c * nn * nb + (long)(p - n0) * nb + bin];
   const float* s = stats + (long)(b * 3 + c) * 4;
   const float coef = (gl[0] + pos_w * gl[3]) / (3.f * B);
-  dxt[gid] = coef * (expf(xt[gid] - s[1]) * s[2] - t);
+  dxt[gid] = (float)((double)coef * (exp((double)xt[gid] - ((double)s[1] + (double)s[3])) * (double)s[2] - (double)t));
 }
 
 // per-(cloud, axis) upstream gradients g[B*3] (trajectory heads weight each cloud by its step mask,
@@ -309,7 +322,7 @@ __global__ void pos_ce_bwd_w_kernel(const act_t* __restrict__ xt, const float* _
   const int n0 = off[b], nn = off[b + 1] - n0;
   const float t = tgt[(long)3 * nb * n0 + (long)c * nn * nb + (long)(p - n0) * nb + bin];
   const float* s = stats + (long)(b * 3 + c) * 4;
-  dxt[gid] = g[b * 3 + c] * (expf(xt[gid] - s[1]) * s[2] - t);
+  dxt[gid] = (float)((double)g[b * 3 + c] * (exp((double)xt[gid] - ((double)s[1] + (double)s[3])) * (double)s[2] - (double)t));
 }
 
 // dae_out = dae_saved * (upstream weight of its column): rot columns g[1] + rot_w * g[3], open column g[2] + g[3]
@@ -701,7 +714,7 @@ int lotus_cloud_max_bwd(const act_t* dy, const int* arg, const int* batch, int n
 }
 
 // floats the caller must provide as pos_stats: [B*3][4] statistics + the slice partials behind them
-size_t lotus_loss_stats_floats(int B) { return (size_t)B * 3 * 4 * (1 + POS_CE_SPLITS); }
+size_t lotus_loss_stats_floats(int B) { return (size_t)B * 3 * (4 + POS_CE_PART * POS_CE_SPLITS); }
 
 // losses[4] = (pos, rot, open, total); pos_stats (lotus_loss_stats_floats(B) floats; the leading [B*3][4] are
 // what backward reads) and dae [B][nrot*3+1] are saved for backward.

@@ -747,6 +747,9 @@ def add(a, b):
 
 # Test-only taps of the two arg-max tables of the model (SerializedPooling's segment max, model.py:760-765, and the head's
 # per-cloud max, simple_policy_ptv3.py:117-119).  ARG_TAP: a list that receives (kind, int32 table) in forward order.
+# A third routing decision of the same kind ("leaky"): the sign pattern of the head's LeakyReLU(0.02) pre-activation
+# (simple_policy_ptv3.py:42,113-115) — a pre-activation within rounding of zero gets slope 1 in one arithmetic and 0.02 in the
+# other; the tap / injection is the saved pre-activation tensor itself (only its signs matter to backward).
 # ARG_INJECT: a list of int32 tables consumed in the same order — the backward pass then routes the gradient of every
 # (segment, channel) to the row the INJECTED table names while the forward values stay the kernel's own.  This is how
 # tests/test_gpu_fullsize_oracle.py separates "a near-tie was broken the other way" (a discrete re-routing both fp32
@@ -761,7 +764,7 @@ def _arg_hook(kind, arg):
     if ARG_INJECT:
         k2, inj = ARG_INJECT.pop(0)
         assert k2 == kind and tuple(inj.shape) == tuple(arg.shape), (k2, kind, tuple(inj.shape), tuple(arg.shape))
-        return inj.to(device=arg.device, dtype=torch.int32).contiguous()
+        return inj.to(device=arg.device, dtype=arg.dtype).contiguous()
     return arg
 
 
@@ -1757,6 +1760,8 @@ class HeadLossFn(torch.autograd.Function):
         B = len(lvl.counts)
         h, hpre = linear_fwd(x, hw0, hb0, act=ACT_LEAKY, save_pre=True, drop_p=drop_p, seed=seed)
         xt, _ = linear_fwd(h, hw3, hb3)
+        if ARG_TAP is not None or ARG_INJECT:
+            hpre = _arg_hook("leaky", hpre)
         pc = torch.empty(B, C, dtype=x.dtype, device=dev)
         arg = torch.empty(B, C, dtype=torch.int32, device=dev)
         ws = _ws(query("lotus_cloud_max_workspace", B, C), x.device)

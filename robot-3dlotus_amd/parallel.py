@@ -103,23 +103,10 @@ class NativeComm:
     def all_reduce(self, t, op):
         """In place, on the current stream (ops honour _capi.STREAM_OVERRIDE like every other launch)."""
         from . import _capi
-        if _LANE_DIAG is not None:  # (diagnostic: host time spent inside the calls)
-            import time
-            t0 = time.perf_counter()
-            _capi.call("lotus_comm_allreduce", self.handle, t, t.numel(), self._DT[t.dtype], op)
-            d = _LANE_DIAG.setdefault((t.numel(), op), [0, 0.0, 0.0])
-            dt = time.perf_counter() - t0
-            d[0] += 1; d[1] += dt; d[2] = max(d[2], dt)
-            return
         _capi.call("lotus_comm_allreduce", self.handle, t, t.numel(), self._DT[t.dtype], op)
 
 
 _LANES = {}
-_LANE_DIAG = {} if os.environ.get("LOTUS_DIAG_LANE_TIMING") == "1" else None
-if _LANE_DIAG is not None:
-    import atexit
-    import sys as _sys
-    atexit.register(lambda: print("lane timing (numel, op): calls, total s, max s", _LANE_DIAG, file=_sys.stderr))
 
 
 def native_comm(group, lane):
@@ -133,7 +120,7 @@ def native_comm(group, lane):
         return _LANES[key]
     c = None
     if (dist.is_initialized() and dist.get_backend(group) == "nccl" and torch.cuda.is_available()
-            and os.environ.get("LOTUS_DP_NATIVE", "1") != "0" and lane in os.environ.get("LOTUS_DP_LANES", "main,comm").split(",")):
+            and os.environ.get("LOTUS_DP_NATIVE", "1") != "0"):
         err = None
         try:
             c = NativeComm(group)

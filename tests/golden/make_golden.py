@@ -57,7 +57,7 @@ def zero_dropouts(model):
             m.attn_drop = 0.0
 
 
-def run_case(name, spec):
+def run_case(name, spec, out_dir=HERE):
     variant, B, n, ragged, dseed, wseed, wvar, train = spec[:8]
     drop_path = spec[8] if len(spec) > 8 else 0.0
     torch.manual_seed(0)
@@ -135,7 +135,7 @@ def run_case(name, spec):
     hh.remove()
     for k in ("xt", "xr", "xo"):
         out["fp16_gap_" + k] = np.float32((head16[k] - head[k]).abs().max().item())
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **out)
     gaps = {k: float(out["fp16_gap_" + k]) for k in ("xt", "xr", "xo")}
     print(f"{name}: {os.path.getsize(path) / 1e6:.2f} MB  losses="

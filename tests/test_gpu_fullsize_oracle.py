@@ -36,6 +36,7 @@ PERMS = [[1, 3, 0, 2], [0, 1, 2, 3], [3, 2, 1, 0], [2, 0, 3, 1], [1, 0, 2, 3]]
 # next to the float32 oracle's.  Defects of the size these bars could hide (a dropped 0.1 % term) are caught where ties are
 # rare: the fixtures and the live-oracle tests compare every whole gradient at 1e-4 (measured 5e-6 ... 1.4e-5) at 1-2 k points.
 GRAD_TOL = 1e-4
+GRAD_TOL_ROUTED = 2e-5  # every gradient once ALL discrete routing decisions are the yardstick's (measured: 5.0e-6 ... 7.2e-6)
 GRAD_FLOOR = 1e-3
 GRAD_MAX_TOL = 5e-3
 GRAD_MEDIAN_TOL = 2e-5
@@ -99,10 +100,14 @@ def _run(variant, augment, seed, tag):
     finally:
         tap, ops.ARG_TAP = ops.ARG_TAP, None
     # the arg-max tables: the four SerializedPooling levels (model.py:760-765) in encoder order, then the head's cloud max
-    ref_args = [("pool", a) for a in out["pool_arg"]] + [("cloud", out["cloud_arg"])]
+    # ... and, between them, the sign pattern of the head's LeakyReLU pre-activation: a third discrete routing decision
+    ref_args = [("pool", a) for a in out["pool_arg"]] + [("leaky", out["leaky_pre"])] + [("cloud", out["cloud_arg"])]
     assert [k for k, _ in tap] == [k for k, _ in ref_args]
     argdiff = []
     for (kind, a), (_, r) in zip(tap, ref_args):
+        if kind == "leaky":
+            argdiff.append(dict(kind=kind, pairs=int(a.numel()), differ=int(((a.cpu() > 0) != (r > 0)).sum())))
+            continue
         a = a.cpu().long()
         argdiff.append(dict(kind=kind, pairs=int(a.numel()), differ=int((a != r).sum())))
     if augment:
@@ -157,7 +162,7 @@ def _run(variant, augment, seed, tag):
     # gradient has to meet the 1e-4 bar — at the shapes only this test reaches (65 536 rows, split-K, tap-split).
     for p_ in m.parameters():
         p_.grad = None
-    ops.ARG_INJECT = [(k, r.to(torch.int32)) for k, r in ref_args]
+    ops.ARG_INJECT = [(k, r.to(torch.float32 if k == "leaky" else torch.int32)) for k, r in ref_args]
     try:
         _, losses2 = m(_dev_batch(batch), compute_loss=True, compute_final_action=False)
         assert not ops.ARG_INJECT, "not every injected table was consumed"
@@ -170,10 +175,13 @@ def _run(variant, augment, seed, tag):
         inj.append((float((p_.grad.cpu().double() - r).norm()) / (float(r.norm()) + GRAD_FLOOR * gmax), name))
     inj.sort(reverse=True)
     rec["injected_argmax"] = dict(grad_rel_err_max=inj[0][0], grad_rel_err_argmax=inj[0][1], grad_rel_err_median=float(np.median([t[0] for t in inj])),
-                                  n_gradients_above_1e_4=sum(1 for t in inj if t[0] > GRAD_TOL), worst5=[dict(name=t[1], rel=float("%.3g" % t[0])) for t in inj[:5]])
+                                  n_gradients_above_1e_4=sum(1 for t in inj if t[0] > GRAD_TOL), bar=GRAD_TOL_ROUTED, worst5=[dict(name=t[1], rel=float("%.3g" % t[0])) for t in inj[:5]])
+    # Round 6: with the arg-max tables alone the worst gradient was 7.6e-5 (act_proj_head.heatmap_mlp.0.weight, init weights; the
+    # float32 oracle: 1.7e-4) — three of the 8.4 M LeakyReLU pre-activations of the head have the other sign in fp32, i.e. slope
+    # 1 instead of 0.02.  With that sign pattern injected as well, every gradient of every case is within 7.2e-6.
     for rel, name in inj:
-        if rel > GRAD_TOL:
-            fails.append(f"grad {name} with the oracle's arg-max injected: rel {rel:.2e} > {GRAD_TOL}")
+        if rel > GRAD_TOL_ROUTED:
+            fails.append(f"grad {name} with the oracle's routing (arg-max tables + LeakyReLU signs) injected: rel {rel:.2e} > {GRAD_TOL_ROUTED}")
     ledger.record("fullsize_oracle/" + tag, **rec)
     assert not fails, "; ".join(fails[:8])
 

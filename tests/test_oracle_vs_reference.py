@@ -92,3 +92,22 @@ def test_state_template_matches_reference_layout():
             assert tuple(t[k].shape) == tuple(rsd[k].shape), k
         if variant == "v1":
             assert len(t) == 460
+
+
+def test_committed_fixture_equals_what_the_generator_writes(tmp_path):
+    """The committed fixtures ARE the generator's output: regenerate one case from the imported reference
+    and compare every key bit for bit (the 512-point case: its reductions are below the size where the thread count changes the summation order)."""
+    import os
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+
+    mg.run_case("tiny_scaled_train", mg.CASES["tiny_scaled_train"], out_dir=str(tmp_path))
+    new = np.load(os.path.join(str(tmp_path), "tiny_scaled_train.npz"))
+    old = np.load(os.path.join(mg.HERE, "tiny_scaled_train.npz"))
+    assert set(new.files) == set(old.files)
+    diff = [k for k in new.files if not np.array_equal(new[k], old[k])]
+    assert not diff, diff[:10]
