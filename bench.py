@@ -295,7 +295,12 @@ def main():
     ops.set_wgrad_join("end")
     ops.set_gemm_precision(args.gemm_precision)
 
-    PREFETCH_LATE = os.environ.get("LOTUS_BENCH_PREFETCH_LATE") == "1"
+    # When is the NEXT batch announced?  Before this step's forward ("early": its integer front-end runs under the forward) when
+    # the step is data parallel — the host then runs a whole step ahead, which the reducer's extra host work needs — and always
+    # for NEW host batches (the side measurement below: +18 %); after the forward ("late": under the backward pass, the round-5
+    # order) for the single-GPU step on a resident batch, where it measures 0.6 % faster.  LOTUS_BENCH_PREFETCH_LATE=0|1 forces one.
+    _pl = os.environ.get("LOTUS_BENCH_PREFETCH_LATE")
+    PREFETCH_LATE = (reducer is None) if _pl is None else (_pl == "1")
     host_t = [0.0, 0.0, 0.0, 0]  # host seconds inside forward / backward / finish of the steps (enqueue time, no synchronisation)
 
     def step():
@@ -471,6 +476,7 @@ def main():
         hb = [host(i) for i in range(nfresh + nwarm)]
         npts = sum(sum(b["npoints_in_batch"]) for b in hb[nwarm:])
         torch.cuda.synchronize()
+        model.ptv3_model.drop_prefetch()  # (the resident batch announced by the last timed step)
         model.prefetch(hb[0])
         for i in range(nfresh + nwarm):
             if i == nwarm:
@@ -483,10 +489,10 @@ def main():
             else:
                 for p_ in params:
                     p_.grad = None
-            if i + 1 < nfresh + nwarm and not PREFETCH_LATE:
+            if i + 1 < nfresh + nwarm and _pl != "1":
                 model.prefetch(hb[i + 1])
             _, losses = model(hb[i], compute_loss=True, compute_final_action=False)
-            if i + 1 < nfresh + nwarm and PREFETCH_LATE:
+            if i + 1 < nfresh + nwarm and _pl == "1":
                 model.prefetch(hb[i + 1])
             losses["total"].backward()
             if reducer is not None:

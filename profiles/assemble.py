@@ -36,14 +36,15 @@ for key, fl in flags.items():
         continue
     if key == "headline":
         rec = {"flags": fl}
-        for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks", "opt_in_modes", "with_optimizer", "fresh_batches", "cpu_baseline", "roofline", "counters"):
+        for k in ("value", "unit", "ms_per_step", "n_gpus", "rccl_ranks", "host_ms_per_step", "opt_in_modes", "with_optimizer", "fresh_batches", "cpu_baseline", "roofline", "counters"):
             if k in d:
                 rec[k] = d[k]
     else:
         rec = {"flags": fl, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "n_gpus": d["n_gpus"],
                "rccl_ranks": d.get("rccl_ranks")}
-        if "opt_in_modes" in d:
-            rec["opt_in_modes"] = d["opt_in_modes"]
+        for k in ("opt_in_modes", "host_ms_per_step", "comm", "reducer"):
+            if k in d:
+                rec[k] = d[k]
     out[key] = rec
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w"), indent=1)
 print(json.dumps({k: (v.get("value") if isinstance(v, dict) else v) for k, v in out.items()}, indent=1))

@@ -357,6 +357,10 @@ class PointTransformerV3CA(nn.Module):
             return
         self._launch_prefetch(src, counts, wait_current)
 
+    def drop_prefetch(self):
+        """Forget a prefetched (or announced) batch that will not be passed to forward() after all."""
+        self._pending, self._deferred = None, None
+
     def _launch_prefetch(self, src, counts, wait_current):
         perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
         self._pending = self.frontend.launch(src, counts, perms, stream=self._fe_stream, wait_current=wait_current)
