@@ -558,7 +558,9 @@ def main():
                               "points_rank0": int(sum(host_batch["npoints_in_batch"])),
                               # collectives issued through the library's own RCCL communicators (csrc/comm.cpp): "comm" = gradient
                               # buckets on the communication stream, "main" = SyncBN statistics + usage flags in the training stream
-                              "native_rccl_lanes": {"comm": reducer._lane_comm is not None, "main": reducer._lane_main is not None}}
+                              "native_rccl_lanes": {"comm": reducer._lane_comm is not None, "main": reducer._lane_main is not None},
+                              # gradients written by their backward node straight into the bucket buffer (no pack copy)
+                              "gradient_fraction_born_in_bucket": round(reducer.inplace_floats / max(1, reducer.inplace_floats + reducer.copied_floats), 4)}
         if peract:
             out["metric"] = "keystep-samples/sec (train fwd+bwd) 3D-LOTUS RLBench-18task (PerAct) config"
             out["config"]["workload"] = (f"3D-LOTUS v1 network, PerAct preset (BASELINE configs[4]), {args.batch} dense clouds x {args.npoints} pts "

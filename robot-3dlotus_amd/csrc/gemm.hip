@@ -507,31 +507,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
 template <typename T>
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const T* __restrict__ part, T* __restrict__ out, long n,
                                                            long stride, int nz, int accumulate) {
-  // The partials are summed in DOUBLE (fixed order; one rounding at the end): the kernel is bound by its loads, and the sum over
-  // the splits of a 65 536-row weight gradient is where its fp32 error used to come from — the head's first layer, whose
-  // per-row terms cancel (softmax - target sums to zero per cloud), sat at 7.6e-5 of the full-size oracle test's 1e-4 bar.
-  __shared__ double red[16][16][4];
+  // (round 6 measured double accumulation here: +0.27 ms per step on the weight-gradient queue and no change of any gradient
+  // error at full size — the 7.6e-5 it was meant to shrink came from three LeakyReLU sign flips, DESIGN.md section 2: reverted)
+  __shared__ float4 red[16][16];
   const int q = threadIdx.x & 15, zl = threadIdx.x >> 4;
   const long e = ((long)blockIdx.x * 16 + q) * 4;
-  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e + 3 < n) {
     for (int z = zl; z < nz; z += 16) {
       const float4 v = ld4(part + (long)z * stride + e);
-      s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   } else if (e < n) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
     for (int z = zl; z < nz; z += 16)
-      for (int k = 0; k < 4 && e + k < n; ++k) s[k] += (double)ld1(part + (long)z * stride + e + k);
+      for (int k = 0; k < 4 && e + k < n; ++k) t[k] += ld1(part + (long)z * stride + e + k);
+    s = make_float4(t[0], t[1], t[2], t[3]);
   }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) red[zl][q][k] = s[k];
+  red[zl][q] = s;
   __syncthreads();
   if (zl == 0 && e < n) {
-    double t[4] = {red[0][q][0], red[0][q][1], red[0][q][2], red[0][q][3]};
+    float4 t = red[0][q];
     for (int k = 1; k < 16; ++k) {
-      t[0] += red[k][q][0]; t[1] += red[k][q][1]; t[2] += red[k][q][2]; t[3] += red[k][q][3];
+      t.x += red[k][q].x; t.y += red[k][q].y; t.z += red[k][q].z; t.w += red[k][q].w;
     }
-    for (int k = 0; k < 4 && e + k < n; ++k) st1(out + e + k, accumulate ? (float)((double)ld1(out + e + k) + t[k]) : (float)t[k]);
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    for (int k = 0; k < 4 && e + k < n; ++k) st1(out + e + k, accumulate ? ld1(out + e + k) + tv[k] : tv[k]);
   }
 }
 

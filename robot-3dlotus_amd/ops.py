@@ -404,6 +404,20 @@ class WeightShadows:
             p._lotus_b16_ptr = p.data_ptr()
 
 
+# Weight-gradient slabs of a backward node (the flat fp32 buffer its parameter gradients are views of).  A data-parallel reducer
+# can own that memory: GRAD_ARENA(n_floats, device) -> a slice of its bucket buffer (or None), so that the gradients are born where
+# the all-reduce reads them and the bucket flush has nothing to pack (parallel.GradReducer._arena).
+GRAD_ARENA = None
+
+
+def _grad_slab(n, dev):
+    if GRAD_ARENA is not None:
+        t = GRAD_ARENA(int(n), dev)
+        if t is not None:
+            return t
+    return torch.empty(int(n), dtype=torch.float32, device=dev)
+
+
 def _empty_like_rows(x, cols):
     return torch.empty(x.shape[0], cols, dtype=x.dtype, device=x.device)
 
@@ -453,7 +467,7 @@ def linear_wgrad(dy, x, need_bias=True, prec=None, into=None):
     M, N = dy.shape
     K = x.shape[1]
     if into is None:
-        buf = torch.empty(N * K + (N if need_bias else 0), dtype=torch.float32, device=dy.device)
+        buf = _grad_slab(N * K + (N if need_bias else 0), dy.device)
         dw = buf[:N * K].view(N, K)              # one contiguous gradient slab -> a single split-K reduce launch
         db = buf[N * K:] if need_bias else None
     else:
@@ -645,7 +659,7 @@ def conv_wgrad(dy, x, w_shape, nbr, need_bias=True, prec=None, side=True):
     n, cout = dy.shape
     cin, T = x.shape[1], nbr.shape[0]
     nw = cout * T * cin
-    buf = torch.empty(nw + (cout if need_bias else 0), dtype=torch.float32, device=dy.device)
+    buf = _grad_slab(nw + (cout if need_bias else 0), dy.device)
     dw = buf[:nw].view(w_shape)
     db = buf[nw:] if need_bias else None
     nbytes = query("lotus_subm_conv_wgrad_workspace", n, T, cin, cout)
@@ -1045,7 +1059,7 @@ class CpeFn(torch.autograd.Function):
             n_, C = xs.shape
             dev = xs.device
             _, n_grads, n_tmp, ws_main, ws_side, ws_conv = _sizes("cpe", n_, C)
-            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            grads = _grad_slab(n_grads, dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dxc = torch.empty_like(xs)
             side, wss, cs = _side_ctx(dev, ws_side, (saved, tmp, xs, lvl.nbr27), n_)
@@ -1122,7 +1136,7 @@ class FfnFn(torch.autograd.Function):
             M, C = x.shape
             Hd, dev = w1.shape[0], x.device
             _, n_grads, n_tmp, ws_main, ws_side = _sizes("ffn", M, C, Hd)
-            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            grads = _grad_slab(n_grads, dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dx = torch.empty_like(x)
             dz_in = hand_in.take(dy) if hand_in is not None else None
@@ -1201,7 +1215,7 @@ class SelfAttnFn(torch.autograd.Function):
             N, C = x.shape
             dev = x.device
             _, n_grads, n_tmp, ws_main, ws_side = _sizes("self", N, C, H, lvl.npad, lvl.n_self_tiles, lvl.n_extra)
-            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            grads = _grad_slab(n_grads, dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dx = torch.empty_like(x)
             dz_in = ctx.hand_in.take(dy) if ctx.hand_in is not None else None
@@ -1287,7 +1301,7 @@ class CrossAttnFn(torch.autograd.Function):
             L, Cc = context.shape
             dev, G = x.device, lvl.ca_groups
             _, n_grads, n_tmp, ws_main, ws_side = _sizes("cross", N, C, H, L, Cc, lvl.n_ca_blocks, G)
-            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            grads = _grad_slab(n_grads, dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dx = torch.empty_like(x)
             dctx = torch.empty_like(context) if ctx.needs_input_grad[1] else None
@@ -1441,7 +1455,7 @@ class CrossAttnKvFn(torch.autograd.Function):
             N, C = x.shape
             L, dev, G = kv.shape[0], x.device, lvl.ca_groups
             _, n_grads, n_tmp, ws_main, ws_side = _sizes("crosskv", N, C, H, L, lvl.n_ca_blocks, G)
-            grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+            grads = _grad_slab(n_grads, dev)
             tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
             dx = torch.empty_like(x)
             dz_in = hand_in.take(dy) if hand_in is not None else None
@@ -1614,7 +1628,7 @@ class PairFn(torch.autograd.Function):
         dy = dy.contiguous()
         _, _, n_grads, n_tmp, ws_main, ws_side, ws_conv = _sizes(
             "pair", M, C, H, Hd, lvl.npad, lvl.n_self_tiles, lvl.n_extra, L, lvl_ca.n_ca_blocks, lvl_ca.ca_groups)
-        grads = torch.empty(n_grads, dtype=torch.float32, device=dev)
+        grads = _grad_slab(n_grads, dev)
         tmp = torch.empty(n_tmp, dtype=torch.float32, device=dev)
         dx = torch.empty_like(dy)
         dxs = None if same else torch.empty_like(xs)

@@ -166,10 +166,12 @@ class GradReducer:
         if broadcast and (self.world > 1 or self._force):
             for t in list(module.parameters()) + list(module.buffers()):
                 dist.broadcast(t.data, 0, group=group)
-        dev, total = self.params[0].device, sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        dev = self.params[0].device
+        self.flat = None
         self._cap = int(bucket_mb * (1 << 20) / 4)
         self._layout(list(reversed(self.params)), [])
+        # gradient slabs of the backward nodes (ops.GRAD_ARENA): recorded in the learning pass, served from the flat buffer after it
+        self._slab_rec, self._slab_seq, self._slab_i, self._pslab, self._arena_off = [], None, 0, {}, dev.type != "cuda"
         self._handles = []
         self.exposed_events = []
         self._avg = (self.world > 1 or self._force) and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
@@ -198,10 +200,31 @@ class GradReducer:
             p.grad = None
             self._hook_handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
-    def _layout(self, order, cold):
-        """Contiguous buckets of >= cap elements over `order`, then one bucket with the `cold` parameters; every
-        parameter gets a view into the flat buffer."""
+    def _layout(self, order, cold, slabs=None):
+        """Contiguous buckets of >= cap elements over `order`, then one bucket with the `cold` parameters; every parameter
+        gets a view into the flat buffer.  slabs = (sizes, where): the gradient slabs of the backward nodes learnt in the first
+        pass — where[p] = (slab, offset in floats) for a parameter whose gradient is a view of slab number `slab`.  A slab is
+        laid out WHOLE (its node's own layout, 256-byte aligned) at the place of its first-arriving parameter, so that the node
+        can be handed that slice as its output buffer (_arena) and its gradients need no pack copy."""
+        import numpy as np
+        sizes_, where = slabs if slabs else ([], {})
+        # layout units in arrival order: ("slab", id, floats, params) or ("param", p, floats, [p])
+        units, seen_slab = [], {}
+        for p in order:
+            w = where.get(p)
+            if w is None:
+                units.append(["param", p, p.numel(), [p]])
+            elif w[0] in seen_slab:
+                seen_slab[w[0]][3].append(p)
+            else:
+                u = ["slab", w[0], (sizes_[w[0]] + 63) // 64 * 64, [p]]
+                seen_slab[w[0]] = u
+                units.append(u)
+        total = sum(u[2] for u in units) + sum(p.numel() for p in cold)
+        if slabs is not None or getattr(self, "flat", None) is None or self.flat.numel() != total:
+            self.flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
         self.buckets, self._bparams, self._bviews, self._slot = [], [], [], {}
+        self._slab_at = {}
         state = dict(p=[], v=[], n=0, offset=0, start=0)
 
         def close():
@@ -215,38 +238,65 @@ class GradReducer:
         # backward ends), so the order's tail is cut into buckets of <= cap/32, cap/8 and cap/2 elements (1 / 4 / 16 MB at
         # the default 32 MB) counted from the end; everything before them follows the >= cap rule.  (20 MB of exposed
         # all-reduce at the end of every step otherwise: the encoder's level-2 gradients arrive ~3 ms before the stem's.)
-        cuts, end, sizes = set(), len(order), [p.numel() for p in order]
-        if sum(sizes) >= 2 * self._cap and os.environ.get("LOTUS_DIAG_NO_TAPER") != "1":
+        cuts, end, usz = set(), len(units), [u[2] for u in units]
+        if sum(usz) >= 2 * self._cap and os.environ.get("LOTUS_DIAG_NO_TAPER") != "1":
             for tail_cap in (self._cap // 32, self._cap // 8, self._cap // 2):
                 n, i = 0, end
-                while i > 0 and (n == 0 or n + sizes[i - 1] <= tail_cap):
+                while i > 0 and (n == 0 or n + usz[i - 1] <= tail_cap):
                     i -= 1
-                    n += sizes[i]
+                    n += usz[i]
                 if i <= 0:
                     break
-                cuts.add(i)  # a bucket boundary in front of order[i]
+                cuts.add(i)  # a bucket boundary in front of units[i]
                 end = i
-        first_tail = min(cuts) if cuts else len(order)
-        for group_, cap in ((order, self._cap), (cold, None)):
-            for k, p in enumerate(group_):
-                if cap is not None and k in cuts:
-                    close()
+        first_tail = min(cuts) if cuts else len(units)
+        for k, (kind, ident, n, ps) in enumerate(units):
+            if k in cuts:
+                close()
+            base = state["offset"]
+            if kind == "slab":
+                self._slab_at[ident] = base
+            for p in ps:
+                off = base + (where[p][1] if kind == "slab" else 0)
                 self._slot[p] = len(self.buckets)
                 state["p"].append(p)
-                state["v"].append(self.flat[state["offset"]:state["offset"] + p.numel()].view_as(p))
-                state["n"] += p.numel()
-                state["offset"] += p.numel()
-                if cap is not None and k < first_tail and state["n"] >= cap:
-                    close()
-            close()
+                state["v"].append(self.flat[off:off + p.numel()].view_as(p))
+            state["n"] += n
+            state["offset"] += n
+            if k < first_tail and state["n"] >= self._cap:
+                close()
+        close()
+        for p in cold:
+            self._slot[p] = len(self.buckets)
+            state["p"].append(p)
+            state["v"].append(self.flat[state["offset"]:state["offset"] + p.numel()].view_as(p))
+            state["offset"] += p.numel()
+        close()
         self._count = [len(ps) for ps in self._bparams]
         self._view = {p: v for ps, vs in zip(self._bparams, self._bviews) for p, v in zip(ps, vs)}
-        import numpy as np
         index = {p: i for i, p in enumerate(self.params)}
         self._bindex = [np.asarray([index[p] for p in ps], dtype=np.int64) for ps in self._bparams]
         self._rearm()
 
+    def _arena(self, n, dev):
+        """ops.GRAD_ARENA while this reducer's backward runs: the output slab of the next backward node.  Learning pass: a
+        plain tensor, remembered so that the hooks can tell which parameter's gradient lives where in it.  Afterwards: the slab's
+        place in the flat buffer, as long as the nodes ask in the learnt order with the learnt sizes (anything else gets a
+        plain tensor for the rest of the step and is packed by copy as before)."""
+        if self._learning:
+            t = torch.empty(n, dtype=torch.float32, device=dev)
+            self._slab_rec.append((t.data_ptr(), n, t))
+            return t
+        i, seq = self._slab_i, self._slab_seq
+        if seq is None or i >= len(seq) or seq[i][0] != n:
+            self._slab_i = 1 << 30
+            return None
+        self._slab_i = i + 1
+        at = seq[i][1]
+        return None if at is None else self.flat[at:at + n]
+
     def _rearm(self):
+        self._slab_i = 0
         self._pending = [0] * len(self.buckets)
         self._flushed = [False] * len(self.buckets)
         self._ready = [False] * len(self.buckets)
@@ -264,6 +314,12 @@ class GradReducer:
         if self._learning and p not in self._seen:
             self._seen.add(p)
             self._arrival.append(p)
+            if self._slab_rec and p.grad is not None and p.grad.is_contiguous():
+                a = p.grad.data_ptr()
+                for k, (base, n, _) in enumerate(self._slab_rec):
+                    if base <= a and a + 4 * p.numel() <= base + 4 * n:
+                        self._pslab[p] = (k, (a - base) // 4)
+                        break
         self._pending[b] += 1
         if self._pending[b] == self._count[b]:
             # collectives are matched across ranks by issue order: buckets go out strictly in layout order (which IS the
@@ -323,6 +379,7 @@ class GradReducer:
         if self.sparse_hooks:
             self.sparse_hooks = False
             self._dense_hooks()
+        self._arena_off, ops.GRAD_ARENA = True, None  # (a second micro-batch would overwrite the first one's gradients in place)
         self._sync = False
         try:
             yield
@@ -337,12 +394,20 @@ class GradReducer:
         self._used_np[bi if len(have) == len(ps) else bi[have]] = 1  # (one vectorised store: 421 tensor element writes cost ~1 ms)
         lo, hi = self.buckets[b]
         buf = self.flat[lo:hi]
-        grads = [ps[i].grad for i in have]
-        dst = [views[i] for i in have]
+        # gradients that were born in their slot (slabs served by _arena) need no copy
+        move = [i for i in have if ps[i].grad.data_ptr() != views[i].data_ptr()]
+        f0, f1 = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.flat.numel()
+        # (a gradient that sits in the flat buffer but not in its own slot — a node served another node's slab — is copied
+        #  out first: its place may be another parameter's destination)
+        grads = [ps[i].grad.clone() if f0 <= ps[i].grad.data_ptr() < f1 else ps[i].grad for i in move]
+        self.copied_floats += sum(ps[i].numel() for i in move)
+        self.inplace_floats += sum(ps[i].numel() for i in have) - sum(ps[i].numel() for i in move)
+        dst = [views[i] for i in move]
+        missing = [views[i] for i in range(len(ps)) if ps[i].grad is None] if len(have) < len(ps) else []
 
         def pack():
-            if len(have) < len(ps):  # finish(): gradient-less parameters contribute zeros to the average
-                buf.zero_()
+            if missing:  # finish(): gradient-less parameters contribute zeros to the average
+                torch._foreach_zero_(missing)
             if grads and not _DIAG_NO_PACK:
                 torch._foreach_copy_(dst, grads)
             self._reduce(buf)
@@ -405,12 +470,27 @@ class GradReducer:
             if order:
                 hot = [self.params[i] for i in order]
                 hot_set = set(hot)
-                self._layout(hot, [p for p in self.params if p not in hot_set])
+                # slabs: only when every rank can agree on them without another collective — they are a property of the autograd
+                # graph, like the order; a rank whose graph differed simply falls back to copies (sizes are checked per call)
+                slabs = None
+                if self._slab_rec and not self._arena_off and os.environ.get("LOTUS_DP_ARENA", "1") != "0":
+                    slabs = ([n for _, n, _ in self._slab_rec], {index[p]: w for p, w in self._pslab.items()})
+                if self.world > 1:  # rank 0's slabs, like rank 0's order: every rank must lay the flat buffer out identically
+                    box = [slabs]
+                    dist.broadcast_object_list(box, 0, group=self.group)
+                    slabs = box[0]
+                if slabs is not None:
+                    slabs = (slabs[0], {self.params[i]: w for i, w in slabs[1].items()})
+                self._layout(hot, [p for p in self.params if p not in hot_set], slabs)
+                if slabs is not None:  # (served by call order and size; a rank whose nodes ask differently gets plain tensors)
+                    self._slab_seq = [(n, self._slab_at.get(k)) for k, n in enumerate(slabs[0])]
+                self._slab_rec, self._pslab = [], {}
                 self._learning = False
                 if self.sparse_hooks:
                     self._sparse_hooks(hot)
             self._arrival, self._seen = [], set()
         self._rearm()
+        ops.GRAD_ARENA = None if self._arena_off else self._arena
 
     def finish(self):
         """Wait for the outstanding bucket all-reduces (call after backward, before the optimiser).  Afterwards
@@ -433,6 +513,7 @@ class GradReducer:
             e1.record()
             self.exposed_events.append((e0, e1))
         self._keep = []
+        ops.GRAD_ARENA = None
         self.step_id += 1
         if self.world > 1 or self._force:
             self._sync_usage()
@@ -489,6 +570,7 @@ class GradReducer:
         return self._view[p]
 
     _unused, _usage_pending = None, None
+    copied_floats = inplace_floats = 0  # gradient elements packed by copy / born in their bucket slot (since construction)
     used_mask = None       # device int32 [len(params)]: 1 = some rank produced a gradient in the step just finished (exact)
     time_exposed = False   # bench.py: record an event pair around the wait in finish()
     sparse_hooks = True    # one hook per bucket once the arrival order is known (False: a hook on every parameter)

@@ -80,6 +80,11 @@ def _worker_body(rank, world, port, q):
     parallel.enable_sync_batchnorm()
     g_dp = run(m, shard, red)
     rs_dp = m.ptv3_model.embedding.stem.norm.running_var.clone()
+    # two more steps: from the second backward on the nodes write their gradients straight into the bucket buffer (ops.GRAD_ARENA)
+    g_dp2 = run(m, shard, red)
+    g_dp3 = run(m, shard, red)
+    res["arena_inplace_fraction"] = red.inplace_floats / max(1, red.inplace_floats + red.copied_floats)
+    res["arena_steps_equal"] = bool(torch.equal(g_dp2, g_dp3)) and ((g_dp3 - g_dp).norm() / g_dp.norm()).item() < 1e-6
     ops.BnState.reduce = None
     m1 = build()
     g_1 = run(m1, shard, None)
@@ -170,6 +175,8 @@ def test_two_rank_data_parallel_on_device():
         assert res["cross_rank_rv_diff"] == 0.0, res
         assert res["unequal_shards_rel_err"] < 1e-5 and res["unequal_shards_worst_param"] < 1e-5, res
         assert res["unequal_shards_rv_err"] < 1e-6, res
+        # from the second step on most gradients are born in the reducer's bucket buffer, and nothing changes numerically
+        assert res["arena_steps_equal"] and res["arena_inplace_fraction"] > 0.5, res
 
 
 def test_bench_self_launches_its_ranks():
