@@ -27,7 +27,8 @@
  *       LOTUS_CONV_WG_CHUNK=n         points per split of the sparse-convolution weight gradient (default 1024)
  *       LOTUS_CONV_OS=0               bf16 operand modes use the pair-compacted convolution kernel
  *       LOTUS_CONV_OS_F32=1|2|3       exact-fp32 products on the output-stationary convolution kernel (opt-in)
- *       LOTUS_XQ=0|2                  cross attention on the tile kernels / patch attention on the per-query kernels
+ *       LOTUS_XQ=0|2|3                cross attention on the tile kernels / patch attention on the per-query kernels / the
+ *                                     cross-attention backward on the round-5 one-lane-per-query kernel
  *   - lotus_abi_version() changes whenever an existing entry point changes its arguments (3 since round 6: lotus_adamw_step took the usage mask; 2 in round 5); bindings check it.
  */
 #ifndef LOTUS_HIP_H

@@ -1548,10 +1548,273 @@ __global__ __launch_bounds__(128) void xq_bwd_kernel(AttnP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-attention backward, round 6: the key side of a block is ONE 32-wide tile (<= 32 instruction tokens of
+// a cloud) that never leaves the registers, the queries stream through.  xq_bwd_kernel above keeps a whole query per lane (464
+// registers, one wave per SIMD, 1 TB/s); here a query is shared by the two lanes (l31, h) of a wave — lane half h owns the 16
+// channels c = (r & 3) + 8 (r >> 2) + 4 h, which is exactly the row set a 32 x 32 x 2 MFMA hands to that lane half — so that ALL five
+// products are MFMA tiles whose operands are either persistent key-side registers or the lane's own query-side registers:
+//   S^T[key][query]  = Khat * (qhat gq gk)^T + (kb + qb)        A = khat[key = l31][own channels]  (registers, loaded once)
+//   dP^T[key][query] = V * dO^T                                 A = v[key = l31][own channels]     (registers, loaded once)
+//   dx^T[c][query]   = Khat^T * dS^T                            A = khat[own keys][c = l31]        (registers), B = the lane's dS
+//   T[key][c] += dS^T * qhat,  dV[key][c] += Pm^T * dO          over the queries: through wave-private LDS images
+// The lane ends up with dx for exactly the channels it loaded, so q_norm backward is 16 in-lane terms + one lane^32 exchange and
+// dq leaves as four 16-byte stores per lane.  ~215 registers: two waves per SIMD, two 4-wave blocks per CU.  Head width 32, one
+// key chunk, no owner / borrowed rows (the point <-> instruction cross attention); everything else stays on xq_bwd_kernel.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void xq2_bwd_kernel(AttnP p) {
+  constexpr int D = 32, XLD = 33, QLD = 36, ILD = 33;
+  constexpr int WSZ = 2 * 32 * QLD + 2 * 32 * XLD;  // floats per wave: q image, dO image (row stride 36), dS^T and Pm^T (33)
+  __shared__ __attribute__((aligned(16))) float khat_s[32 * 32], v_s[32 * 32], krstd_s[32], kb_s[32], cs_s[NW][32];
+  __shared__ int krow_s[32];
+  __shared__ __attribute__((aligned(16))) float g1_s[32], bkq_s[32];  // gq gk and gq bk per channel (re-read per use: registers are short)
+  __shared__ __attribute__((aligned(16))) float img_s[NW * WSZ];
+  const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1, h = blockIdx.y;
+  const int* bd = p.blocks + blockIdx.x * 6;
+  const int first_tile = bd[0], n_tiles = bd[1], tile_step = bd[2], part_slot = bd[3], k_start = bd[4], k_len = bd[5];
+  if (k_len > 32) __builtin_trap();  // (the caller promised k_max <= 32)
+  if (tid < 32) krow_s[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+  __syncthreads();
+  xq_load_keys<D>(p, h, krow_s, k_len, 32, khat_s, v_s);
+  __syncthreads();
+  xq_norm_keys<D>(p.eps, k_len, 32, khat_s, krstd_s);
+  __syncthreads();
+  if (tid < 32) {  // kb_j = bq . kn_j
+    float a = 0.f;
+    for (int c = 0; c < D; ++c) a += (khat_s[tid * 32 + c] * p.kn_w[c] + p.kn_b[c]) * p.qn_b[c];
+    kb_s[tid] = a;
+    g1_s[tid] = p.qn_w[tid] * p.kn_w[tid];
+    bkq_s[tid] = p.qn_w[tid] * p.kn_b[tid];
+  }
+  __syncthreads();
+  // persistent key-side fragments of this lane: register r <-> channel (or key) (r & 3) + 8 (r >> 2) + 4 hh
+  float KA[16], VA[16], KT[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    KA[r] = khat_s[l31 * 32 + c];
+    VA[r] = v_s[l31 * 32 + c];
+    KT[r] = khat_s[c * 32 + l31];
+  }
+  auto chan4 = [&](const float* tab, int g) { return *reinterpret_cast<const float4*>(tab + 8 * g + 4 * hh); };  // this lane's channels
+  f32x16 accT = zero16(), accV = zero16();
+  float cs = 0.f;
+  float* Qi = img_s + wave * WSZ;
+  float* Gi = Qi + 32 * QLD;
+  float* Xd = Gi + 32 * QLD;
+  float* Xp = Xd + 32 * XLD;
+  const unsigned s0 = (unsigned)p.drop_seed;
+  const int qi = wave * 32 + l31;
+  const int coff = h * D + 4 * hh;  // this lane's channels: coff + 8 g + e
+
+  for (int ti = 0; ti < n_tiles; ++ti) {
+    const int tile = first_tile + ti * tile_step;
+    const int q_start = p.tiles[tile * 4 + 0], q_len = p.tiles[tile * 4 + 1];
+    const int pos = q_start + qi;
+    const bool act = qi < q_len;
+    const long row = act ? (p.qidx ? (long)p.qidx[pos] : (long)pos) : 0;
+    float qh[16], go[16];
+    float Di = 0.f;
+    {
+      const act_t* qp = p.q + row * p.q_ld + p.q_off + coff;
+      const act_t* gp = p.dout + row * p.out_ld + coff;
+      const act_t* op = p.out + row * p.out_ld + coff;
+      float4 qv[4], gv[4], ov[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        qv[g] = act ? ld4(qp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gv[g] = act ? ld4(gp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+        ov[g] = act ? ld4(op + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        qh[4 * g] = qv[g].x; qh[4 * g + 1] = qv[g].y; qh[4 * g + 2] = qv[g].z; qh[4 * g + 3] = qv[g].w;
+        go[4 * g] = gv[g].x; go[4 * g + 1] = gv[g].y; go[4 * g + 2] = gv[g].z; go[4 * g + 3] = gv[g].w;
+        Di += (gv[g].x * ov[g].x + gv[g].y * ov[g].y) + (gv[g].z * ov[g].z + gv[g].w * ov[g].w);
+      }
+    }
+    Di += __shfl_xor(Di, 32, 64);
+    float m = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m += qh[r];
+    m += __shfl_xor(m, 32, 64);
+    m *= (1.f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float t = qh[r] - m;
+      var += t * t;
+    }
+    var += __shfl_xor(var, 32, 64);
+    const float rs = rsqrtf(var * (1.f / D) + p.eps);
+    float qb = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bk4 = chan4(bkq_s, g);
+      const float bk[4] = {bk4.x, bk4.y, bk4.z, bk4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        qh[4 * g + e] = (qh[4 * g + e] - m) * rs;
+        qb = fmaf(qh[4 * g + e], bk[e], qb);
+      }
+    }
+    qb += __shfl_xor(qb, 32, 64);
+    const float lse = act ? p.lse[(long)pos * p.H + h] : INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // the query-side images of the products that reduce over the queries
+      *reinterpret_cast<float4*>(Qi + l31 * QLD + 8 * g + 4 * hh) = make_float4(qh[4 * g], qh[4 * g + 1], qh[4 * g + 2], qh[4 * g + 3]);
+      *reinterpret_cast<float4*>(Gi + l31 * QLD + 8 * g + 4 * hh) = make_float4(go[4 * g], go[4 * g + 1], go[4 * g + 2], go[4 * g + 3]);
+    }
+    // ---- S^T and dP^T for this lane's query and the 16 keys of its half
+    f32x16 aS, aP = zero16();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 k4 = *reinterpret_cast<const float4*>(kb_s + 8 * g + 4 * hh);
+      aS[4 * g] = k4.x + qb; aS[4 * g + 1] = k4.y + qb; aS[4 * g + 2] = k4.z + qb; aS[4 * g + 3] = k4.w + qb;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 g4 = chan4(g1_s, g);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = 4 * g + e;
+        aS = __builtin_amdgcn_mfma_f32_32x32x2f32(KA[s], qh[s] * gg[e], aS, 0, 0, 0);
+        aP = __builtin_amdgcn_mfma_f32_32x32x2f32(VA[s], go[s], aP, 0, 0, 0);
+      }
+    }
+    const unsigned long long rb = (((unsigned long long)tile * p.H + h) * AT + qi) * AT;
+    const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+    float dsr[16];
+    float dsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = (r & 3) + 8 * (r >> 2) + 4 * hh;
+      const float pj = j < k_len ? __expf(aS[r] * p.scale - lse) : 0.f;
+      const bool keep = !p.drop_thresh || keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh);
+      const float pmj = keep ? pj * p.drop_inv_keep : 0.f;
+      const float ds = p.scale * pj * ((keep ? aP[r] * p.drop_inv_keep : 0.f) - Di);
+      dsr[r] = ds;
+      dsum += ds;
+      Xd[j * XLD + l31] = ds;
+      Xp[j * XLD + l31] = pmj;
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    // ---- dx^T: this lane's channels of its query, then q_norm backward and the dq row
+    f32x16 aX = zero16();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aX = __builtin_amdgcn_mfma_f32_32x32x2f32(KT[s], dsr[s], aX, 0, 0, 0);
+    float a = 0.f, b = 0.f, dqh[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 g4 = chan4(g1_s, g), bk4 = chan4(bkq_s, g);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bk[4] = {bk4.x, bk4.y, bk4.z, bk4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        dqh[r] = fmaf(gg[e], aX[r], bk[e] * dsum);
+        a += dqh[r];
+        b = fmaf(dqh[r], qh[r], b);
+      }
+    }
+    a += __shfl_xor(a, 32, 64);
+    b += __shfl_xor(b, 32, 64);
+    a *= (1.f / D); b *= (1.f / D);
+    if (act) {
+      act_t* dqp = p.dq + row * p.dq_ld + p.dq_off + coff;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        st4(dqp + 8 * g, make_float4(rs * (dqh[4 * g] - a - qh[4 * g] * b), rs * (dqh[4 * g + 1] - a - qh[4 * g + 1] * b),
+                                     rs * (dqh[4 * g + 2] - a - qh[4 * g + 2] * b), rs * (dqh[4 * g + 3] - a - qh[4 * g + 3] * b)));
+    }
+    __syncthreads();  // the wave's images are complete (block barrier: the waves walk the tiles in step)
+    // ---- T += dS^T qhat, dV += Pm^T dO over this wave's 32 queries; lane = (key | channel) l31, lane half = query half
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int qq = hh * 16 + s;
+      const float xd = Xd[l31 * XLD + qq], xp = Xp[l31 * XLD + qq];
+      cs += xd;
+      accT = __builtin_amdgcn_mfma_f32_32x32x2f32(xd, Qi[qq * QLD + l31], accT, 0, 0, 0);
+      accV = __builtin_amdgcn_mfma_f32_32x32x2f32(xp, Gi[qq * QLD + l31], accV, 0, 0, 0);
+    }
+    __syncthreads();  // before the next tile overwrites the images
+  }
+  // ---- the block's keys: sum the waves, finish d k / d v and the LayerNorm parameter partials (as xq_bwd_kernel)
+  float* T_s = img_s;                       // [NW][32][ILD]
+  float* V_s = T_s + NW * 32 * ILD;         // [NW][32][ILD]
+  float* dkn_s = V_s + NW * 32 * ILD;       // [32][ILD]
+  float* gq_s = dkn_s + 32 * ILD;           // [64][ILD]
+  static_assert(2 * NW * 32 * ILD + 96 * ILD <= NW * WSZ, "epilogue scratch fits the tile images");
+  cs += __shfl_xor(cs, 32, 64);
+  if (hh == 0) cs_s[wave][l31] = cs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    T_s[(wave * 32 + key) * ILD + l31] = accT[r];
+    V_s[(wave * 32 + key) * ILD + l31] = accV[r];
+  }
+  __syncthreads();
+  act_t* dkv = p.dkv + (long)part_slot * p.dkv_part_stride;
+  for (int i = tid; i < 32 * 32; i += NW * 64) {
+    const int j = i >> 5, c = i & 31;
+    float T = 0.f, csj = 0.f, dv = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      T += T_s[(w * 32 + j) * ILD + c];
+      dv += V_s[(w * 32 + j) * ILD + c];
+      csj += cs_s[w][j];
+    }
+    const float kn = khat_s[j * 32 + c] * p.kn_w[c] + p.kn_b[c];
+    dkn_s[j * ILD + c] = j < k_len ? p.qn_w[c] * T + p.qn_b[c] * csj : 0.f;
+    gq_s[j * ILD + c] = j < k_len ? kn * T : 0.f;
+    gq_s[(32 + j) * ILD + c] = j < k_len ? kn * csj : 0.f;
+    V_s[j * ILD + c] = dv;  // (wave 0's slab now holds the sum: each (j, c) is read and written by this thread only)
+  }
+  __syncthreads();
+  if (tid < 32) {  // column sums over the keys
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f, l3 = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 32; ++j) {
+      l0 += gq_s[j * ILD + tid];
+      l1 += gq_s[(32 + j) * ILD + tid];
+      const float g = dkn_s[j * ILD + tid];
+      l2 += g * khat_s[j * 32 + tid];
+      l3 += g;
+    }
+    float* lnp = p.ln_part + ((long)(blockIdx.x * p.H + h) * 4) * 32;
+    lnp[tid] = l0; lnp[32 + tid] = l1; lnp[64 + tid] = l2; lnp[96 + tid] = l3;
+  }
+  for (int i = tid; i < 32 * 8; i += NW * 64) {  // k_norm backward per key row (8 lanes per row) + the dV rows
+    const int j = i >> 3, c4 = i & 7;
+    float g[4], kh[4];
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = c4 * 4 + e;
+      kh[e] = khat_s[j * 32 + c];
+      g[e] = dkn_s[j * ILD + c] * p.kn_w[c];
+      a += g[e];
+      b = fmaf(g[e], kh[e], b);
+    }
+    a += __shfl_xor(a, 1, 8); a += __shfl_xor(a, 2, 8); a += __shfl_xor(a, 4, 8);
+    b += __shfl_xor(b, 1, 8); b += __shfl_xor(b, 2, 8); b += __shfl_xor(b, 4, 8);
+    a *= (1.f / D); b *= (1.f / D);
+    if (j < k_len) {
+      const float krs = krstd_s[j];
+      const int c = c4 * 4;
+      act_t* kp = dkv + (long)krow_s[j] * p.dkv_ld + h * D + c;
+      st4(kp + p.dk_off, make_float4(krs * (g[0] - a - kh[0] * b), krs * (g[1] - a - kh[1] * b), krs * (g[2] - a - kh[2] * b),
+                                     krs * (g[3] - a - kh[3] * b)));
+      st4(kp + p.dv_off, make_float4(V_s[j * ILD + c], V_s[j * ILD + c + 1], V_s[j * ILD + c + 2], V_s[j * ILD + c + 3]));
+    }
+  }
+}
+
 // Query-per-lane kernels: fp32 operand mode (or a caller-declared short key side, k_max <= 32: cross attention in every
 // mode), head widths 32 / 24 / 16, no atomic accumulation; backward needs blocks that are "one key chunk, many tiles" or
 // "one tile, many chunks" — k_max (the caller's upper bound of k_len, 0 = unknown: a patch, up to 128) tells which.
-// LOTUS_XQ: 0 = tile kernels everywhere, 1 (default) = short key sides only, 2 = also the patch attention in fp32 mode.
+// LOTUS_XQ: 0 = tile kernels everywhere, 1 (default) = short key sides only, 2 = also the patch attention in fp32 mode,
+// 3 = as 1 but the cross-attention backward on the round-5 one-lane-per-query kernel (A/B of xq2_bwd_kernel).
 // Measured stand-alone at the bench size (tools/attn_ab.py, us per launch, tile -> query per lane): cross attention forward
 // 22 / 36 / 21 / 12.5 -> 15 / 24 / 13 / 11.6, backward 79 / 94 / 73 / 57 -> 66 / 73 / 52 / 40 (levels 0 (C 64), 0 (C 128), 1,
 // 2); in the training step 0.95 -> 0.63 ms and +1.2 % throughput.  The 128-key patch attention LOSES on this path (forward
@@ -1566,7 +1829,7 @@ static int xq_mode() {
 static bool xq_ok(int k_max, int precision, int atomic_out, int d) {
   const bool geom = !atomic_out && (d == 32 || d == 24 || d == 16);
   const bool short_keys = k_max > 0 && k_max <= 32;
-  return geom && ((short_keys && xq_mode() >= 1) || (!short_keys && precision == 0 && !LOTUS_ACT_IS_BF16 && xq_mode() >= 2));
+  return geom && ((short_keys && xq_mode() >= 1) || (!short_keys && precision == 0 && !LOTUS_ACT_IS_BF16 && xq_mode() == 2));
 }
 
 static int check_geom(int H, int d) { return (d % 4 == 0 && d <= 32 && d >= 4 && H > 0) ? 0 : -1; }
@@ -1649,7 +1912,10 @@ int lotus_attention_bwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   const int prec = precision;
   StopEventOnLast stop_ev;
   if (xq_ok(k_max, precision, atomic_out, d)) {
-    if (d == 32) LOTUS_LAUNCH(xq_bwd_kernel<32>, dim3(nblocks, H), dim3(128), 0, st, p);
+    // the cross attention proper (head width 32, <= 32 keys, plain rows): keys in registers, queries streamed (xq2_bwd_kernel)
+    if (d == 32 && k_max > 0 && k_max <= 32 && !owner && !p.dkv_extra && xq_mode() != 3)
+      LOTUS_LAUNCH(xq2_bwd_kernel<4>, dim3(nblocks, H), dim3(256), 0, st, p);
+    else if (d == 32) LOTUS_LAUNCH(xq_bwd_kernel<32>, dim3(nblocks, H), dim3(128), 0, st, p);
     else if (d == 24) LOTUS_LAUNCH(xq_bwd_kernel<24>, dim3(nblocks, H), dim3(128), 0, st, p);
     else LOTUS_LAUNCH(xq_bwd_kernel<16>, dim3(nblocks, H), dim3(128), 0, st, p);
   } else if (prec == 3) {
