@@ -29,6 +29,10 @@
  *       LOTUS_CONV_OS_F32=1|2|3       exact-fp32 products on the output-stationary convolution kernel (opt-in)
  *       LOTUS_XQ=0|2|3                cross attention on the tile kernels / patch attention on the per-query kernels / the
  *                                     cross-attention backward on the round-5 one-lane-per-query kernel
+ *   - dropout masks are a stateless function of (seed, element index): one 32-bit hash decides two consecutive elements (since
+ *     ABI version 2: the mask stream of a seed differs from version-1 builds), so the drop probability of the dense / LayerNorm /
+ *     elementwise entry points is quantised to t / 65536, t >= 1, and kept elements are scaled by 1 / (1 - t / 65536) — the
+ *     probability actually applied (round 6); the attention entry points use one hash per element and 1 / (1 - p).
  *   - lotus_abi_version() changes whenever an existing entry point changes its arguments (3 since round 6: lotus_adamw_step took the usage mask; 2 in round 5); bindings check it.
  */
 #ifndef LOTUS_HIP_H

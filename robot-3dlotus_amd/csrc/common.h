@@ -129,11 +129,13 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // round 5), and libm's erff costs ~35 of them per element (two polynomial branches under exec masks + an exp with error
 // compensation): GELU on the [65536, 512] hidden layer was as expensive as the product that feeds it.  Here
 //   erfc(t) = 2^-q(t),  q = degree-8 minimax fit of -log2 erfc on [0, 4] weighted by erfc (|error of 2^-q| <= 1.1e-7,
-//   tools/fit_erfc.py), erfc(t > 4) < 1.6e-8 is held at erfc(4);   2 Phi(x) = erfc(-x / sqrt 2) = x >= 0 ? 2 - e : e
+//   tools/fit_erfc.py), erfc(t > 4) < 1.6e-8 by extrapolation, 0 from t = 8;   2 Phi(x) = erfc(-x / sqrt 2) = x >= 0 ? 2 - e : e
 // costs 8 fma + v_exp_f32 + 5: |gelu - exact| <= 1.2e-7 max(1, |gelu|), |gelu' - exact| <= 1.3e-7 (float64 reference,
 // 4 M points in [-12, 12]); negative arguments have no cancellation (erfc is formed directly).
 __device__ __forceinline__ float lotus_two_phi(float x) {  // 2 Phi(x)
-  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 4.0f);
+  // (beyond the fit range the polynomial keeps growing — q(5) = 40, q(6) = 65, q(8) = 270 — so 2^-q runs smoothly into 0: a
+  //  clamp at 4 held erfc at 1.5e-8 and made gelu(x << 0) = 0.75e-8 x instead of 0; NaN inputs still give a finite cdf)
+  const float t = fminf(fabsf(x) * 0.70710678118654752440f, 8.0f);
   float q = 4.435278970e-05f;
   q = fmaf(q, t, -4.369438975e-04f);
   q = fmaf(q, t, 1.460380852e-03f);
@@ -178,6 +180,17 @@ __device__ __forceinline__ uint32_t lotus_hash32(uint64_t seed, uint64_t idx) {
 // One 32-bit hash decides TWO consecutive elements (its halves against the upper 16 bits of the threshold: the drop
 // probability is quantised to 2^-16): the hash is three integer multiplies (quarter rate) + five logic operations of
 // vector ALU, which an fp32-MFMA kernel pays in MFMA time (round 5).
+// Host side of the pair hash: the threshold and the scale of the probability the kernels actually apply, t16 / 65536 (at least
+// 2^-16 for p > 0) — with 1 / (1 - p) of the unquantised p the expectation was off by up to 2^-16 / (1 - p), and p < 2^-16
+// dropped nothing yet scaled.  The attention kernels compare one full 32-bit hash per element and keep 1 / (1 - p).
+static inline void lotus_drop_setup(float p, unsigned* thresh, float* inv_keep) {
+  if (!(p > 0.f)) { *thresh = 0; *inv_keep = 1.f; return; }
+  unsigned t16 = (unsigned)((double)p * 65536.0);
+  if (t16 == 0) t16 = 1;
+  if (t16 > 65535) t16 = 65535;
+  *thresh = t16 << 16;
+  *inv_keep = (float)(1.0 / (1.0 - (double)t16 / 65536.0));
+}
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float inv_keep) {
   const uint32_t hv = lotus_hash32(seed, idx >> 1);
   return ((idx & 1) ? (hv >> 16) : (hv & 0xffffu)) >= (thresh >> 16) ? inv_keep : 0.f;

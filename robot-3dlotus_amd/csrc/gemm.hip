@@ -730,14 +730,7 @@ static int launch_gemm(GemmP& p, int nz, hipStream_t st) {
 
 static void set_drop(GemmP& p, float drop_p, unsigned long long seed) {
   p.drop_seed = seed;
-  if (drop_p > 0.f) {
-    p.drop_thresh = (unsigned)(drop_p * 4294967296.0);
-    if (p.drop_thresh == 0) p.drop_thresh = 1;
-    p.drop_inv_keep = 1.f / (1.f - drop_p);
-  } else {
-    p.drop_thresh = 0;
-    p.drop_inv_keep = 1.f;
-  }
+  lotus_drop_setup(drop_p, &p.drop_thresh, &p.drop_inv_keep);
 }
 
 // sum of split-K partials + the full epilogue (bias, pre, act, act', dropout, residual), float4 wide

@@ -651,9 +651,7 @@ int lotus_layernorm_bwd(const act_t* dy, const act_t* x, const float* mean, cons
   LnBwdP p;
   p.dz = (dz && drop_p > 0.f) ? dz : nullptr;
   p.drop_seed = drop_seed;
-  p.drop_thresh = (unsigned)(drop_p * 4294967296.0);
-  if (p.dz && p.drop_thresh == 0) p.drop_thresh = 1;
-  p.drop_inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  lotus_drop_setup(drop_p, &p.drop_thresh, &p.drop_inv_keep);
   LOTUS_CHECK_ARG(!dz || drop_p > 0.f, "lotus_layernorm_bwd: dz needs drop_p > 0");
   p.dy = dy; p.x = x; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.add = add; p.dx = dx;
   p.part = (float*)workspace; p.M = M; p.C = C;

@@ -800,11 +800,10 @@ int lotus_add(const act_t* a, const act_t* b, act_t* y, long n, void* stream) {
 int lotus_dropout(const act_t* x, act_t* y, long n, float p, unsigned long long seed, void* stream) {
   LOTUS_CHECK_ARG(x && y && p >= 0.f && p < 1.f, "lotus_dropout: bad arguments");
   if (n == 0) return LOTUS_OK;
-  unsigned th = (unsigned)(p * 4294967296.0);
-  if (p > 0.f && th == 0) th = 1;
+  unsigned th; float inv;
+  lotus_drop_setup(p, &th, &inv);
   int g = cdiv(n, 256);
-  LOTUS_LAUNCH(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th,
-                     1.f / (1.f - p));
+  LOTUS_LAUNCH(dropout_mask_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, x, y, n, seed, th, inv);
   LOTUS_LAUNCH_CHECK("lotus_dropout");
   return LOTUS_OK;
 }
@@ -813,21 +812,16 @@ int lotus_dropout(const act_t* x, act_t* y, long n, float p, unsigned long long 
 int lotus_drop_path(const act_t* branch, const act_t* x, act_t* y, int M, int C, float p, unsigned long long seed, void* stream) {
   LOTUS_CHECK_ARG(branch && y && M >= 0 && C > 0 && C % 4 == 0 && p >= 0.f && p < 1.f, "lotus_drop_path: bad arguments");
   if (M == 0) return LOTUS_OK;
-  unsigned th = (unsigned)(p * 4294967296.0);
-  if (p > 0.f && th == 0) th = 1;
+  unsigned th; float inv;
+  lotus_drop_setup(p, &th, &inv);
   const long total4 = (long)M * (C / 4);
   int g = cdiv(total4, 256);
-  LOTUS_LAUNCH(drop_path_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, branch, x, y, total4, C / 4, seed, th,
-               p > 0.f ? 1.f / (1.f - p) : 1.f);
+  LOTUS_LAUNCH(drop_path_kernel, dim3(g > 4096 ? 4096 : g), dim3(256), 0, (hipStream_t)stream, branch, x, y, total4, C / 4, seed, th, inv);
   LOTUS_LAUNCH_CHECK("lotus_drop_path");
   return LOTUS_OK;
 }
 
-static void drop_params(float p, unsigned* th, float* inv) {
-  *th = (unsigned)(p * 4294967296.0);
-  if (p > 0.f && *th == 0) *th = 1;
-  *inv = p > 0.f ? 1.f / (1.f - p) : 1.f;
-}
+static void drop_params(float p, unsigned* th, float* inv) { lotus_drop_setup(p, th, inv); }
 
 int lotus_step_act_fwd(const act_t* base, const float* bias, act_t* out, int M, int C, int act, float drop_p,
                        unsigned long long drop_seed, void* stream) {

@@ -280,9 +280,22 @@ def _end_of_backward():
     _HELD.clear()  # (freed behind the join: whatever re-uses the memory is enqueued after it)
 
 
+def _abandoned_backward():
+    """A forward pass starts while the end-of-backward callback of an earlier backward pass is still pending: that pass raised (the
+    autograd engine drops its queued callbacks then — e.g. an out-of-memory error the trainer catches and skips).  Join the side
+    stream and release what was held for it, or every later backward would append to _HELD for good and never join again
+    (ADVICE r5)."""
+    global _END_CB_PENDING
+    _END_CB_PENDING = False
+    sync_side_stream()
+    _HELD.clear()
+
+
 def _fwd(fn):
     """forward() decorator: the node remembers the operand precision it was computed in."""
     def wrapped(ctx, *args):
+        if _END_CB_PENDING and _IN_NODE == 0:
+            _abandoned_backward()
         ctx.prec, ctx.bf = _PREC, _capi.BF16
         return fn(ctx, *args)
     return staticmethod(wrapped)

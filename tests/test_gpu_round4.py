@@ -308,14 +308,15 @@ def test_bf16_linear_big_levels_match_float64_masters_and_shadows(M, N, K, shado
                                act=ops.ACT_GELU, drop_p=0.1, seed=77)
         yn, _ = ops.linear_fwd(x.to(BF), wk, b)   # no epilogue extras
     torch.cuda.synchronize()
-    # (a) float64: pre-activation and the plain product exactly rounded; with dropout the kept elements are scaled by 1/0.9
+    # (a) float64: pre-activation and the plain product exactly rounded; with dropout the kept elements are scaled by 1 / keep_q
     pre64 = x.double() @ w.double().t() + b.double()
     for name, got, ref in (("pre", p, pre64), ("plain", yn, pre64)):
         gd, rd = got.double(), ref
         tol = 2.0 ** -8 * rd.abs() * 1.001 + 3e-6 * float(rd.abs().max())
         assert bool(((gd - rd).abs() <= tol).all()), (name, float(((gd - rd).abs() - tol).max()))
         assert float((gd == rd.to(BF).double()).double().mean()) >= 0.98, name
-    full = torch.nn.functional.gelu(pre64) / 0.9 + res.double()
+    keep_q = 1 - int(0.1 * 65536) / 65536   # the keep probability the 16-bit threshold applies (round 6: the scale follows it)
+    full = torch.nn.functional.gelu(pre64) / keep_q + res.double()
     kept = (y.double() - res.double()).abs() > 0          # dropped elements equal the residual exactly
     assert 0.88 < float(kept.double().mean()) < 0.92
     err = ((y.double() - full).abs() - (2.0 ** -8 * full.abs() * 1.001 + 5e-6 * float(full.abs().max())))[kept]
@@ -328,7 +329,7 @@ def test_bf16_linear_big_levels_match_float64_masters_and_shadows(M, N, K, shado
     # input gradient against float64 where no dropout hit
     pd = pre.double().requires_grad_(True)
     torch.nn.functional.gelu(pd).sum().backward()
-    dref = (dy.double() @ w.double()) * pd.grad / 0.9
+    dref = (dy.double() @ w.double()) * pd.grad / keep_q
     keptd = (dx.double() - add.double()).abs() > 0
     errd = ((dx.double() - (dref + add.double())).abs() - (2.0 ** -8 * (dref + add.double()).abs() * 1.001 + 5e-6 * float(dref.abs().max())))[keptd]
     assert float(errd.max()) <= 0, float(errd.max())

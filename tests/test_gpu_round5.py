@@ -115,3 +115,56 @@ def test_no_per_tensor_allocator_events_between_streams():
         ops._end_of_backward = orig
         ops.set_wgrad_join(prev)
     assert seen and (seen[0] > 50 or ops.SIDE is None) and len(ops._HELD) == 0
+
+
+def test_a_backward_pass_that_raises_does_not_leave_the_side_stream_unjoined():
+    """autograd drops its queued callbacks when backward raises, so the deferred join ("end" mode) never ran, the pending
+    flag stayed set and every later backward appended to ops._HELD without ever joining again.  The next forward now notices."""
+    import torch
+    import golden_util as gu
+    from robot_3dlotus_amd import config as lcfg, ops, synth
+    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
+    from weights_util import seeded_state_dict
+
+    cfg = lcfg.preset("tiny")
+    m = SimplePolicyPTV3CA(cfg)
+    m.load_state_dict(seeded_state_dict(gu.state_template(cfg), 7, "scaled"))
+    m = m.cuda().train()
+    m.ptv3_model.proj_drop = m.ptv3_model.attn_drop = 0.0   # (so that two passes over the same batch give the same gradients)
+    m.act_proj_head.dropout = 0.0
+    m.ptv3_model.order_perms = [[0, 1, 2, 3], [3, 2, 1, 0]]
+    b = synth.synth_batch(2, 400, ragged=True, seed=3)
+    dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else ([t.cuda() for t in v] if k == "disc_pos_probs" else v)) for k, v in b.items()}
+    ops.set_wgrad_join("end")
+    try:
+        _, losses = m(dict(dev), compute_loss=True, compute_final_action=False)
+
+        # txt_fc's backward runs late (every cross-attention block feeds it): the head and most blocks have run — and queued the
+        # end-of-backward callback — when it raises
+        def boom(ctx, dy):
+            raise RuntimeError("boom")
+
+        keep = ops.LinearFn.backward
+        ops.LinearFn.backward = staticmethod(boom)
+        try:
+            with pytest.raises(RuntimeError, match="boom"):
+                losses["total"].backward()
+        finally:
+            ops.LinearFn.backward = keep
+        assert ops._END_CB_PENDING, "the failing pass was meant to leave the callback pending"
+        for p in m.parameters():
+            p.grad = None
+        _, l2 = m(dict(dev), compute_loss=True, compute_final_action=False)   # notices the abandoned pass
+        assert not ops._HELD
+        l2["total"].backward()
+        torch.cuda.synchronize()
+        assert not ops._END_CB_PENDING and not ops._HELD
+        ref = [p.grad.clone() for p in m.parameters()]
+        for p in m.parameters():
+            p.grad = None
+        _, l3 = m(dict(dev), compute_loss=True, compute_final_action=False)
+        l3["total"].backward()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, p.grad) for a, p in zip(ref, m.parameters()))
+    finally:
+        ops.set_wgrad_join("node")
