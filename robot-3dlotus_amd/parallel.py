@@ -422,8 +422,17 @@ class GradReducer:
             comm = self._comm
             comm.wait_stream(torch.cuda.current_stream())
             ops.sync_side_stream(target=comm.cuda_stream)
-            with torch.cuda.stream(comm):
-                pack()
+            if grads or missing or self._lane_comm is None:
+                with torch.cuda.stream(comm):
+                    pack()
+            else:
+                # nothing to pack (every gradient of the bucket was born in its slot): the flush is ONE C-ABI call, sent to the
+                # communication stream by the launch override — torch's stream context costs ~30 us of host time per flush
+                prev, _capi.STREAM_OVERRIDE = _capi.STREAM_OVERRIDE, comm.cuda_stream
+                try:
+                    self._reduce(buf)
+                finally:
+                    _capi.STREAM_OVERRIDE = prev
             # the adopted gradient tensors were allocated on the backward stream and are read on `comm`: keep them
             # alive until finish() has made the backward stream wait for `comm` (cheaper than 421 record_stream calls)
             self._keep.extend(grads)
