@@ -1810,11 +1810,115 @@ __global__ __launch_bounds__(NW * 64, 2) void xq2_bwd_kernel(AttnP p) {
   }
 }
 
+// Cross-attention forward in the same layout (round 6): the scores of a query against the <= 32 keys are one MFMA tile (A = the
+// normalised keys, scale folded in: registers), softmax is 16 in-lane values + one lane^32 exchange, O^T = V^T P^T a second tile
+// whose B operand is the lane's own probabilities; no LDS beyond the key set-up, no barrier after it.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void xq2_fwd_kernel(AttnP p) {
+  constexpr int D = 32;
+  __shared__ __attribute__((aligned(16))) float kn_s[32 * 32], v_s[32 * 32], krstd_s[32], gq_s[32], bq_s[32];
+  __shared__ int krow_s[32];
+  const int tid = threadIdx.x, wave = tid >> 6, l31 = tid & 31, hh = (tid >> 5) & 1, h = blockIdx.y;
+  const int q_start = p.tiles[blockIdx.x * 4 + 0], q_len = p.tiles[blockIdx.x * 4 + 1];
+  const int k_start = p.tiles[blockIdx.x * 4 + 2], k_len = p.tiles[blockIdx.x * 4 + 3];
+  if (k_len > 32) __builtin_trap();  // (the caller promised k_max <= 32)
+  if (tid < 32) {
+    krow_s[tid] = tid < k_len ? (p.kidx ? p.kidx[k_start + tid] : k_start + tid) : -1;
+    gq_s[tid] = p.qn_w[tid];
+    bq_s[tid] = p.qn_b[tid];
+  }
+  __syncthreads();
+  xq_load_keys<D>(p, h, krow_s, k_len, 32, kn_s, v_s);
+  __syncthreads();
+  xq_norm_keys<D>(p.eps, k_len, 32, kn_s, krstd_s);
+  __syncthreads();
+  for (int i = tid; i < 32 * 32; i += NW * 64) {  // affine part of k_norm, the softmax scale folded in
+    const int c = i & 31;
+    kn_s[i] = (kn_s[i] * p.kn_w[c] + p.kn_b[c]) * p.scale;
+  }
+  __syncthreads();
+  float KA[16], VT[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    KA[r] = kn_s[l31 * 32 + c];
+    VT[r] = v_s[c * 32 + l31];
+  }
+  const int qi = wave * 32 + l31;
+  const int pos = q_start + qi;
+  const bool act = qi < q_len;
+  const long row = act ? (p.qidx ? (long)p.qidx[pos] : (long)pos) : 0;
+  const int coff = h * D + 4 * hh;
+  float qn[16];
+  {
+    const act_t* qp = p.q + row * p.q_ld + p.q_off + coff;
+    float4 qv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) qv[g] = act ? ld4(qp + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { qn[4 * g] = qv[g].x; qn[4 * g + 1] = qv[g].y; qn[4 * g + 2] = qv[g].z; qn[4 * g + 3] = qv[g].w; }
+  }
+  float m = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) m += qn[r];
+  m += __shfl_xor(m, 32, 64);
+  m *= (1.f / D);
+  float var = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float t = qn[r] - m;
+    var += t * t;
+  }
+  var += __shfl_xor(var, 32, 64);
+  const float rs = rsqrtf(var * (1.f / D) + p.eps);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 g4 = *reinterpret_cast<const float4*>(gq_s + 8 * g + 4 * hh), b4 = *reinterpret_cast<const float4*>(bq_s + 8 * g + 4 * hh);
+    qn[4 * g] = fmaf((qn[4 * g] - m) * rs, g4.x, b4.x);
+    qn[4 * g + 1] = fmaf((qn[4 * g + 1] - m) * rs, g4.y, b4.y);
+    qn[4 * g + 2] = fmaf((qn[4 * g + 2] - m) * rs, g4.z, b4.z);
+    qn[4 * g + 3] = fmaf((qn[4 * g + 3] - m) * rs, g4.w, b4.w);
+  }
+  f32x16 aS = zero16();
+#pragma unroll
+  for (int s = 0; s < 16; ++s) aS = __builtin_amdgcn_mfma_f32_32x32x2f32(KA[s], qn[s], aS, 0, 0, 0);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    aS[r] = j < k_len ? aS[r] : -INFINITY;
+    mx = fmaxf(mx, aS[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  const unsigned long long rb = (((unsigned long long)blockIdx.x * p.H + h) * AT + qi) * AT;
+  const unsigned lo0 = (unsigned)rb, c2 = (unsigned)(rb >> 32) * 0x7FEB352Du + (unsigned)(p.drop_seed >> 32);
+  const unsigned s0 = (unsigned)p.drop_seed;
+  float l = 0.f, w[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int j = (r & 3) + 8 * (r >> 2) + 4 * hh;
+    const float pj = mx > -INFINITY ? __expf(aS[r] - mx) : 0.f;
+    l += pj;
+    w[r] = (!p.drop_thresh || keep_lo(lo0 + (unsigned)j, s0, c2, p.drop_thresh)) ? pj * p.drop_inv_keep : 0.f;
+  }
+  l += __shfl_xor(l, 32, 64);
+  f32x16 aO = zero16();
+#pragma unroll
+  for (int s = 0; s < 16; ++s) aO = __builtin_amdgcn_mfma_f32_32x32x2f32(VT[s], w[s], aO, 0, 0, 0);
+  if (!act) return;
+  const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (p.lse && hh == 0) p.lse[(long)pos * p.H + h] = mx + logf(l);
+  act_t* op = p.out + row * p.out_ld + coff;
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+    st4(op + 8 * g, make_float4(aO[4 * g] * inv, aO[4 * g + 1] * inv, aO[4 * g + 2] * inv, aO[4 * g + 3] * inv));
+}
+
 // Query-per-lane kernels: fp32 operand mode (or a caller-declared short key side, k_max <= 32: cross attention in every
 // mode), head widths 32 / 24 / 16, no atomic accumulation; backward needs blocks that are "one key chunk, many tiles" or
 // "one tile, many chunks" — k_max (the caller's upper bound of k_len, 0 = unknown: a patch, up to 128) tells which.
 // LOTUS_XQ: 0 = tile kernels everywhere, 1 (default) = short key sides only, 2 = also the patch attention in fp32 mode,
-// 3 = as 1 but the cross-attention backward on the round-5 one-lane-per-query kernel (A/B of xq2_bwd_kernel).
+// 3 = as 1 but the cross attention on the round-5 one-lane-per-query kernels (A/B of xq2_fwd / xq2_bwd_kernel).
 // Measured stand-alone at the bench size (tools/attn_ab.py, us per launch, tile -> query per lane): cross attention forward
 // 22 / 36 / 21 / 12.5 -> 15 / 24 / 13 / 11.6, backward 79 / 94 / 73 / 57 -> 66 / 73 / 52 / 40 (levels 0 (C 64), 0 (C 128), 1,
 // 2); in the training step 0.95 -> 0.63 ms and +1.2 % throughput.  The 128-key patch attention LOSES on this path (forward
@@ -1853,7 +1957,9 @@ int lotus_attention_fwd(const act_t* q, long q_ld, int q_off, const act_t* kv, l
   p.out = out; p.out_ld = out_ld; p.lse = lse; p.H = H; p.d = d; p.scale = scale; p.eps = eps;
   set_attn_drop(p, drop_p, drop_seed);
   if (xq_ok(k_max, precision, 0, d)) {  // one lane per query, keys as LDS broadcast rows
-    if (d == 32) LOTUS_LAUNCH(xq_fwd_kernel<32>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
+    if (d == 32 && k_max > 0 && k_max <= 32 && !owner && xq_mode() != 3)  // the cross attention proper: key tile in registers
+      LOTUS_LAUNCH(xq2_fwd_kernel<4>, dim3(ntiles, H), dim3(256), 0, (hipStream_t)stream, p);
+    else if (d == 32) LOTUS_LAUNCH(xq_fwd_kernel<32>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
     else if (d == 24) LOTUS_LAUNCH(xq_fwd_kernel<24>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
     else LOTUS_LAUNCH(xq_fwd_kernel<16>, dim3(ntiles, H), dim3(128), 0, (hipStream_t)stream, p);
     LOTUS_LAUNCH_CHECK("lotus_attention_fwd(query per lane)");
