@@ -193,6 +193,32 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def _watchdog(rank, limit_s):
+    """-> tick(what=None).  A daemon thread ends the process (exit code 17, Python stacks of all threads on stderr) when
+    `limit_s` seconds pass without a tick."""
+    import faulthandler
+    import threading
+
+    state = {"t": time.monotonic(), "what": "start-up"}
+
+    def tick(what=None):
+        state["t"] = time.monotonic()
+        if what is not None:
+            state["what"] = what
+
+    def watch():
+        while True:
+            time.sleep(min(5.0, limit_s / 4))
+            if time.monotonic() - state["t"] > limit_s:
+                print(f"bench.py: rank {rank} made no progress for {limit_s:.0f} s (last stage: {state['what']}); giving up",
+                      file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                os._exit(17)
+
+    threading.Thread(target=watch, daemon=True, name="bench-watchdog").start()
+    return tick
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,6 +280,9 @@ def main():
                          f"(backend is {dist.get_backend() if dist.is_initialized() else None})")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # N > 1: a collective that never completes (a rank that died, a transport that does not come up) would otherwise hold the
+    # node until the caller's own limit; every step ticks, and LOTUS_BENCH_WATCHDOG_S seconds without one end the rank loudly
+    tick = _watchdog(rank, float(os.environ.get("LOTUS_BENCH_WATCHDOG_S", "300"))) if world > 1 else (lambda what=None: None)
     dp_stream = None
     if dist.is_initialized() and os.environ.get("LOTUS_DIAG_NO_PRIME") != "1":
         dp_stream = parallel.training_stream()  # the step's four streams, created back to back before any communicator exists
@@ -304,6 +333,7 @@ def main():
     host_t = [0.0, 0.0, 0.0, 0]  # host seconds inside forward / backward / finish of the steps (enqueue time, no synchronisation)
 
     def step():
+        tick()
         t0 = time.perf_counter()
         if reducer is not None:
             reducer.zero_grad()
@@ -340,9 +370,11 @@ def main():
     if dp_stream is not None:
         hi = dp_stream
     torch.cuda.set_stream(hi)
+    tick("warm-up steps")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    tick("timed steps")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -563,7 +595,9 @@ def main():
                               "points_rank0": int(sum(host_batch["npoints_in_batch"])),
                               # collectives issued through the library's own RCCL communicators (csrc/comm.cpp): "comm" = gradient
                               # buckets on the communication stream, "main" = SyncBN statistics + usage flags in the training stream
-                              "native_rccl_lanes": {"comm": reducer._lane_comm is not None, "main": reducer._lane_main is not None},
+                              "native_rccl_lanes": {"comm": reducer._lane_comm is not None, "main": reducer._lane_main is not None,
+                                                    # lotus_stream_probe: a collective parked on one of the two streams cannot hold the other back
+                                                    "streams_independent": reducer.lanes_independent},
                               # gradients written by their backward node straight into the bucket buffer (no pack copy)
                               "gradient_fraction_born_in_bucket": round(reducer.inplace_floats / max(1, reducer.inplace_floats + reducer.copied_floats), 4)}
         if peract:

@@ -82,14 +82,24 @@ int lotus_streamlink_destroy(unsigned long long link);
  *                                torch.distributed — the bootstrap stays there)
  *   lotus_comm_create(id, n, r)  collective over the n ranks -> opaque handle, 0 on failure (device = the caller's current one)
  *   lotus_comm_allreduce(...)    in place on `buf`; dtype 0 = f32, 1 = f64, 2 = i32; op 0 = sum, 1 = max, 2 = average.
- *                                Collectives of one communicator must be issued in the same order on every rank and from one
- *                                stream at a time (parallel.py keeps one communicator per stream that sends). */
+ *                                Collectives of one communicator must be issued in the same order on every rank; RCCL
+ *                                runs them in that order even when they are issued from different streams (parallel.py keeps
+ *                                one communicator per sending stream so that the two streams do NOT wait for each other,
+ *                                after lotus_stream_probe below has shown that they cannot block each other either). */
 int lotus_comm_load(const char* path);
 int lotus_comm_version(void);
 int lotus_comm_unique_id(void* id128_host);
 unsigned long long lotus_comm_create(const void* id128_host, int nranks, int rank);
 int lotus_comm_allreduce(unsigned long long comm, void* buf, size_t count, int dtype, int op, void* stream);
 int lotus_comm_destroy(unsigned long long comm);
+/* Two communicators in flight (gradient buckets on the communication stream, statistics on the training stream) are only safe
+ * when a collective kernel that waits for its peers on one stream cannot hold back the other stream — which is a property of
+ * the hardware queues the two HIP streams were mapped to, not of the program (csrc/stream_probe.hip has the deadlock picture).
+ * lotus_stream_probe parks a kernel on `blocked` (it spins on a host flag, and leaves by itself after timeout_ms + 500 ms),
+ * launches a second one on `other` and reports whether that one completed while the first was parked:
+ * 1 = independent, 0 = `other` waits for `blocked`, < 0 = error.  Synchronises both streams before it returns; 1..2000 ms.
+ * parallel.GradReducer calls it once per process before it creates the second communicator. */
+int lotus_stream_probe(void* blocked, void* other, int timeout_ms);
 
 /* ---- operand precision: a PER-CALL argument (`precision`) of the dense, sparse-convolution and attention entry points
  * (no process-wide state: two models with different precisions can share a process).  0 = fp32 MFMA, exact products

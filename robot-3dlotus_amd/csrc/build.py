@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["lotus_capi.cpp", "comm.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip"]
+SOURCES = ["lotus_capi.cpp", "comm.cpp", "blocks.cpp", "gemm.hip", "gemm_dma.hip", "conv.hip", "conv_pairs.hip", "norm.hip", "attention.hip", "front_end.hip", "pool_head.hip", "optim.hip", "stream_probe.hip"]
 HEADERS = ["common.h", "mma.h", "gemm_common.h", "gemm_dma.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # measurement builds (never the shipped library): LOTUS_BUILD_DEFINES="LOTUS_EXP_SKIP_PROBE" python build.py --force

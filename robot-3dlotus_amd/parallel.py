@@ -137,6 +137,39 @@ def native_comm(group, lane):
     return c
 
 
+_RETIRED_STREAMS = []
+
+
+def _checked_comm_stream(group):
+    """-> (communication stream, independent): the package's "comm" stream, verified with lotus_stream_probe against the CURRENT
+    stream (the training stream: make it current before building the reducer) in both directions — a kernel parked on one
+    must not stop the other.  HIP deals its streams onto GPU_MAX_HW_QUEUES hardware queues in creation order, so a stream that
+    shares the training stream's queue is retired (kept alive: its slot stays taken) and the next one tried, four times.
+    `independent` is the MIN over the ranks of the group, so that every rank builds the same communicators.
+    LOTUS_DP_PROBE=0 skips the check (independent = True)."""
+    st = _capi.step_stream("comm")
+    if os.environ.get("LOTUS_DP_PROBE", "1") == "0":
+        return st, True
+    cur = torch.cuda.current_stream()
+    ok = False
+    for _ in range(4):
+        res = [_capi.query("lotus_stream_probe", a.cuda_stream, b.cuda_stream, 50) for a, b in ((st, cur), (cur, st))]
+        if min(res) < 0:
+            raise _capi.LotusError("lotus_stream_probe failed: " + _capi.lib().last_error())
+        ok = res == [1, 1]
+        if ok:
+            break
+        _RETIRED_STREAMS.append(st)
+        st = _capi._STEP_STREAMS["comm"] = torch.cuda.Stream(priority=_capi.STREAM_PRIORITY)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0 and dist.get_rank(group) == 0:
+        import sys
+        print("lotus parallel: the communication stream cannot run independently of the training stream on some rank "
+              "(shared hardware queue); gradient buckets and statistics share ONE communicator", file=sys.stderr)
+    return st, bool(int(flag.item()))
+
+
 class GradReducer:
     """Flat-buffer bucketed gradient averaging with backward overlap.
 
@@ -177,10 +210,17 @@ class GradReducer:
         self._avg = (self.world > 1 or self._force) and dist.get_backend(group) == "nccl"  # RCCL averages in the collective
         # native lanes (collective construction, same order on every rank): buckets on the communication stream, usage flags
         # on the training stream
-        self._lane_comm = native_comm(group, "comm") if (self._avg and dev.type == "cuda") else None
-        self._lane_main = native_comm(group, "main") if (self._avg and dev.type == "cuda") else None
-        self._arrival, self._seen, self._learning = [], set(), True
         self._comm, self._keep = None, []
+        self._lane_comm = self._lane_main = None
+        self.lanes_independent = None
+        if self._avg and dev.type == "cuda":
+            self._lane_main = native_comm(group, "main")
+            # two communicators in flight need two streams that cannot hold each other back (csrc/stream_probe.hip): checked
+            # on the device, decided together; without it the buckets share the statistics' communicator, whose collectives
+            # RCCL orders by itself — slower (a statistics message can queue behind a bucket), never a deadlock
+            self._comm, self.lanes_independent = _checked_comm_stream(group)
+            self._lane_comm = native_comm(group, "comm") if self.lanes_independent else self._lane_main
+        self._arrival, self._seen, self._learning = [], set(), True
         self._sync = True
         self._index = {p: i for i, p in enumerate(self.params)}
         pin = dev.type == "cuda"

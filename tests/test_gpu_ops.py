@@ -406,6 +406,21 @@ def test_patch_attention_query_per_lane_path():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
+def test_cross_attention_round5_short_key_kernels_still_agree():
+    """LOTUS_XQ=3 routes the 32-wide heads of the cross attention back to the query-per-lane kernels of round 5 (the A/B partner
+    of xq2_fwd_kernel / xq2_bwd_kernel, csrc/attention.hip): they stay in the library as the path of the 16- and 24-wide heads, so
+    they keep the same fp64 check on the 32-wide shapes too.  Read once per process, hence the child interpreter."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_cross_attention_fwd_bwd"], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, LOTUS_XQ="3"), cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 @pytest.mark.parametrize("prec,tol", [(3, 1e-4), (1, 4e-2)])
 @pytest.mark.parametrize("C,H", [(64, 2), (128, 4), (768, 32)])
 def test_patch_attention_bf16_operand_paths(prec, tol, C, H):

@@ -219,7 +219,8 @@ def test_one_rank_rccl_rehearsal_of_the_data_parallel_step():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["rccl_ranks"] == 1 and out["config"]["dist_backend"] == "nccl" and out["value"] > 0
     # ... and the collectives of the step went through the library's own communicators (csrc/comm.cpp), not ProcessGroupNCCL
-    assert out["reducer"]["native_rccl_lanes"] == {"comm": True, "main": True}, out["reducer"]
+    # ... on two streams that lotus_stream_probe found unable to hold each other back
+    assert out["reducer"]["native_rccl_lanes"] == {"comm": True, "main": True, "streams_independent": True}, out["reducer"]
 
 
 _NATIVE_SCRIPT = r"""
@@ -231,6 +232,7 @@ from robot_3dlotus_amd import parallel
 os.environ["LOTUS_FORCE_COLLECTIVES"] = "1"
 parallel.init_distributed()
 dev = torch.device("cuda", 0)
+torch.cuda.set_stream(parallel.training_stream())  # what a data-parallel trainer does right after init_distributed()
 res = {}
 lane = parallel.native_comm(None, "main")
 res["lane"] = lane is not None
@@ -244,6 +246,7 @@ torch.manual_seed(0)
 net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.GELU(), torch.nn.Linear(256, 256), torch.nn.GELU(), torch.nn.Linear(256, 8)).to(dev)
 red = parallel.GradReducer(net, bucket_mb=0.05)
 res["lanes"] = [red._lane_comm is not None, red._lane_main is not None]
+res["independent"], res["one_comm"], res["retired"] = red.lanes_independent, red._lane_comm is red._lane_main, len(parallel._RETIRED_STREAMS)
 x = torch.randn(32, 64, device=dev)
 for _ in range(3):
     red.zero_grad()
@@ -264,23 +267,32 @@ dist.destroy_process_group()
 """
 
 
-@pytest.mark.parametrize("native", ["1", "0"])
+@pytest.mark.parametrize("native", ["1", "0", "one-queue"])
 def test_native_rccl_lanes_and_their_fallback(native):
     """csrc/comm.cpp: all-reduces issued straight into the caller's stream on the library's own RCCL communicators (one-rank
     communicators here: known answers for the three dtype / op pairs the step uses, the reducer's averaged gradients equal to the
-    plain backward pass bit for bit, the usage mask), and LOTUS_DP_NATIVE=0 -> the same results through ProcessGroupNCCL."""
+    plain backward pass bit for bit, the usage mask), and LOTUS_DP_NATIVE=0 -> the same results through ProcessGroupNCCL.
+    "one-queue": GPU_MAX_HW_QUEUES=1 puts every stream on one hardware queue — lotus_stream_probe must see that a collective parked
+    on the communication stream would hold the training stream back (the two-communicator deadlock, csrc/stream_probe.hip), and
+    the reducer must then keep ONE communicator for buckets and statistics, with the same gradients."""
     import json
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["LOTUS_DP_NATIVE"] = native
+    env["LOTUS_DP_NATIVE"] = "0" if native == "0" else "1"
+    if native == "one-queue":
+        env["GPU_MAX_HW_QUEUES"] = "1"
     r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _NATIVE_SCRIPT], capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res["grads_equal"] and res["mask"], res
     if native == "1":
         assert res["lane"] and res["answers"] and res["lanes"] == [True, True], res
+        assert res["independent"] is True and not res["one_comm"], res
+    elif native == "one-queue":
+        assert res["lane"] and res["answers"] and res["lanes"] == [True, True], res
+        assert res["independent"] is False and res["one_comm"] and res["retired"] == 4, res
     else:
         assert not res["lane"] and res["lanes"] == [False, False], res

@@ -519,3 +519,20 @@ def test_world8_gloo_tapered_buckets_unequal_shards_and_a_flipping_parameter():
     res = run(31500 + (os.getpid() % 2000)) or run(35500 + (os.getpid() % 2000))
     assert res is not None, "gloo workers did not finish"
     assert all(r[1] for r in res), res
+
+
+def test_bench_watchdog_ends_a_rank_that_stopped_ticking():
+    """bench.py --gpus N > 1: a rank stuck in a collective must not hold the node until the caller's limit — no tick within
+    LOTUS_BENCH_WATCHDOG_S ends the process with exit code 17 and the Python stacks on stderr; a ticking rank lives."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "tick = bench._watchdog(3, 0.6)\n"
+            "for _ in range(10): time.sleep(0.2); tick('alive')\n"
+            "print('still here', flush=True)\n"
+            "time.sleep(30)\n") % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=root)
+    assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
+    assert "still here" in r.stdout and "rank 3 made no progress" in r.stderr and "last stage: alive" in r.stderr
