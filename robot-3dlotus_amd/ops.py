@@ -242,11 +242,6 @@ class _OnSide:
         self.on = _side() is not None
         if not self.on:
             return self
-        self.prev = _capi.STREAM_OVERRIDE
-        if self.prev:  # inside a _SideRegion: the launches already go to the side stream, behind what they read
-            if _JOIN == "end":
-                _hold_for_side(self.reads, _SIDES[_CUR][0])
-            return self
         _CUR = _RR
         _RR = (_RR + 1) % _NSIDE
         side, ptr = _SIDES[_CUR]
@@ -258,7 +253,7 @@ class _OnSide:
 
     def __exit__(self, *a):
         if self.on:
-            _capi.STREAM_OVERRIDE = self.prev
+            _capi.STREAM_OVERRIDE = 0
 
 
 _HELD = []  # tensors the weight-gradient stream reads, kept alive until the end-of-backward join (deferred-join mode)
@@ -329,74 +324,7 @@ def _joined(fn):
 
 
 def _ws(nbytes, dev):
-    if _WS_SIDE:  # inside a _SideRegion: the side stream's own workspace (slot 0 belongs to the launches of the main stream)
-        return _side_ws(nbytes, dev)
     return WS.get(nbytes, dev, slot=0)
-
-
-_WS_SIDE = False
-_TMP_SINK = None  # inside a _SideRegion: the list that keeps the helpers' local temporaries alive (see _SideRegion)
-
-
-def _tmp(t):
-    if _TMP_SINK is not None:
-        _TMP_SINK.append(t)
-    return t
-
-
-def _side_force():
-    """The weight-gradient stream, also outside a backward pass (None: side streams are off)."""
-    global _IN_NODE
-    if not _SIDE_ON:
-        return None
-    if SIDE is None:
-        _IN_NODE += 1
-        try:
-            _side()
-        finally:
-            _IN_NODE -= 1
-    return SIDE
-
-
-class _SideRegion:
-    """A run of launches on the weight-gradient stream that is NOT a weight gradient: a whole sub-graph whose result the main
-    stream needs much later (the skip half of SerializedUnpooling, UnpoolSkipFn).  On entry the side stream is ordered behind
-    everything the main stream has enqueued; inside, every ops.call() goes to the side stream with that stream's workspace and
-    arrival counters; torch's current stream is left alone, so every tensor is allocated from the MAIN stream's pool: results
-    are read by the main stream after it has waited for `done()`'s event, and everything else the side stream touches —
-    inputs that autograd frees on return, temporaries of the helpers (collected in `keep` through _tmp) — must stay referenced
-    until that wait has been enqueued (the caller keeps `keep`): memory freed earlier could be handed to a main-stream kernel
-    while the side stream still uses it."""
-
-    def __init__(self, keep):
-        self.keep = keep
-        self.on = False
-
-    def __enter__(self):
-        global _WS_SIDE, _TMP_SINK, _CUR
-        st = _side_force()
-        if st is None or _capi.STREAM_OVERRIDE:
-            return self
-        self.on = True
-        _CUR = 0
-        self.stream, ptr = _SIDES[0]
-        _capi.call_raw("lotus_streamlink_wait", _LINK, _capi.stream_ptr(), ptr)
-        self.prev = (_WS_SIDE, _TMP_SINK)
-        _WS_SIDE, _TMP_SINK = True, self.keep
-        _capi.STREAM_OVERRIDE = ptr
-        return self
-
-    def __exit__(self, *a):
-        global _WS_SIDE, _TMP_SINK
-        if self.on:
-            _capi.STREAM_OVERRIDE = 0
-            _WS_SIDE, _TMP_SINK = self.prev
-
-    def done(self, ev):
-        """Record `ev` behind the region's launches -> True (False: the region ran on the main stream, nothing to wait for)."""
-        if self.on:
-            ev.record(self.stream)
-        return self.on
 
 
 _COUNTERS = {}
@@ -918,7 +846,7 @@ def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS
     if training and _BN_FUSED and BnState.reduce is None and x.shape[0] > 0:
         # local batch statistics: statistics, their reduction, mean / invstd and the running averages in ONE launch
         M, C = x.shape
-        sums = _tmp(torch.empty(2 * C + 1, dtype=torch.float64, device=x.device))
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
         mean = torch.empty(C, dtype=torch.float32, device=x.device)
         invstd = torch.empty(C, dtype=torch.float32, device=x.device)
         ws = _ws(query("lotus_batchnorm_workspace", M, C), x.device)
@@ -928,7 +856,7 @@ def bn_fwd(x, g, b, rmean, rvar, training, act, momentum=BN_MOMENTUM, eps=BN_EPS
         call("lotus_batchnorm_apply", x, mean, invstd, g, b, y, M, C, act)
         return y, mean, invstd
     if training:
-        sums = _tmp(torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device))
+        sums = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
         _bn_stats(x, sums)
         if BnState.reduce is not None:
             BnState.reduce(sums)
@@ -986,7 +914,7 @@ def _bn_bwd_apply(dy, x, mean, invstd, g, b, training, act, sums, reduced):
 
 def bn_bwd(dy, x, mean, invstd, g, b, training, act):
     C = x.shape[1]
-    sums = _tmp(torch.empty(2 * C + 1, dtype=torch.float64, device=x.device))
+    sums = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
     reduced = None
     if training and BnState.reduce is not None:
         reduced = _bn_bwd_stats(dy, x, mean, invstd, g, b, act, sums, want_params=True)
@@ -1828,121 +1756,6 @@ class UnpoolFn(torch.autograd.Function):
         dws, dbs = linear_wgrad(dls, xp)
         dxp = linear_dgrad(dls, ctx.wk[1])
         return dxc, dxp, dwu, dbu, dgu, dbetau, None, None, dws, dbs, dgs, dbetas, None, None, None, None
-
-
-# ---- SerializedUnpooling with the skip half AHEAD of its consumer (one process, local BatchNorm statistics).
-# skip = GELU(BN(Linear_skip(parent))) depends on the ENCODER output of its level only, which exists long before the decoder
-# gets there, and its gradient is not needed before the encoder stage of that level runs backward.  UnpoolFn computes both
-# halves where the reference does (model.py:817-828): the level-0 / level-1 skip halves then sit on the critical stream
-# next to the largest kernels of the step, while the deepest encoder / decoder stages in between are chains of small
-# launches that leave most of the GPU idle in both directions.  Split in three nodes, the backbone issues the skip halves
-# of all levels right before the deepest encoder stage, on the weight-gradient stream (idle in forward):
-#   a, b = SkipFanFn(x_s)            a feeds the next stage's pooling, b the skip half: the node exists for its backward,
-#                                    where the main stream waits for the skip half's gradient and adds the two
-#   skip_s = UnpoolSkipFn(b, ...)    forward and backward on the side stream (_SideRegion)
-#   x = UnpoolUpFn(x_coarse, skip_s) the up half + the sum, where UnpoolFn sits; waits for skip_s
-# Autograd runs the UnpoolSkipFn nodes where they were created: right after the deepest stage's backward, deepest level
-# first.  Same kernels, same operands, same order of every sum: bit-identical to UnpoolFn (tests/test_gpu_round6.py).
-# With SyncBatchNorm the statistics are collectives issued in one order on every rank: UnpoolFn stays.
-class SkipSlot:
-    """Events and keep-alive lists of one level's skip half (see _SideRegion for what must stay referenced, and until when)."""
-
-    def __init__(self):
-        self.ev_f = torch.cuda.Event()
-        self.ev_b = torch.cuda.Event()
-        self.keep_f = self.keep_b = None
-        self.pend_f = self.pend_b = False
-
-    def wait_fwd(self):
-        if self.pend_f:
-            torch.cuda.current_stream().wait_event(self.ev_f)
-        self.pend_f, self.keep_f = False, None
-
-    def wait_bwd(self):
-        if self.pend_b:
-            torch.cuda.current_stream().wait_event(self.ev_b)
-        self.pend_b, self.keep_b = False, None
-
-
-class SkipFanFn(torch.autograd.Function):
-    @_fwd
-    def forward(ctx, x, slot):
-        ctx.slot = slot
-        return x.view_as(x), x.view_as(x)
-
-    @_joined
-    def backward(ctx, da, db):
-        ctx.slot.wait_bwd()  # db was written by the side stream
-        if da is None or db is None:
-            return (db if da is None else da), None
-        return add(da.contiguous(), db.contiguous()), None
-
-
-class UnpoolSkipFn(torch.autograd.Function):
-    @_fwd
-    def forward(ctx, xp, ws_, bs, gs, betas, rms, rvs, training, slot):
-        (wsk,), _ = _wk(ws_)
-        ctx.wk = wsk
-        slot.wait_fwd()  # (a forward pass whose decoder never ran)
-        keep = []
-        with _SideRegion(keep) as reg:
-            ls, _ = linear_fwd(xp, wsk, bs)
-            skip, ms, is_ = bn_fwd(ls, gs, betas, rms, rvs, training, ACT_GELU)
-        slot.pend_f, slot.keep_f = reg.done(slot.ev_f), keep
-        ctx.save_for_backward(xp, ws_, gs, betas, ls, ms, is_)
-        ctx.meta = (training, slot)
-        return skip
-
-    @_joined
-    def backward(ctx, dskip):
-        xp, ws_, gs, betas, ls, ms, is_ = ctx.saved_tensors
-        training, slot = ctx.meta
-        dskip = dskip.contiguous()
-        slot.wait_bwd()
-        keep = [dskip]
-        with _SideRegion(keep) as reg:
-            dls, dgs, dbetas = bn_bwd(dskip, ls, ms, is_, gs, betas, training, ACT_GELU)
-            keep.append(dls)
-            dws, dbs = linear_wgrad(dls, xp)
-            dxp = linear_dgrad(dls, ctx.wk)
-        slot.pend_b, slot.keep_b = reg.done(slot.ev_b), keep
-        return dxp, dws, dbs, dgs, dbetas, None, None, None, None
-
-
-class UnpoolUpFn(torch.autograd.Function):
-    @_fwd
-    def forward(ctx, xc, skip, wu, bu, gu, betau, rmu, rvu, child, training, slot):
-        (wuk,), _ = _wk(wu)
-        ctx.wk = wuk
-        lu, _ = linear_fwd(xc, wuk, bu)
-        up, mu, iu = bn_fwd(lu, gu, betau, rmu, rvu, training, ACT_GELU)
-        slot.wait_fwd()  # skip was written by the side stream
-        x = torch.empty_like(skip)
-        call("lotus_unpool_fwd", skip, up, child.cluster, skip.shape[0], skip.shape[1], x)
-        ctx.save_for_backward(xc, wu, gu, betau, lu, mu, iu)
-        ctx.meta = (child, training)
-        return x
-
-    @_joined
-    def backward(ctx, dx):
-        xc, wu, gu, betau, lu, mu, iu = ctx.saved_tensors
-        child, training = ctx.meta
-        C = wu.shape[0]
-        dx = dx.contiguous()
-        dup = torch.empty(child.n, C, dtype=dx.dtype, device=dx.device)
-        call("lotus_unpool_bwd", dx, child.members, child.seg_start, child.n, C, dup)
-        dlu, dgu, dbetau = bn_bwd(dup, lu, mu, iu, gu, betau, training, ACT_GELU)
-        dwu, dbu = linear_wgrad(dlu, xc)
-        dxc = linear_dgrad(dlu, ctx.wk)
-        return dxc, dx, dwu, dbu, dgu, dbetau, None, None, None, None, None
-
-
-SKIP_AHEAD = os.environ.get("LOTUS_SKIP_AHEAD", "0") == "1"  # (off until measured on the GPU)
-
-
-def skip_ahead_enabled():
-    """The skip halves of the unpoolings ahead of the decoder: single-process BatchNorm statistics only."""
-    return SKIP_AHEAD and BnState.reduce is None
 
 
 class LinearFn(torch.autograd.Function):

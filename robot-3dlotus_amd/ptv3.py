@@ -360,7 +360,6 @@ class PointTransformerV3CA(nn.Module):
     def drop_prefetch(self):
         """Forget a prefetched (or announced) batch that will not be passed to forward() after all."""
         self._pending, self._deferred = None, None
-        self._skip_slots = []
 
     def _launch_prefetch(self, src, counts, wait_current):
         perms = self.order_perms if self.order_perms is not None else draw_order_perms(self.num_stages, self.shuffle_orders)
@@ -419,11 +418,6 @@ class PointTransformerV3CA(nn.Module):
                 wb += [c.attn.kv.weight, c.attn.kv.bias]
             ops.KvAllFn.apply(context, bank, *wb)
         skips = []
-        # the skip halves of the unpoolings are issued ahead of the deepest stage, on the weight-gradient stream (ops.UnpoolSkipFn)
-        ahead = ops.skip_ahead_enabled() and self.num_stages > 1
-        if ahead and len(self._skip_slots) != self.num_stages - 1:
-            self._skip_slots = [ops.SkipSlot() for _ in range(self.num_stages - 1)]
-        skip_ready = None
         for s in range(self.num_stages):
             enc, lvl = self.enc[s], levels[s]
             site += 1
@@ -441,31 +435,16 @@ class PointTransformerV3CA(nn.Module):
                     continue
                 x, hand = blk.run(x, x, lvl.for_order(i % n_ord), p, si, pa, packs[blk], dpath)
                 x = cab.run(x, context, lvl, p, ops.mix_seed(si, 8), pa, hand, bank, cidx[id(cab)])
-            if ahead and s < self.num_stages - 1:
-                x, xb = ops.SkipFanFn.apply(x, self._skip_slots[s])
-                skips.append(xb)
-                if s == self.num_stages - 2:
-                    skip_ready = []
-                    for t in range(self.num_stages - 1):
-                        us = self.dec[self.num_stages - 2 - t].up.proj_skip
-                        skip_ready.append(ops.UnpoolSkipFn.apply(skips[t], us[0].weight, us[0].bias, us[1].weight, us[1].bias,
-                                                                 us[1].running_mean, us[1].running_var, training, self._skip_slots[t]))
-            else:
-                skips.append(x)
+            skips.append(x)
         outs = [self._pack(x, levels[-1])]
         for i, s in enumerate(reversed(range(self.num_stages - 1))):
             dec, lvl, child = self.dec[i], levels[s], levels[s + 1]
             site += 1
             seed = ops.mix_seed(base, site)
             u, us = dec.up.proj, dec.up.proj_skip
-            if ahead:
-                skip = skip_ready[s]
-                x = ops.UnpoolUpFn.apply(x, skip, u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
-                                         u[1].running_var, child, training, self._skip_slots[s])
-            else:
-                x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
-                                             u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
-                                             us[1].running_mean, us[1].running_var, child, training)
+            x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
+                                         u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
+                                         us[1].running_mean, us[1].running_var, child, training)
             for j in range(self.dec_depths[s]):
                 blk, cab = getattr(dec, f"block{j}"), getattr(dec, f"ca_block{j}")
                 si = seed if j == 0 else ops.mix_seed(seed, 16 + j)

@@ -491,60 +491,6 @@ def test_full_size_stream_modes_bit_identical():
             assert torch.equal(u, v), (step, k)
 
 
-def test_skip_halves_ahead_of_the_decoder_are_bit_identical():
-    """ops.UnpoolSkipFn / UnpoolUpFn / SkipFanFn (the skip halves of the four unpoolings issued before the deepest encoder stage
-    on the weight-gradient stream, their backward right behind the deepest stage's) against ops.UnpoolFn (both halves where
-    the reference computes them, model.py:817-828) at the bench configuration, deferred join, prefetched front-end, six steps:
-    the same kernels on the same operands, so every loss and all 460 gradients of every step must be EQUAL — a missing
-    wait, a workspace shared with the main stream or memory handed back too early shows up as a differing bit.  Also with the
-    join per node, and the outputs of an evaluation forward."""
-    from robot_3dlotus_amd import config as lcfg, ops, synth
-    from robot_3dlotus_amd.policy import SimplePolicyPTV3CA
-
-    batches = [_dev_batch(synth.synth_batch(16, 4096, seed=s)) for s in (0, 1)]
-    torch.manual_seed(0)
-    sd = {k: v.clone() for k, v in SimplePolicyPTV3CA(lcfg.preset("v1")).state_dict().items()}
-
-    def run(ahead, join):
-        prev = ops.SKIP_AHEAD
-        ops.SKIP_AHEAD = ahead
-        ops.set_wgrad_join(join)
-        hi = torch.cuda.Stream(priority=-1)
-        try:
-            torch.manual_seed(1)
-            m = SimplePolicyPTV3CA(lcfg.preset("v1"))
-            m.load_state_dict(sd)
-            m = m.cuda().train()
-            out = []
-            with torch.cuda.stream(hi):
-                m.prefetch(batches[0])
-                for i in range(6):
-                    for p in m.parameters():
-                        p.grad = None
-                    _, losses = m(batches[i % 2], compute_loss=True, compute_final_action=False)
-                    m.prefetch(batches[(i + 1) % 2])
-                    losses["total"].backward()
-                    hi.synchronize()
-                    out.append([losses["total"].detach().clone()] + [p.grad.clone() for p in m.parameters()])
-                m.eval()
-                with torch.no_grad():
-                    m(batches[0], compute_loss=False, compute_final_action=False)
-                hi.synchronize()
-                out.append([m.last_pred[0].detach().clone()])
-            return out
-        finally:
-            ops.SKIP_AHEAD = prev
-            ops.set_wgrad_join("node")
-
-    ref = run(False, "end")
-    for join in ("end", "node"):
-        got = run(True, join)
-        for step, (ga, gb) in enumerate(zip(got, ref)):
-            assert len(ga) == len(gb)
-            for k, (u, v) in enumerate(zip(ga, gb)):
-                assert torch.equal(u, v), (join, step, k)
-
-
 def test_models_of_different_precisions_coexist():
     """Operand precision is per call (captured per autograd node): an fp32 model and a bf16 model interleaved in one
     process — forward of one, forward of the other, then both backward passes — give bit-identically the results of
