@@ -283,12 +283,16 @@ def reference_model_config(variant="v1"):
     return to_cfg(cfg)
 
 
-def build_reference_policy(variant="v1", drop_path=0.0):
+def build_reference_policy(variant="v1", drop_path=0.0, enable_flash=True):
+    """enable_flash=False: the reference's OWN attention arithmetic — the padded-patch softmax branch of SerializedAttention
+    (PointTransformerV3/model.py:499-527) and the padded einsum branch of the cross attention (model_ca.py:68-95) — instead of
+    its flash_attn calls, i.e. without this file's flash_attn stand-in anywhere on the path."""
     install_shims()
     from genrobo3d.models.simple_policy_ptv3 import SimplePolicyPTV3CA
 
     cfg = reference_model_config(variant)
     cfg["ptv3_config"]["drop_path"] = drop_path
+    cfg["ptv3_config"]["enable_flash"] = bool(enable_flash)
     return SimplePolicyPTV3CA(cfg), cfg
 
 

@@ -49,6 +49,53 @@ def test_losses_and_grads_match_reference(variant, wvar, B, n, train):
         assert (p.grad - sdg[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
 
 
+@pytest.mark.parametrize("variant,B,n,train", [("tiny", 3, 1024, True), ("tinydeep", 2, 1024, True), ("tinyctx", 2, 900, False)])
+def test_oracle_matches_the_reference_own_attention_arithmetic(variant, B, n, train):
+    """flash_attn is not installed here, so everywhere else the reference runs over the harness' stand-in for it.  With
+    `enable_flash=False` the reference computes both attentions ITSELF — the padded-patch softmax of SerializedAttention
+    (PointTransformerV3/model.py:499-527) and the padded einsum of the cross attention (model_ca.py:68-95; absent words masked
+    with -1e4) — over the same patches and the same key sets as its flash calls.  The oracle (and the HIP kernels checked
+    against it) must agree with THAT code: losses 1e-5, every parameter gradient 1e-4; and the stand-in must agree with it too,
+    which pins the fixtures generated over the stand-in.  (Two-stage configurations with >= 128 points per cloud at both levels:
+    the non-flash branch shrinks the patch size to the smallest cloud of a level, model.py:469-472 — a different function as soon
+    as a cloud is shorter than one patch, as at the deep levels of v1.)"""
+    rh = _harness()
+    from weights_util import seeded_state_dict
+    from robot_3dlotus_amd import config as lcfg, synth
+    from oracle.model import Oracle
+    from make_golden import zero_dropouts
+
+    batch = synth.synth_batch(B, n, ragged=False, seed=33)
+    runs = {}
+    for flash in (False, True):
+        ref, _ = rh.build_reference_policy(variant, enable_flash=flash)
+        if flash:
+            ref.load_state_dict(sd, strict=True)
+        else:
+            sd = seeded_state_dict(ref.state_dict(), 9, "scaled")
+            ref.load_state_dict(sd, strict=True)
+        zero_dropouts(ref)
+        ref.train(train)
+        perms = []
+        with rh.neutralise_half(), rh.record_randperm(perms):
+            torch.manual_seed(4)
+            losses = rh.reference_forward(ref, copy.deepcopy(batch), full=(variant == "v1"))
+        losses["total"].backward()
+        runs[flash] = (ref, losses, perms)
+    ref, losses, perms = runs[False]
+    sdg = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+    out = Oracle(sdg, lcfg.plain(lcfg.preset(variant)), training=train).forward(batch, [p.numpy() for p in perms])
+    out["losses"]["total"].backward()
+    gmax = max(p.grad.norm().item() for p in ref.parameters())
+    stand_in = dict(runs[True][0].named_parameters())
+    for k in losses:
+        assert abs(losses[k].item() - out["losses"][k].item()) < 1e-5 * max(1, abs(losses[k].item())), k
+        assert abs(losses[k].item() - runs[True][1][k].item()) < 1e-5 * max(1, abs(losses[k].item())), k
+    for name, p in ref.named_parameters():
+        assert (p.grad - sdg[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
+        assert (p.grad - stand_in[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
+
+
 def test_encode_matches_reference_all_depths():
     rh = _harness()
     from genrobo3d.models.PointTransformerV3.serialization import encode as ref_encode
