@@ -213,6 +213,7 @@ class GradReducer:
         self._comm, self._keep = None, []
         self._lane_comm = self._lane_main = None
         self.lanes_independent = None
+        self._defer_flush = False
         if self._avg and dev.type == "cuda":
             self._lane_main = native_comm(group, "main")
             # two communicators in flight need two streams that cannot hold each other back (csrc/stream_probe.hip): checked
@@ -220,6 +221,12 @@ class GradReducer:
             # RCCL orders by itself — slower (a statistics message can queue behind a bucket), never a deadlock
             self._comm, self.lanes_independent = _checked_comm_stream(group)
             self._lane_comm = native_comm(group, "comm") if self.lanes_independent else self._lane_main
+            # ONE communicator for both kinds of message: its collectives must be ISSUED in one order on every rank.  The
+            # statistics are (the same program everywhere), the buckets are issued where their last gradient arrives — and a
+            # rank whose usage pattern differs from the learnt one flushes a bucket later than the others (finish()), i.e.
+            # between different statistics messages.  So in this fallback no bucket leaves during backward: finish() sends
+            # them all, in layout order, behind the last statistics message — no overlap, but one order by construction.
+            self._defer_flush = not self.lanes_independent
         self._arrival, self._seen, self._learning = [], set(), True
         self._sync = True
         self._index = {p: i for i, p in enumerate(self.params)}
@@ -365,7 +372,7 @@ class GradReducer:
             # collectives are matched across ranks by issue order: buckets go out strictly in layout order (which IS the
             # arrival order, so nothing waits unless a rank's usage pattern differs from the learnt one)
             self._ready[b] = True
-            while self._next < len(self.buckets) and self._ready[self._next]:
+            while not self._defer_flush and self._next < len(self.buckets) and self._ready[self._next]:
                 self._flush(self._next)
                 self._next += 1
 
@@ -382,7 +389,7 @@ class GradReducer:
         if any(q.grad is None for q in self._bparams[b]):
             return  # (a parameter of the bucket has not arrived — unused this step, or a changed order: finish() flushes it)
         self._ready[b] = True
-        while self._next < len(self.buckets) and self._ready[self._next]:
+        while not self._defer_flush and self._next < len(self.buckets) and self._ready[self._next]:
             self._flush(self._next)
             self._next += 1
 

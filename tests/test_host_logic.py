@@ -440,7 +440,7 @@ def test_grad_reducer_tapers_the_tail_of_the_arrival_order():
 # ---------------------------------------------------------------------------------------------------------------------
 # world 8: tapered buckets + unequal shards + a parameter whose usage flips from step to step, against the
 # gradient ONE process computes for the mean over all clouds.
-def _world8_worker(rank, world, port, q):
+def _world8_worker(rank, world, port, q, defer=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     from robot_3dlotus_amd import parallel
@@ -472,6 +472,7 @@ def _world8_worker(rank, world, port, q):
     m = Net()
     cap_mb = 72 * 4 * 6 / (1 << 20)                       # six layers per full bucket -> several buckets + a tapered tail
     red = parallel.GradReducer(m, bucket_mb=cap_mb)
+    red._defer_flush = defer  # (the one-communicator fallback of the RCCL lanes: every bucket leaves in finish())
     # who runs the optional module: nobody, rank 3 only, nobody again, everybody
     plans = [set(), {3}, set(), set(range(w))]
     ok, detail = True, {}
@@ -517,6 +518,33 @@ def test_world8_gloo_tapered_buckets_unequal_shards_and_a_flipping_parameter():
         return res
 
     res = run(31500 + (os.getpid() % 2000)) or run(35500 + (os.getpid() % 2000))
+    assert res is not None, "gloo workers did not finish"
+    assert all(r[1] for r in res), res
+
+
+def test_world4_gloo_buckets_deferred_to_finish_match_the_single_process_gradient():
+    """The reducer's fallback when the communication stream cannot run independently of the training stream (one RCCL communicator
+    for statistics and buckets: parallel.GradReducer._defer_flush): no bucket is sent from a hook, finish() sends them all in layout
+    order — same gradients, usage flags and unused-parameter handling as the overlapped schedule (the world-8 plan on 4 ranks)."""
+    import queue
+
+    def run(port):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_world8_worker, args=(r, 4, port, q, True)) for r in range(4)]
+        for p in ps:
+            p.start()
+        try:
+            res = [q.get(timeout=240) for _ in ps]
+        except queue.Empty:
+            res = None
+        for p in ps:
+            p.join(timeout=5 if res is None else 60)
+            if p.is_alive():
+                p.kill()
+        return res
+
+    res = run(33500 + (os.getpid() % 2000)) or run(37500 + (os.getpid() % 2000))
     assert res is not None, "gloo workers did not finish"
     assert all(r[1] for r in res), res
 
