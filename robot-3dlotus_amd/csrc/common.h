@@ -43,6 +43,15 @@ struct StopEventOnLast {
   ~StopEventOnLast() { lotus_tls_stop_event = ev; }  // (the owner of the event disarms it)
 };
 
+// The small passes of the critical stream — LayerNorm / BatchNorm statistics and apply, the tap sum of the convolution, pooling
+// and unpooling: vector-ALU and memory work, no MFMA — raise their waves' issue priority (s_setprio 3).  In the backward pass they
+// share every SIMD with the weight-gradient stream's MFMA waves, and an fp32 MFMA leaves no issue slot to a vector-ALU
+// instruction of another wave (tools/ubench/mfma_coissue.hip): at the default priority a 10 us normalisation pass takes 25-145 us
+// in the step.  Measured (round 6, three alternating series, tools/dbg/ab_small_prio*.sh): +0.1 ... +0.5 % of the plain step,
+// +0.7 % of the one-rank RCCL rehearsal (median of 15 fresh processes each).  The same priority on the MFMA kernels of the
+// critical stream (dense, attention, tap convolution) measured 0 ... -0.3 %: they stay at the default.
+#define LOTUS_T_PRIO() __builtin_amdgcn_s_setprio(3)
+
 #define LOTUS_OK 0
 #define LOTUS_E_ARG (-1)
 #define LOTUS_E_LAUNCH (-2)

@@ -59,6 +59,7 @@ static size_t tap_part_bytes(int n, int ND) { return (size_t)27 * ((n + 63) / 64
 __global__ __launch_bounds__(256) void conv_tap_reduce_kernel(const float* __restrict__ part, const int* __restrict__ pos, int n, int ND,
                                                               const float* __restrict__ bias, const act_t* __restrict__ add,
                                                               act_t* __restrict__ y) {
+  LOTUS_T_PRIO();
   const int n4 = ND / 4;
   const long total = (long)n * n4;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {

@@ -28,6 +28,7 @@ __device__ __forceinline__ float group_sum(float v, int lpr) {
 }
 
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnP p) {
+  LOTUS_T_PRIO();
   const int rpb = 256 / p.LPR;
   const int row = blockIdx.x * rpb + threadIdx.x / p.LPR;
   const int l = threadIdx.x % p.LPR;
@@ -99,6 +100,7 @@ struct LnBwdP {
 };
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+  LOTUS_T_PRIO();
   extern __shared__ float red[];  // [rpb][2][C]
   const int rpb = 256 / p.LPR;
   const int rslot = threadIdx.x / p.LPR, l = threadIdx.x % p.LPR;
@@ -251,6 +253,7 @@ struct BnStatP {
 };
 
 __global__ __launch_bounds__(256) void bn_stat_kernel(BnStatP p) {
+  LOTUS_T_PRIO();
   extern __shared__ double dred[];  // [rslots][2][C]
   const int c4 = p.C / 4;
   const int tpr = c4 < 256 ? c4 : 256;  // threads per row
@@ -495,6 +498,7 @@ struct BnApplyP {
 };
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyP p) {
+  LOTUS_T_PRIO();
   const int c4 = p.C / 4;
   // The launch makes gridDim.x * 256 a multiple of c4, so a thread keeps ONE column quad for its whole grid-stride
   // walk: the per-column constants (incl. the two fp64 divisions of the backward) are loaded / computed once, and the

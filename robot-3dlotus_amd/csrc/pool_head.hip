@@ -13,6 +13,7 @@ int lotus_reduce_parts(const float* part, float* out, long n, long stride, int n
 __global__ void pool_max_fwd_kernel(const act_t* __restrict__ x, const int* __restrict__ members,
                                     const int* __restrict__ seg, int nc, int C, act_t* __restrict__ y,
                                     int* __restrict__ arg) {
+  LOTUS_T_PRIO();
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)nc * c4) return;
@@ -38,6 +39,7 @@ __global__ void pool_max_fwd_kernel(const act_t* __restrict__ x, const int* __re
 // dx[p][:] = (arg[cluster[p]][:] == p) ? dy[cluster[p]][:] : 0
 __global__ void pool_max_bwd_kernel(const act_t* __restrict__ dy, const int* __restrict__ arg,
                                     const int* __restrict__ cluster, int n, int C, act_t* __restrict__ dx) {
+  LOTUS_T_PRIO();
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c4) return;
@@ -51,6 +53,7 @@ __global__ void pool_max_bwd_kernel(const act_t* __restrict__ dy, const int* __r
 // x[p][:] = skip[p][:] + up[cluster[p]][:]
 __global__ void unpool_fwd_kernel(const act_t* __restrict__ skip, const act_t* __restrict__ up,
                                   const int* __restrict__ cluster, int n, int C, act_t* __restrict__ x) {
+  LOTUS_T_PRIO();
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)n * c4) return;
@@ -63,6 +66,7 @@ __global__ void unpool_fwd_kernel(const act_t* __restrict__ skip, const act_t* _
 // dup[c][:] = sum over members of dx
 __global__ void unpool_bwd_kernel(const act_t* __restrict__ dx, const int* __restrict__ members,
                                   const int* __restrict__ seg, int nc, int C, act_t* __restrict__ dup) {
+  LOTUS_T_PRIO();
   const int c4 = C / 4;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)nc * c4) return;
