@@ -1515,8 +1515,10 @@ class CrossAttnKvFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------ (Block, CABlock) pair in one call
-# "auto" (default): the pair node is used where the step is HOST-bound — bf16 storage, or fewer than ~40 k points per
-# step — and the five sub-block nodes where it is GPU-bound.  Measured on MI355X (A/B inside one call): the pair node lowers
+# "auto" (default): the pair node is used where the host, not the GPU, sets the pace — bf16 storage, and every stage whose
+# LEVEL holds fewer than ~40 k points (round 6: decided per stage, not per step: 7 of the 9 stages of the 16 x 4096 step, host
+# floor 10.8 -> 8.0 ms per step at unchanged throughput, 1 083.3 against 1 083.4 samples/s — a process on a slow host stays
+# GPU-bound) — and the five sub-block nodes on the large levels.  Measured on MI355X (A/B inside one call): the pair node lowers
 # the host's enqueue time per step from 12.1 to 8.4 ms and lifts the PerAct bf16 step at 16 clouds from 1216-1356 to
 # 1447-1452 samples/s, but costs the fp32 step at 16 x 4096 points 1.5 % (880 -> 866): its temporaries of all five
 # sub-blocks are one allocation per pair, while separate nodes hand the same few hundred MB back to the allocator and get
@@ -1535,12 +1537,18 @@ _PAIR_PARAM_SLOTS = ("CW CB LW LB G0 B0 G1 B1 WQKV BQKV QNW QNB KNW KNB WP BP G2
 _PAIR_LINEAR = (2, 8, 14, 18, 20, 24, 30, 34, 36)   # indices (in that order) of the dense-layer weights: candidates for bf16 shadows
 
 
-def pair_enabled(rows0=0):
-    """rows0: points of the step at the input level (the "auto" rule looks at it)."""
+def pair_enabled(rows, rows0=None):
+    """rows: points of the level the stage runs on, rows0: points of the step's input level (the "auto" rule looks at them)."""
     if not composites_enabled():
         return False
     if _PAIR == "auto":
-        return _capi.BF16 or rows0 <= _PAIR_AUTO_ROWS
+        if _capi.BF16:
+            return True
+        if BnState.reduce is not None or GRAD_ARENA is not None:
+            # data parallel: the pair node hands its 38 gradients to the reducer at once, the buckets leave in bursts (one-rank
+            # rehearsal 1 055-1 056 against 1 058-1 062 samples/s) — per step as in round 5
+            return (rows if rows0 is None else rows0) <= _PAIR_AUTO_ROWS
+        return rows <= _PAIR_AUTO_ROWS
     return _PAIR
 
 

@@ -410,7 +410,7 @@ class PointTransformerV3CA(nn.Module):
                              st.norm.running_var, levels[0], training)
         ops.sync_side_stream()  # the packed convolution weights (they overlapped the stem)
         bank, cidx = None, self._cab_index
-        self._pair_on = ops.pair_enabled(levels[0].n)
+        self._pair_on = False  # decided per stage below: ops.pair_enabled(points of the stage's level)
         if self.kv_group and context is not None and len(self._cablocks) > 1:
             bank = ops.KvBank()
             wb = []
@@ -422,6 +422,7 @@ class PointTransformerV3CA(nn.Module):
             enc, lvl = self.enc[s], levels[s]
             site += 1
             seed = ops.mix_seed(base, site)
+            self._pair_on = ops.pair_enabled(lvl.n, levels[0].n)
             if s > 0:
                 d, bn = enc.down, enc.down.norm[0]
                 x = ops.PoolFn.apply(x, d.proj.weight, d.proj.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var,
@@ -441,6 +442,7 @@ class PointTransformerV3CA(nn.Module):
             dec, lvl, child = self.dec[i], levels[s], levels[s + 1]
             site += 1
             seed = ops.mix_seed(base, site)
+            self._pair_on = ops.pair_enabled(lvl.n, levels[0].n)
             u, us = dec.up.proj, dec.up.proj_skip
             x, skip = ops.UnpoolFn.apply(x, skips[s], u[0].weight, u[0].bias, u[1].weight, u[1].bias, u[1].running_mean,
                                          u[1].running_var, us[0].weight, us[0].bias, us[1].weight, us[1].bias,
