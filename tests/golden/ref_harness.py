@@ -340,13 +340,15 @@ def reference_mp_config(variant="mp"):
     return to_cfg(cfg)
 
 
-def build_reference_mp(variant="mp"):
+def build_reference_mp(variant="mp", enable_flash=True):
+    """enable_flash=False: the reference's own attention arithmetic instead of its flash_attn calls (see build_reference_policy)."""
     install_shims()
     if "einops" not in sys.modules:
         import einops  # noqa: F401  (installed in this image)
     from genrobo3d.models.motion_planner_ptv3 import MotionPlannerPTV3CA
 
     cfg = reference_mp_config(variant)
+    cfg["ptv3_config"]["enable_flash"] = bool(enable_flash)
     return MotionPlannerPTV3CA(cfg), cfg
 
 

@@ -96,6 +96,43 @@ def test_oracle_matches_the_reference_own_attention_arithmetic(variant, B, n, tr
         assert (p.grad - stand_in[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
 
 
+@pytest.mark.parametrize("variant", ["mp_tiny", "mp_tinyctx"])
+def test_motion_planner_fixtures_stand_on_the_reference_own_attention_arithmetic(variant):
+    """The 3D-LOTUS++ motion planner (motion_planner_ptv3.py) over the same backbone: with `enable_flash=False` the reference runs
+    its own attention arithmetic; the run over the harness' flash stand-in — what tests/golden/mp_*.npz were generated with — must
+    agree with it (losses 1e-5, every parameter gradient 1e-4).  Two-stage variants, >= 128 points per cloud at both levels."""
+    rh = _harness()
+    from weights_util import seeded_state_dict
+    from robot_3dlotus_amd import synth
+    from make_golden import zero_dropouts
+
+    batch = synth.synth_batch_mp(2, 1024, ragged=False, seed=35)
+    runs = {}
+    sd = None
+    for flash in (False, True):
+        ref, _ = rh.build_reference_mp(variant, enable_flash=flash)
+        if sd is None:
+            sd = seeded_state_dict(ref.state_dict(), 10, "scaled")
+        ref.load_state_dict(sd, strict=True)
+        zero_dropouts(ref)
+        ref.train(True)
+        with rh.neutralise_half():
+            torch.manual_seed(5)
+            losses = rh.reference_forward_mp(ref, copy.deepcopy(batch))
+        losses["total"].backward()
+        runs[flash] = (ref, losses)
+    own, stand_in = runs[False], runs[True]
+    for k in own[1]:
+        assert abs(own[1][k].item() - stand_in[1][k].item()) < 1e-5 * max(1, abs(own[1][k].item())), k
+    gmax = max(p.grad.norm().item() for p in own[0].parameters() if p.grad is not None)
+    other = dict(stand_in[0].named_parameters())
+    for name, p in own[0].named_parameters():
+        if p.grad is None:
+            assert other[name].grad is None, name
+            continue
+        assert (p.grad - other[name].grad).norm().item() <= 1e-4 * p.grad.norm().item() + 1e-6 * gmax, name
+
+
 def test_encode_matches_reference_all_depths():
     rh = _harness()
     from genrobo3d.models.PointTransformerV3.serialization import encode as ref_encode
